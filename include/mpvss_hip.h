@@ -1,0 +1,159 @@
+/* mpvss_hip.h -- C ABI of the MI355X-native batch group-exponentiation engine for mpvss-rs.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference crate: the modexp inner
+ * loops behind `distribute_secret`, `DLEQ::prove/verify` and `verify_distribution_shares`.
+ * A Rust `impl Group for HipModpGroup` binds these symbols with
+ * `extern "C"`; nothing here exposes C++, HIP or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MPVSS_E_* code; nothing throws or
+ *     aborts across the boundary; `mpvss_last_error(ctx)` gives a human-readable reason.
+ *     (The reference returns `false`/`None` for structural problems and only panics on
+ *     programmer errors such as threshold > n, src/participant.rs:166 -> MPVSS_E_INVALID.)
+ *   - the caller owns every buffer; the library keeps no pointer after a call returns.
+ *   - `space` says where the array arguments live: MPVSS_HOST (ordinary host memory) or
+ *     MPVSS_DEVICE (HIP device memory of the context's GPU, e.g. a torch tensor's
+ *     data_ptr()).  Scalar-like arguments documented as "host" are always host pointers.
+ *   - MODP-2048 encoding: every element and scalar is a fixed 256-byte big-endian unsigned
+ *     integer (zero padded).  The reference's minimal-length `element_to_bytes`
+ *     (src/groups/modp.rs:150-152) only matters inside the Fiat-Shamir transcript, which
+ *     the library frames itself (src/dleq.rs:58-61).  Elements need not be reduced: like
+ *     `BigInt::modpow` the engine reduces them mod q (src/groups/modp.rs:154-156 does no
+ *     validation).  Positions are the 1-based share indices (src/participant.rs:186).
+ *   - a context may be used from several host threads (calls are serialised internally);
+ *     `Group: Send + Sync` in the reference (src/group.rs:24).
+ */
+#ifndef MPVSS_HIP_H
+#define MPVSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPVSS_OK 0
+#define MPVSS_E_INVALID (-1)   /* bad argument (null pointer, n == 0 where forbidden, t > n, position < 0) */
+#define MPVSS_E_DEVICE (-2)    /* HIP runtime error (see mpvss_last_error) */
+#define MPVSS_E_NOMEM (-3)     /* workspace allocation failed */
+#define MPVSS_E_UNSUPPORTED (-4)
+
+#define MPVSS_HOST 0
+#define MPVSS_DEVICE 1
+
+#define MPVSS_MODP_BYTES 256   /* element / scalar width of the RFC 3526 group-14 encoding */
+
+typedef struct mpvss_ctx mpvss_ctx;
+
+/* ---- context ------------------------------------------------------------------------ */
+
+/* Number of visible HIP devices (0 when there is no GPU; the library never falls back to
+ * a CPU path -- every compute entry point then fails with MPVSS_E_DEVICE). */
+int mpvss_device_count(void);
+
+/* Create an engine bound to one GPU.  Replaces `ModpGroup::new()` (src/groups/modp.rs:44-69)
+ * as the object the host-side Group impl holds in its `Arc`. */
+int mpvss_ctx_create(int device_id, mpvss_ctx** out);
+void mpvss_ctx_destroy(mpvss_ctx* ctx);
+const char* mpvss_last_error(const mpvss_ctx* ctx);
+
+/* Optional: run the engine's kernels on a caller-provided hipStream_t (passed as void*). */
+int mpvss_ctx_set_stream(mpvss_ctx* ctx, void* hip_stream);
+/* Block until everything queued by this context has finished. */
+int mpvss_ctx_synchronize(mpvss_ctx* ctx);
+
+/* ---- Group operations, batched ------------------------------------------------------- */
+
+/* out[i] = bases[i]^exps[i] mod q.            Replaces n calls of ModpGroup::exp
+ * (src/groups/modp.rs:122-128).  bases/exps/out: n x 256 bytes. */
+int mpvss_modp_batch_exp(mpvss_ctx* ctx, int space, const uint8_t* bases, const uint8_t* exps, size_t n,
+                         uint8_t* out);
+
+/* out[i] = a[i]*b[i] mod q.                   Replaces ModpGroup::mul (src/groups/modp.rs:130-132). */
+int mpvss_modp_batch_mul(mpvss_ctx* ctx, int space, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+
+/* out[i] = base^exps[i] mod q for ONE base (host pointer, 256 bytes): the shape of
+ * generate_public_key (modp.rs:176-178), commitments C_j = g^a_j (participant.rs:189-193) and
+ * a1 = g^w (dleq.rs:207-216). */
+int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const uint8_t* base_host, const uint8_t* exps,
+                                    size_t n, uint8_t* out);
+
+/* ---- the commitment multi-exp -------------------------------------------------------- */
+
+/* X[i] = prod_{j<t} C_j^(positions[i]^j mod (q-1)) mod q.
+ * Replaces the loop at src/participant.rs:423-434 (= 207-215, = src/mpvss.rs:110-123).
+ * commitments: t x 256 bytes; positions: n int64 (each >= 0); x_out: n x 256 bytes. */
+int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                           const int64_t* positions, size_t n, uint8_t* x_out);
+
+/* ---- DLEQ verifier commitments -------------------------------------------------------- */
+
+/* a1[i] = g1^r[i] * h1[i]^c_i,  a2[i] = g2[i]^r[i] * h2[i]^c_i   (src/dleq.rs:66-84).
+ * g1_host: one shared 256-byte base (host pointer).  c: one shared 256-byte challenge when
+ * c_per_share == 0 (always a host pointer), else n x 256 bytes in `space`.
+ * h1, g2, h2, r, a1_out, a2_out: n x 256 bytes in `space`. */
+int mpvss_modp_dleq_commitments(mpvss_ctx* ctx, int space, const uint8_t* g1_host, const uint8_t* h1,
+                                const uint8_t* g2, const uint8_t* h2, const uint8_t* r, const uint8_t* c,
+                                int c_per_share, size_t n, uint8_t* a1_out, uint8_t* a2_out);
+
+/* ---- verify_distribution_shares ------------------------------------------------------- */
+
+/* Whole-box verification, src/participant.rs:399-455 (= src/mpvss.rs:90-144):
+ *   for each share i (in array order): X_i (commit_eval), (a1_i, a2_i) = DLEQ commitments with
+ *   (g, X_i, y_i, Y_i, r_i, c); transcript += framed(X_i) framed(Y_i) framed(a1_i) framed(a2_i)
+ *   (minimal-length big-endian bytes, u64-BE length prefix, src/dleq.rs:58-61,87-99);
+ *   *verdict = ( int(SHA256(SHA256(transcript))) mod (q-1)/2 == challenge ).
+ * commitments t x 256; positions n; pubkeys (y_i), shares (Y_i), responses (r_i): n x 256, all in
+ * `space`.  challenge: 256 bytes, host.  Outputs are host pointers: verdict (0/1),
+ * digest32_out (optional, SHA-256 of the transcript), and optional n x 256 dumps of X, a1, a2
+ * (pass NULL to skip).  An empty box (n == 0) hashes the empty transcript, as the reference does. */
+int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                   const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
+                                   const uint8_t* responses, size_t n, const uint8_t* challenge_host,
+                                   int* verdict, uint8_t* digest32_out, uint8_t* x_out_host,
+                                   uint8_t* a1_out_host, uint8_t* a2_out_host);
+
+/* ---- verify_share, batched -------------------------------------------------------------- */
+
+/* n independent share-box proofs, src/participant.rs:361-386 -> src/dleq.rs:275-302:
+ *   a1 = G^r_i * pk_i^c_i, a2 = S_i^r_i * Y_i^c_i,
+ *   verdicts[i] = ( hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1) framed(a2))) == c_i ).
+ * pk, s (decrypted shares S_i), y (encrypted shares Y_i), c, r: n x 256 in `space`;
+ * verdicts: n bytes, host. */
+int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
+                             const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_host);
+
+/* ---- distribute_secret, group part ------------------------------------------------------ */
+
+/* Dealer side of src/participant.rs:160-286 with the randomness as INPUT (the reference draws
+ * it from thread_rng, polynomial.rs:34-47 / modp.rs:162-174): given the polynomial values
+ * p_i = P(i) mod (q-1) and witnesses w_i, computes
+ *   X_i = prod C_j^(i^j)  (same loop as the verifier, participant.rs:207-215),
+ *   Y_i = y_i^p_i (participant.rs:219), a1_i = g^w_i, a2_i = y_i^w_i (dleq.rs:207-216),
+ * and the transcript digest SHA256(framed(X_i) framed(Y_i) framed(a1_i) framed(a2_i) ...)
+ * (participant.rs:238-252).  Scalar-field work (responses r_i = w_i - p_i*c, polynomial
+ * evaluation) stays on the host.  All arrays in `space`; digest32_out is a host pointer. */
+int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                          const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
+                          const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out,
+                          uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out);
+
+/* ---- hashing helpers (host only; Group::hash_to_scalar, src/groups/modp.rs:142-148) ------ */
+
+/* out32 = SHA-256(data) */
+void mpvss_sha256(const uint8_t* data, size_t len, uint8_t out32[32]);
+/* out256 = int_BE(SHA256(data)) mod (q-1)/2 as 256-byte big-endian */
+void mpvss_modp_hash_to_scalar(const uint8_t* data, size_t len, uint8_t out256[256]);
+
+/* ---- timing hooks for bench.py ------------------------------------------------------------ */
+
+/* Milliseconds the GPU spent in the kernels of the most recent compute call on this context,
+ * measured with hipEvents on the engine's own stream (kernel id: 0 = commit_eval, 1 = dual_exp
+ * launches summed, 2 = table builds summed).  Returns a negative value when unavailable. */
+double mpvss_last_kernel_ms(const mpvss_ctx* ctx, int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPVSS_HIP_H */

@@ -1,0 +1,204 @@
+"""ctypes binding of the engine's C ABI (include/mpvss_hip.h).
+
+This is the same set of symbols a Rust `extern "C"` block would bind.  There
+is NO CPU fallback here or in the library: if libmpvss_hip.so is missing, or no HIP device is
+present, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpvss_hip.so")
+
+MPVSS_HOST = 0
+MPVSS_DEVICE = 1
+EB = 256
+
+# every symbol include/mpvss_hip.h declares
+EXPORTED_SYMBOLS = (
+    "mpvss_device_count", "mpvss_ctx_create", "mpvss_ctx_destroy", "mpvss_last_error",
+    "mpvss_ctx_set_stream", "mpvss_ctx_synchronize",
+    "mpvss_modp_batch_exp", "mpvss_modp_batch_mul", "mpvss_modp_batch_exp_fixed_base",
+    "mpvss_modp_commit_eval", "mpvss_modp_dleq_commitments", "mpvss_modp_verify_distribution",
+    "mpvss_modp_verify_shares", "mpvss_modp_distribute", "mpvss_sha256", "mpvss_modp_hash_to_scalar",
+    "mpvss_last_kernel_ms",
+)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mpvss_rs_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u8p, i64p, sz, ci = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int
+    lib.mpvss_device_count.restype = ci
+    lib.mpvss_ctx_create.argtypes = [ci, C.POINTER(vp)]
+    lib.mpvss_ctx_destroy.argtypes = [vp]
+    lib.mpvss_ctx_destroy.restype = None
+    lib.mpvss_last_error.argtypes = [vp]
+    lib.mpvss_last_error.restype = C.c_char_p
+    lib.mpvss_ctx_set_stream.argtypes = [vp, vp]
+    lib.mpvss_ctx_synchronize.argtypes = [vp]
+    lib.mpvss_modp_batch_exp.argtypes = [vp, ci, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_batch_mul.argtypes = [vp, ci, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_batch_exp_fixed_base.argtypes = [vp, ci, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_commit_eval.argtypes = [vp, ci, u8p, sz, i64p, sz, u8p]
+    lib.mpvss_modp_dleq_commitments.argtypes = [vp, ci, u8p, u8p, u8p, u8p, u8p, u8p, ci, sz, u8p, u8p]
+    lib.mpvss_modp_verify_distribution.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p,
+                                                   C.POINTER(ci), u8p, u8p, u8p, u8p]
+    lib.mpvss_modp_verify_shares.argtypes = [vp, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_distribute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
+    lib.mpvss_sha256.argtypes = [u8p, sz, u8p]
+    lib.mpvss_sha256.restype = None
+    lib.mpvss_modp_hash_to_scalar.argtypes = [u8p, sz, u8p]
+    lib.mpvss_modp_hash_to_scalar.restype = None
+    lib.mpvss_last_kernel_ms.argtypes = [vp, ci]
+    lib.mpvss_last_kernel_ms.restype = C.c_double
+    return lib
+
+
+def _buf(b: Optional[bytes]):
+    """bytes -> (keepalive, void*)"""
+    if b is None:
+        return None, None
+    arr = (C.c_uint8 * len(b)).from_buffer_copy(b)
+    return arr, C.cast(arr, C.c_void_p)
+
+
+def _out(nbytes: int):
+    arr = (C.c_uint8 * max(nbytes, 1))()
+    return arr, C.cast(arr, C.c_void_p)
+
+
+class Engine:
+    """One engine context bound to one GPU (host-buffer convenience API; device-pointer calls go
+    through `.lib` / `.ctx` directly, see bench.py)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        if self.lib.mpvss_device_count() <= 0:
+            raise EngineError("no HIP device visible: the MI355X engine has no CPU fallback")
+        ctx = C.c_void_p()
+        rc = self.lib.mpvss_ctx_create(device_id, C.byref(ctx))
+        if rc != 0:
+            raise EngineError(f"mpvss_ctx_create failed: {rc}")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mpvss_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.mpvss_last_error(self.ctx)
+            raise EngineError(f"{what} failed: rc={rc} {msg.decode() if msg else ''}")
+
+    def kernel_ms(self, kernel_id: int) -> float:
+        return self.lib.mpvss_last_kernel_ms(self.ctx, kernel_id)
+
+    # ---- Group ops
+    def batch_mul(self, a: bytes, b: bytes) -> bytes:
+        n = len(a) // EB
+        ka, pa = _buf(a); kb, pb = _buf(b); ko, po = _out(n * EB)
+        self._check(self.lib.mpvss_modp_batch_mul(self.ctx, MPVSS_HOST, pa, pb, n, po), "batch_mul")
+        return bytes(ko)[: n * EB]
+
+    def batch_exp(self, bases: bytes, exps: bytes) -> bytes:
+        n = len(bases) // EB
+        ka, pa = _buf(bases); kb, pb = _buf(exps); ko, po = _out(n * EB)
+        self._check(self.lib.mpvss_modp_batch_exp(self.ctx, MPVSS_HOST, pa, pb, n, po), "batch_exp")
+        return bytes(ko)[: n * EB]
+
+    def batch_exp_fixed_base(self, base: bytes, exps: bytes) -> bytes:
+        n = len(exps) // EB
+        ka, pa = _buf(base); kb, pb = _buf(exps); ko, po = _out(n * EB)
+        self._check(self.lib.mpvss_modp_batch_exp_fixed_base(self.ctx, MPVSS_HOST, pa, pb, n, po),
+                    "batch_exp_fixed_base")
+        return bytes(ko)[: n * EB]
+
+    def commit_eval(self, commitments: bytes, positions: Sequence[int]) -> bytes:
+        t = len(commitments) // EB
+        n = len(positions)
+        kc, pc = _buf(commitments)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        ko, po = _out(n * EB)
+        self._check(self.lib.mpvss_modp_commit_eval(self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), n, po),
+                    "commit_eval")
+        return bytes(ko)[: n * EB]
+
+    def dleq_commitments(self, g1: bytes, h1: bytes, g2: bytes, h2: bytes, r: bytes, c: bytes,
+                         c_per_share: bool) -> Tuple[bytes, bytes]:
+        n = len(h1) // EB
+        k = [_buf(x) for x in (g1, h1, g2, h2, r, c)]
+        k1, p1 = _out(n * EB); k2, p2 = _out(n * EB)
+        self._check(self.lib.mpvss_modp_dleq_commitments(self.ctx, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                         k[4][1], k[5][1], int(c_per_share), n, p1, p2),
+                    "dleq_commitments")
+        return bytes(k1)[: n * EB], bytes(k2)[: n * EB]
+
+    def verify_distribution(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, shares: bytes,
+                            responses: bytes, challenge: bytes, dump: bool = False):
+        t = len(commitments) // EB
+        n = len(positions)
+        kc, pc = _buf(commitments); ky, py = _buf(pubkeys); kY, pY = _buf(shares); kr, pr = _buf(responses)
+        kch, pch = _buf(challenge)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        verdict = C.c_int(0)
+        kd, pd = _out(32)
+        if dump:
+            kx, px = _out(n * EB); k1, p1 = _out(n * EB); k2, p2 = _out(n * EB)
+        else:
+            kx = k1 = k2 = None
+            px = p1 = p2 = None
+        self._check(self.lib.mpvss_modp_verify_distribution(
+            self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pY, pr, n, pch, C.byref(verdict), pd,
+            px, p1, p2), "verify_distribution")
+        out = {"verdict": bool(verdict.value), "digest": bytes(kd)[:32]}
+        if dump:
+            out.update(X=bytes(kx)[: n * EB], a1=bytes(k1)[: n * EB], a2=bytes(k2)[: n * EB])
+        return out
+
+    def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes) -> bytes:
+        n = len(pk) // EB
+        k = [_buf(x) for x in (pk, s, y, c, r)]
+        kv, pv = _out(n)
+        self._check(self.lib.mpvss_modp_verify_shares(self.ctx, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                      k[4][1], n, pv), "verify_shares")
+        return bytes(kv)[:n]
+
+    def distribute(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, p_values: bytes,
+                   witnesses: bytes):
+        t = len(commitments) // EB
+        n = len(positions)
+        kc, pc = _buf(commitments); ky, py = _buf(pubkeys); kp, pp = _buf(p_values); kw, pw = _buf(witnesses)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        outs = [_out(n * EB) for _ in range(4)]
+        kd, pd = _out(32)
+        self._check(self.lib.mpvss_modp_distribute(self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pp, pw,
+                                                   n, outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd),
+                    "distribute")
+        X, Y, a1, a2 = (bytes(o[0])[: n * EB] for o in outs)
+        return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32]}
+
+
+def sha256(data: bytes) -> bytes:
+    lib = load_library()
+    kd, pd = _buf(data if data else b"\0")
+    ko, po = _out(32)
+    lib.mpvss_sha256(pd, len(data), po)
+    return bytes(ko)[:32]

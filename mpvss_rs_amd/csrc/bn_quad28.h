@@ -1,0 +1,155 @@
+// 2048-bit Montgomery arithmetic for gfx950, "quad" layout: one number is spread over the
+// four lanes of a DPP quad (16 numbers per 64-lane wavefront).
+//
+// Representation
+//   radix 2^28, L = 76 limbs (capacity 2128 bits, R = 2^2128), lane q of the quad owns limbs
+//   19q .. 19q+18 in registers.  Limbs are "almost normalised": every limb <= 2^28 - 1 + 2^9.
+//   Values are kept in [0, 2N) (R > 4N, so no conditional subtraction inside a chain).
+//
+// Why this shape (measured on MI355X, profiles/r01_ubench_valu_issue_rates.txt):
+//   * v_mad_u64_u32 issues every ~3.4 cycles per SIMD with >= 4 waves resident but a
+//     carry-producing add (v_add_co/v_addc) costs the same, so a radix-2^32 schoolbook row
+//     (1 mad + 1 addc per product) is ~1.85x the cost of a radix-2^28 row whose products are
+//     accumulated carry-free in 64-bit column accumulators (1 mad per product).
+//   * one wave alone reaches only ~1/3 of the mad issue rate, so >= 4 waves per SIMD are
+//     needed, i.e. <= 128 VGPRs: a whole 2048-bit operand per lane (64+ VGPRs per operand)
+//     does not fit, a quarter of one (19 limbs) does.
+//   * quad_perm DPP moves data between the four lanes at full VALU rate (no LDS round trip).
+//
+// Montgomery product (CIOS, one b-limb per step, accumulators shift one limb per step):
+//   the second operand is read limb by limb from LDS (all four lanes read the same word ->
+//   broadcast, 16 distinct banks per half-wave -> conflict free).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bn {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int W = 28;
+constexpr int L = 76;
+constexpr int LPL = 19;              // limbs per lane
+constexpr u32 MASK = (1u << W) - 1;
+constexpr int NUMS_PER_WAVE = 16;
+constexpr int SLOT_WORDS = 76;       // LDS words per number operand slot (304 B = 19 x 16 B)
+
+// quad_perm selectors: dpp_ctrl = p0 | p1<<2 | p2<<4 | p3<<6
+constexpr int QP_BCAST0 = 0x00;                          // every lane reads lane 0
+constexpr int QP_DOWN = 1 | (2 << 2) | (3 << 4) | (3 << 6);  // lane q reads lane q+1 (lane 3 reads itself)
+constexpr int QP_UP = 0 | (0 << 2) | (1 << 4) | (2 << 6);    // lane q reads lane q-1 (lane 0 reads itself)
+
+__device__ __forceinline__ u32 quad_bcast0(u32 v) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)v, QP_BCAST0, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32 quad_from_next(u32 v) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)v, QP_DOWN, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32 quad_from_prev(u32 v) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)v, QP_UP, 0xf, 0xf, true);
+}
+
+struct Lane {
+  u32 q;         // lane index inside the quad, 0..3
+  u32 not_top;   // all ones unless q == 3
+  u32 is_low;    // all ones iff q == 0
+  u32 not_low;   // all ones unless q == 0
+};
+
+__device__ __forceinline__ Lane make_lane() {
+  Lane ln;
+  ln.q = threadIdx.x & 3;
+  ln.not_top = (ln.q != 3) ? 0xffffffffu : 0u;
+  ln.is_low = (ln.q == 0) ? 0xffffffffu : 0u;
+  ln.not_low = ~ln.is_low;
+  return ln;
+}
+
+// r = a * b * R^-1 (mod N), result almost normalised and < 2N when a, b < 2N.
+//   a   : this lane's 19 limbs of the first operand (registers)
+//   b   : LDS pointer to the 76 limbs of the second operand of THIS number
+//   n   : this lane's 19 limbs of the modulus (registers)
+// N0INV == 1 for the RFC 3526 prime (N = -1 mod 2^64), the multiply folds away.
+template <u32 N0INV>
+__device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ b,
+                                         const u32 (&n)[LPL], const Lane& ln) {
+  u64 T[LPL];
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) T[k] = 0;
+  u64 cin = 0;  // carry out of the retired limb, lane 0 only
+#pragma nounroll
+  for (int o = 0; o < L / LPL; ++o) {
+#pragma unroll
+    for (int rr = 0; rr < LPL; ++rr) {
+      // local position k lives in T[(k + rr) % LPL]
+      const u32 bi = b[o * LPL + rr];
+#pragma unroll
+      for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)a[k] * bi;
+      const u32 t0 = (u32)T[rr] + (u32)cin;
+      const u32 m = quad_bcast0((t0 * N0INV) & MASK);
+#pragma unroll
+      for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)m * n[k];
+      // lane 0: limb 0 is now 0 mod 2^28, retire it and keep its carry
+      const u64 low = T[rr] + cin;
+      const u64 c = low >> W;
+      cin = ((u64)((u32)(c >> 32) & ln.is_low) << 32) | ((u32)c & ln.is_low);
+      // every lane hands its lowest column to the lane below; the top lane starts a fresh one
+      const u32 lo = quad_from_next((u32)T[rr]) & ln.not_top;
+      const u32 hi = quad_from_next((u32)(T[rr] >> 32)) & ln.not_top;
+      T[rr] = ((u64)hi << 32) | lo;
+    }
+  }
+  // L is a multiple of LPL, so local position k is back in T[k].
+  T[0] += cin;
+  // pass 1: carry-propagate inside the lane
+  u64 c = 0;
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) {
+    const u64 v = T[k] + c;
+    r[k] = (u32)v & MASK;
+    c = v >> W;
+  }
+  // pass 2: hand the lane's carry-out (< 2^37) to the next lane, one more local step
+  const u32 cl = quad_from_prev((u32)c) & ln.not_low;
+  const u32 ch = quad_from_prev((u32)(c >> 32)) & ln.not_low;
+  const u64 v = (u64)r[0] + (((u64)ch << 32) | cl);
+  r[0] = (u32)v & MASK;
+  r[1] += (u32)(v >> W);
+}
+
+// ---- operand slot helpers (one wave = 16 numbers, slot = 76 words per number) -------------
+
+// store this lane's 19 limbs into the number's LDS slot
+__device__ __forceinline__ void slot_store(u32* slot, const u32 (&a)[LPL], const Lane& ln) {
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) slot[ln.q * LPL + k] = a[k];
+}
+
+__device__ __forceinline__ void slot_load(u32 (&a)[LPL], const u32* slot, const Lane& ln) {
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) a[k] = slot[ln.q * LPL + k];
+}
+
+// copy 76 words global -> LDS slot with 16-byte accesses: chunk c (0..18) is handled by lane c & 3
+__device__ __forceinline__ void slot_fill_from_global(u32* slot, const u32* __restrict__ g, const Lane& ln) {
+  const uint4* g4 = reinterpret_cast<const uint4*>(g);
+  uint4* s4 = reinterpret_cast<uint4*>(slot);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const int idx = c * 4 + (int)ln.q;
+    if (idx < 19) s4[idx] = g4[idx];
+  }
+}
+
+__device__ __forceinline__ void slot_spill_to_global(u32* __restrict__ g, const u32* slot, const Lane& ln) {
+  uint4* g4 = reinterpret_cast<uint4*>(g);
+  const uint4* s4 = reinterpret_cast<const uint4*>(slot);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const int idx = c * 4 + (int)ln.q;
+    if (idx < 19) g4[idx] = s4[idx];
+  }
+}
+
+}  // namespace bn

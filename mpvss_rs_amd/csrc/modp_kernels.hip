@@ -1,0 +1,392 @@
+// MODP-2048 batch group-exponentiation kernels for gfx950 (MI355X).
+//
+// These are the device side of the hot path of the reference's
+//   Participant<ModpGroup>::verify_distribution_shares  (src/participant.rs:399-455)
+//   DLEQ verifier commitments                            (src/dleq.rs:66-84)
+//   ModpGroup::exp / ModpGroup::mul                      (src/groups/modp.rs:122-132)
+// re-designed for CDNA4: one number per DPP quad, radix-2^28 carry-free column
+// accumulation (see bn_quad28.h), one wavefront (16 numbers) per workgroup so that waves
+// never synchronise with each other, window tables in an HBM workspace, second operand of
+// every product staged in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bn_quad28.h"
+#include "modp_kernels.h"
+
+#ifndef MODP_WAVES_PER_EU
+#define MODP_WAVES_PER_EU 4
+#endif
+#define WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MODP_WAVES_PER_EU, MODP_WAVES_PER_EU)))
+
+using namespace bn;
+
+namespace {
+
+// device-resident constants: [0]=N, [1]=R^2 mod N, [2]=R mod N (Montgomery one), [3]=plain 1
+struct ModpConsts {
+  u32 n[L];
+  u32 r2[L];
+  u32 one_m[L];
+  u32 one[L];
+};
+
+__device__ __forceinline__ void load_lane_limbs(u32 (&a)[LPL], const u32* __restrict__ g, const Lane& ln) {
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) a[k] = g[ln.q * LPL + k];
+}
+
+__device__ __forceinline__ void store_lane_limbs(u32* __restrict__ g, const u32 (&a)[LPL], const Lane& ln) {
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) g[ln.q * LPL + k] = a[k];
+}
+
+// limb j (28 bits at bit offset 28 j) of a 256-byte big-endian integer
+__device__ __forceinline__ u32 be256_limb(const uint8_t* __restrict__ be, int j) {
+  const int o = W * j;
+  const int p = o >> 3, s = o & 7;
+  u32 w = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = 255 - (p + t);
+    if (idx >= 0) w |= (u32)be[idx] << (8 * t);
+  }
+  return (w >> s) & MASK;
+}
+
+__device__ __forceinline__ void load_be256(u32 (&a)[LPL], const uint8_t* __restrict__ be, const Lane& ln) {
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) a[k] = be256_limb(be, (int)ln.q * LPL + k);
+}
+
+// plain integer (any value < 2^2048) -> Montgomery form, via the LDS slot
+__device__ __forceinline__ void to_mont(u32 (&a)[LPL], u32* slot, const ModpConsts* __restrict__ cs,
+                                        const u32 (&n)[LPL], const Lane& ln) {
+  slot_fill_from_global(slot, cs->r2, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Montgomery (or plain, if `plain`) almost-normalised value in `a` -> canonical residue in
+// [0, N) written as 256 big-endian bytes.  Uses the LDS slot as scratch.
+__device__ __forceinline__ void store_canonical_be256(uint8_t* __restrict__ out, u32 (&a)[LPL], bool from_montgomery,
+                                                      u32* slot, const ModpConsts* __restrict__ cs,
+                                                      const u32 (&n)[LPL], const Lane& ln, bool write) {
+  if (from_montgomery) {
+    slot_fill_from_global(slot, cs->one, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+  }
+  slot_store(slot, a, ln);
+  __builtin_amdgcn_wave_barrier();
+  if (ln.q == 0) {
+    // exact carry propagation
+    u32 c = 0;
+#pragma nounroll
+    for (int j = 0; j < L; ++j) {
+      const u32 v = slot[j] + c;
+      slot[j] = v & MASK;
+      c = v >> W;
+    }
+    // value < 2N: subtract N once if value >= N
+    int ge = 1;  // value >= N ?  (decided by the most significant differing limb)
+#pragma nounroll
+    for (int j = L - 1; j >= 0; --j) {
+      const u32 x = slot[j], y = cs->n[j];
+      if (x != y) { ge = x > y; break; }
+    }
+    if (ge) {
+      u32 borrow = 0;
+#pragma nounroll
+      for (int j = 0; j < L; ++j) {
+        const u32 d = slot[j] - cs->n[j] - borrow;
+        borrow = (d >> 31) & 1;  // operands < 2^28, so a wrap sets the top bit
+        slot[j] = d & MASK;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (write) {
+    // lane q emits little-endian 32-bit words 16q .. 16q+15 (byte-swapped, mirrored position)
+    u32* out32 = reinterpret_cast<u32*>(out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int wd = (int)ln.q * 16 + i;
+      const int bit = 32 * wd;
+      const int j = bit / W, s = bit % W;
+      const u64 two = (u64)slot[j] | ((u64)(j + 1 < L ? slot[j + 1] : 0u) << W);
+      const u32 v = (u32)(two >> s);
+      out32[63 - wd] = __builtin_bswap32(v);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void square_into(u32 (&a)[LPL], u32* slot, const u32 (&n)[LPL], const Lane& ln) {
+  slot_store(slot, a, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);
+  __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// out[x] = a[x] * b[x] mod q          (Group::mul, modp.rs:130-132)
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+k_modp_mul(const uint8_t* __restrict__ a_be, const uint8_t* __restrict__ b_be, uint8_t* __restrict__ out_be,
+           int count, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], a[LPL], b[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(a, a_be + (size_t)x * 256, ln);
+  load_be256(b, b_be + (size_t)x * 256, ln);
+  to_mont(a, slot, cs, n, ln);          // aR
+  slot_store(slot, b, ln);              // plain b
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);  // a*b (plain, < 2N)
+  __builtin_amdgcn_wave_barrier();
+  store_canonical_be256(out_be + (size_t)x * 256, a, false, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
+// plain 256-byte big-endian integers -> Montgomery limb form ([count][76] words)
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+k_modp_to_mont(const uint8_t* __restrict__ in_be, u32* __restrict__ out_m, int count,
+               const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], a[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(a, in_be + (size_t)x * 256, ln);
+  to_mont(a, slot, cs, n, ln);
+  if (live) store_lane_limbs(out_m + (size_t)x * L, a, ln);
+}
+
+// ---------------------------------------------------------------------------------------
+// X_i = prod_j C_j^(i^j)   (participant.rs:423-434) evaluated by Horner's rule in the
+// exponent:  X_i = (..((C_{t-1})^i * C_{t-2})^i .. )^i * C_0 .  Identical group element for
+// every C_j (C_j^(i^j mod (q-1)) == C_j^(i^j) for units, and both sides are 0 when some
+// C_j == 0 mod q because every i^j >= 1), hence identical canonical bytes.
+//   cm        : commitments in Montgomery limb form [t][76]
+//   positions : i (>= 0) per share
+//   x_m       : optional, X_i in Montgomery limb form [count][76]
+//   x_be      : optional, X_i canonical 256-byte big-endian
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+k_modp_commit_eval(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions, int count,
+                   u32* __restrict__ x_m, uint8_t* __restrict__ x_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL], base[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  const u64 pos = (u64)positions[x];
+  // wave-wide maximum bit length of the positions
+  int nb = 64 - __builtin_clzll(pos | 1);
+  if (pos == 0) nb = 0;
+#pragma unroll
+  for (int off = 32; off >= 4; off >>= 1) {
+    const int other = __shfl_xor(nb, off);
+    nb = other > nb ? other : nb;
+  }
+  nb = __builtin_amdgcn_readfirstlane(nb);
+
+  load_lane_limbs(acc, cm + (size_t)(t - 1) * L, ln);
+  for (int j = t - 2; j >= 0; --j) {
+    // acc <- acc^pos  (left-to-right binary over nb bits; numbers with fewer bits start from one)
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) base[k] = acc[k];
+    bool started = false;
+    for (int bit = nb - 1; bit >= 0; --bit) {
+      const bool mine = (pos >> bit) & 1;
+      if (!started) {
+        // first processed bit: res = mine ? base : one
+#pragma unroll
+        for (int k = 0; k < LPL; ++k) acc[k] = mine ? base[k] : cs->one_m[ln.q * LPL + k];
+        started = true;
+        continue;
+      }
+      square_into(acc, slot, n, ln);
+      if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+#pragma unroll
+        for (int k = 0; k < LPL; ++k) slot[ln.q * LPL + k] = mine ? base[k] : cs->one_m[ln.q * LPL + k];
+        __builtin_amdgcn_wave_barrier();
+        mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!started) {
+      // every position in the wave is 0: acc^0 = 1
+#pragma unroll
+      for (int k = 0; k < LPL; ++k) acc[k] = cs->one_m[ln.q * LPL + k];
+    }
+    // acc <- acc * C_j
+    slot_fill_from_global(slot, cm + (size_t)j * L, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (x_m != nullptr && live) store_lane_limbs(x_m + (size_t)x * L, acc, ln);
+  if (x_be != nullptr) store_canonical_be256(x_be + (size_t)x * 256, acc, true, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
+// Window table: tab[x][e] = base_x^e (Montgomery form), e = 0..15.
+//   base_be : [count][256] big-endian (stride 0 when `count` == 1 shared base)
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+k_modp_build_table(const uint8_t* __restrict__ base_be, int count, u32* __restrict__ tab,
+                   const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], b[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(b, base_be + (size_t)x * 256, ln);
+  to_mont(b, slot, cs, n, ln);
+  u32* my = tab + (size_t)x * 16 * L;
+  load_lane_limbs(acc, cs->one_m, ln);
+  if (live) store_lane_limbs(my, acc, ln);
+  if (live) store_lane_limbs(my + L, b, ln);
+  slot_store(slot, b, ln);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) acc[k] = b[k];
+  for (int e = 2; e < 16; ++e) {
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (live) store_lane_limbs(my + (size_t)e * L, acc, ln);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// out[x] = B1[x]^e1[x] * B2[x]^e2[x]  mod q    (dleq.rs:66-84: a = g^r * h^c)
+// Straus interleaving with 4-bit fixed windows over precomputed tables.
+//   tab1, tab2     : window tables; *_stride = 16*76 words per number, or 0 for a shared base
+//   e1_be          : [count][256] exponents (2048 bit)
+//   e2_be          : [count][256] or, when e2_stride == 0, one shared [256] exponent
+//   e2_windows     : number of low 4-bit windows of e2 that may be non-zero (64 for a 256-bit
+//                    challenge, 512 for a full-width exponent)
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+k_modp_dual_exp(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __restrict__ tab2, size_t tab2_stride,
+                const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride,
+                int e2_windows, int count, uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  const u32* t1 = tab1 + (size_t)x * tab1_stride;
+  const u32* t2 = tab2 + (size_t)x * tab2_stride;
+  const uint8_t* e1 = e1_be + (size_t)x * 256;
+  const uint8_t* e2 = e2_be + (size_t)x * e2_stride;
+  const int first_e2 = 512 - e2_windows;
+
+  for (int w = 0; w < 512; ++w) {
+    const u32 byte1 = e1[w >> 1];
+    const u32 d1 = (w & 1) ? (byte1 & 15) : (byte1 >> 4);
+    if (w == 0) {
+      load_lane_limbs(acc, t1 + (size_t)d1 * L, ln);
+    } else {
+      for (int s = 0; s < 4; ++s) square_into(acc, slot, n, ln);
+      slot_fill_from_global(slot, t1 + (size_t)d1 * L, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (w >= first_e2) {
+      const u32 byte2 = e2[w >> 1];
+      const u32 d2 = (w & 1) ? (byte2 & 15) : (byte2 >> 4);
+      slot_fill_from_global(slot, t2 + (size_t)d2 * L, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  store_canonical_be256(out_be + (size_t)x * 256, acc, true, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
+// host-callable launchers (plain C linkage, used by mpvss_capi.cpp)
+// ---------------------------------------------------------------------------------------
+
+
+extern "C" int modp_consts_upload(void** dev_consts) {
+  ModpConsts h;
+  for (int j = 0; j < L; ++j) {
+    h.n[j] = MODP_N_LIMBS[j];
+    h.r2[j] = MODP_R2_LIMBS[j];
+    h.one_m[j] = MODP_ONE_M_LIMBS[j];
+    h.one[j] = (j == 0) ? 1u : 0u;
+  }
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, sizeof(ModpConsts));
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpy(d, &h, sizeof(ModpConsts), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return (int)e;
+  *dev_consts = d;
+  return 0;
+}
+
+static inline int grid_for(int count) { return (count + NUMS_PER_WAVE - 1) / NUMS_PER_WAVE; }
+
+extern "C" int modp_launch_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int count, const void* cs,
+                               hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_mul, dim3(grid_for(count)), dim3(64), 0, s, a, b, out, count, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_to_mont(const uint8_t* in, uint32_t* out_m, int count, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_to_mont, dim3(grid_for(count)), dim3(64), 0, s, in, out_m, count,
+                     (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_commit_eval(const uint32_t* cm, int t, const int64_t* positions, int count,
+                                       uint32_t* x_m, uint8_t* x_be, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(64), 0, s, cm, t, positions, count, x_m,
+                     x_be, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_build_table(const uint8_t* base_be, int count, uint32_t* tab, const void* cs,
+                                       hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_build_table, dim3(grid_for(count)), dim3(64), 0, s, base_be, count, tab,
+                     (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_dual_exp(const uint32_t* tab1, size_t tab1_stride, const uint32_t* tab2,
+                                    size_t tab2_stride, const uint8_t* e1, const uint8_t* e2, size_t e2_stride,
+                                    int e2_windows, int count, uint8_t* out, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_dual_exp, dim3(grid_for(count)), dim3(64), 0, s, tab1, tab1_stride, tab2,
+                     tab2_stride, e1, e2, e2_stride, e2_windows, count, out, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}

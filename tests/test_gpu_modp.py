@@ -1,0 +1,195 @@
+"""GPU parity tests (MODP-2048): the HIP engine, called through its C ABI, against the CPU oracle.
+Bit-exact equality is the bar (integer/byte work)."""
+import random
+
+import pytest
+
+import mpvss_oracle as O
+from helpers import EB, cat, make_modp_instance, modp_keygen, split
+
+pytestmark = pytest.mark.gpu
+
+G = O.ModpGroup()
+Q = G.q
+EDGE = [0, 1, 2, 4, Q - 1, Q, Q + 1, (1 << 2048) - 1, 1 << 2047, (1 << 2040) - 1, 0xFFFFFFF, 1 << 28, (1 << 56) - 1]
+
+
+def fx(v):
+    return v.to_bytes(EB, "big")
+
+
+def test_batch_mul_matches_oracle(engine):
+    rng = random.Random(11)
+    a = [rng.randrange(1 << 2048) for _ in range(70)] + EDGE + EDGE
+    b = [rng.randrange(1 << 2048) for _ in range(70)] + EDGE + EDGE[::-1]
+    out = split(engine.batch_mul(b"".join(map(fx, a)), b"".join(map(fx, b))))
+    assert out == [(x * y) % Q for x, y in zip(a, b)]          # modp.rs:130-132
+
+
+def test_batch_exp_matches_oracle(engine):
+    rng = random.Random(12)
+    bases = [rng.randrange(1 << 2048) for _ in range(20)] + EDGE + [2, 4, 3]
+    exps = [rng.randrange(1 << 2048) for _ in range(20)] + EDGE[::-1] + [0, 1, (1 << 2048) - 1]
+    out = split(engine.batch_exp(b"".join(map(fx, bases)), b"".join(map(fx, exps))))
+    assert out == [pow(x, e, Q) for x, e in zip(bases, exps)]  # modp.rs:122-128
+
+
+def test_batch_exp_fixed_base(engine):
+    rng = random.Random(13)
+    exps = [rng.randrange(Q - 1) for _ in range(33)] + [0, 1, 2]
+    for base in (2, 4, rng.randrange(Q)):
+        out = split(engine.batch_exp_fixed_base(fx(base), b"".join(map(fx, exps))))
+        assert out == [pow(base, e, Q) for e in exps]
+
+
+def test_single_element_and_ragged_counts(engine):
+    rng = random.Random(14)
+    for n in (1, 2, 15, 16, 17, 31, 33):
+        a = [rng.randrange(Q) for _ in range(n)]
+        b = [rng.randrange(Q) for _ in range(n)]
+        assert split(engine.batch_mul(b"".join(map(fx, a)), b"".join(map(fx, b)))) == [x * y % Q for x, y in zip(a, b)]
+    assert engine.batch_mul(b"", b"") == b""
+
+
+def test_commit_eval_matches_reference_loop(engine):
+    rng = random.Random(15)
+    t = 5
+    commitments = [pow(4, rng.randrange(Q - 1), Q) for _ in range(t)]
+    positions = list(range(1, 41)) + [0, 12345, (1 << 40) + 5, (1 << 62) + 1, 65536, 65535]
+    out = split(engine.commit_eval(cat(G, commitments), positions))
+    assert out == [O.commitment_eval(G, commitments, i) for i in positions]   # participant.rs:423-434
+
+
+def test_commit_eval_edge_commitments(engine):
+    # unreduced, zero and one commitments; t = 1
+    for commitments in ([0, 5, 7], [Q + 3, Q - 1, 1], [1, 1, 1], [9]):
+        positions = [1, 2, 3, 17]
+        out = split(engine.commit_eval(cat(G, [c % (1 << 2048) for c in commitments]), positions))
+        assert out == [O.commitment_eval(G, commitments, i) for i in positions]
+
+
+def test_dleq_commitments(engine):
+    rng = random.Random(16)
+    n = 19
+    h1 = [rng.randrange(Q) for _ in range(n)]
+    g2 = [rng.randrange(Q) for _ in range(n)]
+    h2 = [rng.randrange(Q) for _ in range(n)]
+    r = [rng.randrange(Q - 1) for _ in range(n)]
+    c = rng.randrange(1 << 256)
+    a1, a2 = engine.dleq_commitments(fx(4), cat(G, h1), cat(G, g2), cat(G, h2), cat(G, r), fx(c), False)
+    exp = [O.dleq_verifier_commitments(G, 4, h1[i], g2[i], h2[i], r[i], c) for i in range(n)]   # dleq.rs:66-84
+    assert split(a1) == [e[0] for e in exp]
+    assert split(a2) == [e[1] for e in exp]
+    # per-share, full-width challenges
+    cs = [rng.randrange(Q - 1) for _ in range(n)]
+    a1, a2 = engine.dleq_commitments(fx(2), cat(G, h1), cat(G, g2), cat(G, h2), cat(G, r), cat(G, cs), True)
+    exp = [O.dleq_verifier_commitments(G, 2, h1[i], g2[i], h2[i], r[i], cs[i]) for i in range(n)]
+    assert split(a1) == [e[0] for e in exp]
+    assert split(a2) == [e[1] for e in exp]
+
+
+@pytest.mark.parametrize("n,t,seed", [(3, 3, 1), (20, 4, 2), (37, 7, 3)])
+def test_verify_distribution_honest_and_tampered(engine, n, t, seed):
+    g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, seed)
+    flat = O.box_to_flat(g, box)
+    res = engine.verify_distribution(flat["commitments"], flat["positions"], flat["publickeys"], flat["shares"],
+                                     flat["responses"], flat["challenge"], dump=True)
+    trace = {}
+    assert O.verify_distribution_shares(g, box, trace) is True
+    assert res["verdict"] is True
+    assert res["digest"] == trace["digest"] == box["_digest"]
+    assert split(res["X"]) == trace["X"] == box["_X"]
+    assert split(res["a1"]) == trace["a1"] == box["_a1"]
+    assert split(res["a2"]) == trace["a2"] == box["_a2"]
+    # negative tests the reference lacks: one flipped bit anywhere => reject, same digest as oracle
+    rng = random.Random(seed)
+    for field in ("responses", "shares", "commitments", "publickeys", "challenge"):
+        bad = dict(flat)
+        buf = bytearray(flat[field])
+        idx = rng.randrange(len(buf))
+        buf[idx] ^= 1 << rng.randrange(8)
+        bad[field] = bytes(buf)
+        res = engine.verify_distribution(bad["commitments"], bad["positions"], bad["publickeys"], bad["shares"],
+                                         bad["responses"], bad["challenge"], dump=False)
+        # oracle on the same tampered flat box
+        obox = flat_to_box(g, bad)
+        otrace = {}
+        overdict = O.verify_distribution_shares(g, obox, otrace)
+        assert res["verdict"] == overdict
+        assert res["digest"] == otrace["digest"]
+        assert res["verdict"] is False
+
+
+def flat_to_box(g, flat):
+    n, t = flat["n"], flat["t"]
+    cm = split(flat["commitments"])
+    pk = split(flat["publickeys"])
+    sh = split(flat["shares"])
+    rs = split(flat["responses"])
+    keys = [g.element_to_bytes(p) for p in pk]
+    return {"commitments": cm, "publickeys": pk,
+            "positions": dict(zip(keys, flat["positions"])),
+            "shares": dict(zip(keys, sh)), "responses": dict(zip(keys, rs)),
+            "challenge": int.from_bytes(flat["challenge"], "big"), "U": 0}
+
+
+def test_verify_distribution_minimal_length_framing(engine):
+    """X_1 = 2^36 is hashed as 5 bytes, not 256."""
+    g = O.ModpGroup()
+    pks = [g.generate_public_key(k) for k in (5, 9)]
+    box = O.distribute_secret(g, 0x4869, pks, 2, [7, 11], [13, 17])
+    assert box["_digest"].hex() == "5b1da312869d00956a82fb60dc26147ec3d37e2b751fa633f11f74b8f567e333"
+    flat = O.box_to_flat(g, box)
+    res = engine.verify_distribution(flat["commitments"], flat["positions"], flat["publickeys"], flat["shares"],
+                                     flat["responses"], flat["challenge"], dump=True)
+    assert res["verdict"] is True
+    assert res["digest"] == box["_digest"]
+    assert split(res["X"])[0] == 1 << 36
+
+
+def test_verify_distribution_empty_box(engine):
+    import hashlib
+    res = engine.verify_distribution(b"", [], b"", b"", b"", bytes(256))
+    assert res["digest"] == hashlib.sha256(b"").digest()
+    assert res["verdict"] is False
+
+
+def test_verify_shares_batch(engine):
+    g, privs, pks, coeffs, ws, box = make_modp_instance(9, 3, 21)
+    rng = random.Random(5)
+    sbs = [O.extract_secret_share(g, box, k, modp_keygen(g, rng)) for k in privs]
+    keys = [g.element_to_bytes(p) for p in pks]
+    Y = [box["shares"][k] for k in keys]
+    S = [sb["share"] for sb in sbs]
+    c = [sb["challenge"] for sb in sbs]
+    r = [sb["response"] for sb in sbs]
+    # tamper a few
+    r[2] ^= 1
+    S[5] = S[5] * 2 % Q
+    c[7] ^= 1 << 200
+    verdicts = engine.verify_shares(cat(g, pks), cat(g, S), cat(g, Y), cat(g, c), cat(g, r))
+    exp = [O.dleq_verify(g, g.generator(), pks[i], S[i], Y[i], c[i], r[i]) for i in range(9)]   # participant.rs:361-386
+    assert list(verdicts) == [int(v) for v in exp]
+    assert exp == [True, True, False, True, True, False, True, False, True]
+
+
+def test_distribute_group_part(engine):
+    g, privs, pks, coeffs, ws, box = make_modp_instance(11, 4, 31)
+    order = g.group_order_int()
+    positions = list(range(1, 12))
+    p_vals = [O.poly_get_value(coeffs, i) % order for i in positions]
+    res = engine.distribute(cat(g, box["commitments"]), positions, cat(g, pks), cat(g, p_vals), cat(g, ws))
+    keys = [g.element_to_bytes(p) for p in pks]
+    assert split(res["X"]) == box["_X"]
+    assert split(res["Y"]) == [box["shares"][k] for k in keys]
+    assert split(res["a1"]) == box["_a1"]
+    assert split(res["a2"]) == box["_a2"]
+    assert res["digest"] == box["_digest"]
+
+
+def test_rejects_bad_arguments(engine):
+    from mpvss_rs_amd import EngineError
+    with pytest.raises(EngineError):
+        engine.commit_eval(fx(4), [-1])
+    with pytest.raises(EngineError):
+        engine.distribute(cat(G, [4, 4, 4]), [1, 2], cat(G, [2, 2]), cat(G, [1, 1]), cat(G, [1, 1]))   # t > n
