@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DLEQ share verifications/sec, 2048-bit MODP, n=65536 t=256 per GPU.
+
+A "step" is one complete `verify_distribution_shares` (src/participant.rs:399-455 of the
+reference) over a synthetic honest-dealer box whose arrays are already resident in HBM:
+commitment multi-exp X_i, DLEQ commitments a1_i/a2_i (HIP kernels), device->host copy of
+X/Y/a1/a2, the ordered SHA-256 transcript on the host and the challenge comparison.  The box
+must verify (verdict True) and reproduce the dealer's transcript digest or the run aborts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling:
+      the box has N x 65536 participants, rank g holds the contiguous block g)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from mpvss_rs_amd import capi  # noqa: E402
+
+EB = 256
+Q = int(
+    "ffffffffffffffffc90fdaa22168c234c4c6628b80dc1cd129024e088a67cc74020bbea63b139b22514a08798e3404ddef9519b3cd3a43"
+    "1b302b0a6df25f14374fe1356d6d51c245e485b576625e7ec6f44c42e9a637ed6b0bff5cb6f406b7edee386bfb5a899fa5ae9f24117c4b"
+    "1fe649286651ece45b3dc2007cb8a163bf0598da48361c55d39a69163fa8fd24cf5f83655d23dca3ad961c62f356208552bb9ed5290770"
+    "96966d670c354e4abc9804f1746c08ca18217c32905e462e36ce3be39e772c180e86039b2783a2ec07a28fb5c55df06f4c52c9de2bcbf6"
+    "955817183995497cea956ae515d2261898fa051015728e5a8aacaa68ffffffffffffffff", 16)
+ORDER = Q - 1
+SEED = 0x6D70767373          # "mpvss"; Python random.Random (MT19937) streams, documented in DESIGN.md
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_SHARE = 1536  # read y,Y,r + write X,a1,a2 (6 x 256 B)
+# measured issue rate (profiles/r01_ubench_valu_issue_rates.txt): one v_mad_u64_u32 wave-instruction
+# per ~3.37 cycles per SIMD with >= 4 waves; a 2048-bit Montgomery product = 2*76*76 lane-mads
+MAD_CYCLES = 3.37
+MODMUL_CYCLES_PER_SIMD = 2 * 76 * 19 * MAD_CYCLES / 16   # 2888 wave-mads per 16 numbers
+PEAK_MODMUL_PER_S = 1024 * 2.4e9 / MODMUL_CYCLES_PER_SIMD  # 256 CUs x 4 SIMDs at 2.4 GHz
+
+
+def fx(v: int) -> bytes:
+    return v.to_bytes(EB, "big")
+
+
+def keygen(rng: random.Random) -> int:
+    while True:                                   # modp.rs:162-174
+        k = rng.randrange(Q)
+        if math.gcd(k, ORDER) == 1:
+            return k
+
+
+def horner_modmuls(positions, t):
+    """Montgomery products the commit_eval kernel executes for one 16-share wave (see
+    k_modp_commit_eval): per Horner step (nb-1) squarings, one product per lower bit position at
+    which any share of the wave has the bit set, plus the product with C_j."""
+    total = 0
+    for w in range(0, len(positions), 16):
+        grp = positions[w:w + 16]
+        nb = max(grp).bit_length()
+        anyset = 0
+        for p in grp:
+            anyset |= p
+        mults = bin(anyset & ((1 << max(nb - 1, 0)) - 1)).count("1")
+        per_step = max(nb - 1, 0) + mults + 1
+        total += len(grp) * per_step * (t - 1)
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=65536, help="participants per GPU")
+    ap.add_argument("--t", type=int, default=256, help="threshold")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the CPU port (-1: 2 per core, 0: skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    eng = capi.Engine(local_rank)     # raises if the HIP library or the GPU is missing
+    lib, ctx = eng.lib, eng.ctx
+    n, t = args.n, args.t
+    n_total = n * world
+    lo = rank * n
+
+    # ---------------- synthetic honest-dealer box (deterministic) ----------------
+    t_setup = time.time()
+    rng_c = random.Random(SEED)                       # polynomial coefficients: same on every rank
+    coeffs = [rng_c.randrange(ORDER) for _ in range(t)]
+    rng = random.Random(SEED * 1000003 + rank)       # this rank's participants
+    privs = [keygen(rng) for _ in range(n)]
+    wits = [keygen(rng) for _ in range(n)]
+    positions = list(range(lo + 1, lo + n + 1))
+    # P(i) mod (q-1)   (polynomial.rs:50-58 evaluates over Z, the caller reduces; Horner is the same value)
+    pvals = []
+    rc = list(reversed(coeffs))
+    for i in positions:
+        acc = 0
+        for a in rc:
+            acc = acc * i + a
+        pvals.append(acc % ORDER)
+    commitments = eng.batch_exp_fixed_base(fx(4), b"".join(fx(a) for a in coeffs))        # C_j = g^a_j
+    pubkeys = eng.batch_exp_fixed_base(fx(2), b"".join(fx(k) for k in privs))             # y_i = G^x_i
+    dres = eng.distribute(commitments, positions, pubkeys, b"".join(map(fx, pvals)), b"".join(map(fx, wits)))
+    shares = dres["Y"]
+    # dealer transcript over ALL ranks in order -> challenge
+    inter = bytearray()
+    for i in range(n):
+        s = slice(i * EB, (i + 1) * EB)
+        inter += dres["X"][s] + dres["Y"][s] + dres["a1"][s] + dres["a2"][s]
+    if world > 1:
+        commdev = dev
+        if rank == 0:
+            state = capi.transcript_init()
+        else:
+            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
+            dist.recv(buf, src=rank - 1)
+            state = bytes(buf.cpu().numpy().tobytes())
+        state = capi.transcript_absorb(state, bytes(inter))
+        if rank + 1 < world:
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1)
+            dg = torch.zeros(32, dtype=torch.uint8, device=commdev)
+        else:
+            _, digest = capi.transcript_verdict(state, bytes(EB))
+            dg = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(commdev)
+        dist.broadcast(dg, src=world - 1)
+        dealer_digest = bytes(dg.cpu().numpy().tobytes())
+    else:
+        state = capi.transcript_absorb(capi.transcript_init(), bytes(inter))
+        _, dealer_digest = capi.transcript_verdict(state, bytes(EB))
+    import hashlib
+    c = int.from_bytes(hashlib.sha256(dealer_digest).digest(), "big") % ((Q - 1) // 2)    # modp.rs:142-148
+    challenge = fx(c)
+    responses = b"".join(fx((w - (p * c) % ORDER) % ORDER) for w, p in zip(wits, pvals))   # dleq.rs:42-50
+    del inter
+    setup_s = time.time() - t_setup
+
+    # ---------------- inputs resident in HBM ----------------
+    def dev_u8(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_cm, d_pk, d_sh, d_rs = dev_u8(commitments), dev_u8(pubkeys), dev_u8(shares), dev_u8(responses)
+    d_pos = torch.tensor(positions, dtype=torch.int64, device=dev)
+    ch_buf = (C.c_uint8 * EB).from_buffer_copy(challenge)
+    torch.cuda.synchronize()
+
+    def vp(tensor):
+        return C.c_void_p(tensor.data_ptr())
+
+    def compute_block():
+        rcode = lib.mpvss_modp_verify_block_compute(ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), vp(d_pk),
+                                                    vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p))
+        eng._check(rcode, "verify_block_compute")
+
+    kernel_ms = {0: [], 1: [], 2: []}
+    host_hash_s = []
+
+    def step():
+        """one verify_distribution_shares over the (sharded) box; returns (verdict, digest)"""
+        compute_block()
+        if world == 1:
+            state = capi.transcript_init()
+        elif rank == 0:
+            state = capi.transcript_init()
+        else:
+            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=dev)
+            dist.recv(buf, src=rank - 1)
+            state = bytes(buf.cpu().numpy().tobytes())
+        lib.mpvss_ctx_synchronize(ctx)
+        t0 = time.perf_counter()
+        state = eng.verify_block_absorb(state)
+        host_hash_s.append(time.perf_counter() - t0)
+        for k in kernel_ms:
+            kernel_ms[k].append(eng.kernel_ms(k))
+        if world == 1:
+            return capi.transcript_verdict(state, challenge)
+        out = torch.zeros(33, dtype=torch.uint8, device=dev)
+        if rank + 1 < world:
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(dev), dst=rank + 1)
+        else:
+            verdict, digest = capi.transcript_verdict(state, challenge)
+            out = torch.frombuffer(bytearray(bytes([int(verdict)]) + digest), dtype=torch.uint8).to(dev)
+        dist.broadcast(out, src=world - 1)
+        raw = bytes(out.cpu().numpy().tobytes())
+        return bool(raw[0]), raw[1:33]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        verdict, digest = step()
+        assert verdict is True and digest == dealer_digest, "parity gate failed in warm-up"
+    for k in kernel_ms:
+        kernel_ms[k].clear()
+    host_hash_s.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        verdict, digest = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    value = n_total * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    ce_ms = sum(kernel_ms[0]) / max(len(kernel_ms[0]), 1)
+    de_ms = sum(kernel_ms[1]) / max(len(kernel_ms[1]), 1)
+    tb_ms = sum(kernel_ms[2]) / max(len(kernel_ms[2]), 1)
+
+    # work accounting (Montgomery products executed per step on this rank)
+    mm_commit = horner_modmuls(positions, t)
+    mm_dual = n * 2 * (2044 + 511 + 64 + 1)           # two Straus chains per share
+    mm_table = n * (3 * 15)                            # three 16-entry tables per share (+1 to_mont each)
+    achieved_modmul = (mm_commit + mm_dual + mm_table) / ((ce_ms + de_ms + tb_ms) * 1e-3)
+    peak_modmul = PEAK_MODMUL_PER_S
+
+    result = {
+        "metric": "DLEQ share verifications/sec, 2048-bit MODP, n=65536 t=256",
+        "value": value,
+        "unit": "share verifications/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 limbs (radix 2^28), u64 accumulators",
+        "data": "synthetic",
+        "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n} t={t} per GPU "
+                               f"({n_total} participants in the box), honest-dealer box, inputs resident in HBM",
+                   "n_per_gpu": n, "t": t, "parallelism": f"participants sharded x{world}"},
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_modp_commit_eval",
+            "achieved": ALGO_BYTES_PER_SHARE * n / (ce_ms * 1e-3) / 1e9 if ce_ms > 0 else None,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": (ALGO_BYTES_PER_SHARE * n / (ce_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if ce_ms > 0 else None,
+            "traffic": None,
+            "kernel_ms": ce_ms,
+        },
+        "compute": {
+            "bound": "valu v_mad_u64_u32 issue",
+            "achieved": achieved_modmul, "peak": peak_modmul, "unit": "2048-bit Montgomery products/s",
+            "frac": achieved_modmul / peak_modmul,
+            "modmul_per_share": (mm_commit + mm_dual + mm_table) / n,
+            "kernel_ms": {"commit_eval": ce_ms, "dual_exp_x2": de_ms, "tables": tb_ms},
+        },
+        "host": {"transcript_sha256_ms": 1e3 * sum(host_hash_s) / max(len(host_hash_s), 1), "setup_s": setup_s},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            result["roofline"]["traffic"] = json.load(open(traffic_file)).get("k_modp_commit_eval_bytes_per_launch")
+        except Exception:
+            pass
+
+    # ---------------- CPU baseline (rank 0, N == 1 only): the C port of the reference sequence ----------------
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from concurrent.futures import ThreadPoolExecutor
+
+        from modp_ref import ModpRef
+        ref = ModpRef()
+        # Threads that really run in parallel here (cpu_count() ignores cgroup quotas): calibrate with
+        # short full-width modpows, 1 thread vs many.
+        nthreads = min(os.cpu_count() or 1, 64)
+        bb, ee = int.from_bytes(commitments[:EB], "big"), ORDER - 12345
+        t1 = time.perf_counter(); ref.modpow(bb, ee); single = time.perf_counter() - t1
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            t1 = time.perf_counter()
+            list(ex.map(lambda _: ref.modpow(bb, ee), range(2 * nthreads)))
+            par = time.perf_counter() - t1
+        cores = max(1, min(nthreads, int(round(2 * nthreads * single / par))))
+        # one share costs ~(sum of exponent bits) * 1.5 Montgomery products; aim for ~15 s of wall time
+        est_share_s = single * (sum(min(17 * j, 2048) for j in range(t)) + 2 * 2048 + 2 * 256) / 2048.0
+        k = args.cpu_sample if args.cpu_sample > 0 else max(cores, min(8 * cores, int(15.0 * cores / max(est_share_s, 1e-3))))
+        k = min(k, n)
+        idx = sorted({int((j + 0.5) * n / k) for j in range(k)})
+        # GPU outputs for the sampled shares (one more, untimed, dumped verification)
+        X = (C.c_uint8 * (n * EB))(); A1 = (C.c_uint8 * (n * EB))(); A2 = (C.c_uint8 * (n * EB))()
+        v = C.c_int(0); dg = (C.c_uint8 * 32)()
+        eng._check(lib.mpvss_modp_verify_distribution(ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), vp(d_pk),
+                                                      vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p), C.byref(v),
+                                                      dg, X, A1, A2), "verify_distribution(dump)")
+        Xb, A1b, A2b = bytes(X), bytes(A1), bytes(A2)
+
+        def work(i):
+            s = slice(i * EB, (i + 1) * EB)
+            return ref.share_work(commitments, positions[i], pubkeys[s], shares[s], responses[s], challenge)
+        tc = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            outs = list(ex.map(work, idx))
+        cpu_s = time.perf_counter() - tc
+        for i, (x, a1, a2) in zip(idx, outs):
+            s = slice(i * EB, (i + 1) * EB)
+            assert (x, a1, a2) == (Xb[s], A1b[s], A2b[s]), f"GPU/CPU mismatch at share {i}"
+        result["cpu_baseline"] = {
+            "value": len(idx) / cpu_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
+            "sample": f"{len(idx)} of {n} shares (positions spread over [1,{n}], all t={t} commitments), "
+                      f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
+                      f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,28 @@ int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* com
                                    int* verdict, uint8_t* digest32_out, uint8_t* x_out_host,
                                    uint8_t* a1_out_host, uint8_t* a2_out_host);
 
+/* Sharded form of the same verification (one engine per GPU, contiguous blocks of shares per
+ * engine, blocks absorbed in share order).  `state` is an opaque MPVSS_TRANSCRIPT_STATE_BYTES
+ * running-hash state that travels from the engine holding block k to the one holding block k+1:
+ *   mpvss_transcript_init(state);
+ *   for each block in order:  ..._verify_block_compute(block);  ..._verify_block_absorb(state);
+ *   mpvss_modp_transcript_verdict(state, challenge, &verdict, digest);
+ * `compute` only enqueues GPU work (kernels + device-to-host copies) and returns; `absorb` waits
+ * for it, so the wait for the previous block's state overlaps this block's GPU work.
+ * mpvss_modp_verify_distribution == init + compute + absorb + verdict on one engine. */
+#define MPVSS_TRANSCRIPT_STATE_BYTES 128
+void mpvss_transcript_init(uint8_t* state);
+int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                    const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
+                                    const uint8_t* responses, size_t n, const uint8_t* challenge_host);
+int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* a1_out_host,
+                                   uint8_t* a2_out_host);
+/* Host-only: extend the transcript with `count` 256-byte elements, each framed as
+ * u64-BE(minimal length) || minimal-length big-endian bytes (src/dleq.rs:58-61, modp.rs:150-152). */
+int mpvss_modp_transcript_absorb(uint8_t* state, const uint8_t* elements, size_t count);
+int mpvss_modp_transcript_verdict(const uint8_t* state, const uint8_t* challenge_host, int* verdict,
+                                  uint8_t* digest32_out);
+
 /* ---- verify_share, batched -------------------------------------------------------------- */
 
 /* n independent share-box proofs, src/participant.rs:361-386 -> src/dleq.rs:275-302:

@@ -25,7 +25,11 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_commit_eval", "mpvss_modp_dleq_commitments", "mpvss_modp_verify_distribution",
     "mpvss_modp_verify_shares", "mpvss_modp_distribute", "mpvss_sha256", "mpvss_modp_hash_to_scalar",
     "mpvss_last_kernel_ms",
+    "mpvss_transcript_init", "mpvss_modp_verify_block_compute", "mpvss_modp_verify_block_absorb",
+    "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
 )
+
+TRANSCRIPT_STATE_BYTES = 128
 
 
 class EngineError(RuntimeError):
@@ -62,6 +66,12 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_hash_to_scalar.restype = None
     lib.mpvss_last_kernel_ms.argtypes = [vp, ci]
     lib.mpvss_last_kernel_ms.restype = C.c_double
+    lib.mpvss_transcript_init.argtypes = [u8p]
+    lib.mpvss_transcript_init.restype = None
+    lib.mpvss_modp_verify_block_compute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
+    lib.mpvss_modp_transcript_verdict.argtypes = [u8p, u8p, C.POINTER(ci), u8p]
+    lib.mpvss_modp_transcript_absorb.argtypes = [u8p, u8p, sz]
     return lib
 
 
@@ -173,6 +183,22 @@ class Engine:
             out.update(X=bytes(kx)[: n * EB], a1=bytes(k1)[: n * EB], a2=bytes(k2)[: n * EB])
         return out
 
+    # ---- sharded verification (one engine per GPU; see mpvss_rs_amd/sharding.py)
+    def verify_block_compute(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, shares: bytes,
+                             responses: bytes, challenge: bytes) -> None:
+        t = len(commitments) // EB
+        n = len(positions)
+        kc, pc = _buf(commitments); ky, py = _buf(pubkeys); kY, pY = _buf(shares); kr, pr = _buf(responses)
+        kch, pch = _buf(challenge)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        self._check(self.lib.mpvss_modp_verify_block_compute(self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p),
+                                                             py, pY, pr, n, pch), "verify_block_compute")
+
+    def verify_block_absorb(self, state: bytes) -> bytes:
+        ks, ps = _buf(state)
+        self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, None, None, None), "verify_block_absorb")
+        return bytes(ks)
+
     def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes) -> bytes:
         n = len(pk) // EB
         k = [_buf(x) for x in (pk, s, y, c, r)]
@@ -202,3 +228,29 @@ def sha256(data: bytes) -> bytes:
     ko, po = _out(32)
     lib.mpvss_sha256(pd, len(data), po)
     return bytes(ko)[:32]
+
+
+def transcript_init() -> bytes:
+    lib = load_library()
+    ks, ps = _out(TRANSCRIPT_STATE_BYTES)
+    lib.mpvss_transcript_init(ps)
+    return bytes(ks)[:TRANSCRIPT_STATE_BYTES]
+
+
+def transcript_verdict(state: bytes, challenge: bytes):
+    lib = load_library()
+    ks, ps = _buf(state); kc, pc = _buf(challenge); kd, pd = _out(32)
+    v = C.c_int(0)
+    rc = lib.mpvss_modp_transcript_verdict(ps, pc, C.byref(v), pd)
+    if rc != 0:
+        raise EngineError(f"transcript_verdict failed: {rc}")
+    return bool(v.value), bytes(kd)[:32]
+
+
+def transcript_absorb(state: bytes, elements: bytes) -> bytes:
+    lib = load_library()
+    ks, ps = _buf(state); ke, pe = _buf(elements if elements else b"\0")
+    rc = lib.mpvss_modp_transcript_absorb(ps, pe, len(elements) // EB)
+    if rc != 0:
+        raise EngineError(f"transcript_absorb failed: {rc}")
+    return bytes(ks)

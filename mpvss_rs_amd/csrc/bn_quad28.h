@@ -53,7 +53,7 @@ __device__ __forceinline__ u32 quad_from_prev(u32 v) {
 struct Lane {
   u32 q;         // lane index inside the quad, 0..3
   u32 not_top;   // all ones unless q == 3
-  u32 is_low;    // all ones iff q == 0
+  u32 low01;     // 1 iff q == 0, else 0
   u32 not_low;   // all ones unless q == 0
 };
 
@@ -61,8 +61,11 @@ __device__ __forceinline__ Lane make_lane() {
   Lane ln;
   ln.q = threadIdx.x & 3;
   ln.not_top = (ln.q != 3) ? 0xffffffffu : 0u;
-  ln.is_low = (ln.q == 0) ? 0xffffffffu : 0u;
-  ln.not_low = ~ln.is_low;
+  ln.low01 = (ln.q == 0) ? 1u : 0u;
+  ln.not_low = (ln.q != 0) ? 0xffffffffu : 0u;
+  // Opaque to the optimiser: otherwise `x & mask` becomes v_cndmask_b32 on an SGPR-pair condition,
+  // which issues ~4x slower than v_and_b32 on gfx950 (profiles/r01_ubench_valu_issue_rates.txt).
+  asm volatile("" : "+v"(ln.not_top), "+v"(ln.low01), "+v"(ln.not_low));
   return ln;
 }
 
@@ -71,37 +74,57 @@ __device__ __forceinline__ Lane make_lane() {
 //   b   : LDS pointer to the 76 limbs of the second operand of THIS number
 //   n   : this lane's 19 limbs of the modulus (registers)
 // N0INV == 1 for the RFC 3526 prime (N = -1 mod 2^64), the multiply folds away.
+//
+// One step (one limb b_i of b), per lane: 19 mads a[k]*b_i, m from lane 0's lowest column,
+// 19 mads m*n[k]; lane 0's lowest column is then 0 mod 2^28: its upper bits are added to the
+// next column and the column is retired; every lane hands its lowest column to the lane below
+// (lane 3 starts a fresh zero column).  Column accumulators stay below 2^64 (76 steps x 2
+// products < 2^56.01 each, checked exhaustively for worst-case limbs in tests/test_limb_model.py).
 template <u32 N0INV>
 __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ b,
                                          const u32 (&n)[LPL], const Lane& ln) {
   u64 T[LPL];
 #pragma unroll
   for (int k = 0; k < LPL; ++k) T[k] = 0;
-  u64 cin = 0;  // carry out of the retired limb, lane 0 only
+  u32 bnext = b[0];   // software prefetch of the next b limb (one LDS read in flight)
 #pragma nounroll
   for (int o = 0; o < L / LPL; ++o) {
 #pragma unroll
     for (int rr = 0; rr < LPL; ++rr) {
       // local position k lives in T[(k + rr) % LPL]
-      const u32 bi = b[o * LPL + rr];
+      const u32 bi = bnext;
+      {
+        const int nxt = o * LPL + rr + 1;
+        bnext = b[nxt < L ? nxt : L - 1];
+      }
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)a[k] * bi;
-      const u32 t0 = (u32)T[rr] + (u32)cin;
-      const u32 m = quad_bcast0((t0 * N0INV) & MASK);
+      const u32 m = quad_bcast0(((u32)T[rr] * N0INV) & MASK);
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)m * n[k];
-      // lane 0: limb 0 is now 0 mod 2^28, retire it and keep its carry
-      const u64 low = T[rr] + cin;
-      const u64 c = low >> W;
-      cin = ((u64)((u32)(c >> 32) & ln.is_low) << 32) | ((u32)c & ln.is_low);
+      // lane 0: the lowest column is now 0 mod 2^28; move its upper bits (< 2^37) into the next
+      // column.  The multiplications by low01 (0/1) do the lane masking inside the adds.
+      {
+        const u64 ret = T[rr];
+        const u32 c_lo = (u32)(ret >> W);
+        const u32 c_hi = (u32)(ret >> 32) >> W;
+        u64& nx = T[(rr + 1) % LPL];
+        nx += (u64)c_lo * ln.low01;
+        const u32 nhi = (u32)(nx >> 32) + c_hi * ln.low01;
+        nx = ((u64)nhi << 32) | (u32)nx;
+      }
       // every lane hands its lowest column to the lane below; the top lane starts a fresh one
       const u32 lo = quad_from_next((u32)T[rr]) & ln.not_top;
       const u32 hi = quad_from_next((u32)(T[rr] >> 32)) & ln.not_top;
       T[rr] = ((u64)hi << 32) | lo;
+      // Pin the row-wise order: without this LLVM reassociates the 19-fold unrolled body into a
+      // column-wise (product-scanning) form that keeps every b_i and m_i of the block live and
+      // no longer fits 128 VGPRs (4 waves/SIMD).  The empty asm makes each accumulator opaque.
+#pragma unroll
+      for (int k = 0; k < LPL; ++k) asm volatile("" : "+v"(T[k]));
     }
   }
   // L is a multiple of LPL, so local position k is back in T[k].
-  T[0] += cin;
   // pass 1: carry-propagate inside the lane
   u64 c = 0;
 #pragma unroll

@@ -17,6 +17,13 @@
 #define MODP_WAVES_PER_EU 4
 #endif
 #define WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MODP_WAVES_PER_EU, MODP_WAVES_PER_EU)))
+// Waves per workgroup.  Waves never talk to each other; 4-wave workgroups only exist because a CU
+// admits more resident waves that way than as single-wave workgroups.
+#ifndef MODP_WPB
+#define MODP_WPB 4
+#endif
+#define BLOCK_THREADS (64 * MODP_WPB)
+#define NUMS_PER_BLOCK (NUMS_PER_WAVE * MODP_WPB)
 
 using namespace bn;
 
@@ -135,12 +142,12 @@ __device__ __forceinline__ void square_into(u32 (&a)[LPL], u32* slot, const u32 
 // ---------------------------------------------------------------------------------------
 // out[x] = a[x] * b[x] mod q          (Group::mul, modp.rs:130-132)
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_mul(const uint8_t* __restrict__ a_be, const uint8_t* __restrict__ b_be, uint8_t* __restrict__ out_be,
            int count, const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
@@ -159,12 +166,12 @@ k_modp_mul(const uint8_t* __restrict__ a_be, const uint8_t* __restrict__ b_be, u
 // ---------------------------------------------------------------------------------------
 // plain 256-byte big-endian integers -> Montgomery limb form ([count][76] words)
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_to_mont(const uint8_t* __restrict__ in_be, u32* __restrict__ out_m, int count,
                const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
@@ -182,80 +189,99 @@ k_modp_to_mont(const uint8_t* __restrict__ in_be, u32* __restrict__ out_m, int c
 // C_j == 0 mod q because every i^j >= 1), hence identical canonical bytes.
 //   cm        : commitments in Montgomery limb form [t][76]
 //   positions : i (>= 0) per share
-//   x_m       : optional, X_i in Montgomery limb form [count][76]
-//   x_be      : optional, X_i canonical 256-byte big-endian
+//   x_be      : X_i canonical 256-byte big-endian
+// The whole evaluation is one loop around a single Montgomery-product site: every step only
+// chooses which LDS operand (own copy = square, saved base, Montgomery one, C_j) it multiplies by.
+// LDS per wave: operand slot + saved-base slot per number, one shared slot holding one_m.
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_commit_eval(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions, int count,
-                   u32* __restrict__ x_m, uint8_t* __restrict__ x_be, const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+                   uint8_t* __restrict__ x_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_BLOCK + MODP_WPB) * SLOT_WORDS];
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
-  u32 n[LPL], acc[LPL], base[LPL];
+  u32* bslot = lds + (NUMS_PER_BLOCK + (threadIdx.x >> 2)) * SLOT_WORDS;
+  u32* oneslot = lds + (2 * NUMS_PER_BLOCK + (threadIdx.x >> 6)) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
   load_lane_limbs(n, cs->n, ln);
+  if ((threadIdx.x & 63) < 4) slot_fill_from_global(oneslot, cs->one_m, ln);
   const u64 pos = (u64)positions[x];
   // wave-wide maximum bit length of the positions
-  int nb = 64 - __builtin_clzll(pos | 1);
-  if (pos == 0) nb = 0;
+  int nb = (pos == 0) ? 0 : 64 - __builtin_clzll(pos);
 #pragma unroll
   for (int off = 32; off >= 4; off >>= 1) {
     const int other = __shfl_xor(nb, off);
     nb = other > nb ? other : nb;
   }
   nb = __builtin_amdgcn_readfirstlane(nb);
+  __builtin_amdgcn_wave_barrier();
 
   load_lane_limbs(acc, cm + (size_t)(t - 1) * L, ln);
-  for (int j = t - 2; j >= 0; --j) {
-    // acc <- acc^pos  (left-to-right binary over nb bits; numbers with fewer bits start from one)
-#pragma unroll
-    for (int k = 0; k < LPL; ++k) base[k] = acc[k];
-    bool started = false;
-    for (int bit = nb - 1; bit >= 0; --bit) {
+  // Program (one Montgomery-product site):
+  //   for j = t-2 .. 0:   base = acc; acc = topbit ? base : one
+  //                       for bit = nb-2 .. 0: SQUARE; CONDMUL (by base or one, skipped if no lane needs it)
+  //                       CMUL (by C_j)
+  //   FINAL (by plain 1: leave the Montgomery domain)
+  enum { K_SQUARE, K_CONDMUL, K_CMUL, K_FINAL };
+  int j = t - 2, bit = 0, kind = K_FINAL;
+  auto begin_coefficient = [&]() {
+    if (nb == 0) {   // every position of the wave is 0: acc^0 = 1
+      load_lane_limbs(acc, cs->one_m, ln);
+      kind = K_CMUL;
+      return;
+    }
+    slot_store(bslot, acc, ln);
+    if (!((pos >> (nb - 1)) & 1)) load_lane_limbs(acc, cs->one_m, ln);
+    bit = nb - 2;
+    kind = (bit >= 0) ? K_SQUARE : K_CMUL;
+  };
+  if (j >= 0) begin_coefficient();
+  while (true) {
+    const u32* bptr = slot;
+    bool skip = false;
+    if (kind == K_SQUARE) {
+      slot_store(slot, acc, ln);
+    } else if (kind == K_CONDMUL) {
       const bool mine = (pos >> bit) & 1;
-      if (!started) {
-        // first processed bit: res = mine ? base : one
-#pragma unroll
-        for (int k = 0; k < LPL; ++k) acc[k] = mine ? base[k] : cs->one_m[ln.q * LPL + k];
-        started = true;
-        continue;
-      }
-      square_into(acc, slot, n, ln);
-      if (__builtin_amdgcn_ballot_w64(mine) != 0) {
-#pragma unroll
-        for (int k = 0; k < LPL; ++k) slot[ln.q * LPL + k] = mine ? base[k] : cs->one_m[ln.q * LPL + k];
-        __builtin_amdgcn_wave_barrier();
-        mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
-        __builtin_amdgcn_wave_barrier();
-      }
+      skip = __builtin_amdgcn_ballot_w64(mine) == 0;
+      bptr = mine ? bslot : oneslot;
+    } else if (kind == K_CMUL) {
+      slot_fill_from_global(slot, cm + (size_t)j * L, ln);
+    } else {
+      slot_fill_from_global(slot, cs->one, ln);
     }
-    if (!started) {
-      // every position in the wave is 0: acc^0 = 1
-#pragma unroll
-      for (int k = 0; k < LPL; ++k) acc[k] = cs->one_m[ln.q * LPL + k];
+    if (!skip) {
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
+      __builtin_amdgcn_wave_barrier();
     }
-    // acc <- acc * C_j
-    slot_fill_from_global(slot, cm + (size_t)j * L, ln);
-    __builtin_amdgcn_wave_barrier();
-    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
-    __builtin_amdgcn_wave_barrier();
+    if (kind == K_FINAL) break;
+    if (kind == K_SQUARE) {
+      kind = K_CONDMUL;
+    } else if (kind == K_CONDMUL) {
+      --bit;
+      kind = (bit >= 0) ? K_SQUARE : K_CMUL;
+    } else {
+      --j;
+      if (j >= 0) begin_coefficient(); else kind = K_FINAL;
+    }
   }
-  if (x_m != nullptr && live) store_lane_limbs(x_m + (size_t)x * L, acc, ln);
-  if (x_be != nullptr) store_canonical_be256(x_be + (size_t)x * 256, acc, true, slot, cs, n, ln, live);
+  store_canonical_be256(x_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
 }
 
 // ---------------------------------------------------------------------------------------
 // Window table: tab[x][e] = base_x^e (Montgomery form), e = 0..15.
 //   base_be : [count][256] big-endian (stride 0 when `count` == 1 shared base)
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_build_table(const uint8_t* __restrict__ base_be, int count, u32* __restrict__ tab,
                    const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
@@ -286,13 +312,13 @@ k_modp_build_table(const uint8_t* __restrict__ base_be, int count, u32* __restri
 //   e2_windows     : number of low 4-bit windows of e2 that may be non-zero (64 for a 256-bit
 //                    challenge, 512 for a full-width exponent)
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_dual_exp(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __restrict__ tab2, size_t tab2_stride,
                 const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride,
                 int e2_windows, int count, uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_WAVE + (threadIdx.x >> 2);
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
@@ -304,28 +330,35 @@ k_modp_dual_exp(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __r
   const uint8_t* e2 = e2_be + (size_t)x * e2_stride;
   const int first_e2 = 512 - e2_windows;
 
-  for (int w = 0; w < 512; ++w) {
-    const u32 byte1 = e1[w >> 1];
-    const u32 d1 = (w & 1) ? (byte1 & 15) : (byte1 >> 4);
-    if (w == 0) {
-      load_lane_limbs(acc, t1 + (size_t)d1 * L, ln);
-    } else {
-      for (int s = 0; s < 4; ++s) square_into(acc, slot, n, ln);
-      slot_fill_from_global(slot, t1 + (size_t)d1 * L, ln);
-      __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (w >= first_e2) {
-      const u32 byte2 = e2[w >> 1];
-      const u32 d2 = (w & 1) ? (byte2 & 15) : (byte2 >> 4);
-      slot_fill_from_global(slot, t2 + (size_t)d2 * L, ln);
-      __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
-      __builtin_amdgcn_wave_barrier();
-    }
+  // Program (one Montgomery-product site): window w = 0..511 of the exponents, most significant
+  // first: 4 x SQUARE (w > 0), MUL by tab1[d1], MUL by tab2[d2] (only the low e2_windows windows),
+  // then FINAL (by plain 1).  The first window loads tab1[d1] instead of multiplying into one.
+  {
+    const u32 byte1 = e1[0];
+    load_lane_limbs(acc, t1 + (size_t)(byte1 >> 4) * L, ln);
   }
-  store_canonical_be256(out_be + (size_t)x * 256, acc, true, slot, cs, n, ln, live);
+  int w = 0, s = (first_e2 == 0) ? 5 : 6;     // step inside the window: 0..3 square, 4 tab1, 5 tab2, 6 next
+  while (true) {
+    if (s == 6) { ++w; s = 0; }
+    const bool final_step = (w == 512);
+    if (final_step) {
+      slot_fill_from_global(slot, cs->one, ln);
+    } else if (s < 4) {
+      slot_store(slot, acc, ln);
+    } else {
+      const uint8_t* e = (s == 4) ? e1 : e2;
+      const u32 byte = e[w >> 1];
+      const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+      slot_fill_from_global(slot, ((s == 4) ? t1 : t2) + (size_t)d * L, ln);
+    }
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    if (final_step) break;
+    ++s;
+    if (s == 5 && w < first_e2) s = 6;
+  }
+  store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -350,18 +383,18 @@ extern "C" int modp_consts_upload(void** dev_consts) {
   return 0;
 }
 
-static inline int grid_for(int count) { return (count + NUMS_PER_WAVE - 1) / NUMS_PER_WAVE; }
+static inline int grid_for(int count) { return (count + NUMS_PER_BLOCK - 1) / NUMS_PER_BLOCK; }
 
 extern "C" int modp_launch_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int count, const void* cs,
                                hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_mul, dim3(grid_for(count)), dim3(64), 0, s, a, b, out, count, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_mul, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, a, b, out, count, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 
 extern "C" int modp_launch_to_mont(const uint8_t* in, uint32_t* out_m, int count, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_to_mont, dim3(grid_for(count)), dim3(64), 0, s, in, out_m, count,
+  hipLaunchKernelGGL(k_modp_to_mont, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, in, out_m, count,
                      (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
@@ -369,7 +402,8 @@ extern "C" int modp_launch_to_mont(const uint8_t* in, uint32_t* out_m, int count
 extern "C" int modp_launch_commit_eval(const uint32_t* cm, int t, const int64_t* positions, int count,
                                        uint32_t* x_m, uint8_t* x_be, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(64), 0, s, cm, t, positions, count, x_m,
+  (void)x_m;
+  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, cm, t, positions, count,
                      x_be, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
@@ -377,7 +411,7 @@ extern "C" int modp_launch_commit_eval(const uint32_t* cm, int t, const int64_t*
 extern "C" int modp_launch_build_table(const uint8_t* base_be, int count, uint32_t* tab, const void* cs,
                                        hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_build_table, dim3(grid_for(count)), dim3(64), 0, s, base_be, count, tab,
+  hipLaunchKernelGGL(k_modp_build_table, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, base_be, count, tab,
                      (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
@@ -386,7 +420,7 @@ extern "C" int modp_launch_dual_exp(const uint32_t* tab1, size_t tab1_stride, co
                                     size_t tab2_stride, const uint8_t* e1, const uint8_t* e2, size_t e2_stride,
                                     int e2_windows, int count, uint8_t* out, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_dual_exp, dim3(grid_for(count)), dim3(64), 0, s, tab1, tab1_stride, tab2,
+  hipLaunchKernelGGL(k_modp_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab1_stride, tab2,
                      tab2_stride, e1, e2, e2_stride, e2_windows, count, out, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }

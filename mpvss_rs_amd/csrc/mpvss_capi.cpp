@@ -45,6 +45,7 @@ struct mpvss_ctx {
   std::vector<Span> spans;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  size_t blk_n = 0;   // shares of the block whose results wait in the pinned staging
 };
 
 namespace {
@@ -542,6 +543,139 @@ extern "C" int mpvss_modp_dleq_commitments(mpvss_ctx* ctx, int space, const uint
 }
 
 // ---- verify_distribution_shares --------------------------------------------------------------------
+// Split in three so that a box can be sharded over several engines (one per GPU):
+//   compute : GPU work of one contiguous block of shares; X, Y, a1, a2 land in pinned host staging
+//   absorb  : waits for the GPU and extends the ordered transcript hash with the block
+//   verdict : finishes the hash and compares with the challenge
+namespace {
+
+static_assert(sizeof(mpvss::Sha256) <= MPVSS_TRANSCRIPT_STATE_BYTES, "transcript state size");
+
+int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
+                                const uint8_t* responses, size_t n, const uint8_t* challenge_host) {
+  ctx->blk_n = 0;
+  if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
+  if (n == 0) return MPVSS_OK;
+  if (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff)
+    return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  spans_reset(ctx);
+  RET_IF(stage_commitments(ctx, space, commitments, t));
+  const uint32_t* tg;
+  RET_IF(shared_table(ctx, g_bytes(0), &tg));
+  const void* dchal;
+  RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->in_e, &dchal));
+  const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
+  RET_IF(ensure_pinned(ctx, n * EB * 4));
+  uint8_t* hX = (uint8_t*)ctx->pin;
+  uint8_t* hY = hX + n * EB;
+  uint8_t* h1 = hY + n * EB;
+  uint8_t* h2 = h1 + n * EB;
+  for (size_t off = 0; off < n; off += MAX_CHUNK) {
+    const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
+    const int64_t* dpos;
+    RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
+    const void *dy, *dY, *dr;
+    RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->in_a, &dy));
+    RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->in_b, &dY));
+    RET_IF(stage_in(ctx, space, responses + off * EB, cnt * EB, ctx->in_c, &dr));
+    RET_IF(ensure(ctx, ctx->xbe, cnt * EB));
+    RET_IF(ensure(ctx, ctx->out1, cnt * EB));
+    RET_IF(ensure(ctx, ctx->out2, cnt * EB));
+    uint8_t* dX = (uint8_t*)ctx->xbe.p;
+    uint8_t* da1 = (uint8_t*)ctx->out1.p;
+    uint8_t* da2 = (uint8_t*)ctx->out2.p;
+    // X_i                                                  participant.rs:423-434
+    TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
+                                                 ctx->consts, ctx->stream));
+    // a1_i = g^r_i * X_i^c, a2_i = y_i^r_i * Y_i^c           dleq.rs:66-84
+    RET_IF(dleq_side(ctx, tg, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1));
+    RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
+                     0, c_windows, cnt, da2));
+    HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB,
+                               space == MPVSS_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // staging buffers are reused
+  }
+  ctx->blk_n = n;
+  return MPVSS_OK;
+}
+
+int verify_block_absorb_locked(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out, uint8_t* a1_out, uint8_t* a2_out) {
+  if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
+  const size_t n = ctx->blk_n;
+  if (n == 0) return MPVSS_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  RET_IF(spans_collect(ctx));   // synchronises the stream
+  mpvss::Sha256 tr;
+  memcpy(&tr, state, sizeof(tr));
+  const uint8_t* hX = (const uint8_t*)ctx->pin;
+  const uint8_t* hY = hX + n * EB;
+  const uint8_t* h1 = hY + n * EB;
+  const uint8_t* h2 = h1 + n * EB;
+  for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99, share order = array order
+    frame_update(tr, hX + i * EB);
+    frame_update(tr, hY + i * EB);
+    frame_update(tr, h1 + i * EB);
+    frame_update(tr, h2 + i * EB);
+  }
+  memcpy(state, &tr, sizeof(tr));
+  if (x_out) memcpy(x_out, hX, n * EB);
+  if (a1_out) memcpy(a1_out, h1, n * EB);
+  if (a2_out) memcpy(a2_out, h2, n * EB);
+  ctx->blk_n = 0;
+  return MPVSS_OK;
+}
+
+}  // namespace
+
+extern "C" void mpvss_transcript_init(uint8_t* state) {
+  memset(state, 0, MPVSS_TRANSCRIPT_STATE_BYTES);
+  mpvss::Sha256 tr;
+  memcpy(state, &tr, sizeof(tr));
+}
+
+extern "C" int mpvss_modp_transcript_absorb(uint8_t* state, const uint8_t* elements, size_t count) {
+  if (!state || (count && !elements)) return MPVSS_E_INVALID;
+  mpvss::Sha256 tr;
+  memcpy(&tr, state, sizeof(tr));
+  for (size_t i = 0; i < count; ++i) frame_update(tr, elements + i * EB);
+  memcpy(state, &tr, sizeof(tr));
+  return MPVSS_OK;
+}
+
+extern "C" int mpvss_modp_transcript_verdict(const uint8_t* state, const uint8_t* challenge_host, int* verdict,
+                                             uint8_t* digest32_out) {
+  if (!state || !challenge_host || !verdict) return MPVSS_E_INVALID;
+  mpvss::Sha256 tr;
+  memcpy(&tr, state, sizeof(tr));
+  uint8_t digest[32];
+  tr.final(digest);
+  if (digest32_out) memcpy(digest32_out, digest, 32);
+  *verdict = challenge_matches(digest, challenge_host) ? 1 : 0;   // participant.rs:451-454
+  return MPVSS_OK;
+}
+
+extern "C" int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                               const int64_t* positions, const uint8_t* pubkeys,
+                                               const uint8_t* shares, const uint8_t* responses, size_t n,
+                                               const uint8_t* challenge_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
+                                     challenge_host);
+}
+
+extern "C" int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host,
+                                              uint8_t* a1_out_host, uint8_t* a2_out_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_block_absorb_locked(ctx, state, x_out_host, a1_out_host, a2_out_host);
+}
+
 extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                               const int64_t* positions, const uint8_t* pubkeys,
                                               const uint8_t* shares, const uint8_t* responses, size_t n,
@@ -551,70 +685,12 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!verdict || !challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify_distribution: bad argument");
   *verdict = 0;
-  if (n > 0 && (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff))
-    return fail(ctx, MPVSS_E_INVALID, "verify_distribution: bad argument (t must be >= 1)");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  spans_reset(ctx);
-  mpvss::Sha256 transcript;
-  if (n > 0) {
-    RET_IF(stage_commitments(ctx, space, commitments, t));
-    const uint32_t* tg;
-    RET_IF(shared_table(ctx, g_bytes(0), &tg));
-    const void* dchal;
-    RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->in_e, &dchal));
-    const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
-    for (size_t off = 0; off < n; off += MAX_CHUNK) {
-      const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
-      const int64_t* dpos;
-      RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
-      const void *dy, *dY, *dr;
-      RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->in_a, &dy));
-      RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->in_b, &dY));
-      RET_IF(stage_in(ctx, space, responses + off * EB, cnt * EB, ctx->in_c, &dr));
-      RET_IF(ensure(ctx, ctx->xbe, cnt * EB));
-      RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-      RET_IF(ensure(ctx, ctx->out2, cnt * EB));
-      uint8_t* dX = (uint8_t*)ctx->xbe.p;
-      uint8_t* da1 = (uint8_t*)ctx->out1.p;
-      uint8_t* da2 = (uint8_t*)ctx->out2.p;
-      // X_i                                                  participant.rs:423-434
-      TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
-                                                   ctx->consts, ctx->stream));
-      // a1_i = g^r_i * X_i^c, a2_i = y_i^r_i * Y_i^c           dleq.rs:66-84
-      RET_IF(dleq_side(ctx, tg, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1));
-      RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr,
-                       (const uint8_t*)dchal, 0, c_windows, cnt, da2));
-      // bring X, Y, a1, a2 to the host and extend the ordered transcript  dleq.rs:87-99
-      const size_t need = cnt * EB * 4;
-      RET_IF(ensure_pinned(ctx, need));
-      uint8_t* hX = (uint8_t*)ctx->pin;
-      uint8_t* hY = hX + cnt * EB;
-      uint8_t* h1 = hY + cnt * EB;
-      uint8_t* h2 = h1 + cnt * EB;
-      HIPCHK(ctx, hipMemcpyAsync(hX, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      if (space == MPVSS_DEVICE)
-        HIPCHK(ctx, hipMemcpyAsync(hY, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(h1, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(h2, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      const uint8_t* Ysrc = (space == MPVSS_DEVICE) ? hY : shares + off * EB;
-      for (size_t i = 0; i < cnt; ++i) {
-        frame_update(transcript, hX + i * EB);
-        frame_update(transcript, Ysrc + i * EB);
-        frame_update(transcript, h1 + i * EB);
-        frame_update(transcript, h2 + i * EB);
-      }
-      if (x_out_host) memcpy(x_out_host + off * EB, hX, cnt * EB);
-      if (a1_out_host) memcpy(a1_out_host + off * EB, h1, cnt * EB);
-      if (a2_out_host) memcpy(a2_out_host + off * EB, h2, cnt * EB);
-    }
-    RET_IF(spans_collect(ctx));
-  }
-  uint8_t digest[32];
-  transcript.final(digest);
-  if (digest32_out) memcpy(digest32_out, digest, 32);
-  *verdict = challenge_matches(digest, challenge_host) ? 1 : 0;   // participant.rs:451-454
-  return MPVSS_OK;
+  uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
+  mpvss_transcript_init(state);
+  RET_IF(verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
+                                     challenge_host));
+  RET_IF(verify_block_absorb_locked(ctx, state, x_out_host, a1_out_host, a2_out_host));
+  return mpvss_modp_transcript_verdict(state, challenge_host, verdict, digest32_out);
 }
 
 // ---- verify_share, batched ----------------------------------------------------------------------------

@@ -108,7 +108,7 @@ static int cmp_n(const u32* a, const u32* b, int n) {
   for (int i = n - 1; i >= 0; --i) if (a[i] != b[i]) return a[i] > b[i] ? 1 : -1;
   return 0;
 }
-static int is_zero(const u32* a, int n) { for (int i = 0; i < n; ++i) if (a[i]) return 0; return 1; }
+
 static int bitlen(const u32* a, int n) {
   for (int i = n - 1; i >= 0; --i) if (a[i]) return 32 * i + 32 - __builtin_clz(a[i]);
   return 0;

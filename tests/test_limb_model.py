@@ -1,0 +1,84 @@
+"""Integer model of the kernels' quad-lane radix-2^28 Montgomery product (mpvss_rs_amd/csrc/bn_quad28.h):
+same step order, same lazy carries, same two-pass normalisation.  Checks (a) the result, (b) that no
+64-bit column accumulator can overflow even for worst-case "almost normalised" limbs, (c) the limb
+bound the next product relies on."""
+import random
+
+import mpvss_oracle as O
+
+N = O.ModpGroup().q
+W, L, LPL = 28, 76, 19
+M = (1 << W) - 1
+R = 1 << (W * L)
+NL = [(N >> (W * j)) & M for j in range(L)]
+N0INV = (-pow(N, -1, 1 << W)) % (1 << W)
+LIMB_BOUND = M + 512
+
+
+def mont_mul_model(a, b, stats, bound_only=False):
+    T = [0] * L
+    for i in range(L):
+        bi = b[i]
+        for j in range(L):
+            T[j] += a[j] * bi
+        m = ((T[0] & 0xFFFFFFFF) * N0INV) & M
+        for j in range(L):
+            T[j] += m * NL[j]
+        assert T[0] & M == 0
+        c_lo = (T[0] >> W) & 0xFFFFFFFF
+        c_hi = (T[0] >> 32) >> W
+        assert (T[0] >> W) == c_lo + (c_hi << 32)
+        T[1] += c_lo
+        assert ((T[1] >> 32) + c_hi) < (1 << 32)          # the hi-word add cannot wrap
+        T[1] += c_hi << 32
+        stats["maxacc"] = max(stats["maxacc"], max(T))
+        assert max(T) < (1 << 64)
+        T = T[1:] + [0]
+    if bound_only:
+        return None
+    # pass 1 inside each lane, pass 2 across lanes
+    limbs, couts = [0] * L, [0] * 4
+    for q in range(4):
+        c = 0
+        for k in range(LPL):
+            v = T[q * LPL + k] + c
+            assert v < (1 << 64)
+            limbs[q * LPL + k] = v & M
+            c = v >> W
+        couts[q] = c
+    assert couts[3] == 0
+    for q in range(1, 4):
+        v = limbs[q * LPL] + couts[q - 1]
+        limbs[q * LPL] = v & M
+        limbs[q * LPL + 1] += v >> W
+    return limbs
+
+
+def val(l):
+    return sum(x << (W * j) for j, x in enumerate(l))
+
+
+def tolimbs(v):
+    return [(v >> (W * j)) & M for j in range(L)]
+
+
+def test_model_matches_montgomery_product_and_bounds():
+    assert N0INV == 1
+    rng = random.Random(5)
+    rinv = pow(R, -1, N)
+    stats = {"maxacc": 0}
+    for it in range(60):
+        a, b = rng.randrange(2 * N), rng.randrange(2 * N)
+        if it < 3:
+            a = b = 2 * N - 1
+        r = mont_mul_model(tolimbs(a), tolimbs(b), stats)
+        v = val(r)
+        assert v % N == (a * b * rinv) % N and v < 2 * N
+        assert max(r) <= LIMB_BOUND
+    assert stats["maxacc"] < (1 << 64)
+
+
+def test_worst_case_limbs_do_not_overflow():
+    stats = {"maxacc": 0}
+    mont_mul_model([LIMB_BOUND] * L, [LIMB_BOUND] * L, stats, bound_only=True)     # far above 2N as an integer: bound check only
+    assert stats["maxacc"].bit_length() <= 64

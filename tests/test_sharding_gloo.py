@@ -1,0 +1,128 @@
+"""world_size-2 CPU test (gloo) of the multi-GPU host logic: contiguous blocks, the running-hash state
+carried rank to rank, verdict broadcast, and the all-gather of per-share verdicts.  The GPU engine is
+replaced by an oracle-backed stand-in with the same block interface (tests may use the oracle)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBlockEngine:
+    """Same block interface as mpvss_rs_amd.capi.Engine, computed by the CPU oracle."""
+
+    def __init__(self):
+        import mpvss_oracle as O
+        self.O, self.G = O, O.ModpGroup()
+        self._pending = b""
+
+    def verify_block_compute(self, commitments, positions, pubkeys, shares, responses, challenge):
+        O, G = self.O, self.G
+        sp = lambda b: [int.from_bytes(b[i:i + 256], "big") for i in range(0, len(b), 256)]
+        cm, pk, sh, rs = sp(commitments), sp(pubkeys), sp(shares), sp(responses)
+        c = int.from_bytes(challenge, "big")
+        out = bytearray()
+        for i, y, Y, r in zip(positions, pk, sh, rs):
+            X = O.commitment_eval(G, cm, i)
+            a1, a2 = O.dleq_verifier_commitments(G, G.subgroup_generator(), X, y, Y, r, c)
+            for e in (X, Y, a1, a2):
+                out += e.to_bytes(256, "big")
+        self._pending = bytes(out)
+
+    def verify_block_absorb(self, state):
+        from mpvss_rs_amd import capi
+        st = capi.transcript_absorb(state, self._pending)
+        self._pending = b""
+        return st
+
+    def verify_shares(self, pk, s, y, c, r):
+        O, G = self.O, self.G
+        sp = lambda b: [int.from_bytes(b[i:i + 256], "big") for i in range(0, len(b), 256)]
+        return bytes(int(O.dleq_verify(G, G.generator(), *a)) for a in zip(sp(pk), sp(s), sp(y), sp(c), sp(r)))
+
+
+def _worker(rank, world, port, tamper, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random
+
+    import torch.distributed as dist
+
+    import mpvss_oracle as O
+    from helpers import cat, make_modp_instance, modp_keygen
+    from mpvss_rs_amd.sharding import ShardedVerifier, block_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, t = 7, 3     # ragged split: 3 + 4
+        g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, seed=77)
+        flat = O.box_to_flat(g, box)
+        if tamper:
+            buf = bytearray(flat["responses"]); buf[5 * 256 + 17] ^= 2; flat["responses"] = bytes(buf)
+        lo, hi = block_range(n, world, rank)
+        sl = slice(lo * 256, hi * 256)
+        sv = ShardedVerifier(OracleBlockEngine())
+        verdict, digest, counts = sv.verify_distribution(flat["commitments"], flat["positions"][lo:hi],
+                                                         flat["publickeys"][sl], flat["shares"][sl],
+                                                         flat["responses"][sl], flat["challenge"])
+        # share-box verdicts, all-gathered
+        rng = random.Random(5)
+        sbs = [O.extract_secret_share(g, box, k, modp_keygen(g, rng)) for k in privs]
+        keys = [g.element_to_bytes(p) for p in pks]
+        S = [s["share"] for s in sbs]; c = [s["challenge"] for s in sbs]; r = [s["response"] for s in sbs]
+        r[1] ^= 1; r[6] ^= 4
+        Y = [box["shares"][k] for k in keys]
+        block = max(block_range(n, world, k)[1] - block_range(n, world, k)[0] for k in range(world))
+        allv = sv.verify_shares(cat(g, pks[lo:hi]), cat(g, S[lo:hi]), cat(g, Y[lo:hi]), cat(g, c[lo:hi]),
+                                cat(g, r[lo:hi]), block)
+        q.put((rank, verdict, digest, counts, list(allv)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("tamper", [False, True])
+def test_two_rank_sharded_verification(tamper):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mpvss_oracle as O
+    from helpers import make_modp_instance
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tamper, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process oracle answer for the same (possibly tampered) box
+    g, privs, pks, coeffs, ws, box = make_modp_instance(7, 3, seed=77)
+    if tamper:
+        key = g.element_to_bytes(pks[5])
+        rbytes = bytearray(box["responses"][key].to_bytes(256, "big")); rbytes[17] ^= 2
+        box["responses"][key] = int.from_bytes(rbytes, "big")
+    tr = {}
+    expect = O.verify_distribution_shares(g, box, tr)
+    assert expect is (not tamper)
+    for rank, verdict, digest, counts, allv in results:
+        assert verdict is expect and digest == tr["digest"]
+        assert counts == [3, 4]
+        assert allv == [1, 0, 1, 1, 1, 1, 0]
+
+
+def test_block_range_partitions_everything():
+    from mpvss_rs_amd.sharding import block_range
+    for n in (0, 1, 7, 65536, 1048576 + 3):
+        for world in (1, 2, 3, 8):
+            blocks = [block_range(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
