@@ -40,11 +40,11 @@ ORDER = Q - 1
 SEED = 0x6D70767373          # "mpvss"; Python random.Random (MT19937) streams, documented in DESIGN.md
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SHARE = 1536  # read y,Y,r + write X,a1,a2 (6 x 256 B)
-# measured issue rate (profiles/r01_ubench_valu_issue_rates.txt): one v_mad_u64_u32 wave-instruction
-# per ~3.37 cycles per SIMD with >= 4 waves; a 2048-bit Montgomery product = 2*76*76 lane-mads
-MAD_CYCLES = 3.37
-MODMUL_CYCLES_PER_SIMD = 2 * 76 * 19 * MAD_CYCLES / 16   # 2888 wave-mads per 16 numbers
-PEAK_MODMUL_PER_S = 1024 * 2.4e9 / MODMUL_CYCLES_PER_SIMD  # 256 CUs x 4 SIMDs at 2.4 GHz
+# measured sustained issue rate (tools/ubench_clock.hip, profiles/r01_ubench_sustained_mad_clock.txt): one
+# v_mad_u64_u32 wave-instruction per 2.07 ns per SIMD from 2 waves/SIMD up (~4.35 cycles at the ~2.1 GHz the
+# chip holds under this load); a 2048-bit Montgomery product = 2*76*76 lane-mads = 2888 wave-mads per 16 numbers
+MAD_NS_PER_SIMD = 2.07
+PEAK_MODMUL_PER_S = 1024 / (2 * 76 * 19 / 16 * MAD_NS_PER_SIMD * 1e-9)   # 256 CUs x 4 SIMDs -> 2.74e9
 
 
 def fx(v: int) -> bytes:
@@ -174,23 +174,19 @@ def main():
         eng._check(rcode, "verify_block_compute")
 
     kernel_ms = {0: [], 1: [], 2: []}
-    host_hash_s = []
+    host_absorb_s = []
 
-    def step():
-        """one verify_distribution_shares over the (sharded) box; returns (verdict, digest)"""
-        compute_block()
-        if world == 1:
-            state = capi.transcript_init()
-        elif rank == 0:
+    def finish_block():
+        """absorb the oldest in-flight block into the (chained) transcript; returns (verdict, digest)"""
+        if world == 1 or rank == 0:
             state = capi.transcript_init()
         else:
             buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=dev)
             dist.recv(buf, src=rank - 1)
             state = bytes(buf.cpu().numpy().tobytes())
-        lib.mpvss_ctx_synchronize(ctx)
         t0 = time.perf_counter()
-        state = eng.verify_block_absorb(state)
-        host_hash_s.append(time.perf_counter() - t0)
+        state = eng.verify_block_absorb(state)          # waits for this block's GPU work, then hashes it
+        host_absorb_s.append(time.perf_counter() - t0)
         for k in kernel_ms:
             kernel_ms[k].append(eng.kernel_ms(k))
         if world == 1:
@@ -205,24 +201,34 @@ def main():
         raw = bytes(out.cpu().numpy().tobytes())
         return bool(raw[0]), raw[1:33]
 
+    def run_steps(k):
+        """k complete verifications of the box, software-pipelined: the GPU work of verification i+1 is
+        enqueued before the host hashes verification i (two blocks in flight at most)."""
+        results = []
+        compute_block()
+        for i in range(k):
+            if i + 1 < k:
+                compute_block()
+            results.append(finish_block())
+        return results
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        verdict, digest = step()
+    for verdict, digest in run_steps(args.warmup) if args.warmup > 0 else []:
         assert verdict is True and digest == dealer_digest, "parity gate failed in warm-up"
     for k in kernel_ms:
         kernel_ms[k].clear()
-    host_hash_s.clear()
+    host_absorb_s.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        verdict, digest = step()
+    results = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
+    for verdict, digest in results:
+        assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -236,7 +242,7 @@ def main():
 
     # work accounting (Montgomery products executed per step on this rank)
     mm_commit = horner_modmuls(positions, t)
-    mm_dual = n * 2 * (2044 + 511 + 64 + 1)           # two Straus chains per share
+    mm_dual = n * ((2044 + 511 + 64 + 1) + (316 + 511 + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
     mm_table = n * (3 * 15)                            # three 16-entry tables per share (+1 to_mont each)
     achieved_modmul = (mm_commit + mm_dual + mm_table) / ((ce_ms + de_ms + tb_ms) * 1e-3)
     peak_modmul = PEAK_MODMUL_PER_S
@@ -274,7 +280,8 @@ def main():
             "modmul_per_share": (mm_commit + mm_dual + mm_table) / n,
             "kernel_ms": {"commit_eval": ce_ms, "dual_exp_x2": de_ms, "tables": tb_ms},
         },
-        "host": {"transcript_sha256_ms": 1e3 * sum(host_hash_s) / max(len(host_hash_s), 1), "setup_s": setup_s},
+        "host": {"absorb_wait_plus_sha256_ms": 1e3 * sum(host_absorb_s) / max(len(host_absorb_s), 1), "setup_s": setup_s,
+                 "pipelining": "GPU work of verification i+1 enqueued before the host hashes verification i"},
     }
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):

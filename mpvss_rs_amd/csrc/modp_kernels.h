@@ -20,6 +20,12 @@ int modp_launch_build_table(const uint8_t* base_be, int count, uint32_t* tab, co
 int modp_launch_dual_exp(const uint32_t* tab1, size_t tab1_stride, const uint32_t* tab2, size_t tab2_stride,
                          const uint8_t* e1, const uint8_t* e2, size_t e2_stride, int e2_windows, int count,
                          uint8_t* out, const void* cs, hipStream_t s);
+#define MODP_COMB_WORDS (512 * 16 * MODP_L)   /* fixed-base comb table, words */
+int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb, const void* cs, hipStream_t s);
+int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
+                              const uint8_t* e2, size_t e2_stride, int e2_windows, int count, uint8_t* out,
+                              const void* cs, hipStream_t s);
+int modp_occupancy_report(int* out5);
 #ifdef __cplusplus
 }
 #endif

@@ -362,6 +362,131 @@ k_modp_dual_exp(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __r
 }
 
 // ---------------------------------------------------------------------------------------
+// Fixed-base comb table of one base g:  comb[k][d] = g^(d * 16^k)  (Montgomery form), k = 0..511,
+// d = 0..15  (2.5 MB, built once per context and base, L2/MALL resident afterwards).
+//   step 1 (one quad, sequential): comb[k][1] = comb[k-1][1]^16
+//   step 2 (one number per k):     comb[k][d] = comb[k][d-1] * comb[k][1]
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_comb_bases(const uint8_t* __restrict__ base_be, u32* __restrict__ comb, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  const bool writer = (blockIdx.x == 0) && (threadIdx.x < 4);
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(acc, base_be, ln);
+  // op 0: to Montgomery form (by R^2); then 4 squarings per k
+  for (int op = 0; op <= 511 * 4; ++op) {
+    if (op == 0) slot_fill_from_global(slot, cs->r2, ln); else slot_store(slot, acc, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    if (writer && (op % 4) == 0) store_lane_limbs(comb + ((size_t)(op / 4) * 16 + 1) * L, acc, ln);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_comb_rows(u32* __restrict__ comb, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < 512;
+  const int k = live ? xi : 511;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  u32* row = comb + (size_t)k * 16 * L;
+  load_lane_limbs(acc, cs->one_m, ln);
+  if (live) store_lane_limbs(row, acc, ln);
+  load_lane_limbs(acc, row + L, ln);
+  slot_store(slot, acc, ln);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = 2; d < 16; ++d) {
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (live) store_lane_limbs(row + (size_t)d * L, acc, ln);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// out[x] = g^e1[x] * B2[x]^e2[x] with g given as a comb table (no squarings for the g part):
+//   phase A: acc = B2^e2 by 4-bit windows over tab2 (only the low e2_windows windows)
+//   phase B: acc = prod_k comb[k][digit_k(e1)], then times the saved phase-A value
+// This is a1 = g^r * X^c (dleq.rs:75-77) with g the subgroup generator, and G^r * pk^c of verify_share.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2, size_t tab2_stride,
+                     const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride,
+                     int e2_windows, int count, uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[2 * NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32* pslot = lds + (NUMS_PER_BLOCK + (threadIdx.x >> 2)) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  const u32* t2 = tab2 + (size_t)x * tab2_stride;
+  const uint8_t* e1 = e1_be + (size_t)x * 256;
+  const uint8_t* e2 = e2_be + (size_t)x * e2_stride;
+  const int first_e2 = 512 - e2_windows;
+
+  // steps: A(w, s): w = first_e2..511, s = 0..3 square (w > first_e2), 4 = table product
+  //        B(k):    k = 0..511 comb product (k = 0 loads), then P = product with phase-A value, F = final
+  enum { PH_A, PH_B, PH_P, PH_F };
+  int phase = (e2_windows > 0) ? PH_A : PH_B;
+  int w = first_e2, s = 4, k = 0;
+  if (phase == PH_A) {
+    const u32 byte = e2[w >> 1];
+    const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+    load_lane_limbs(acc, t2 + (size_t)d * L, ln);       // first window: load instead of multiply
+    s = 5;
+  }
+  while (true) {
+    const u32* bptr = slot;
+    bool skip = false;
+    if (phase == PH_A) {
+      if (s == 5) { ++w; s = 0; }
+      if (w == 512) {
+        slot_store(pslot, acc, ln);                      // save B2^e2
+        phase = PH_B; k = 0;
+        continue;
+      }
+      if (s < 4) {
+        slot_store(slot, acc, ln);
+      } else {
+        const u32 byte = e2[w >> 1];
+        const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+        slot_fill_from_global(slot, t2 + (size_t)d * L, ln);
+      }
+      ++s;
+    } else if (phase == PH_B) {
+      const u32 byte = e1[255 - (k >> 1)];
+      const u32 d = (k & 1) ? (byte >> 4) : (byte & 15);
+      const u32* entry = comb + ((size_t)k * 16 + d) * L;
+      if (k == 0) { load_lane_limbs(acc, entry, ln); skip = true; }
+      else slot_fill_from_global(slot, entry, ln);
+      ++k;
+      if (k == 512) phase = (e2_windows > 0) ? PH_P : PH_F;
+    } else if (phase == PH_P) {
+      bptr = pslot;
+      phase = PH_F;
+    } else {
+      slot_fill_from_global(slot, cs->one, ln);
+      phase = PH_F + 1;
+    }
+    if (!skip) {
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (phase == PH_F + 1) break;
+  }
+  store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
 // host-callable launchers (plain C linkage, used by mpvss_capi.cpp)
 // ---------------------------------------------------------------------------------------
 
@@ -380,6 +505,18 @@ extern "C" int modp_consts_upload(void** dev_consts) {
   e = hipMemcpy(d, &h, sizeof(ModpConsts), hipMemcpyHostToDevice);
   if (e != hipSuccess) return (int)e;
   *dev_consts = d;
+  return 0;
+}
+
+// Residency report for tuning: max resident workgroups per CU the runtime computes for each kernel.
+extern "C" int modp_occupancy_report(int* out5) {
+  const void* ks[5] = {(const void*)k_modp_commit_eval, (const void*)k_modp_dual_exp, (const void*)k_modp_build_table,
+                       (const void*)k_modp_to_mont, (const void*)k_modp_mul};
+  for (int i = 0; i < 5; ++i) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ks[i], BLOCK_THREADS, 0);
+    out5[i] = (e == hipSuccess) ? nb * MODP_WPB : -(int)e;
+  }
   return 0;
 }
 
@@ -422,5 +559,20 @@ extern "C" int modp_launch_dual_exp(const uint32_t* tab1, size_t tab1_stride, co
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab1_stride, tab2,
                      tab2_stride, e1, e2, e2_stride, e2_windows, count, out, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb, const void* cs, hipStream_t s) {
+  hipLaunchKernelGGL(k_modp_comb_bases, dim3(1), dim3(BLOCK_THREADS), 0, s, base_be_dev, comb, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_comb_rows, dim3(grid_for(512)), dim3(BLOCK_THREADS), 0, s, comb, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride,
+                                         const uint8_t* e1, const uint8_t* e2, size_t e2_stride, int e2_windows,
+                                         int count, uint8_t* out, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
+                     e1, e2, e2_stride, e2_windows, count, out, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }

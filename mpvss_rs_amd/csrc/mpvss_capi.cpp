@@ -36,16 +36,35 @@ struct mpvss_ctx {
   std::mutex mu;
   // grow-only device workspace
   DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
+  DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
+  bool comb_ready[2] = {false, false};
   // pinned host staging
   void* pin = nullptr;
   size_t pin_cap = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
   double kernel_ms[3] = {-1, -1, -1};
   struct Span { int id; hipEvent_t a, b; };
-  std::vector<Span> spans;
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-  size_t blk_n = 0;   // shares of the block whose results wait in the pinned staging
+  struct SpanSet {
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+  };
+  SpanSet main_spans;
+  SpanSet* sp = &main_spans;   // where TIMED_LAUNCH records
+  // Two verify blocks may be in flight (compute of block k+1 is enqueued before block k is absorbed):
+  // each has its own pinned staging, timing events and completion event.
+  struct BlockSlot {
+    void* pin = nullptr;
+    size_t cap = 0;
+    size_t n = 0;
+    bool busy = false;
+    bool check_positions = false;
+    hipEvent_t done = nullptr;
+    SpanSet spans;
+    double kernel_ms[3] = {0, 0, 0};
+  };
+  BlockSlot slot[2];
+  unsigned head = 0, tail = 0;   // next slot to fill / to absorb
 };
 
 namespace {
@@ -122,37 +141,42 @@ int stage_in(mpvss_ctx* ctx, int space, const void* src, size_t bytes, DevBuf& b
 
 // kernel timing spans (hipEvents on the engine's stream)
 int span_begin(mpvss_ctx* ctx, int id) {
+  mpvss_ctx::SpanSet& ss = *ctx->sp;
   for (int k = 0; k < 2; ++k) {
-    if (ctx->ev_used == ctx->ev_pool.size()) {
+    if (ss.ev_used == ss.ev_pool.size()) {
       hipEvent_t e;
       HIPCHK(ctx, hipEventCreate(&e));
-      ctx->ev_pool.push_back(e);
+      ss.ev_pool.push_back(e);
     }
-    ++ctx->ev_used;
+    ++ss.ev_used;
   }
-  mpvss_ctx::Span s{id, ctx->ev_pool[ctx->ev_used - 2], ctx->ev_pool[ctx->ev_used - 1]};
+  mpvss_ctx::Span s{id, ss.ev_pool[ss.ev_used - 2], ss.ev_pool[ss.ev_used - 1]};
   HIPCHK(ctx, hipEventRecord(s.a, ctx->stream));
-  ctx->spans.push_back(s);
+  ss.spans.push_back(s);
   return 0;
 }
 int span_end(mpvss_ctx* ctx) {
-  HIPCHK(ctx, hipEventRecord(ctx->spans.back().b, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->sp->spans.back().b, ctx->stream));
   return 0;
 }
 void spans_reset(mpvss_ctx* ctx) {
-  ctx->spans.clear();
-  ctx->ev_used = 0;
-  for (double& m : ctx->kernel_ms) m = -1;
+  ctx->sp->spans.clear();
+  ctx->sp->ev_used = 0;
+  if (ctx->sp == &ctx->main_spans)
+    for (double& m : ctx->kernel_ms) m = -1;
+}
+int spans_sum(mpvss_ctx* ctx, mpvss_ctx::SpanSet& ss, double out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = 0;
+  for (auto& s : ss.spans) {
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, s.a, s.b));
+    out[s.id] += ms;
+  }
+  return 0;
 }
 int spans_collect(mpvss_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (double& m : ctx->kernel_ms) m = 0;
-  for (auto& s : ctx->spans) {
-    float ms = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, s.a, s.b));
-    ctx->kernel_ms[s.id] += ms;
-  }
-  return 0;
+  return spans_sum(ctx, ctx->main_spans, ctx->kernel_ms);
 }
 
 struct Timed {
@@ -201,6 +225,19 @@ int check_positions_host(mpvss_ctx* ctx, const int64_t* pos, size_t n) {
   return 0;
 }
 
+const uint8_t* g_bytes(int g) {
+  static uint8_t b[3][EB];
+  static bool init = false;
+  if (!init) {
+    memset(b, 0, sizeof(b));
+    b[0][EB - 1] = 4;  // subgroup generator g = 2^2 (modp.rs:65-66)
+    b[1][EB - 1] = 2;  // main generator G (modp.rs:64)
+    b[2][EB - 1] = 1;
+    init = true;
+  }
+  return b[g];
+}
+
 // the shared 16-entry table of one base (host bytes) into ctx->tabg
 int shared_table(mpvss_ctx* ctx, const uint8_t* base_host, const uint32_t** tab) {
   RET_IF(ensure(ctx, ctx->tabg, TABW * 4 + EB));
@@ -208,6 +245,28 @@ int shared_table(mpvss_ctx* ctx, const uint8_t* base_host, const uint32_t** tab)
   HIPCHK(ctx, hipMemcpyAsync(dbase, base_host, EB, hipMemcpyHostToDevice, ctx->stream));
   TIMED_LAUNCH(ctx, 2, modp_launch_build_table(dbase, 1, (uint32_t*)ctx->tabg.p, ctx->consts, ctx->stream));
   *tab = (const uint32_t*)ctx->tabg.p;
+  return 0;
+}
+
+// which of the two well-known generators a 256-byte base is: 0 -> g = 4, 1 -> G = 2, -1 -> neither
+int generator_id(const uint8_t* base_host) {
+  for (size_t i = 0; i < EB - 1; ++i)
+    if (base_host[i] != 0) return -1;
+  if (base_host[EB - 1] == 4) return 0;
+  if (base_host[EB - 1] == 2) return 1;
+  return -1;
+}
+
+// fixed-base comb table of generator `gid` (modp.rs:64-66), built once per context (about 25 ms)
+int comb_table(mpvss_ctx* ctx, int gid, const uint32_t** comb) {
+  if (!ctx->comb_ready[gid]) {
+    RET_IF(ensure(ctx, ctx->comb[gid], (size_t)MODP_COMB_WORDS * 4 + EB));
+    uint8_t* dbase = (uint8_t*)ctx->comb[gid].p + (size_t)MODP_COMB_WORDS * 4;
+    HIPCHK(ctx, hipMemcpyAsync(dbase, g_bytes(gid), EB, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_comb_build(dbase, (uint32_t*)ctx->comb[gid].p, ctx->consts, ctx->stream));
+    ctx->comb_ready[gid] = true;
+  }
+  *comb = (const uint32_t*)ctx->comb[gid].p;
   return 0;
 }
 
@@ -228,19 +287,6 @@ int small_vec_to_host(mpvss_ctx* ctx, int space, const uint8_t* src, size_t byte
     memcpy(out.data(), src, bytes);
   }
   return 0;
-}
-
-const uint8_t* g_bytes(int g) {
-  static uint8_t b[3][EB];
-  static bool init = false;
-  if (!init) {
-    memset(b, 0, sizeof(b));
-    b[0][EB - 1] = 4;  // subgroup generator g = 2^2 (modp.rs:65-66)
-    b[1][EB - 1] = 2;  // main generator G (modp.rs:64)
-    b[2][EB - 1] = 1;
-    init = true;
-  }
-  return b[g];
 }
 
 int copy_out(mpvss_ctx* ctx, int space, void* dst, const void* dev_src, size_t bytes) {
@@ -296,11 +342,16 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->pos, &ctx->cm, &ctx->xbe,
-                    &ctx->out1, &ctx->out2, &ctx->tab1, &ctx->tab2, &ctx->tabg, &ctx->cbuf})
+                    &ctx->out1, &ctx->out2, &ctx->tab1, &ctx->tab2, &ctx->tabg, &ctx->cbuf, &ctx->comb[0], &ctx->comb[1]})
     if (b->p) (void)hipFree(b->p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
-  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
+  for (auto& sl : ctx->slot) {
+    if (sl.pin) (void)hipHostFree(sl.pin);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -396,8 +447,12 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
   if (!base_host || !exps || !out) return fail(ctx, MPVSS_E_INVALID, "batch_exp_fixed_base: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   spans_reset(ctx);
-  const uint32_t* tg;
-  RET_IF(shared_table(ctx, base_host, &tg));
+  const uint32_t* tg = nullptr;
+  const uint32_t* cg = nullptr;
+  if (generator_id(base_host) >= 0)
+    RET_IF(comb_table(ctx, generator_id(base_host), &cg));
+  else
+    RET_IF(shared_table(ctx, base_host, &tg));
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void* de;
@@ -407,8 +462,12 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
       RET_IF(ensure(ctx, ctx->out1, cnt * EB));
       dout = (uint8_t*)ctx->out1.p;
     }
-    TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
-                                              dout, ctx->consts, ctx->stream));
+    if (cg)
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
+                                                     dout, ctx->consts, ctx->stream));
+    else
+      TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
+                                                dout, ctx->consts, ctx->stream));
     if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out + off * EB, dout, cnt * EB));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -473,16 +532,21 @@ namespace {
 // from b1_dev.  c: device pointer, stride c_stride (0 shared).
 int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, const uint8_t* b2_dev,
               const uint8_t* r_dev, const uint8_t* c_dev, size_t c_stride, int c_windows, size_t cnt,
-              uint8_t* out_dev) {
+              uint8_t* out_dev, const uint32_t* comb_b1 = nullptr) {
   const uint32_t *t1, *t2;
   size_t s1 = TABW;
+  RET_IF(number_tables(ctx, b2_dev, cnt, ctx->tab2, &t2));
+  if (comb_b1) {   // B1 is a generator with a comb table: no squarings for B1^r
+    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(comb_b1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt,
+                                                   out_dev, ctx->consts, ctx->stream));
+    return 0;
+  }
   if (shared_b1) {
     t1 = shared_b1;
     s1 = 0;
   } else {
     RET_IF(number_tables(ctx, b1_dev, cnt, ctx->tab1, &t1));
   }
-  RET_IF(number_tables(ctx, b2_dev, cnt, ctx->tab2, &t2));
   TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(t1, s1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt, out_dev,
                                             ctx->consts, ctx->stream));
   return 0;
@@ -499,8 +563,12 @@ extern "C" int mpvss_modp_dleq_commitments(mpvss_ctx* ctx, int space, const uint
     return fail(ctx, MPVSS_E_INVALID, "dleq_commitments: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   spans_reset(ctx);
-  const uint32_t* tg;
-  RET_IF(shared_table(ctx, g1_host, &tg));
+  const uint32_t* tg = nullptr;
+  const uint32_t* cg = nullptr;
+  if (generator_id(g1_host) >= 0)
+    RET_IF(comb_table(ctx, generator_id(g1_host), &cg));
+  else
+    RET_IF(shared_table(ctx, g1_host, &tg));
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void *dh1, *dg2, *dh2, *dr, *dc;
@@ -529,7 +597,7 @@ extern "C" int mpvss_modp_dleq_commitments(mpvss_ctx* ctx, int space, const uint
     } else if (!fits_256_bits(c)) {
       cw = 512;
     }
-    RET_IF(dleq_side(ctx, tg, nullptr, (const uint8_t*)dh1, (const uint8_t*)dr, (const uint8_t*)dc, cs, cw, cnt, d1));
+    RET_IF(dleq_side(ctx, tg, nullptr, (const uint8_t*)dh1, (const uint8_t*)dr, (const uint8_t*)dc, cs, cw, cnt, d1, cg));
     RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dg2, (const uint8_t*)dh2, (const uint8_t*)dr, (const uint8_t*)dc, cs,
                      cw, cnt, d2));
     if (space == MPVSS_HOST) {
@@ -554,28 +622,55 @@ static_assert(sizeof(mpvss::Sha256) <= MPVSS_TRANSCRIPT_STATE_BYTES, "transcript
 int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                 const uint8_t* responses, size_t n, const uint8_t* challenge_host) {
-  ctx->blk_n = 0;
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
-  if (n == 0) return MPVSS_OK;
-  if (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff)
+  if (n > 0 && (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff))
     return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1)");
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head & 1];
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: two blocks already in flight, absorb one first");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  sl.n = n;
+  sl.check_positions = false;
+  sl.busy = true;
+  ++ctx->head;
+  if (n == 0) return MPVSS_OK;
+  struct Restore {
+    mpvss_ctx* c;
+    ~Restore() { c->sp = &c->main_spans; }
+  } restore{ctx};
+  ctx->sp = &sl.spans;
   spans_reset(ctx);
+  const size_t need = n * EB * 4 + n * 8;
+  if (need > sl.cap) {
+    if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
+    sl.pin = nullptr;
+    sl.cap = 0;
+    hipError_t e = hipHostMalloc(&sl.pin, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(block staging)", e);
+    sl.cap = need;
+  }
   RET_IF(stage_commitments(ctx, space, commitments, t));
-  const uint32_t* tg;
-  RET_IF(shared_table(ctx, g_bytes(0), &tg));
+  const uint32_t* cg;
+  RET_IF(comb_table(ctx, 0, &cg));
   const void* dchal;
   RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->in_e, &dchal));
   const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
-  RET_IF(ensure_pinned(ctx, n * EB * 4));
-  uint8_t* hX = (uint8_t*)ctx->pin;
+  uint8_t* hX = (uint8_t*)sl.pin;
   uint8_t* hY = hX + n * EB;
   uint8_t* h1 = hY + n * EB;
   uint8_t* h2 = h1 + n * EB;
+  int64_t* hpos = (int64_t*)(h2 + n * EB);
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const int64_t* dpos;
-    RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
+    if (space == MPVSS_HOST) {
+      RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
+    } else {
+      // device-resident positions are validated when the block is absorbed (no host sync here)
+      dpos = positions + off;
+      HIPCHK(ctx, hipMemcpyAsync(hpos + off, dpos, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+      sl.check_positions = true;
+    }
     const void *dy, *dY, *dr;
     RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->in_a, &dy));
     RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->in_b, &dY));
@@ -590,32 +685,37 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
                                                  ctx->consts, ctx->stream));
     // a1_i = g^r_i * X_i^c, a2_i = y_i^r_i * Y_i^c           dleq.rs:66-84
-    RET_IF(dleq_side(ctx, tg, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1));
+    RET_IF(dleq_side(ctx, nullptr, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1, cg));
     RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
                      0, c_windows, cnt, da2));
     HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB,
-                               space == MPVSS_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // staging buffers are reused
+    if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
-  ctx->blk_n = n;
+  HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   return MPVSS_OK;
 }
 
 int verify_block_absorb_locked(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out, uint8_t* a1_out, uint8_t* a2_out) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
-  const size_t n = ctx->blk_n;
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail & 1];
+  if (!sl.busy) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
+  const size_t n = sl.n;
+  sl.busy = false;
+  ++ctx->tail;
   if (n == 0) return MPVSS_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  RET_IF(spans_collect(ctx));   // synchronises the stream
-  mpvss::Sha256 tr;
-  memcpy(&tr, state, sizeof(tr));
-  const uint8_t* hX = (const uint8_t*)ctx->pin;
+  HIPCHK(ctx, hipEventSynchronize(sl.done));
+  RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
+  const uint8_t* hX = (const uint8_t*)sl.pin;
   const uint8_t* hY = hX + n * EB;
   const uint8_t* h1 = hY + n * EB;
   const uint8_t* h2 = h1 + n * EB;
+  if (sl.check_positions) RET_IF(check_positions_host(ctx, (const int64_t*)(h2 + n * EB), n));
+  mpvss::Sha256 tr;
+  memcpy(&tr, state, sizeof(tr));
   for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99, share order = array order
     frame_update(tr, hX + i * EB);
     frame_update(tr, hY + i * EB);
@@ -626,7 +726,6 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out, u
   if (x_out) memcpy(x_out, hX, n * EB);
   if (a1_out) memcpy(a1_out, h1, n * EB);
   if (a2_out) memcpy(a2_out, h2, n * EB);
-  ctx->blk_n = 0;
   return MPVSS_OK;
 }
 
@@ -703,8 +802,8 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
   if (!pk || !s || !y || !c || !r || !verdicts_host) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   spans_reset(ctx);
-  const uint32_t* tG;
-  RET_IF(shared_table(ctx, g_bytes(1), &tG));
+  const uint32_t* cG;
+  RET_IF(comb_table(ctx, 1, &cG));
   std::vector<uint8_t> hc, hpk, hy;
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
@@ -723,8 +822,8 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
     uint8_t* da1 = (uint8_t*)ctx->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->out2.p;
     // a1 = G^r * pk^c ; a2 = S^r * Y^c                       dleq.rs:66-84 via participant.rs:376-385
-    RET_IF(dleq_side(ctx, tG, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB, c_windows,
-                     cnt, da1));
+    RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB,
+                     c_windows, cnt, da1, cG));
     RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)ds, (const uint8_t*)dy, (const uint8_t*)dr, (const uint8_t*)dc, EB,
                      c_windows, cnt, da2));
     RET_IF(ensure_pinned(ctx, cnt * EB * 2));
@@ -766,8 +865,8 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
   mpvss::Sha256 transcript;
   if (n > 0) {
     RET_IF(stage_commitments(ctx, space, commitments, t));
-    const uint32_t* tg;
-    RET_IF(shared_table(ctx, g_bytes(0), &tg));
+    const uint32_t* cg;
+    RET_IF(comb_table(ctx, 0, &cg));
     for (size_t off = 0; off < n; off += MAX_CHUNK) {
       const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
       const int64_t* dpos;
@@ -797,8 +896,8 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
       TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
                                                 (int)cnt, da2, ctx->consts, ctx->stream));
       // a1 = g^w (dleq.rs:207-211)
-      TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
-                                                da1, ctx->consts, ctx->stream));
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
+                                                     da1, ctx->consts, ctx->stream));
       RET_IF(ensure_pinned(ctx, cnt * EB * 4));
       uint8_t* hX = (uint8_t*)ctx->pin;
       uint8_t* hY = hX + cnt * EB;
