@@ -161,6 +161,49 @@ int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* commitments,
                           const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out,
                           uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out);
 
+/* ---- elliptic-curve groups --------------------------------------------------------------------
+ * The same entry points for the reference's two curve groups, selected by `group`:
+ *   MPVSS_GROUP_SECP256K1    src/groups/secp256k1.rs:38-189     elements 33-byte SEC1 compressed
+ *                            (the identity is 33 zero bytes, k256's GroupEncoding), scalars 32-byte big-endian
+ *   MPVSS_GROUP_RISTRETTO255 src/groups/ristretto255.rs:45-253  elements 32-byte canonical ristretto255,
+ *                            scalars 32-byte little-endian
+ * Group law is written additively in the reference (exp = scalar multiplication, mul = point addition).
+ * The reference's typed elements/scalars cannot hold an invalid encoding or a scalar >= the group
+ * order; here such input makes the call fail with MPVSS_E_INVALID (mpvss_last_error names the index).
+ * hash_to_scalar: SHA-256 then mod n (secp256k1.rs:121-131); SHA-512, little-endian, mod l
+ * (ristretto255.rs:196-205).  Array shapes mirror the MODP calls with 256 replaced by the group's
+ * element / scalar width; the challenge is 32 bytes. */
+#define MPVSS_GROUP_SECP256K1 1
+#define MPVSS_GROUP_RISTRETTO255 2
+
+/* out[i] = scalars[i] * bases[i]      Secp256k1Group::exp secp256k1.rs:91-100, Ristretto255Group::exp ristretto255.rs:161-170 */
+int mpvss_ec_batch_exp(mpvss_ctx* ctx, int group, int space, const uint8_t* bases, const uint8_t* scalars, size_t n,
+                       uint8_t* out);
+/* out[i] = a[i] + b[i]                ::mul secp256k1.rs:102-107, ristretto255.rs:172-177 */
+int mpvss_ec_batch_mul(mpvss_ctx* ctx, int group, int space, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+/* X[i] = sum_j (positions[i]^j mod order) * C_j     src/participant.rs:1404-1417 (secp256k1), 1847-1860 (ristretto255) */
+int mpvss_ec_commit_eval(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
+                         const int64_t* positions, size_t n, uint8_t* x_out);
+/* a1[i] = r[i]*g1 + c_i*h1[i], a2[i] = r[i]*g2[i] + c_i*h2[i]      src/dleq.rs:66-84 */
+int mpvss_ec_dleq_commitments(mpvss_ctx* ctx, int group, int space, const uint8_t* g1_host, const uint8_t* h1,
+                              const uint8_t* g2, const uint8_t* h2, const uint8_t* r, const uint8_t* c, int c_per_share,
+                              size_t n, uint8_t* a1_out, uint8_t* a2_out);
+/* src/participant.rs:1384-1442 (secp256k1), 1827-1885 (ristretto255) */
+int mpvss_ec_verify_distribution(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
+                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
+                                 const uint8_t* responses, size_t n, const uint8_t* challenge_host, int* verdict,
+                                 uint8_t* digest32_out, uint8_t* x_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host);
+/* src/participant.rs:1346-1371 (secp256k1), 1789-1814 (ristretto255) */
+int mpvss_ec_verify_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
+                           const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_host);
+/* group part of src/participant.rs:1094-1274 (secp256k1), 1573-1717 (ristretto255); randomness is input */
+int mpvss_ec_distribute(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
+                        const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
+                        const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out, uint8_t* a1_out,
+                        uint8_t* a2_out, uint8_t* digest32_out);
+/* Group::hash_to_scalar(data), host only; out32 in the group's scalar byte order */
+int mpvss_ec_hash_to_scalar(int group, const uint8_t* data, size_t len, uint8_t out32[32]);
+
 /* ---- hashing helpers (host only; Group::hash_to_scalar, src/groups/modp.rs:142-148) ------ */
 
 /* out32 = SHA-256(data) */

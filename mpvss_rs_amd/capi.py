@@ -27,7 +27,13 @@ EXPORTED_SYMBOLS = (
     "mpvss_last_kernel_ms",
     "mpvss_transcript_init", "mpvss_modp_verify_block_compute", "mpvss_modp_verify_block_absorb",
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
+    "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
+    "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
 )
+
+GROUP_SECP256K1 = 1
+GROUP_RISTRETTO255 = 2
+EC_ENC = {GROUP_SECP256K1: 33, GROUP_RISTRETTO255: 32}
 
 TRANSCRIPT_STATE_BYTES = 128
 
@@ -72,6 +78,15 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
     lib.mpvss_modp_transcript_verdict.argtypes = [u8p, u8p, C.POINTER(ci), u8p]
     lib.mpvss_modp_transcript_absorb.argtypes = [u8p, u8p, sz]
+    lib.mpvss_ec_batch_exp.argtypes = [vp, ci, ci, u8p, u8p, sz, u8p]
+    lib.mpvss_ec_batch_mul.argtypes = [vp, ci, ci, u8p, u8p, sz, u8p]
+    lib.mpvss_ec_commit_eval.argtypes = [vp, ci, ci, u8p, sz, i64p, sz, u8p]
+    lib.mpvss_ec_dleq_commitments.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, u8p, ci, sz, u8p, u8p]
+    lib.mpvss_ec_verify_distribution.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p,
+                                                 C.POINTER(ci), u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_verify_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
     return lib
 
 
@@ -199,6 +214,81 @@ class Engine:
         self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, None, None, None), "verify_block_absorb")
         return bytes(ks)
 
+    # ---- elliptic-curve groups (group = GROUP_SECP256K1 | GROUP_RISTRETTO255)
+    def ec_batch_exp(self, group: int, bases: bytes, scalars: bytes) -> bytes:
+        n = len(scalars) // 32
+        ka, pa = _buf(bases); kb, pb = _buf(scalars); ko, po = _out(n * EC_ENC[group])
+        self._check(self.lib.mpvss_ec_batch_exp(self.ctx, group, MPVSS_HOST, pa, pb, n, po), "ec_batch_exp")
+        return bytes(ko)[: n * EC_ENC[group]]
+
+    def ec_batch_mul(self, group: int, a: bytes, b: bytes) -> bytes:
+        n = len(a) // EC_ENC[group]
+        ka, pa = _buf(a); kb, pb = _buf(b); ko, po = _out(n * EC_ENC[group])
+        self._check(self.lib.mpvss_ec_batch_mul(self.ctx, group, MPVSS_HOST, pa, pb, n, po), "ec_batch_mul")
+        return bytes(ko)[: n * EC_ENC[group]]
+
+    def ec_commit_eval(self, group: int, commitments: bytes, positions: Sequence[int]) -> bytes:
+        e = EC_ENC[group]
+        t, n = len(commitments) // e, len(positions)
+        kc, pc = _buf(commitments)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        ko, po = _out(n * e)
+        self._check(self.lib.mpvss_ec_commit_eval(self.ctx, group, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), n, po),
+                    "ec_commit_eval")
+        return bytes(ko)[: n * e]
+
+    def ec_dleq_commitments(self, group: int, g1: bytes, h1: bytes, g2: bytes, h2: bytes, r: bytes, c: bytes,
+                            c_per_share: bool) -> Tuple[bytes, bytes]:
+        e = EC_ENC[group]
+        n = len(r) // 32
+        k = [_buf(x) for x in (g1, h1, g2, h2, r, c)]
+        k1, p1 = _out(n * e); k2, p2 = _out(n * e)
+        self._check(self.lib.mpvss_ec_dleq_commitments(self.ctx, group, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                       k[4][1], k[5][1], int(c_per_share), n, p1, p2),
+                    "ec_dleq_commitments")
+        return bytes(k1)[: n * e], bytes(k2)[: n * e]
+
+    def ec_verify_distribution(self, group: int, commitments: bytes, positions: Sequence[int], pubkeys: bytes,
+                               shares: bytes, responses: bytes, challenge: bytes, dump: bool = False):
+        e = EC_ENC[group]
+        t, n = len(commitments) // e, len(positions)
+        kc, pc = _buf(commitments); ky, py = _buf(pubkeys); kY, pY = _buf(shares); kr, pr = _buf(responses)
+        kch, pch = _buf(challenge)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        verdict = C.c_int(0)
+        kd, pd = _out(32)
+        kx, px = _out(n * e) if dump else (None, None)
+        k1, p1 = _out(n * e) if dump else (None, None)
+        k2, p2 = _out(n * e) if dump else (None, None)
+        self._check(self.lib.mpvss_ec_verify_distribution(
+            self.ctx, group, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pY, pr, n, pch, C.byref(verdict), pd,
+            px, p1, p2), "ec_verify_distribution")
+        out = {"verdict": bool(verdict.value), "digest": bytes(kd)[:32]}
+        if dump:
+            out.update(X=bytes(kx)[: n * e], a1=bytes(k1)[: n * e], a2=bytes(k2)[: n * e])
+        return out
+
+    def ec_verify_shares(self, group: int, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes) -> bytes:
+        n = len(r) // 32
+        k = [_buf(x) for x in (pk, s, y, c, r)]
+        kv, pv = _out(n)
+        self._check(self.lib.mpvss_ec_verify_shares(self.ctx, group, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                    k[4][1], n, pv), "ec_verify_shares")
+        return bytes(kv)[:n]
+
+    def ec_distribute(self, group: int, commitments: bytes, positions: Sequence[int], pubkeys: bytes, p_values: bytes,
+                      witnesses: bytes):
+        e = EC_ENC[group]
+        t, n = len(commitments) // e, len(positions)
+        kc, pc = _buf(commitments); ky, py = _buf(pubkeys); kp, pp = _buf(p_values); kw, pw = _buf(witnesses)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        outs = [_out(n * e) for _ in range(4)]
+        kd, pd = _out(32)
+        self._check(self.lib.mpvss_ec_distribute(self.ctx, group, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pp, pw,
+                                                 n, outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd), "ec_distribute")
+        X, Y, a1, a2 = (bytes(o[0])[: n * e] for o in outs)
+        return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32]}
+
     def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes) -> bytes:
         n = len(pk) // EB
         k = [_buf(x) for x in (pk, s, y, c, r)]
@@ -254,3 +344,13 @@ def transcript_absorb(state: bytes, elements: bytes) -> bytes:
     if rc != 0:
         raise EngineError(f"transcript_absorb failed: {rc}")
     return bytes(ks)
+
+
+def ec_hash_to_scalar(group: int, data: bytes) -> bytes:
+    lib = load_library()
+    kd, pd = _buf(data if data else b"\0")
+    ko, po = _out(32)
+    rc = lib.mpvss_ec_hash_to_scalar(group, pd, len(data), po)
+    if rc != 0:
+        raise EngineError(f"ec_hash_to_scalar failed: {rc}")
+    return bytes(ko)[:32]

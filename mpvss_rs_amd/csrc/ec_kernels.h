@@ -1,0 +1,20 @@
+// Internal launch interface between the C-ABI layer and the elliptic-curve kernels.
+// group: 1 = secp256k1 (33-byte SEC1 compressed points, 32-byte big-endian scalars),
+//        2 = ristretto255 (32-byte points, 32-byte little-endian scalars).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+int ec_point_words(int group);
+int ec_launch_decode(int group, const uint8_t* enc, int count, uint32_t* pts, uint8_t* ok, hipStream_t s);
+int ec_launch_commit_eval(int group, const uint32_t* cm, int t, const int64_t* positions, int count, uint8_t* x_enc,
+                          hipStream_t s);
+int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uint8_t* k1, const uint8_t* p2,
+                       const uint8_t* k2, size_t k2_stride, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
+int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
+#ifdef __cplusplus
+}
+#endif

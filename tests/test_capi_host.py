@@ -52,3 +52,11 @@ def test_no_cpu_fallback():
         pytest.skip("a GPU is present")
     with pytest.raises(capi.EngineError):
         capi.Engine(0)
+
+
+def test_ec_hash_to_scalar_host():
+    import mpvss_oracle as O
+    for name, gid in (("secp256k1", capi.GROUP_SECP256K1), ("ristretto255", capi.GROUP_RISTRETTO255)):
+        G = O.GROUPS[name]()
+        for data in (b"", b"test data", bytes(range(32)), b"\xff" * 100):
+            assert capi.ec_hash_to_scalar(gid, data) == G.scalar_to_bytes(G.hash_to_scalar(data))

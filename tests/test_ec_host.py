@@ -1,0 +1,86 @@
+"""CPU unit tests of the kernels' elliptic-curve arithmetic: mpvss_rs_amd/csrc/ec_{field,curves}.h are plain
+C++, so the very code the gfx950 kernels run is compiled here with g++ (tests/ec_host_shim.cpp) and compared
+with the oracle: field ops, complete group law incl. P+P, P+(-P) and the identity, encodings, scalar mults."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+import mpvss_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "libec_host.so")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    src = os.path.join(HERE, "ec_host_shim.cpp")
+    deps = [src] + [os.path.join(HERE, "..", "mpvss_rs_amd", "csrc", f) for f in ("ec_field.h", "ec_curves.h", "ec_consts.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", LIB])
+    return C.CDLL(LIB)
+
+
+def buf(b):
+    return (C.c_uint8 * len(b)).from_buffer_copy(b)
+
+
+@pytest.mark.parametrize("curve,p", [(0, O.SECP_P), (1, O.ED_P)])
+def test_field_ops(shim, curve, p):
+    rng = random.Random(curve + 1)
+    for it in range(200):
+        a, b = rng.randrange(p), rng.randrange(p)
+        if it < 4:
+            a = b = p - 1
+        if it == 5:
+            a = 0
+        if it == 6:
+            a = b = (1 << 256) - 1          # non-canonical input is reduced
+        for op, want in ((0, a * b % p), (1, a * a % p), (2, (a - b) % p), (4, (a + b) % p)):
+            out = (C.c_uint8 * 32)()
+            shim.fe_op(curve, op, buf(a.to_bytes(32, "little")), buf(b.to_bytes(32, "little")), out)
+            assert int.from_bytes(bytes(out), "little") == want
+    a = rng.randrange(1, p)
+    out = (C.c_uint8 * 32)()
+    shim.fe_op(curve, 3, buf(a.to_bytes(32, "little")), buf(bytes(32)), out)
+    want = pow(a, p - 2, p) if curve == 0 else pow(a, (p - 5) // 8, p)
+    assert int.from_bytes(bytes(out), "little") == want
+
+
+@pytest.mark.parametrize("curve,name", [(0, "secp256k1"), (1, "ristretto255")])
+def test_group_law_and_encodings(shim, curve, name):
+    G = O.GROUPS[name]()
+    rng = random.Random(7 + curve)
+    order = G.group_order_int()
+    out = (C.c_uint8 * G.elem_len)()
+    shim.ec_gen(curve, out)
+    assert bytes(out) == G.element_to_bytes(G.generator())
+    B = G.generator()
+    pts = [G.exp(B, rng.randrange(1, order)) for _ in range(6)]
+    ident = G.identity()
+    e = G.element_to_bytes
+    for a, b in [(pts[0], pts[1]), (pts[0], pts[0]), (pts[0], G.element_inverse(pts[0])), (ident, pts[2]),
+                 (pts[2], ident), (ident, ident)]:
+        assert shim.ec_add(curve, buf(e(a)), buf(e(b)), out, 0) == 0
+        assert bytes(out) == e(G.mul(a, b))
+    for a in pts + [ident]:
+        shim.ec_add(curve, buf(e(a)), buf(e(a)), out, 1)
+        assert bytes(out) == e(G.mul(a, a))
+    s = G.scalar_to_bytes
+    for k in [0, 1, 2, 3, order - 1, rng.randrange(order)]:
+        assert shim.ec_dual(curve, buf(e(pts[3])), buf(s(k)), None, None, out) == 0
+        assert bytes(out) == e(G.exp(pts[3], k))
+    k1, k2 = rng.randrange(order), rng.randrange(order)
+    shim.ec_dual(curve, buf(e(pts[4])), buf(s(k1)), buf(e(pts[5])), buf(s(k2)), out)
+    assert bytes(out) == e(G.mul(G.exp(pts[4], k1), G.exp(pts[5], k2)))
+    for k in [0, 1, 5, 65536, 65535, (1 << 40) + 77]:
+        shim.ec_small(curve, buf(e(pts[0])), C.c_uint64(k), out)
+        assert bytes(out) == e(G.exp(pts[0], k))
+    # invalid encodings are rejected
+    bad = [b"\x05" + bytes(32), b"\x02" + (O.SECP_P).to_bytes(32, "big")] if curve == 0 else \
+          [bytes.fromhex("01" + "00" * 31), bytes.fromhex("ed" + "ff" * 30 + "7f")]
+    for x in bad:
+        assert shim.ec_decode_ok(curve, buf(x)) == 0

@@ -1,0 +1,127 @@
+"""GPU parity tests for the secp256k1 and ristretto255 groups: engine (C ABI) vs oracle and vs golden fixtures."""
+import glob
+import json
+import os
+import random
+
+import pytest
+
+import mpvss_oracle as O
+from mpvss_rs_amd import capi
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GID = {"secp256k1": capi.GROUP_SECP256K1, "ristretto255": capi.GROUP_RISTRETTO255}
+
+
+def mk(name):
+    return O.GROUPS[name](), GID[name]
+
+
+def enc(G, pts):
+    return b"".join(G.element_to_bytes(p) for p in pts)
+
+
+def sc(G, ks):
+    return b"".join(G.scalar_to_bytes(k) for k in ks)
+
+
+def split(b, n):
+    return [b[i:i + n] for i in range(0, len(b), n)]
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_exp_and_mul(engine, name):
+    G, gid = mk(name)
+    rng = random.Random(41)
+    order = G.group_order_int()
+    B = G.generator()
+    pts = [G.exp(B, rng.randrange(1, order)) for _ in range(70)] + [G.identity(), B]
+    ks = [rng.randrange(order) for _ in range(68)] + [0, 1, order - 1, 2]
+    out = engine.ec_batch_exp(gid, enc(G, pts), sc(G, ks))
+    assert split(out, G.elem_len) == [G.element_to_bytes(G.exp(p, k)) for p, k in zip(pts, ks)]
+    qs = pts[1:] + pts[:1]
+    qs[5] = G.element_inverse(pts[5])     # P + (-P)
+    qs[6] = pts[6]                        # P + P
+    out = engine.ec_batch_mul(gid, enc(G, pts), enc(G, qs))
+    assert split(out, G.elem_len) == [G.element_to_bytes(G.mul(p, q)) for p, q in zip(pts, qs)]
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_commit_eval_and_dleq(engine, name):
+    G, gid = mk(name)
+    rng = random.Random(42)
+    order = G.group_order_int()
+    B = G.generator()
+    cm = [G.exp(B, rng.randrange(order)) for _ in range(5)]
+    positions = list(range(1, 40)) + [0, 65536, 65535, (1 << 40) + 3]
+    out = engine.ec_commit_eval(gid, enc(G, cm), positions)
+    assert split(out, G.elem_len) == [G.element_to_bytes(O.commitment_eval(G, cm, i)) for i in positions]
+    n = 33
+    h1 = [G.exp(B, rng.randrange(order)) for _ in range(n)]
+    g2 = [G.exp(B, rng.randrange(order)) for _ in range(n)]
+    h2 = [G.exp(B, rng.randrange(order)) for _ in range(n)]
+    r = [rng.randrange(order) for _ in range(n)]
+    c = rng.randrange(order)
+    a1, a2 = engine.ec_dleq_commitments(gid, G.element_to_bytes(B), enc(G, h1), enc(G, g2), enc(G, h2), sc(G, r),
+                                        G.scalar_to_bytes(c), False)
+    exp = [O.dleq_verifier_commitments(G, B, h1[i], g2[i], h2[i], r[i], c) for i in range(n)]
+    assert split(a1, G.elem_len) == [G.element_to_bytes(e[0]) for e in exp]
+    assert split(a2, G.elem_len) == [G.element_to_bytes(e[1]) for e in exp]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "secp256k1_*.json")) +
+                                        glob.glob(os.path.join(HERE, "golden", "ristretto255_*.json"))),
+                         ids=os.path.basename)
+def test_ec_fixture_on_gpu(engine, path):
+    fx = json.load(open(path))
+    gid = GID[fx["group"]]
+    b = fx["box"]
+    cat = lambda hs: bytes.fromhex("".join(hs))
+    res = engine.ec_verify_distribution(gid, cat(b["commitments"]), b["positions"], cat(b["publickeys"]), cat(b["shares"]),
+                                        cat(b["responses"]), bytes.fromhex(b["challenge"]), dump=True)
+    assert res["verdict"] is True
+    assert res["digest"].hex() == fx["expected"]["transcript_digest"]
+    assert res["X"].hex() == "".join(fx["expected"]["X"])
+    assert res["a1"].hex() == "".join(fx["expected"]["a1"])
+    assert res["a2"].hex() == "".join(fx["expected"]["a2"])
+    for tam in fx["tampered"]:
+        res = engine.ec_verify_distribution(gid, cat(tam["commitments"]), b["positions"], cat(b["publickeys"]),
+                                            cat(tam["shares"]), cat(tam["responses"]), bytes.fromhex(tam["challenge"]))
+        assert res["verdict"] is False
+        assert res["digest"].hex() == tam["transcript_digest"]
+    sb = fx["expected"]["share_boxes"]
+    verdicts = engine.ec_verify_shares(gid, cat(b["publickeys"]), cat([s["share"] for s in sb]), cat(b["shares"]),
+                                       cat([s["challenge"] for s in sb]), cat([s["response"] for s in sb]))
+    assert list(verdicts) == [1] * fx["n"]
+    # one tampered share box
+    rs = [bytearray.fromhex(s["response"]) for s in sb]
+    rs[1][7] ^= 1
+    verdicts = engine.ec_verify_shares(gid, cat(b["publickeys"]), cat([s["share"] for s in sb]), cat(b["shares"]),
+                                       cat([s["challenge"] for s in sb]), b"".join(bytes(x) for x in rs))
+    assert list(verdicts) == [1, 0] + [1] * (fx["n"] - 2)
+    # dealer side from the recorded randomness
+    G = O.GROUPS[fx["group"]]()
+    order = G.group_order_int()
+    coeffs = [int(c, 16) for c in fx["inputs"]["coefficients"]]
+    ws = [int(x, 16) for x in fx["inputs"]["witnesses"]]
+    pvals = [G.scalar_from_bigint(O.poly_get_value(coeffs, i) % order) for i in b["positions"]]
+    cm = engine.ec_batch_exp(gid, G.element_to_bytes(G.generator()) * fx["t"],
+                             sc(G, [G.scalar_from_bigint(c) for c in coeffs]))
+    assert cm.hex() == "".join(b["commitments"])
+    d = engine.ec_distribute(gid, cm, b["positions"], cat(b["publickeys"]), sc(G, pvals), sc(G, ws))
+    assert d["X"].hex() == "".join(fx["expected"]["X"]) and d["Y"].hex() == "".join(b["shares"])
+    assert d["a1"].hex() == "".join(fx["expected"]["a1"]) and d["a2"].hex() == "".join(fx["expected"]["a2"])
+    assert d["digest"].hex() == fx["expected"]["transcript_digest"]
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_rejects_invalid_encodings_and_scalars(engine, name):
+    G, gid = mk(name)
+    good = G.element_to_bytes(G.generator())
+    bad = (b"\x05" + bytes(32)) if name == "secp256k1" else bytes.fromhex("01" + "00" * 31)
+    with pytest.raises(capi.EngineError):
+        engine.ec_batch_mul(gid, good + bad, good + good)
+    with pytest.raises(capi.EngineError):
+        engine.ec_batch_exp(gid, good, G.scalar_to_bytes(G.group_order_int()) if name == "secp256k1"
+                            else G.group_order_int().to_bytes(32, "little"))
