@@ -11,7 +11,7 @@ import os
 from typing import Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpvss_hip.so")
+LIB_PATH = os.environ.get("MPVSS_HIP_LIB", os.path.join(_HERE, "libmpvss_hip.so"))   # override only for A/B tuning builds
 
 MPVSS_HOST = 0
 MPVSS_DEVICE = 1

@@ -55,6 +55,7 @@ struct Lane {
   u32 not_top;   // all ones unless q == 3
   u32 low01;     // 1 iff q == 0, else 0
   u32 not_low;   // all ones unless q == 0
+  u32 mask28;    // 2^28 - 1 in a VGPR (lets the compiler fuse "broadcast & mask" into one v_and_b32_dpp)
 };
 
 __device__ __forceinline__ Lane make_lane() {
@@ -65,7 +66,8 @@ __device__ __forceinline__ Lane make_lane() {
   ln.not_low = (ln.q != 0) ? 0xffffffffu : 0u;
   // Opaque to the optimiser: otherwise `x & mask` becomes v_cndmask_b32 on an SGPR-pair condition,
   // which issues ~4x slower than v_and_b32 on gfx950 (profiles/r01_ubench_valu_issue_rates.txt).
-  asm volatile("" : "+v"(ln.not_top), "+v"(ln.low01), "+v"(ln.not_low));
+  ln.mask28 = MASK;
+  asm volatile("" : "+v"(ln.not_top), "+v"(ln.low01), "+v"(ln.not_low), "+v"(ln.mask28));
   return ln;
 }
 
@@ -99,7 +101,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
       }
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)a[k] * bi;
-      const u32 m = quad_bcast0(((u32)T[rr] * N0INV) & MASK);
+      const u32 m = quad_bcast0((u32)T[rr] * N0INV) & ln.mask28;
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)m * n[k];
       // lane 0: the lowest column is now 0 mod 2^28; move its upper bits (< 2^37) into the next
@@ -110,7 +112,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
         const u32 c_hi = (u32)(ret >> 32) >> W;
         u64& nx = T[(rr + 1) % LPL];
         nx += (u64)c_lo * ln.low01;
-        const u32 nhi = (u32)(nx >> 32) + c_hi * ln.low01;
+        const u32 nhi = __umul24(c_hi, ln.low01) + (u32)(nx >> 32);   // v_mad_u32_u24 on the high word
         nx = ((u64)nhi << 32) | (u32)nx;
       }
       // every lane hands its lowest column to the lane below; the top lane starts a fresh one
@@ -120,8 +122,10 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
       // Pin the row-wise order: without this LLVM reassociates the 19-fold unrolled body into a
       // column-wise (product-scanning) form that keeps every b_i and m_i of the block live and
       // no longer fits 128 VGPRs (4 waves/SIMD).  The empty asm makes each accumulator opaque.
+#ifndef MODP_NO_PIN
 #pragma unroll
       for (int k = 0; k < LPL; ++k) asm volatile("" : "+v"(T[k]));
+#endif
     }
   }
   // L is a multiple of LPL, so local position k is back in T[k].

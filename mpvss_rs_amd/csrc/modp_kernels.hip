@@ -13,10 +13,16 @@
 #include "bn_quad28.h"
 #include "modp_kernels.h"
 
+// Occupancy target.  Measured on MI355X (n=65536, t=256): 3 waves/SIMD without spills (135 VGPRs) beats
+// 4 waves/SIMD with a few spilled values (128 VGPRs); v_mad_u64_u32 already issues at its full rate from
+// 2 waves/SIMD (profiles/r01_ubench_sustained_mad_clock.txt).
 #ifndef MODP_WAVES_PER_EU
-#define MODP_WAVES_PER_EU 4
+#define MODP_WAVES_PER_EU 3
 #endif
-#define WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MODP_WAVES_PER_EU, MODP_WAVES_PER_EU)))
+#ifndef MODP_WAVES_PER_EU_MAX
+#define MODP_WAVES_PER_EU_MAX MODP_WAVES_PER_EU
+#endif
+#define WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MODP_WAVES_PER_EU, MODP_WAVES_PER_EU_MAX)))
 // Waves per workgroup.  Waves never talk to each other; 4-wave workgroups only exist because a CU
 // admits more resident waves that way than as single-wave workgroups.
 #ifndef MODP_WPB
