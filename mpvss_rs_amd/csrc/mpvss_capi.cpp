@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -18,7 +19,17 @@ namespace {
 
 constexpr size_t EB = MPVSS_MODP_BYTES;          // element / scalar bytes
 constexpr size_t TABW = MODP_TABLE_WORDS;        // words per 16-entry window table
-constexpr size_t MAX_CHUNK = 1u << 18;           // shares per pass (bounds the table workspace: 2 x 1.2 GiB)
+// shares per pass (bounds the table workspace: 2 x 1.2 GiB).  MPVSS_MAX_CHUNK lowers it so that the tests can
+// drive the multi-chunk path with small inputs.
+static size_t max_chunk_init() {
+  const char* e = getenv("MPVSS_MAX_CHUNK");
+  if (e) {
+    const long v = atol(e);
+    if (v >= 16) return (size_t)v;
+  }
+  return (size_t)1 << 18;
+}
+static const size_t MAX_CHUNK = max_chunk_init();
 
 struct DevBuf {
   void* p = nullptr;
@@ -631,9 +642,11 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   sl.n = n;
   sl.check_positions = false;
-  sl.busy = true;
-  ++ctx->head;
-  if (n == 0) return MPVSS_OK;
+  if (n == 0) {
+    sl.busy = true;
+    ++ctx->head;
+    return MPVSS_OK;
+  }
   struct Restore {
     mpvss_ctx* c;
     ~Restore() { c->sp = &c->main_spans; }
@@ -695,6 +708,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+  sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
+  ++ctx->head;
   return MPVSS_OK;
 }
 

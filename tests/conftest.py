@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch ships its own HIP runtime: load it BEFORE libmpvss_hip.so pulls in the system one, otherwise a later
+# torch.cuda initialisation in the same process finds no GPU (bench.py imports torch first for the same reason).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:

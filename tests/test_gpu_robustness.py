@@ -1,0 +1,132 @@
+"""Paths the parity tests do not reach by themselves: device-resident buffers (torch tensors' data_ptr), the
+multi-chunk loop, two blocks in flight (pipelining), concurrent host threads on one context, a caller stream."""
+import ctypes as C
+import os
+import random
+import subprocess
+import sys
+import threading
+
+import pytest
+
+import mpvss_oracle as O
+from helpers import EB, cat, make_modp_instance, split
+from mpvss_rs_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_device_resident_buffers_match_host_buffers(engine):
+    import torch
+    g, privs, pks, coeffs, ws, box = make_modp_instance(21, 4, 5)
+    flat = O.box_to_flat(g, box)
+    host = engine.verify_distribution(flat["commitments"], flat["positions"], flat["publickeys"], flat["shares"],
+                                      flat["responses"], flat["challenge"], dump=True)
+    dev = torch.device("cuda", 0)
+    t8 = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_cm, d_pk, d_sh, d_rs = t8(flat["commitments"]), t8(flat["publickeys"]), t8(flat["shares"]), t8(flat["responses"])
+    d_pos = torch.tensor(flat["positions"], dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    n, t = flat["n"], flat["t"]
+    ch = (C.c_uint8 * EB).from_buffer_copy(flat["challenge"])
+    verdict = C.c_int(0)
+    dg = (C.c_uint8 * 32)()
+    X = (C.c_uint8 * (n * EB))(); A1 = (C.c_uint8 * (n * EB))(); A2 = (C.c_uint8 * (n * EB))()
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    rc = engine.lib.mpvss_modp_verify_distribution(engine.ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), vp(d_pk), vp(d_sh),
+                                                   vp(d_rs), n, C.cast(ch, C.c_void_p), C.byref(verdict), dg, X, A1, A2)
+    assert rc == 0 and verdict.value == 1
+    assert bytes(dg) == host["digest"] and bytes(X) == host["X"] and bytes(A1) == host["a1"] and bytes(A2) == host["a2"]
+    # device outputs of a Group-level call
+    out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+    rc = engine.lib.mpvss_modp_commit_eval(engine.ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), n, vp(out))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bytes(out.cpu().numpy().tobytes()) == host["X"]
+    # negative position in a device array is reported, not silently computed
+    d_bad = d_pos.clone(); d_bad[3] = -7
+    rc = engine.lib.mpvss_modp_commit_eval(engine.ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_bad), n, vp(out))
+    assert rc == -1
+
+
+def test_two_blocks_in_flight_then_absorbed_in_order(engine):
+    g, privs, pks, coeffs, ws, box = make_modp_instance(10, 3, 6)
+    flat = O.box_to_flat(g, box)
+    a = slice(0, 4 * EB); b = slice(4 * EB, 10 * EB)
+    engine.verify_block_compute(flat["commitments"], flat["positions"][:4], flat["publickeys"][a], flat["shares"][a],
+                                flat["responses"][a], flat["challenge"])
+    engine.verify_block_compute(flat["commitments"], flat["positions"][4:], flat["publickeys"][b], flat["shares"][b],
+                                flat["responses"][b], flat["challenge"])
+    with pytest.raises(capi.EngineError):      # a third block is refused until one is absorbed
+        engine.verify_block_compute(flat["commitments"], flat["positions"][:4], flat["publickeys"][a], flat["shares"][a],
+                                    flat["responses"][a], flat["challenge"])
+    st = engine.verify_block_absorb(capi.transcript_init())
+    st = engine.verify_block_absorb(st)
+    verdict, digest = capi.transcript_verdict(st, flat["challenge"])
+    assert verdict is True and digest == box["_digest"]
+    with pytest.raises(capi.EngineError):
+        engine.verify_block_absorb(st)         # nothing left in flight
+
+
+def test_concurrent_host_threads_share_one_context(engine):
+    rng = random.Random(3)
+    q = O.ModpGroup().q
+    jobs = []
+    for k in range(4):
+        a = [rng.randrange(q) for _ in range(40)]
+        e = [rng.randrange(1 << 200) for _ in range(40)]
+        jobs.append((a, e))
+    results = [None] * 4
+
+    def work(i):
+        a, e = jobs[i]
+        results[i] = split(engine.batch_exp(b"".join(x.to_bytes(EB, "big") for x in a),
+                                            b"".join(x.to_bytes(EB, "big") for x in e)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for (a, e), r in zip(jobs, results):
+        assert r == [pow(x, y, q) for x, y in zip(a, e)]
+
+
+def test_multi_chunk_path_in_a_subprocess():
+    """MPVSS_MAX_CHUNK=16 makes a 45-share box run as three chunks through every chunked entry point."""
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mpvss_oracle as O
+from helpers import make_modp_instance, cat, split
+from mpvss_rs_amd import Engine
+eng = Engine(0)
+g, privs, pks, coeffs, ws, box = make_modp_instance(45, 3, 9)
+flat = O.box_to_flat(g, box)
+res = eng.verify_distribution(flat["commitments"], flat["positions"], flat["publickeys"], flat["shares"],
+                              flat["responses"], flat["challenge"], dump=True)
+assert res["verdict"] is True and res["digest"] == box["_digest"]
+assert split(res["X"]) == box["_X"] and split(res["a1"]) == box["_a1"] and split(res["a2"]) == box["_a2"]
+order = g.group_order_int()
+pv = [O.poly_get_value(coeffs, i) %% order for i in flat["positions"]]
+d = eng.distribute(flat["commitments"], flat["positions"], flat["publickeys"], cat(g, pv), cat(g, ws))
+assert d["digest"] == box["_digest"]
+out = split(eng.batch_exp(flat["publickeys"], flat["responses"]))
+assert out == [pow(y, r, g.q) for y, r in zip(pks, split(flat["responses"]))]
+print("chunked ok")
+''' % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MPVSS_MAX_CHUNK="16")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "chunked ok" in out.stdout
+
+
+def test_caller_provided_stream(engine):
+    import torch
+    from mpvss_rs_amd import Engine
+    eng = Engine(0)
+    s = torch.cuda.Stream()
+    assert eng.lib.mpvss_ctx_set_stream(eng.ctx, C.c_void_p(s.cuda_stream)) == 0
+    q = O.ModpGroup().q
+    out = split(eng.batch_mul((5).to_bytes(EB, "big") * 3, (7).to_bytes(EB, "big") * 3))
+    assert out == [35, 35, 35]
+    assert eng.lib.mpvss_ctx_synchronize(eng.ctx) == 0
+    eng.close()
