@@ -204,6 +204,17 @@ int mpvss_ec_distribute(mpvss_ctx* ctx, int group, int space, const uint8_t* com
 /* Group::hash_to_scalar(data), host only; out32 in the group's scalar byte order */
 int mpvss_ec_hash_to_scalar(int group, const uint8_t* data, size_t len, uint8_t out32[32]);
 
+/* ---- extract_secret_share, batched (the callers on the other side of the path) --------------------------------
+ * n participants decrypt their encrypted share and build the DLEQ proof at once, src/participant.rs:294-353
+ * (secp256k1 :1282-1338, ristretto255 :1725-1781):  S_i = Y_i^(1/x_i),  a1_i = G^w_i,  a2_i = S_i^w_i,
+ * c_i = hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1_i) framed(a2_i))).
+ * xinv = x_i^-1 mod the group order (host work: util.rs:33-41 / Scalar::invert) and the witnesses w are inputs;
+ * the response r_i = w_i - x_i c_i (dleq.rs:42-50) stays with the host.  s_out in `space`; c_out_host: n scalars. */
+int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* y, const uint8_t* xinv,
+                              const uint8_t* w, size_t n, uint8_t* s_out, uint8_t* c_out_host);
+int mpvss_ec_extract_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* y,
+                            const uint8_t* xinv, const uint8_t* w, size_t n, uint8_t* s_out, uint8_t* c_out_host);
+
 /* ---- hashing helpers (host only; Group::hash_to_scalar, src/groups/modp.rs:142-148) ------ */
 
 /* out32 = SHA-256(data) */

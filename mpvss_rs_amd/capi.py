@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
+    "mpvss_modp_extract_shares", "mpvss_ec_extract_shares",
 )
 
 GROUP_SECP256K1 = 1
@@ -87,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_verify_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
+    lib.mpvss_modp_extract_shares.argtypes = [vp, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
+    lib.mpvss_ec_extract_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
     return lib
 
 
@@ -213,6 +216,23 @@ class Engine:
         ks, ps = _buf(state)
         self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, None, None, None), "verify_block_absorb")
         return bytes(ks)
+
+    def extract_shares(self, pk: bytes, y: bytes, xinv: bytes, w: bytes) -> Tuple[bytes, bytes]:
+        n = len(pk) // EB
+        k = [_buf(x) for x in (pk, y, xinv, w)]
+        ks, ps = _out(n * EB); kc, pc = _out(n * EB)
+        self._check(self.lib.mpvss_modp_extract_shares(self.ctx, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1], n, ps, pc),
+                    "extract_shares")
+        return bytes(ks)[: n * EB], bytes(kc)[: n * EB]
+
+    def ec_extract_shares(self, group: int, pk: bytes, y: bytes, xinv: bytes, w: bytes) -> Tuple[bytes, bytes]:
+        e = EC_ENC[group]
+        n = len(xinv) // 32
+        k = [_buf(x) for x in (pk, y, xinv, w)]
+        ks, ps = _out(n * e); kc, pc = _out(n * 32)
+        self._check(self.lib.mpvss_ec_extract_shares(self.ctx, group, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1], n,
+                                                     ps, pc), "ec_extract_shares")
+        return bytes(ks)[: n * e], bytes(kc)[: n * 32]
 
     # ---- elliptic-curve groups (group = GROUP_SECP256K1 | GROUP_RISTRETTO255)
     def ec_batch_exp(self, group: int, bases: bytes, scalars: bytes) -> bytes:

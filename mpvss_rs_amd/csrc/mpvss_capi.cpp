@@ -942,6 +942,69 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
   return MPVSS_OK;
 }
 
+// ---- extract_secret_share, batched ---------------------------------------------------
+// n participants decrypt their share and prove it at once, src/participant.rs:294-353:
+//   S_i = Y_i^(1/x_i)            (:310-314; the inverse mod q-1 is host work, util.rs:33-41, and an input here)
+//   a1_i = G^w_i, a2_i = S_i^w_i (dleq.rs:207-216)
+//   c_i = hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1_i) framed(a2_i)))   (:329-343)
+// The response r_i = w_i - x_i*c_i (dleq.rs:42-50) is scalar-field work and stays with the host.
+extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* y,
+                                         const uint8_t* xinv, const uint8_t* w, size_t n, uint8_t* s_out,
+                                         uint8_t* c_out_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return MPVSS_OK;
+  if (!pk || !y || !xinv || !w || !s_out || !c_out_host) return fail(ctx, MPVSS_E_INVALID, "extract_shares: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  spans_reset(ctx);
+  const uint32_t* cG;
+  RET_IF(comb_table(ctx, 1, &cG));
+  std::vector<uint8_t> hpk, hy;
+  for (size_t off = 0; off < n; off += MAX_CHUNK) {
+    const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
+    const void *dy, *dxi, *dw;
+    RET_IF(stage_in(ctx, space, y + off * EB, cnt * EB, ctx->in_a, &dy));
+    RET_IF(stage_in(ctx, space, xinv + off * EB, cnt * EB, ctx->in_b, &dxi));
+    RET_IF(stage_in(ctx, space, w + off * EB, cnt * EB, ctx->in_c, &dw));
+    uint8_t* dS = s_out + off * EB;
+    if (space == MPVSS_HOST) {
+      RET_IF(ensure(ctx, ctx->xbe, cnt * EB));
+      dS = (uint8_t*)ctx->xbe.p;
+    }
+    RET_IF(ensure(ctx, ctx->out1, cnt * EB));
+    RET_IF(ensure(ctx, ctx->out2, cnt * EB));
+    uint8_t* da1 = (uint8_t*)ctx->out1.p;
+    uint8_t* da2 = (uint8_t*)ctx->out2.p;
+    RET_IF(exp_dev(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, cnt, dS));                       // S = Y^(1/x)
+    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
+                                                   da1, ctx->consts, ctx->stream));                // a1 = G^w
+    RET_IF(exp_dev(ctx, dS, (const uint8_t*)dw, cnt, da2));                                        // a2 = S^w
+    RET_IF(ensure_pinned(ctx, cnt * EB * 3));
+    uint8_t* hS = (uint8_t*)ctx->pin;
+    uint8_t* h1 = hS + cnt * EB;
+    uint8_t* h2 = h1 + cnt * EB;
+    HIPCHK(ctx, hipMemcpyAsync(hS, dS, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h1, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h2, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    RET_IF(small_vec_to_host(ctx, space, pk + off * EB, cnt * EB, hpk));
+    RET_IF(small_vec_to_host(ctx, space, y + off * EB, cnt * EB, hy));
+    for (size_t i = 0; i < cnt; ++i) {
+      mpvss::Sha256 h;
+      frame_update(h, hpk.data() + i * EB);
+      frame_update(h, hy.data() + i * EB);
+      frame_update(h, h1 + i * EB);
+      frame_update(h, h2 + i * EB);
+      uint8_t digest[32];
+      h.final(digest);
+      mpvss_modp_hash_to_scalar(digest, 32, c_out_host + (off + i) * EB);
+    }
+    if (space == MPVSS_HOST) memcpy(s_out + off * EB, hS, cnt * EB);
+  }
+  RET_IF(spans_collect(ctx));
+  return MPVSS_OK;
+}
+
 // =====================================================================================================
 // Elliptic-curve groups: secp256k1 (src/groups/secp256k1.rs) and ristretto255 (src/groups/ristretto255.rs)
 // =====================================================================================================
@@ -1409,5 +1472,59 @@ extern "C" int mpvss_ec_hash_to_scalar(int group, const uint8_t* data, size_t le
     }
   }
   for (int i = 0; i < 32; ++i) out32[i] = (uint8_t)(r[i / 8] >> (8 * (i % 8)));
+  return MPVSS_OK;
+}
+
+// ---- extract_secret_share, batched, EC groups (participant.rs:1282-1338, 1725-1781) ---------------------------
+extern "C" int mpvss_ec_extract_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* y,
+                                       const uint8_t* xinv, const uint8_t* wit, size_t n, uint8_t* s_out,
+                                       uint8_t* c_out_host) {
+  EC_PROLOGUE("ec_extract_shares");
+  if (n == 0) return MPVSS_OK;
+  if (!pk || !y || !xinv || !wit || !s_out || !c_out_host || n > 0x7fffffff)
+    return fail(ctx, MPVSS_E_INVALID, "ec_extract_shares: bad argument");
+  RET_IF(ec_check_scalars(ctx, gi, space, xinv, n, "inverse private keys"));
+  RET_IF(ec_check_scalars(ctx, gi, space, wit, n, "witnesses"));
+  const uint8_t* dg;
+  RET_IF(ec_generator_dev(ctx, gi, w, nullptr, &dg));
+  const void *dy, *dxi, *dw;
+  RET_IF(stage_in(ctx, space, y, n * gi->enc, w.a, &dy));
+  RET_IF(stage_in(ctx, space, xinv, n * 32, w.d, &dxi));
+  RET_IF(stage_in(ctx, space, wit, n * 32, w.e, &dw));
+  uint8_t* dS = s_out;
+  if (space == MPVSS_HOST) { RET_IF(ensure(ctx, w.x, n * gi->enc)); dS = (uint8_t*)w.x.p; }
+  RET_IF(ensure(ctx, w.o1, n * gi->enc));
+  RET_IF(ensure(ctx, w.o2, n * gi->enc));
+  RET_IF(ensure(ctx, w.ok, 3 * (n > 4096 ? n : 4096)));
+  uint8_t *d1 = (uint8_t*)w.o1.p, *d2 = (uint8_t*)w.o2.p, *ok = (uint8_t*)w.ok.p;
+  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dy, gi->enc, (const uint8_t*)dxi, nullptr, nullptr, 0, (int)n,
+                                          dS, ok, ctx->stream));                       // S = (1/x) * Y
+  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n, d1, ok + n,
+                                          ctx->stream));                               // a1 = w * G
+  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dS, gi->enc, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n, d2, ok + 2 * n,
+                                          ctx->stream));                               // a2 = w * S
+  RET_IF(ensure_pinned(ctx, n * gi->enc * 3));
+  uint8_t* hS = (uint8_t*)ctx->pin;
+  uint8_t* h1 = hS + n * gi->enc;
+  uint8_t* h2 = h1 + n * gi->enc;
+  HIPCHK(ctx, hipMemcpyAsync(hS, dS, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h1, d1, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h2, d2, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
+  RET_IF(ec_check_ok(ctx, ok, 3 * n, "encrypted shares"));
+  std::vector<uint8_t> hpk, hy;
+  RET_IF(small_vec_to_host(ctx, space, pk, n * gi->enc, hpk));
+  RET_IF(small_vec_to_host(ctx, space, y, n * gi->enc, hy));
+  for (size_t i = 0; i < n; ++i) {
+    mpvss::Sha256 h;
+    ec_frame_update(h, hpk.data() + i * gi->enc, gi->enc);
+    ec_frame_update(h, hy.data() + i * gi->enc, gi->enc);
+    ec_frame_update(h, h1 + i * gi->enc, gi->enc);
+    ec_frame_update(h, h2 + i * gi->enc, gi->enc);
+    uint8_t digest[32];
+    h.final(digest);
+    ec_hash_to_scalar(gi, digest, c_out_host + i * 32);
+  }
+  if (space == MPVSS_HOST) memcpy(s_out, hS, n * gi->enc);
+  RET_IF(spans_collect(ctx));
   return MPVSS_OK;
 }
