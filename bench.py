@@ -80,8 +80,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536, help="participants per GPU")
-    ap.add_argument("--t", type=int, default=256, help="threshold")
+    ap.add_argument("--participants", dest="n", type=int, default=65536, help="participants per GPU")
+    ap.add_argument("--threshold", dest="t", type=int, default=256, help="threshold")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the CPU port (-1: 2 per core, 0: skip)")
     args = ap.parse_args()
 
@@ -92,12 +92,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
+    # MPVSS_BENCH_SMOKE_ONE_GPU=1: run every rank on cuda:0 with the gloo backend -- only to exercise the
+    # multi-rank control flow on a single-GPU box; real runs use one GPU per rank and RCCL ("nccl").
+    smoke_one_gpu = os.environ.get("MPVSS_BENCH_SMOKE_ONE_GPU") == "1"
+    if smoke_one_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if smoke_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    commdev = torch.device("cpu") if smoke_one_gpu else dev      # where the tiny exchange tensors live
 
     eng = capi.Engine(local_rank)     # raises if the HIP library or the GPU is missing
     lib, ctx = eng.lib, eng.ctx
@@ -131,7 +140,6 @@ def main():
         s = slice(i * EB, (i + 1) * EB)
         inter += dres["X"][s] + dres["Y"][s] + dres["a1"][s] + dres["a2"][s]
     if world > 1:
-        commdev = dev
         if rank == 0:
             state = capi.transcript_init()
         else:
@@ -181,7 +189,7 @@ def main():
         if world == 1 or rank == 0:
             state = capi.transcript_init()
         else:
-            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=dev)
+            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
             dist.recv(buf, src=rank - 1)
             state = bytes(buf.cpu().numpy().tobytes())
         t0 = time.perf_counter()
@@ -191,25 +199,29 @@ def main():
             kernel_ms[k].append(eng.kernel_ms(k))
         if world == 1:
             return capi.transcript_verdict(state, challenge)
-        out = torch.zeros(33, dtype=torch.uint8, device=dev)
+        out = torch.zeros(33, dtype=torch.uint8, device=commdev)
         if rank + 1 < world:
-            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(dev), dst=rank + 1)
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1)
         else:
             verdict, digest = capi.transcript_verdict(state, challenge)
-            out = torch.frombuffer(bytearray(bytes([int(verdict)]) + digest), dtype=torch.uint8).to(dev)
+            out = torch.frombuffer(bytearray(bytes([int(verdict)]) + digest), dtype=torch.uint8).to(commdev)
         dist.broadcast(out, src=world - 1)
         raw = bytes(out.cpu().numpy().tobytes())
         return bool(raw[0]), raw[1:33]
 
-    def run_steps(k):
-        """k complete verifications of the box, software-pipelined: the GPU work of verification i+1 is
-        enqueued before the host hashes verification i (two blocks in flight at most)."""
+    def run_steps(k, depth=3):
+        """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
+        enqueued while the host (and, on several GPUs, the rank-to-rank hash chain) finishes older ones."""
         results = []
-        compute_block()
-        for i in range(k):
-            if i + 1 < k:
-                compute_block()
+        issued = 0
+        while issued < min(depth, k):
+            compute_block()
+            issued += 1
+        for _ in range(k):
             results.append(finish_block())
+            if issued < k:
+                compute_block()
+                issued += 1
         return results
 
     def barrier():
@@ -230,7 +242,7 @@ def main():
     for verdict, digest in results:
         assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=commdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -281,10 +293,10 @@ def main():
             "kernel_ms": {"commit_eval": ce_ms, "dual_exp_x2": de_ms, "tables": tb_ms},
         },
         "host": {"absorb_wait_plus_sha256_ms": 1e3 * sum(host_absorb_s) / max(len(host_absorb_s), 1), "setup_s": setup_s,
-                 "pipelining": "GPU work of verification i+1 enqueued before the host hashes verification i"},
+                 "pipelining": "up to 3 verifications in flight: GPU work of i+1, i+2 enqueued while the host hashes i"},
     }
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape
         try:
             result["roofline"]["traffic"] = json.load(open(traffic_file)).get("k_modp_commit_eval_bytes_per_launch")
         except Exception:

@@ -38,6 +38,10 @@ struct DevBuf {
 
 }  // namespace
 
+struct EcWork {   // device workspace of the elliptic-curve entry points
+  DevBuf a, b, c, d, e, pos, cm, cmenc, x, o1, o2, ok, gen, chal;
+};
+
 struct mpvss_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -62,7 +66,7 @@ struct mpvss_ctx {
   };
   SpanSet main_spans;
   SpanSet* sp = &main_spans;   // where TIMED_LAUNCH records
-  // Two verify blocks may be in flight (compute of block k+1 is enqueued before block k is absorbed):
+  // Up to NSLOT verify blocks may be in flight (compute of block k+1.. is enqueued before block k is absorbed):
   // each has its own pinned staging, timing events and completion event.
   struct BlockSlot {
     void* pin = nullptr;
@@ -74,8 +78,10 @@ struct mpvss_ctx {
     SpanSet spans;
     double kernel_ms[3] = {0, 0, 0};
   };
-  BlockSlot slot[2];
+  static constexpr unsigned NSLOT = 4;
+  BlockSlot slot[NSLOT];
   unsigned head = 0, tail = 0;   // next slot to fill / to absorb
+  EcWork ecwork;
 };
 
 namespace {
@@ -354,6 +360,10 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->pos, &ctx->cm, &ctx->xbe,
                     &ctx->out1, &ctx->out2, &ctx->tab1, &ctx->tab2, &ctx->tabg, &ctx->cbuf, &ctx->comb[0], &ctx->comb[1]})
+    if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&ctx->ecwork.a, &ctx->ecwork.b, &ctx->ecwork.c, &ctx->ecwork.d, &ctx->ecwork.e, &ctx->ecwork.pos,
+                    &ctx->ecwork.cm, &ctx->ecwork.cmenc, &ctx->ecwork.x, &ctx->ecwork.o1, &ctx->ecwork.o2, &ctx->ecwork.ok,
+                    &ctx->ecwork.gen, &ctx->ecwork.chal})
     if (b->p) (void)hipFree(b->p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
@@ -636,8 +646,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
   if (n > 0 && (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff))
     return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1)");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head & 1];
-  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: two blocks already in flight, absorb one first");
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: four blocks already in flight, absorb one first");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   sl.n = n;
@@ -715,7 +725,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
 
 int verify_block_absorb_locked(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out, uint8_t* a1_out, uint8_t* a2_out) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail & 1];
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
   if (!sl.busy) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
   const size_t n = sl.n;
   sl.busy = false;
@@ -1099,18 +1109,7 @@ inline void ec_frame_update(mpvss::Sha256& h, const uint8_t* e, size_t len) {
   h.update(e, len);
 }
 
-struct EcWork {
-  DevBuf a, b, c, d, e, pos, cm, cmenc, x, o1, o2, ok, gen, chal;
-};
-EcWork& ecw(mpvss_ctx* ctx) {
-  static std::mutex m;
-  static std::vector<std::pair<mpvss_ctx*, EcWork*>> all;
-  std::lock_guard<std::mutex> lk(m);
-  for (auto& p : all)
-    if (p.first == ctx) return *p.second;
-  all.emplace_back(ctx, new EcWork());
-  return *all.back().second;
-}
+EcWork& ecw(mpvss_ctx* ctx) { return ctx->ecwork; }
 
 int ec_check_ok(mpvss_ctx* ctx, const uint8_t* ok_dev, size_t n, const char* what) {
   std::vector<uint8_t> h(n);
