@@ -25,7 +25,26 @@ int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb, const voi
 int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
                               const uint8_t* e2, size_t e2_stride, int e2_windows, int count, uint8_t* out,
                               const void* cs, hipStream_t s);
+int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
+                                    const uint8_t* e2, size_t e2_stride, int e2_windows, int count, uint8_t* out, int mode,
+                                    uint32_t* p_m, const void* cs, hipStream_t s);
 int modp_occupancy_report(int* out5);
+/* forward-difference evaluation of X_i for consecutive positions (see modp_kernels.hip) */
+int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_t* cm_b, int split, int t, const int64_t* positions,
+                                  int count, uint32_t* x_m, uint8_t* x_be, const int* gate, int want, const void* cs,
+                                  hipStream_t s);
+int modp_fd_tpad(int t);
+int modp_launch_fd_check_positions(const int64_t* positions, int count, int* flag, hipStream_t s);
+int modp_launch_fd_seed_positions(const int64_t* positions, int chains, int chain_len, int t, int64_t* seedpos,
+                                  hipStream_t s);
+int modp_launch_fd_check_inverses(const uint32_t* cm, const uint32_t* cminv, int t, int* flag, uint8_t* scratch_be,
+                                  const void* cs, hipStream_t s);
+int modp_launch_fd_table(const uint32_t* seeds, int chains, int t, uint32_t* state, const int* gate, const void* cs,
+                         hipStream_t s);
+int modp_launch_fd_step(const uint32_t* state, int chains, int t, int chain_len, int count, uint32_t* x_m,
+                        const int* gate, const void* cs, hipStream_t s);
+int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,
+                          hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

@@ -201,11 +201,18 @@ k_modp_to_mont(const uint8_t* __restrict__ in_be, u32* __restrict__ out_m, int c
 // LDS per wave: operand slot + saved-base slot per number, one shared slot holding one_m.
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
-k_modp_commit_eval(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions, int count,
-                   uint8_t* __restrict__ x_be, const ModpConsts* __restrict__ cs) {
+k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, int split, int t,
+                   const int64_t* __restrict__ positions, int count, uint8_t* __restrict__ x_be,
+                   u32* __restrict__ x_m, const int* __restrict__ gate, int gate_want,
+                   const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_BLOCK + MODP_WPB) * SLOT_WORDS];
+  // gate: the forward-difference path (below) and this kernel exclude each other through a device flag,
+  // so that the choice needs no host synchronisation
+  if (gate != nullptr && *gate != gate_want) return;
   const Lane ln = make_lane();
   const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  // numbers >= split evaluate the second commitment set (the inverted commitments of the seed phase)
+  const u32* __restrict__ cm = (xi >= split) ? cm_b : cm_a;
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
@@ -257,6 +264,7 @@ k_modp_commit_eval(const u32* __restrict__ cm, int t, const int64_t* __restrict_
     } else if (kind == K_CMUL) {
       slot_fill_from_global(slot, cm + (size_t)j * L, ln);
     } else {
+      if (x_m != nullptr) break;                      // keep the Montgomery form (seed values)
       slot_fill_from_global(slot, cs->one, ln);
     }
     if (!skip) {
@@ -275,7 +283,164 @@ k_modp_commit_eval(const u32* __restrict__ cm, int t, const int64_t* __restrict_
       if (j >= 0) begin_coefficient(); else kind = K_FINAL;
     }
   }
+  if (x_m != nullptr) {
+    if (live) store_lane_limbs(x_m + (size_t)x * L, acc, ln);
+    return;
+  }
   store_canonical_be256(x_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
+}
+
+// =======================================================================================
+// Forward differences in the exponent (consecutive positions only).
+// X(i) = g^P(i) with deg P = t-1, so the t-th multiplicative difference of the sequence X(c), X(c+1), ..
+// is constant: with D_k(c) = "Delta^k X (c)" (D_0 = X, D_k(c) = D_{k-1}(c+1) / D_{k-1}(c)),
+//   D_k(c+1) = D_k(c) * D_{k+1}(c)   for k < t-1,   D_{t-1} constant,
+// i.e. ONE Montgomery product per share and coefficient instead of ~24 for Horner's rule.  A chain of
+// consecutive positions is served by t numbers (one per k) that step in lock-step inside one workgroup.
+//   seeds  : X(c+k) and X(c+k)^-1, k < t, for each chain start c -- by the Horner kernel above, the inverses as
+//            the same polynomial over the inverted commitments C_j^-1
+//   table  : E_l[k] = E_{l-1}[k+1] F_{l-1}[k],  F_l[k] = F_{l-1}[k+1] E_{l-1}[k]  (E_0 = X, F_0 = X^-1); D_l = E_l[0]
+//   step   : D_k <- D_k * D_{k+1}, output D_0
+// Canonical results are identical to Horner's by uniqueness of the group element.
+// Chains of one workgroup: 1024 threads = 256 quads = 256 / tpad chains of tpad >= t numbers.
+// =======================================================================================
+constexpr int FD_QUADS = 256;
+constexpr int FD_THREADS = 4 * FD_QUADS;
+
+// flag = 1 iff positions[i] == positions[0] + i for all i (and no negative / overflowing value)
+extern "C" __global__ void k_modp_fd_check_positions(const int64_t* __restrict__ positions, int count,
+                                                      int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t p0 = positions[0];
+  const bool ok = p0 >= 0 && p0 < ((int64_t)1 << 61) && positions[i] == p0 + i;
+  if (!ok) atomicAnd(flag, 0);
+}
+
+// seedpos[(set * chains + s) * t + k] = positions[0] + s * chain_len + k
+extern "C" __global__ void k_modp_fd_seed_positions(const int64_t* __restrict__ positions, int chains, int chain_len,
+                                                     int t, int64_t* __restrict__ seedpos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * chains * t) return;
+  const int k = i % t, s = (i / t) % chains;
+  seedpos[i] = positions[0] + (int64_t)s * chain_len + k;
+}
+
+// every commitment must be invertible: prod[j] = C_j * C_j^-1 must be 1, otherwise clear the flag
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_fd_check_inverses(const u32* __restrict__ cm, const u32* __restrict__ cminv, int t, int* __restrict__ flag,
+                         uint8_t* __restrict__ scratch_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < t;
+  const int x = live ? xi : t - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], a[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(a, cm + (size_t)x * L, ln);
+  slot_fill_from_global(slot, cminv + (size_t)x * L, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);          // C * C^-1 in Montgomery form
+  __builtin_amdgcn_wave_barrier();
+  store_canonical_be256(scratch_be + (size_t)x * 256, a, true, slot, cs, n, ln, live);
+  if (live && ln.q == 0) {
+    bool one = scratch_be[(size_t)x * 256 + 255] == 1;
+    for (int i = 0; i < 255; ++i) one = one && (scratch_be[(size_t)x * 256 + i] == 0);
+    if (!one) atomicAnd(flag, 0);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(FD_THREADS)
+k_modp_fd_table(const u32* __restrict__ seeds, int chains, int t, int tpad, u32* __restrict__ state,
+                const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[2 * FD_QUADS * SLOT_WORDS];
+  if (*gate != 1) return;
+  const Lane ln = make_lane();
+  const int qi = threadIdx.x >> 2;
+  const int cpw = FD_QUADS / tpad;
+  const int k = qi % tpad;
+  const int chain_i = blockIdx.x * cpw + qi / tpad;
+  const bool live = chain_i < chains && k < t;
+  const int chain = chain_i < chains ? chain_i : chains - 1;
+  const int kk = k < t ? k : t - 1;
+  u32* eslot = lds + qi * SLOT_WORDS;
+  u32* fslot = lds + (FD_QUADS + qi) * SLOT_WORDS;
+  const int nbq = (k + 1 < tpad) ? qi + 1 : qi;       // neighbour k+1 (values beyond the triangle are unused)
+  const u32* enb = lds + nbq * SLOT_WORDS;
+  const u32* fnb = lds + (FD_QUADS + nbq) * SLOT_WORDS;
+  u32 n[LPL], E[LPL], F[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(E, seeds + ((size_t)chain * t + kk) * L, ln);
+  load_lane_limbs(F, seeds + ((size_t)(chains + chain) * t + kk) * L, ln);
+  u32* st = state + (size_t)chain * t * L;
+  if (live && k == 0) store_lane_limbs(st, E, ln);
+  // two levels per iteration: the register arrays swap roles (E' lands in F's registers and vice versa)
+  for (int lvl = 1; lvl < t; lvl += 2) {
+    slot_store(eslot, E, ln);
+    slot_store(fslot, F, ln);
+    __syncthreads();
+    mont_mul<MODP_N0INV_C>(F, F, enb, n, ln);          // F regs <- E_l[k] = E_{l-1}[k+1] * F_{l-1}[k]
+    mont_mul<MODP_N0INV_C>(E, E, fnb, n, ln);          // E regs <- F_l[k] = F_{l-1}[k+1] * E_{l-1}[k]
+    __syncthreads();
+    if (live && k == 0) store_lane_limbs(st + (size_t)lvl * L, F, ln);
+    if (lvl + 1 >= t) break;
+    slot_store(eslot, F, ln);                          // roles swapped
+    slot_store(fslot, E, ln);
+    __syncthreads();
+    mont_mul<MODP_N0INV_C>(E, E, enb, n, ln);          // E regs <- E_{l+1}[k]  (E regs held F_l[k])
+    mont_mul<MODP_N0INV_C>(F, F, fnb, n, ln);          // F regs <- F_{l+1}[k]  (F regs held E_l[k])
+    __syncthreads();
+    if (live && k == 0) store_lane_limbs(st + (size_t)(lvl + 1) * L, E, ln);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(FD_THREADS)
+k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int chain_len, int count,
+               u32* __restrict__ x_m, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[(FD_QUADS + 1) * SLOT_WORDS];
+  if (*gate != 1) return;
+  const Lane ln = make_lane();
+  const int qi = threadIdx.x >> 2;
+  const int cpw = FD_QUADS / tpad;
+  const int k = qi % tpad;
+  const int chain_i = blockIdx.x * cpw + qi / tpad;
+  const bool live = chain_i < chains && k < t;
+  const int chain = chain_i < chains ? chain_i : chains - 1;
+  u32* slot = lds + qi * SLOT_WORDS;
+  u32* oneslot = lds + FD_QUADS * SLOT_WORDS;
+  const u32* bptr = (k + 1 < t) ? lds + (qi + 1) * SLOT_WORDS : oneslot;   // D_{t-1} is constant
+  u32 n[LPL], D[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  if (threadIdx.x < 4) slot_fill_from_global(oneslot, cs->one_m, ln);
+  if (k < t) load_lane_limbs(D, state + ((size_t)chain * t + k) * L, ln); else load_lane_limbs(D, cs->one_m, ln);
+  const size_t base = (size_t)chain * chain_len;
+  const bool writer = live && k == 0;
+  if (writer && base < (size_t)count) store_lane_limbs(x_m + base * L, D, ln);
+  for (int step = 1; step < chain_len; ++step) {
+    slot_store(slot, D, ln);
+    __syncthreads();
+    mont_mul<MODP_N0INV_C>(D, D, bptr, n, ln);
+    __syncthreads();
+    if (writer && base + step < (size_t)count) store_lane_limbs(x_m + (base + step) * L, D, ln);
+  }
+}
+
+// Montgomery limb form -> canonical 256-byte big-endian
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_from_mont(const u32* __restrict__ x_m, int count, uint8_t* __restrict__ out_be, const int* __restrict__ gate,
+                 const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  if (gate != nullptr && *gate != 1) return;
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], a[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(a, x_m + (size_t)x * L, ln);
+  store_canonical_be256(out_be + (size_t)x * 256, a, true, slot, cs, n, ln, live);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -423,7 +588,10 @@ k_modp_comb_rows(u32* __restrict__ comb, const ModpConsts* __restrict__ cs) {
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2, size_t tab2_stride,
                      const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride,
-                     int e2_windows, int count, uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs) {
+                     int e2_windows, int count, uint8_t* __restrict__ out_be, int mode, u32* __restrict__ p_m,
+                     const ModpConsts* __restrict__ cs) {
+  // mode 0: the whole product.  mode 1: only g^e1 (needs nothing but the exponent, so it can run before B2 is
+  // known), left in Montgomery form in p_m.  mode 2: B2^e2 times the stored p_m.
   __shared__ __attribute__((aligned(16))) u32 lds[2 * NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
   const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -441,7 +609,7 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
   // steps: A(w, s): w = first_e2..511, s = 0..3 square (w > first_e2), 4 = table product
   //        B(k):    k = 0..511 comb product (k = 0 loads), then P = product with phase-A value, F = final
   enum { PH_A, PH_B, PH_P, PH_F };
-  int phase = (e2_windows > 0) ? PH_A : PH_B;
+  int phase = (e2_windows > 0 && mode != 1) ? PH_A : PH_B;
   int w = first_e2, s = 4, k = 0;
   if (phase == PH_A) {
     const u32 byte = e2[w >> 1];
@@ -455,6 +623,11 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
     if (phase == PH_A) {
       if (s == 5) { ++w; s = 0; }
       if (w == 512) {
+        if (mode == 2) {                                 // multiply by the stored g^e1
+          slot_fill_from_global(pslot, p_m + (size_t)x * L, ln);
+          phase = PH_P;
+          continue;
+        }
         slot_store(pslot, acc, ln);                      // save B2^e2
         phase = PH_B; k = 0;
         continue;
@@ -474,7 +647,7 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
       if (k == 0) { load_lane_limbs(acc, entry, ln); skip = true; }
       else slot_fill_from_global(slot, entry, ln);
       ++k;
-      if (k == 512) phase = (e2_windows > 0) ? PH_P : PH_F;
+      if (k == 512) phase = (mode == 1) ? PH_F + 2 : (e2_windows > 0) ? PH_P : PH_F;
     } else if (phase == PH_P) {
       bptr = pslot;
       phase = PH_F;
@@ -487,7 +660,11 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
       mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
       __builtin_amdgcn_wave_barrier();
     }
-    if (phase == PH_F + 1) break;
+    if (phase >= PH_F + 1) break;
+  }
+  if (mode == 1) {
+    if (live) store_lane_limbs(p_m + (size_t)x * L, acc, ln);
+    return;
   }
   store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
 }
@@ -545,9 +722,65 @@ extern "C" int modp_launch_to_mont(const uint8_t* in, uint32_t* out_m, int count
 extern "C" int modp_launch_commit_eval(const uint32_t* cm, int t, const int64_t* positions, int count,
                                        uint32_t* x_m, uint8_t* x_be, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
-  (void)x_m;
-  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, cm, t, positions, count,
-                     x_be, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, cm, cm, 0x7fffffff, t,
+                     positions, count, x_be, x_m, (const int*)nullptr, 0, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+// Horner kernel gated on the device flag (runs only when *gate == want)
+extern "C" int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_t* cm_b, int split, int t,
+                                             const int64_t* positions, int count, uint32_t* x_m, uint8_t* x_be,
+                                             const int* gate, int want, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, cm_a, cm_b, split, t,
+                     positions, count, x_be, x_m, gate, want, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_fd_tpad(int t) {
+  int p = 16;
+  while (p < t) p <<= 1;
+  return p;
+}
+
+extern "C" int modp_launch_fd_check_positions(const int64_t* positions, int count, int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_modp_fd_check_positions, dim3((count + 255) / 256), dim3(256), 0, s, positions, count, flag);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_seed_positions(const int64_t* positions, int chains, int chain_len, int t,
+                                             int64_t* seedpos, hipStream_t s) {
+  const int total = 2 * chains * t;
+  hipLaunchKernelGGL(k_modp_fd_seed_positions, dim3((total + 255) / 256), dim3(256), 0, s, positions, chains, chain_len,
+                     t, seedpos);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_check_inverses(const uint32_t* cm, const uint32_t* cminv, int t, int* flag,
+                                             uint8_t* scratch_be, const void* cs, hipStream_t s) {
+  hipLaunchKernelGGL(k_modp_fd_check_inverses, dim3(grid_for(t)), dim3(BLOCK_THREADS), 0, s, cm, cminv, t, flag,
+                     scratch_be, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_table(const uint32_t* seeds, int chains, int t, uint32_t* state, const int* gate,
+                                    const void* cs, hipStream_t s) {
+  const int tpad = modp_fd_tpad(t);
+  const int cpw = FD_QUADS / tpad;
+  hipLaunchKernelGGL(k_modp_fd_table, dim3((chains + cpw - 1) / cpw), dim3(FD_THREADS), 0, s, seeds, chains, t, tpad,
+                     state, gate, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_step(const uint32_t* state, int chains, int t, int chain_len, int count, uint32_t* x_m,
+                                   const int* gate, const void* cs, hipStream_t s) {
+  const int tpad = modp_fd_tpad(t);
+  const int cpw = FD_QUADS / tpad;
+  hipLaunchKernelGGL(k_modp_fd_step, dim3((chains + cpw - 1) / cpw), dim3(FD_THREADS), 0, s, state, chains, t, tpad,
+                     chain_len, count, x_m, gate, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,
+                                     hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_from_mont, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, x_m, count, out_be, gate,
+                     (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 
@@ -579,6 +812,17 @@ extern "C" int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* t
                                          int count, uint8_t* out, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
-                     e1, e2, e2_stride, e2_windows, count, out, (const ModpConsts*)cs);
+                     e1, e2, e2_stride, e2_windows, count, out, 0, (uint32_t*)nullptr, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+// the two halves of the same product: mode 1 = g^e1 into p_m (Montgomery form), mode 2 = B2^e2 * p_m
+extern "C" int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride,
+                                               const uint8_t* e1, const uint8_t* e2, size_t e2_stride, int e2_windows,
+                                               int count, uint8_t* out, int mode, uint32_t* p_m, const void* cs,
+                                               hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
+                     e1, e2, e2_stride, e2_windows, count, out, mode, p_m, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }

@@ -8,10 +8,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include <mutex>
 #include <string>
 #include <vector>
 
+#include "host_modq.h"
 #include "modp_kernels.h"
 #include "sha256.h"
 
@@ -51,6 +54,17 @@ struct mpvss_ctx {
   std::mutex mu;
   // grow-only device workspace
   DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
+  DevBuf fd_flag, fd_seedpos, fd_exp, fd_cinv_be, fd_cinv_m, fd_seeds, fd_state, fd_xm, fd_scratch;   // forward differences
+  const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
+  bool fd_exp_ready = false;
+  const uint8_t* cm_src = nullptr;   // the caller's commitments of the current call (host or device, see cm_src_space)
+  int cm_src_space = MPVSS_HOST;
+  DevBuf fd_tabc, tab3, gr_m;   // X tables of a1 in two-stream mode; gr_m: g^r_i in Montgomery form (first half of
+                                // a1, computed before X is known)
+  hipStream_t stream_b = nullptr;                 // second stream: a2 runs beside the serial phases of the X path
+  hipStream_t stream_c = nullptr;                 // helper stream for small synchronous copies that must not wait for A/B
+  std::vector<uint8_t> cm_host, cinv_host;        // commitments and their inverses on the host (forward differences)
+  hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr;
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
   // pinned host staging
@@ -345,6 +359,13 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
     return MPVSS_E_DEVICE;
   }
   ctx->own_stream = true;
+  if (hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_seeds, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete ctx;
+    return MPVSS_E_DEVICE;
+  }
   if (modp_consts_upload(&ctx->consts) != 0) {
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -358,8 +379,11 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream_b) (void)hipStreamSynchronize(ctx->stream_b);
   for (DevBuf* b : {&ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->pos, &ctx->cm, &ctx->xbe,
-                    &ctx->out1, &ctx->out2, &ctx->tab1, &ctx->tab2, &ctx->tabg, &ctx->cbuf, &ctx->comb[0], &ctx->comb[1]})
+                    &ctx->out1, &ctx->out2, &ctx->tab1, &ctx->tab2, &ctx->tabg, &ctx->cbuf, &ctx->comb[0], &ctx->comb[1],
+                    &ctx->fd_flag, &ctx->fd_seedpos, &ctx->fd_exp, &ctx->fd_cinv_be, &ctx->fd_cinv_m, &ctx->fd_seeds,
+                    &ctx->fd_state, &ctx->fd_xm, &ctx->fd_scratch, &ctx->fd_tabc, &ctx->tab3, &ctx->gr_m})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&ctx->ecwork.a, &ctx->ecwork.b, &ctx->ecwork.c, &ctx->ecwork.d, &ctx->ecwork.e, &ctx->ecwork.pos,
                     &ctx->ecwork.cm, &ctx->ecwork.cmenc, &ctx->ecwork.x, &ctx->ecwork.o1, &ctx->ecwork.o2, &ctx->ecwork.ok,
@@ -374,6 +398,10 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream_b) { (void)hipStreamSynchronize(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_b); }
+  if (ctx->stream_c) (void)hipStreamDestroy(ctx->stream_c);
+  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_seeds, ctx->ev_join})
+    if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -502,6 +530,9 @@ namespace {
 int stage_commitments(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t) {
   const void* dc;
   RET_IF(stage_in(ctx, space, commitments, t * EB, ctx->cbuf, &dc));
+  ctx->cm_bytes_dev = (const uint8_t*)dc;
+  ctx->cm_src = commitments;
+  ctx->cm_src_space = space;
   RET_IF(ensure(ctx, ctx->cm, t * MODP_L * 4));
   LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)dc, (uint32_t*)ctx->cm.p, (int)t, ctx->consts, ctx->stream));
   return 0;
@@ -521,6 +552,116 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
   *dpos = (const int64_t*)d;
   return 0;
 }
+
+// ---- X_i for a run of shares: Horner's rule, or forward differences when the positions are consecutive -------
+// Forward differences need t seed values X(c..c+t-1) and their inverses per chain (computed by the Horner kernel,
+// the inverses as the same polynomial over the inverted commitments) and then cost ONE Montgomery product per
+// share and coefficient.  Whether the path applies (consecutive positions, every commitment invertible) is
+// decided ON THE DEVICE through a flag that gates the kernels, so the pipelined callers never synchronise.
+// MPVSS_FD=0 disables the path, MPVSS_FD_CHAINS overrides the number of chains.
+static int fd_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// does the forward-difference path apply to this run of shares?  (host-side part of the decision)
+bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
+  static const int fd_on = fd_env("MPVSS_FD", 1);
+  bool fd = fd_on && t >= 16 && t <= 256 && cnt >= 16 * t && cnt >= 8192;
+  if (fd && hpos) {                       // host positions: decide here; device positions are checked by a kernel
+    for (size_t i = 0; i < cnt && fd; ++i) fd = hpos[i] == hpos[0] + (int64_t)i;
+    fd = fd && hpos[0] >= 0 && hpos[0] < ((int64_t)1 << 61);
+  }
+  return fd;
+}
+
+int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX,
+           hipEvent_t after_seeds = nullptr) {
+  static const int fd_chains_env = fd_env("MPVSS_FD_CHAINS", 0);
+  const bool fd = fd_applies(t, hpos, cnt);
+  if (!fd) {
+    if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
+    TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
+                                                 ctx->consts, ctx->stream));
+    return 0;
+  }
+  // number of chains S: the seeds are 2*S*t Horner evaluations.  16384 of them are one wave per SIMD -- the
+  // cheapest the (latency-bound) seed launch gets -- and they must stay well below the cnt evaluations saved.
+  const int tpad = modp_fd_tpad((int)t);
+  const int cpw = 256 / tpad;
+  int S = fd_chains_env > 0 ? fd_chains_env : (int)(16384 / (2 * t));
+  const int s_max = (int)(cnt / (4 * t));
+  if (S > s_max) S = s_max;
+  S = (S / (4 * cpw)) * (4 * cpw);        // whole workgroups of chains, S*t a multiple of the 64 numbers per block
+  if (S < 4 * cpw) S = 4 * cpw;
+  const int chain_len = (int)((cnt + S - 1) / S);
+  const size_t seeds = (size_t)2 * S * t;
+
+  RET_IF(ensure(ctx, ctx->fd_flag, 64));
+  RET_IF(ensure(ctx, ctx->fd_seedpos, seeds * 8));
+  RET_IF(ensure(ctx, ctx->fd_exp, 256 * EB));
+  RET_IF(ensure(ctx, ctx->fd_cinv_be, t * EB));
+  RET_IF(ensure(ctx, ctx->fd_cinv_m, t * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->fd_seeds, seeds * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->fd_state, (size_t)S * t * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->fd_xm, cnt * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->fd_scratch, t * EB));
+  int* flag = (int*)ctx->fd_flag.p;
+  static const int one = 1;
+  HIPCHK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  RET_IF(span_begin(ctx, 0));
+  if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions(dpos, (int)cnt, flag, ctx->stream));
+  // inverted commitments: Montgomery's batch trick on the host (about a millisecond for t = 256; the same job on
+  // the device is a latency-bound 2048-bit exponentiation of ~20 ms).  A commitment that is 0 mod q has no
+  // inverse: then X is 0 for every share and Horner's rule handles it.
+  {
+    static const hostq::Field* field = nullptr;
+    if (!field) {
+      uint8_t qbe[EB];
+      for (size_t byte = 0; byte < EB; ++byte) {     // assemble q from its 28-bit limbs
+        unsigned v = 0;
+        for (int bit = 0; bit < 8; ++bit) {
+          const size_t b = byte * 8 + bit;
+          v |= ((MODP_N_LIMBS[b / 28] >> (b % 28)) & 1u) << bit;
+        }
+        qbe[EB - 1 - byte] = (uint8_t)v;
+      }
+      field = new hostq::Field(qbe);
+    }
+    ctx->cinv_host.resize(t * EB);
+    const uint8_t* src = ctx->cm_src;
+    if (ctx->cm_src_space == MPVSS_DEVICE) {
+      ctx->cm_host.resize(t * EB);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->cm_host.data(), ctx->cm_src, t * EB, hipMemcpyDeviceToHost, ctx->stream_c));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream_c));
+      src = ctx->cm_host.data();
+    }
+    if (!hostq::batch_invert(*field, src, t, ctx->cinv_host.data())) {
+      static const int zero = 0;
+      HIPCHK(ctx, hipMemcpyAsync(flag, &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->fd_cinv_be.p, ctx->cinv_host.data(), t * EB, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)ctx->fd_cinv_be.p, (uint32_t*)ctx->fd_cinv_m.p, (int)t, ctx->consts,
+                                       ctx->stream));
+  }
+  // seeds, difference tables, stepping, conversion -- all gated on flag == 1
+  LAUNCHCHK(ctx, modp_launch_fd_seed_positions(dpos, S, chain_len, (int)t, (int64_t*)ctx->fd_seedpos.p, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->cm.p, (const uint32_t*)ctx->fd_cinv_m.p, (int)(S * t),
+                                               (int)t, (const int64_t*)ctx->fd_seedpos.p, (int)seeds,
+                                               (uint32_t*)ctx->fd_seeds.p, nullptr, flag, 1, ctx->consts, ctx->stream));
+  if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_table((const uint32_t*)ctx->fd_seeds.p, S, (int)t, (uint32_t*)ctx->fd_state.p, flag,
+                                      ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)ctx->fd_state.p, S, (int)t, chain_len, (int)cnt,
+                                     (uint32_t*)ctx->fd_xm.p, flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_from_mont((const uint32_t*)ctx->fd_xm.p, (int)cnt, dX, flag, ctx->consts, ctx->stream));
+  // fallback: plain Horner when the flag was cleared
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->cm.p, (const uint32_t*)ctx->cm.p, 0x7fffffff, (int)t,
+                                               dpos, (int)cnt, nullptr, dX, flag, 0, ctx->consts, ctx->stream));
+  RET_IF(span_end(ctx));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
@@ -540,8 +681,7 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
     RET_IF(ensure(ctx, ctx->xbe, n * EB));
     dout = (uint8_t*)ctx->xbe.p;
   }
-  TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)n, nullptr, dout,
-                                               ctx->consts, ctx->stream));
+  RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions : nullptr, n, dout));
   if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, x_out, dout, n * EB));
   RET_IF(spans_collect(ctx));
   return MPVSS_OK;
@@ -553,10 +693,10 @@ namespace {
 // from b1_dev.  c: device pointer, stride c_stride (0 shared).
 int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, const uint8_t* b2_dev,
               const uint8_t* r_dev, const uint8_t* c_dev, size_t c_stride, int c_windows, size_t cnt,
-              uint8_t* out_dev, const uint32_t* comb_b1 = nullptr) {
+              uint8_t* out_dev, const uint32_t* comb_b1 = nullptr, DevBuf* t2buf = nullptr) {
   const uint32_t *t1, *t2;
   size_t s1 = TABW;
-  RET_IF(number_tables(ctx, b2_dev, cnt, ctx->tab2, &t2));
+  RET_IF(number_tables(ctx, b2_dev, cnt, t2buf ? *t2buf : ctx->tab2, &t2));
   if (comb_b1) {   // B1 is a generator with a comb table: no squarings for B1^r
     TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(comb_b1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt,
                                                    out_dev, ctx->consts, ctx->stream));
@@ -704,13 +844,61 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* dX = (uint8_t*)ctx->xbe.p;
     uint8_t* da1 = (uint8_t*)ctx->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->out2.p;
-    // X_i                                                  participant.rs:423-434
-    TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
-                                                 ctx->consts, ctx->stream));
-    // a1_i = g^r_i * X_i^c, a2_i = y_i^r_i * Y_i^c           dleq.rs:66-84
-    RET_IF(dleq_side(ctx, nullptr, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1, cg));
-    RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
-                     0, c_windows, cnt, da2));
+    const int64_t* hp = space == MPVSS_HOST ? positions + off : nullptr;
+    static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
+    if (two_streams && ctx->stream_b && fd_applies(t, hp, cnt)) {
+      // Two streams: the forward-difference X path has long phases that occupy few CUs (inverting the
+      // commitments, difference tables, stepping).  a2 = y^r Y^c does not depend on X, so it runs beside them:
+      // its first half from the start, its second half once the seed launch (which wants the whole GPU) is done.
+      RET_IF(ensure(ctx, ctx->tab1, cnt * TABW * 4));     // no reallocation while two streams are live
+      RET_IF(ensure(ctx, ctx->tab2, cnt * TABW * 4));
+      RET_IF(ensure(ctx, ctx->tab3, cnt * TABW * 4));
+      RET_IF(ensure(ctx, ctx->gr_m, cnt * MODP_L * 4));
+      // first part: what fits beside the (tiny) commitment inversion, so that the seed launch has the GPU to itself
+      static const int h1_percent = fd_env("MPVSS_A2_FIRST_PERCENT", 40);
+      const size_t h = ((cnt * (size_t)h1_percent / 100) / 64) * 64;
+      struct Swap {
+        mpvss_ctx* c; hipStream_t a;
+        Swap(mpvss_ctx* c_) : c(c_), a(c_->stream) { c->stream = c->stream_b; }
+        ~Swap() { c->stream = a; }
+      };
+      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
+      {
+        Swap sw(ctx);
+        RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
+                         0, c_windows, h, da2));
+      }
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, ctx->ev_seeds));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_seeds, 0));
+      {
+        Swap sw(ctx);
+        RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
+                         (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
+        // g^r_i needs only the responses: it runs here, beside the stepping phase, instead of after it
+        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
+                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->gr_m.p, ctx->consts,
+                                                             ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
+      }
+      // a1 = g^r * X^c: once X is known only X^c and one product remain
+      {
+        const uint32_t* tx;
+        RET_IF(number_tables(ctx, dX, cnt, ctx->tab3, &tx));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0,
+                                                             c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->gr_m.p,
+                                                             ctx->consts, ctx->stream));
+      }
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    } else {
+      // X_i                                                  participant.rs:423-434
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
+      // a1_i = g^r_i * X_i^c, a2_i = y_i^r_i * Y_i^c           dleq.rs:66-84
+      RET_IF(dleq_side(ctx, nullptr, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1, cg));
+      RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
+                       0, c_windows, cnt, da2));
+    }
     HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
@@ -911,8 +1099,7 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
         da1 = (uint8_t*)ctx->out1.p;
         da2 = (uint8_t*)ctx->out2.p;
       }
-      TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
-                                                   ctx->consts, ctx->stream));
+      RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions + off : nullptr, cnt, dX));
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:214-216)
       const uint32_t* ty;
       RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->tab1, &ty));

@@ -1,0 +1,53 @@
+"""Forward differences in the exponent (consecutive positions) must give exactly Horner's results."""
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+import mpvss_oracle as O
+from helpers import EB, cat, split
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = O.ModpGroup()
+Q = G.q
+
+
+def run(code, env_extra):
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+CODE = r'''
+import sys, random, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mpvss_oracle as O
+from mpvss_rs_amd import Engine
+G = O.ModpGroup(); Q = G.q
+fx = lambda v: v.to_bytes(256, "big")
+rng = random.Random(%d)
+t, n, p0 = %d, %d, %d
+cm = [pow(4, rng.randrange(Q - 1), Q) for _ in range(t)]
+%s
+eng = Engine(0)
+pos = list(range(p0, p0 + n))
+out = eng.commit_eval(b"".join(map(fx, cm)), pos)
+h = hashlib.sha256(out).hexdigest()
+# spot-check against the oracle
+for i in (0, 1, t - 1, t, n // 2, n - 1):
+    assert int.from_bytes(out[i * 256:(i + 1) * 256], "big") == O.commitment_eval(G, cm, pos[i]), i
+print(h)
+'''
+
+
+@pytest.mark.parametrize("t,n,p0,extra", [(16, 4096, 1, ""), (64, 8192, 1, ""), (33, 5000, 777, ""),
+                                           (256, 8192, 1, ""), (64, 8192, 1, "cm[5] = 0"), (64, 8192, 1, "cm[0] = Q")])
+def test_fd_equals_horner(t, n, p0, extra):
+    code = CODE % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), t * 1000 + n, t, n, p0, extra)
+    a = run(code, {"MPVSS_FD": "1"}).strip()
+    b = run(code, {"MPVSS_FD": "0"}).strip()
+    assert a == b and len(a) == 64
