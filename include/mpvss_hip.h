@@ -227,9 +227,13 @@ void mpvss_modp_hash_to_scalar(const uint8_t* data, size_t len, uint8_t out256[2
 /* ---- timing hooks for bench.py ------------------------------------------------------------ */
 
 /* Milliseconds the GPU spent in the kernels of the most recent compute call on this context,
- * measured with hipEvents on the engine's own stream (kernel id: 0 = commit_eval, 1 = dual_exp
- * launches summed, 2 = table builds summed).  Returns a negative value when unavailable. */
+ * measured with hipEvents on the stream each kernel was launched on, summed per kind:
+ *   0 = the X path (k_modp_commit_eval and, for consecutive positions, the forward-difference kernels),
+ *   1 = k_modp_comb_dual_exp (a1), 2 = table builds, 3 = k_modp_dual_exp (a2, batch_exp).
+ * Kernels of different kinds may overlap in time (two streams), so the sums can exceed the wall time.
+ * mpvss_last_kernel_launches gives the number of launches behind each sum.  Negative when unavailable. */
 double mpvss_last_kernel_ms(const mpvss_ctx* ctx, int kernel_id);
+int mpvss_last_kernel_launches(const mpvss_ctx* ctx, int kernel_id);
 
 #ifdef __cplusplus
 }

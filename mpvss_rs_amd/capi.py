@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
-    "mpvss_modp_extract_shares", "mpvss_ec_extract_shares",
+    "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
 )
 
 GROUP_SECP256K1 = 1
@@ -73,6 +73,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_hash_to_scalar.restype = None
     lib.mpvss_last_kernel_ms.argtypes = [vp, ci]
     lib.mpvss_last_kernel_ms.restype = C.c_double
+    lib.mpvss_last_kernel_launches.argtypes = [vp, ci]
     lib.mpvss_transcript_init.argtypes = [u8p]
     lib.mpvss_transcript_init.restype = None
     lib.mpvss_modp_verify_block_compute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p]
@@ -138,6 +139,9 @@ class Engine:
 
     def kernel_ms(self, kernel_id: int) -> float:
         return self.lib.mpvss_last_kernel_ms(self.ctx, kernel_id)
+
+    def kernel_launches(self, kernel_id: int) -> int:
+        return self.lib.mpvss_last_kernel_launches(self.ctx, kernel_id)
 
     # ---- Group ops
     def batch_mul(self, a: bytes, b: bytes) -> bytes:

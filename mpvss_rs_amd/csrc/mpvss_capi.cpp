@@ -64,14 +64,15 @@ struct mpvss_ctx {
   hipStream_t stream_b = nullptr;                 // second stream: a2 runs beside the serial phases of the X path
   hipStream_t stream_c = nullptr;                 // helper stream for small synchronous copies that must not wait for A/B
   std::vector<uint8_t> cm_host, cinv_host;        // commitments and their inverses on the host (forward differences)
-  hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr;
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
   // pinned host staging
   void* pin = nullptr;
   size_t pin_cap = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
-  double kernel_ms[3] = {-1, -1, -1};
+  double kernel_ms[4] = {-1, -1, -1, -1};   // 0 X path, 1 comb_dual_exp (a1), 2 table builds, 3 dual_exp (a2 / exp)
+  int kernel_launches[4] = {0, 0, 0, 0};
   struct Span { int id; hipEvent_t a, b; };
   struct SpanSet {
     std::vector<Span> spans;
@@ -90,7 +91,7 @@ struct mpvss_ctx {
     bool check_positions = false;
     hipEvent_t done = nullptr;
     SpanSet spans;
-    double kernel_ms[3] = {0, 0, 0};
+    double kernel_ms[4] = {0, 0, 0, 0};
   };
   static constexpr unsigned NSLOT = 4;
   BlockSlot slot[NSLOT];
@@ -196,12 +197,13 @@ void spans_reset(mpvss_ctx* ctx) {
   if (ctx->sp == &ctx->main_spans)
     for (double& m : ctx->kernel_ms) m = -1;
 }
-int spans_sum(mpvss_ctx* ctx, mpvss_ctx::SpanSet& ss, double out[3]) {
-  for (int i = 0; i < 3; ++i) out[i] = 0;
+int spans_sum(mpvss_ctx* ctx, mpvss_ctx::SpanSet& ss, double out[4]) {
+  for (int i = 0; i < 4; ++i) { out[i] = 0; ctx->kernel_launches[i] = 0; }
   for (auto& s : ss.spans) {
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, s.a, s.b));
     out[s.id] += ms;
+    ++ctx->kernel_launches[s.id];
   }
   return 0;
 }
@@ -332,7 +334,7 @@ int copy_out(mpvss_ctx* ctx, int space, void* dst, const void* dev_src, size_t b
 int exp_dev(mpvss_ctx* ctx, const uint8_t* bases_dev, const uint8_t* exps_dev, size_t count, uint8_t* out_dev) {
   const uint32_t* t1;
   RET_IF(number_tables(ctx, bases_dev, count, ctx->tab1, &t1));
-  TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(t1, TABW, t1, TABW, exps_dev, exps_dev, EB, 0, (int)count, out_dev,
+  TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, TABW, t1, TABW, exps_dev, exps_dev, EB, 0, (int)count, out_dev,
                                             ctx->consts, ctx->stream));
   return 0;
 }
@@ -362,7 +364,8 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
   if (hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_seeds, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_gr, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return MPVSS_E_DEVICE;
   }
@@ -400,7 +403,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_b) { (void)hipStreamSynchronize(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_b); }
   if (ctx->stream_c) (void)hipStreamDestroy(ctx->stream_c);
-  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_seeds, ctx->ev_join})
+  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_seeds, ctx->ev_join, ctx->ev_gr})
     if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
@@ -427,8 +430,13 @@ extern "C" int mpvss_ctx_synchronize(mpvss_ctx* ctx) {
 }
 
 extern "C" double mpvss_last_kernel_ms(const mpvss_ctx* ctx, int kernel_id) {
-  if (!ctx || kernel_id < 0 || kernel_id > 2) return -1;
+  if (!ctx || kernel_id < 0 || kernel_id > 3) return -1;
   return ctx->kernel_ms[kernel_id];
+}
+
+extern "C" int mpvss_last_kernel_launches(const mpvss_ctx* ctx, int kernel_id) {
+  if (!ctx || kernel_id < 0 || kernel_id > 3) return -1;
+  return ctx->kernel_launches[kernel_id];
 }
 
 extern "C" void mpvss_sha256(const uint8_t* data, size_t len, uint8_t out32[32]) { mpvss::sha256(data, len, out32); }
@@ -515,7 +523,7 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
                                                      dout, ctx->consts, ctx->stream));
     else
-      TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
+      TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
                                                 dout, ctx->consts, ctx->stream));
     if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out + off * EB, dout, cnt * EB));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -708,7 +716,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
   } else {
     RET_IF(number_tables(ctx, b1_dev, cnt, ctx->tab1, &t1));
   }
-  TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(t1, s1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt, out_dev,
+  TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, s1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt, out_dev,
                                             ctx->consts, ctx->stream));
   return 0;
 }
@@ -868,6 +876,11 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         Swap sw(ctx);
         RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
                          0, c_windows, h, da2));
+        // g^r_i needs only the responses: it runs here instead of after the stepping phase
+        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
+                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->gr_m.p, ctx->consts,
+                                                             ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_gr, ctx->stream));
       }
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, ctx->ev_seeds));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_seeds, 0));
@@ -875,17 +888,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         Swap sw(ctx);
         RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
                          (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
-        // g^r_i needs only the responses: it runs here, beside the stepping phase, instead of after it
-        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
-                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->gr_m.p, ctx->consts,
-                                                             ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
       }
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
         const uint32_t* tx;
         RET_IF(number_tables(ctx, dX, cnt, ctx->tab3, &tx));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gr, 0));
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0,
                                                              c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->gr_m.p,
                                                              ctx->consts, ctx->stream));
@@ -1103,9 +1112,9 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:214-216)
       const uint32_t* ty;
       RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->tab1, &ty));
-      TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0,
+      TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0,
                                                 (int)cnt, dY, ctx->consts, ctx->stream));
-      TIMED_LAUNCH(ctx, 1, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
+      TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
                                                 (int)cnt, da2, ctx->consts, ctx->stream));
       // a1 = g^w (dleq.rs:207-211)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
