@@ -52,19 +52,29 @@ struct mpvss_ctx {
   void* consts = nullptr;
   std::string err;
   std::mutex mu;
-  // grow-only device workspace
-  DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
-  DevBuf fd_flag, fd_seedpos, fd_exp, fd_cinv_be, fd_cinv_m, fd_seeds, fd_state, fd_xm, fd_scratch;   // forward differences
-  const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
-  bool fd_exp_ready = false;
-  const uint8_t* cm_src = nullptr;   // the caller's commitments of the current call (host or device, see cm_src_space)
-  int cm_src_space = MPVSS_HOST;
-  DevBuf fd_tabc, tab3, gr_m;   // X tables of a1 in two-stream mode; gr_m: g^r_i in Montgomery form (first half of
-                                // a1, computed before X is known)
-  hipStream_t stream_b = nullptr;                 // second stream: a2 runs beside the serial phases of the X path
+  // Device workspace of one call in flight (grow-only buffers, the stream pair and the events that order them).
+  // work0 serves the ordinary entry points; every verify-block slot has its own, so that several boxes can be in
+  // flight on the GPU at once (the serial phases of one box overlap the wide phases of the next).
+  struct Work {
+    DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
+    DevBuf fd_flag, fd_seedpos, fd_cinv_be, fd_cinv_m, fd_seeds, fd_state, fd_xm;   // forward differences
+    DevBuf fd_tabc, tab3, gr_m;   // X tables of a1 in two-stream mode; gr_m: g^r_i in Montgomery form
+    const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
+    const uint8_t* cm_src = nullptr;         // the caller's commitments (host or device, see cm_src_space)
+    int cm_src_space = MPVSS_HOST;
+    std::vector<uint8_t> cm_host, cinv_host; // commitments and their inverses on the host (forward differences)
+    hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
+    hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr;
+    bool ready = false;
+    std::vector<DevBuf*> all() {
+      return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
+              &fd_seedpos, &fd_cinv_be, &fd_cinv_m, &fd_seeds, &fd_state, &fd_xm, &fd_tabc, &tab3, &gr_m};
+    }
+  };
+  Work work0;
+  Work* w = &work0;                               // workspace of the call being enqueued
+  hipStream_t stream_b = nullptr;                 // second stream of the current workspace
   hipStream_t stream_c = nullptr;                 // helper stream for small synchronous copies that must not wait for A/B
-  std::vector<uint8_t> cm_host, cinv_host;        // commitments and their inverses on the host (forward differences)
-  hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr;
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
   // pinned host staging
@@ -92,6 +102,7 @@ struct mpvss_ctx {
     hipEvent_t done = nullptr;
     SpanSet spans;
     double kernel_ms[4] = {0, 0, 0, 0};
+    Work work;
   };
   static constexpr unsigned NSLOT = 4;
   BlockSlot slot[NSLOT];
@@ -135,6 +146,7 @@ int ensure(mpvss_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));
     HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -271,13 +283,13 @@ const uint8_t* g_bytes(int g) {
   return b[g];
 }
 
-// the shared 16-entry table of one base (host bytes) into ctx->tabg
+// the shared 16-entry table of one base (host bytes) into ctx->w->tabg
 int shared_table(mpvss_ctx* ctx, const uint8_t* base_host, const uint32_t** tab) {
-  RET_IF(ensure(ctx, ctx->tabg, TABW * 4 + EB));
-  uint8_t* dbase = (uint8_t*)ctx->tabg.p + TABW * 4;
+  RET_IF(ensure(ctx, ctx->w->tabg, TABW * 4 + EB));
+  uint8_t* dbase = (uint8_t*)ctx->w->tabg.p + TABW * 4;
   HIPCHK(ctx, hipMemcpyAsync(dbase, base_host, EB, hipMemcpyHostToDevice, ctx->stream));
-  TIMED_LAUNCH(ctx, 2, modp_launch_build_table(dbase, 1, (uint32_t*)ctx->tabg.p, ctx->consts, ctx->stream));
-  *tab = (const uint32_t*)ctx->tabg.p;
+  TIMED_LAUNCH(ctx, 2, modp_launch_build_table(dbase, 1, (uint32_t*)ctx->w->tabg.p, ctx->consts, ctx->stream));
+  *tab = (const uint32_t*)ctx->w->tabg.p;
   return 0;
 }
 
@@ -297,6 +309,7 @@ int comb_table(mpvss_ctx* ctx, int gid, const uint32_t** comb) {
     uint8_t* dbase = (uint8_t*)ctx->comb[gid].p + (size_t)MODP_COMB_WORDS * 4;
     HIPCHK(ctx, hipMemcpyAsync(dbase, g_bytes(gid), EB, hipMemcpyHostToDevice, ctx->stream));
     LAUNCHCHK(ctx, modp_launch_comb_build(dbase, (uint32_t*)ctx->comb[gid].p, ctx->consts, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // once per context: the table is shared by every stream
     ctx->comb_ready[gid] = true;
   }
   *comb = (const uint32_t*)ctx->comb[gid].p;
@@ -333,7 +346,7 @@ int copy_out(mpvss_ctx* ctx, int space, void* dst, const void* dev_src, size_t b
 // out = B^e (count numbers); bases/exps device pointers; uses tab1
 int exp_dev(mpvss_ctx* ctx, const uint8_t* bases_dev, const uint8_t* exps_dev, size_t count, uint8_t* out_dev) {
   const uint32_t* t1;
-  RET_IF(number_tables(ctx, bases_dev, count, ctx->tab1, &t1));
+  RET_IF(number_tables(ctx, bases_dev, count, ctx->w->tab1, &t1));
   TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, TABW, t1, TABW, exps_dev, exps_dev, EB, 0, (int)count, out_dev,
                                             ctx->consts, ctx->stream));
   return 0;
@@ -349,6 +362,33 @@ extern "C" int mpvss_device_count(void) {
   return n;
 }
 
+namespace {
+// streams and ordering events of one workspace (created on first use)
+int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
+  if (w.ready) return 0;
+  if (main_stream) {
+    w.sa = main_stream;
+  } else {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&w.sa, hipStreamNonBlocking));
+  }
+  HIPCHK(ctx, hipStreamCreateWithFlags(&w.sb, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&w.ev_fork, &w.ev_seeds, &w.ev_join, &w.ev_gr})
+    HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  w.ready = true;
+  return 0;
+}
+void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
+  if (w.sa) (void)hipStreamSynchronize(w.sa);
+  if (w.sb) (void)hipStreamSynchronize(w.sb);
+  for (DevBuf* b : w.all())
+    if (b->p) (void)hipFree(b->p);
+  for (hipEvent_t e : {w.ev_fork, w.ev_seeds, w.ev_join, w.ev_gr})
+    if (e) (void)hipEventDestroy(e);
+  if (w.sb) (void)hipStreamDestroy(w.sb);
+  if (w.sa && owns_sa) (void)hipStreamDestroy(w.sa);
+}
+}  // namespace
+
 extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
   if (!out) return MPVSS_E_INVALID;
   *out = nullptr;
@@ -361,19 +401,13 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
     return MPVSS_E_DEVICE;
   }
   ctx->own_stream = true;
-  if (hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_seeds, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_gr, hipEventDisableTiming) != hipSuccess) {
+  if (work_init(ctx, ctx->work0, ctx->stream) != 0 ||
+      hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking) != hipSuccess ||
+      modp_consts_upload(&ctx->consts) != 0) {
     delete ctx;
     return MPVSS_E_DEVICE;
   }
-  if (modp_consts_upload(&ctx->consts) != 0) {
-    (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-    return MPVSS_E_DEVICE;
-  }
+  ctx->stream_b = ctx->work0.sb;
   *out = ctx;
   return MPVSS_OK;
 }
@@ -381,12 +415,9 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
 extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->stream_b) (void)hipStreamSynchronize(ctx->stream_b);
-  for (DevBuf* b : {&ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->pos, &ctx->cm, &ctx->xbe,
-                    &ctx->out1, &ctx->out2, &ctx->tab1, &ctx->tab2, &ctx->tabg, &ctx->cbuf, &ctx->comb[0], &ctx->comb[1],
-                    &ctx->fd_flag, &ctx->fd_seedpos, &ctx->fd_exp, &ctx->fd_cinv_be, &ctx->fd_cinv_m, &ctx->fd_seeds,
-                    &ctx->fd_state, &ctx->fd_xm, &ctx->fd_scratch, &ctx->fd_tabc, &ctx->tab3, &ctx->gr_m})
+  for (auto& sl : ctx->slot) work_destroy(sl.work, true);
+  work_destroy(ctx->work0, ctx->own_stream);
+  for (DevBuf* b : {&ctx->comb[0], &ctx->comb[1]})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&ctx->ecwork.a, &ctx->ecwork.b, &ctx->ecwork.c, &ctx->ecwork.d, &ctx->ecwork.e, &ctx->ecwork.pos,
                     &ctx->ecwork.cm, &ctx->ecwork.cmenc, &ctx->ecwork.x, &ctx->ecwork.o1, &ctx->ecwork.o2, &ctx->ecwork.ok,
@@ -400,11 +431,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
   }
-  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-  if (ctx->stream_b) { (void)hipStreamSynchronize(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_b); }
   if (ctx->stream_c) (void)hipStreamDestroy(ctx->stream_c);
-  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_seeds, ctx->ev_join, ctx->ev_gr})
-    if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -417,6 +444,7 @@ extern "C" int mpvss_ctx_set_stream(mpvss_ctx* ctx, void* hip_stream) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   ctx->stream = (hipStream_t)hip_stream;
+  ctx->work0.sa = ctx->stream;
   ctx->own_stream = false;
   return MPVSS_OK;
 }
@@ -426,6 +454,12 @@ extern "C" int mpvss_ctx_synchronize(mpvss_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->work0.sb));
+  for (auto& sl : ctx->slot)
+    if (sl.work.ready) {
+      HIPCHK(ctx, hipStreamSynchronize(sl.work.sa));
+      HIPCHK(ctx, hipStreamSynchronize(sl.work.sb));
+    }
   return MPVSS_OK;
 }
 
@@ -456,12 +490,12 @@ extern "C" int mpvss_modp_batch_mul(mpvss_ctx* ctx, int space, const uint8_t* a,
   HIPCHK(ctx, hipSetDevice(ctx->device));
   spans_reset(ctx);
   const void *da, *db;
-  RET_IF(stage_in(ctx, space, a, n * EB, ctx->in_a, &da));
-  RET_IF(stage_in(ctx, space, b, n * EB, ctx->in_b, &db));
+  RET_IF(stage_in(ctx, space, a, n * EB, ctx->w->in_a, &da));
+  RET_IF(stage_in(ctx, space, b, n * EB, ctx->w->in_b, &db));
   uint8_t* dout = out;
   if (space == MPVSS_HOST) {
-    RET_IF(ensure(ctx, ctx->out1, n * EB));
-    dout = (uint8_t*)ctx->out1.p;
+    RET_IF(ensure(ctx, ctx->w->out1, n * EB));
+    dout = (uint8_t*)ctx->w->out1.p;
   }
   LAUNCHCHK(ctx, modp_launch_mul((const uint8_t*)da, (const uint8_t*)db, dout, (int)n, ctx->consts, ctx->stream));
   if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out, dout, n * EB));
@@ -481,12 +515,12 @@ extern "C" int mpvss_modp_batch_exp(mpvss_ctx* ctx, int space, const uint8_t* ba
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void *db, *de;
-    RET_IF(stage_in(ctx, space, bases + off * EB, cnt * EB, ctx->in_a, &db));
-    RET_IF(stage_in(ctx, space, exps + off * EB, cnt * EB, ctx->in_b, &de));
+    RET_IF(stage_in(ctx, space, bases + off * EB, cnt * EB, ctx->w->in_a, &db));
+    RET_IF(stage_in(ctx, space, exps + off * EB, cnt * EB, ctx->w->in_b, &de));
     uint8_t* dout = out + off * EB;
     if (space == MPVSS_HOST) {
-      RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-      dout = (uint8_t*)ctx->out1.p;
+      RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+      dout = (uint8_t*)ctx->w->out1.p;
     }
     RET_IF(exp_dev(ctx, (const uint8_t*)db, (const uint8_t*)de, cnt, dout));
     if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out + off * EB, dout, cnt * EB));
@@ -513,11 +547,11 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void* de;
-    RET_IF(stage_in(ctx, space, exps + off * EB, cnt * EB, ctx->in_b, &de));
+    RET_IF(stage_in(ctx, space, exps + off * EB, cnt * EB, ctx->w->in_b, &de));
     uint8_t* dout = out + off * EB;
     if (space == MPVSS_HOST) {
-      RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-      dout = (uint8_t*)ctx->out1.p;
+      RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+      dout = (uint8_t*)ctx->w->out1.p;
     }
     if (cg)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
@@ -534,15 +568,15 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
 
 // ---- commitment multi-exp -----------------------------------------------------------------------
 namespace {
-// commitments (space) -> Montgomery limbs in ctx->cm
+// commitments (space) -> Montgomery limbs in ctx->w->cm
 int stage_commitments(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t) {
   const void* dc;
-  RET_IF(stage_in(ctx, space, commitments, t * EB, ctx->cbuf, &dc));
-  ctx->cm_bytes_dev = (const uint8_t*)dc;
-  ctx->cm_src = commitments;
-  ctx->cm_src_space = space;
-  RET_IF(ensure(ctx, ctx->cm, t * MODP_L * 4));
-  LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)dc, (uint32_t*)ctx->cm.p, (int)t, ctx->consts, ctx->stream));
+  RET_IF(stage_in(ctx, space, commitments, t * EB, ctx->w->cbuf, &dc));
+  ctx->w->cm_bytes_dev = (const uint8_t*)dc;
+  ctx->w->cm_src = commitments;
+  ctx->w->cm_src_space = space;
+  RET_IF(ensure(ctx, ctx->w->cm, t * MODP_L * 4));
+  LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)dc, (uint32_t*)ctx->w->cm.p, (int)t, ctx->consts, ctx->stream));
   return 0;
 }
 
@@ -556,7 +590,7 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
     RET_IF(check_positions_host(ctx, tmp.data(), n));
   }
   const void* d;
-  RET_IF(stage_in(ctx, space, positions, n * 8, ctx->pos, &d));
+  RET_IF(stage_in(ctx, space, positions, n * 8, ctx->w->pos, &d));
   *dpos = (const int64_t*)d;
   return 0;
 }
@@ -589,7 +623,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   const bool fd = fd_applies(t, hpos, cnt);
   if (!fd) {
     if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
-    TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
+    TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->w->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
                                                  ctx->consts, ctx->stream));
     return 0;
   }
@@ -605,16 +639,14 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   const int chain_len = (int)((cnt + S - 1) / S);
   const size_t seeds = (size_t)2 * S * t;
 
-  RET_IF(ensure(ctx, ctx->fd_flag, 64));
-  RET_IF(ensure(ctx, ctx->fd_seedpos, seeds * 8));
-  RET_IF(ensure(ctx, ctx->fd_exp, 256 * EB));
-  RET_IF(ensure(ctx, ctx->fd_cinv_be, t * EB));
-  RET_IF(ensure(ctx, ctx->fd_cinv_m, t * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->fd_seeds, seeds * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->fd_state, (size_t)S * t * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->fd_xm, cnt * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->fd_scratch, t * EB));
-  int* flag = (int*)ctx->fd_flag.p;
+  RET_IF(ensure(ctx, ctx->w->fd_flag, 64));
+  RET_IF(ensure(ctx, ctx->w->fd_seedpos, seeds * 8));
+  RET_IF(ensure(ctx, ctx->w->fd_cinv_be, t * EB));
+  RET_IF(ensure(ctx, ctx->w->fd_cinv_m, t * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->w->fd_seeds, seeds * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->w->fd_state, (size_t)S * t * MODP_L * 4));
+  RET_IF(ensure(ctx, ctx->w->fd_xm, cnt * MODP_L * 4));
+  int* flag = (int*)ctx->w->fd_flag.p;
   static const int one = 1;
   HIPCHK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
@@ -636,35 +668,35 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
       }
       field = new hostq::Field(qbe);
     }
-    ctx->cinv_host.resize(t * EB);
-    const uint8_t* src = ctx->cm_src;
-    if (ctx->cm_src_space == MPVSS_DEVICE) {
-      ctx->cm_host.resize(t * EB);
-      HIPCHK(ctx, hipMemcpyAsync(ctx->cm_host.data(), ctx->cm_src, t * EB, hipMemcpyDeviceToHost, ctx->stream_c));
+    ctx->w->cinv_host.resize(t * EB);
+    const uint8_t* src = ctx->w->cm_src;
+    if (ctx->w->cm_src_space == MPVSS_DEVICE) {
+      ctx->w->cm_host.resize(t * EB);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->w->cm_host.data(), ctx->w->cm_src, t * EB, hipMemcpyDeviceToHost, ctx->stream_c));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream_c));
-      src = ctx->cm_host.data();
+      src = ctx->w->cm_host.data();
     }
-    if (!hostq::batch_invert(*field, src, t, ctx->cinv_host.data())) {
+    if (!hostq::batch_invert(*field, src, t, ctx->w->cinv_host.data())) {
       static const int zero = 0;
       HIPCHK(ctx, hipMemcpyAsync(flag, &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->fd_cinv_be.p, ctx->cinv_host.data(), t * EB, hipMemcpyHostToDevice, ctx->stream));
-    LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)ctx->fd_cinv_be.p, (uint32_t*)ctx->fd_cinv_m.p, (int)t, ctx->consts,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->fd_cinv_be.p, ctx->w->cinv_host.data(), t * EB, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)ctx->w->fd_cinv_be.p, (uint32_t*)ctx->w->fd_cinv_m.p, (int)t, ctx->consts,
                                        ctx->stream));
   }
   // seeds, difference tables, stepping, conversion -- all gated on flag == 1
-  LAUNCHCHK(ctx, modp_launch_fd_seed_positions(dpos, S, chain_len, (int)t, (int64_t*)ctx->fd_seedpos.p, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->cm.p, (const uint32_t*)ctx->fd_cinv_m.p, (int)(S * t),
-                                               (int)t, (const int64_t*)ctx->fd_seedpos.p, (int)seeds,
-                                               (uint32_t*)ctx->fd_seeds.p, nullptr, flag, 1, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_seed_positions(dpos, S, chain_len, (int)t, (int64_t*)ctx->w->fd_seedpos.p, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->w->cm.p, (const uint32_t*)ctx->w->fd_cinv_m.p, (int)(S * t),
+                                               (int)t, (const int64_t*)ctx->w->fd_seedpos.p, (int)seeds,
+                                               (uint32_t*)ctx->w->fd_seeds.p, nullptr, flag, 1, ctx->consts, ctx->stream));
   if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_table((const uint32_t*)ctx->fd_seeds.p, S, (int)t, (uint32_t*)ctx->fd_state.p, flag,
+  LAUNCHCHK(ctx, modp_launch_fd_table((const uint32_t*)ctx->w->fd_seeds.p, S, (int)t, (uint32_t*)ctx->w->fd_state.p, flag,
                                       ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)ctx->fd_state.p, S, (int)t, chain_len, (int)cnt,
-                                     (uint32_t*)ctx->fd_xm.p, flag, ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_from_mont((const uint32_t*)ctx->fd_xm.p, (int)cnt, dX, flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)ctx->w->fd_state.p, S, (int)t, chain_len, (int)cnt,
+                                     (uint32_t*)ctx->w->fd_xm.p, flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_from_mont((const uint32_t*)ctx->w->fd_xm.p, (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->cm.p, (const uint32_t*)ctx->cm.p, 0x7fffffff, (int)t,
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->w->cm.p, (const uint32_t*)ctx->w->cm.p, 0x7fffffff, (int)t,
                                                dpos, (int)cnt, nullptr, dX, flag, 0, ctx->consts, ctx->stream));
   RET_IF(span_end(ctx));
   return 0;
@@ -686,8 +718,8 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
   RET_IF(stage_positions(ctx, space, positions, n, &dpos));
   uint8_t* dout = x_out;
   if (space == MPVSS_HOST) {
-    RET_IF(ensure(ctx, ctx->xbe, n * EB));
-    dout = (uint8_t*)ctx->xbe.p;
+    RET_IF(ensure(ctx, ctx->w->xbe, n * EB));
+    dout = (uint8_t*)ctx->w->xbe.p;
   }
   RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions : nullptr, n, dout));
   if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, x_out, dout, n * EB));
@@ -704,7 +736,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
               uint8_t* out_dev, const uint32_t* comb_b1 = nullptr, DevBuf* t2buf = nullptr) {
   const uint32_t *t1, *t2;
   size_t s1 = TABW;
-  RET_IF(number_tables(ctx, b2_dev, cnt, t2buf ? *t2buf : ctx->tab2, &t2));
+  RET_IF(number_tables(ctx, b2_dev, cnt, t2buf ? *t2buf : ctx->w->tab2, &t2));
   if (comb_b1) {   // B1 is a generator with a comb table: no squarings for B1^r
     TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(comb_b1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt,
                                                    out_dev, ctx->consts, ctx->stream));
@@ -714,7 +746,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
     t1 = shared_b1;
     s1 = 0;
   } else {
-    RET_IF(number_tables(ctx, b1_dev, cnt, ctx->tab1, &t1));
+    RET_IF(number_tables(ctx, b1_dev, cnt, ctx->w->tab1, &t1));
   }
   TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, s1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt, out_dev,
                                             ctx->consts, ctx->stream));
@@ -741,20 +773,20 @@ extern "C" int mpvss_modp_dleq_commitments(mpvss_ctx* ctx, int space, const uint
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void *dh1, *dg2, *dh2, *dr, *dc;
-    RET_IF(stage_in(ctx, space, h1 + off * EB, cnt * EB, ctx->in_a, &dh1));
-    RET_IF(stage_in(ctx, space, g2 + off * EB, cnt * EB, ctx->in_b, &dg2));
-    RET_IF(stage_in(ctx, space, h2 + off * EB, cnt * EB, ctx->in_c, &dh2));
-    RET_IF(stage_in(ctx, space, r + off * EB, cnt * EB, ctx->in_d, &dr));
+    RET_IF(stage_in(ctx, space, h1 + off * EB, cnt * EB, ctx->w->in_a, &dh1));
+    RET_IF(stage_in(ctx, space, g2 + off * EB, cnt * EB, ctx->w->in_b, &dg2));
+    RET_IF(stage_in(ctx, space, h2 + off * EB, cnt * EB, ctx->w->in_c, &dh2));
+    RET_IF(stage_in(ctx, space, r + off * EB, cnt * EB, ctx->w->in_d, &dr));
     if (c_per_share)
-      RET_IF(stage_in(ctx, space, c + off * EB, cnt * EB, ctx->in_e, &dc));
+      RET_IF(stage_in(ctx, space, c + off * EB, cnt * EB, ctx->w->in_e, &dc));
     else
-      RET_IF(stage_in(ctx, MPVSS_HOST, c, EB, ctx->in_e, &dc));
+      RET_IF(stage_in(ctx, MPVSS_HOST, c, EB, ctx->w->in_e, &dc));
     uint8_t *d1 = a1_out + off * EB, *d2 = a2_out + off * EB;
     if (space == MPVSS_HOST) {
-      RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-      RET_IF(ensure(ctx, ctx->out2, cnt * EB));
-      d1 = (uint8_t*)ctx->out1.p;
-      d2 = (uint8_t*)ctx->out2.p;
+      RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+      RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
+      d1 = (uint8_t*)ctx->w->out1.p;
+      d2 = (uint8_t*)ctx->w->out2.p;
     }
     const size_t cs = c_per_share ? EB : 0;
     int cw = 64;   // a 256-bit challenge only touches the low 64 windows
@@ -805,10 +837,16 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     ++ctx->head;
     return MPVSS_OK;
   }
+  // this block runs in its slot's own workspace and stream pair, so that boxes overlap on the GPU
+  RET_IF(work_init(ctx, sl.work, nullptr));
   struct Restore {
     mpvss_ctx* c;
-    ~Restore() { c->sp = &c->main_spans; }
-  } restore{ctx};
+    hipStream_t a, b;
+    ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
+  } restore{ctx, ctx->stream, ctx->stream_b};
+  ctx->w = &sl.work;
+  ctx->stream = sl.work.sa;
+  ctx->stream_b = sl.work.sb;
   ctx->sp = &sl.spans;
   spans_reset(ctx);
   const size_t need = n * EB * 4 + n * 8;
@@ -824,7 +862,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   const uint32_t* cg;
   RET_IF(comb_table(ctx, 0, &cg));
   const void* dchal;
-  RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->in_e, &dchal));
+  RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->w->in_e, &dchal));
   const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
   uint8_t* hX = (uint8_t*)sl.pin;
   uint8_t* hY = hX + n * EB;
@@ -843,25 +881,25 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       sl.check_positions = true;
     }
     const void *dy, *dY, *dr;
-    RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->in_a, &dy));
-    RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->in_b, &dY));
-    RET_IF(stage_in(ctx, space, responses + off * EB, cnt * EB, ctx->in_c, &dr));
-    RET_IF(ensure(ctx, ctx->xbe, cnt * EB));
-    RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-    RET_IF(ensure(ctx, ctx->out2, cnt * EB));
-    uint8_t* dX = (uint8_t*)ctx->xbe.p;
-    uint8_t* da1 = (uint8_t*)ctx->out1.p;
-    uint8_t* da2 = (uint8_t*)ctx->out2.p;
+    RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
+    RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->w->in_b, &dY));
+    RET_IF(stage_in(ctx, space, responses + off * EB, cnt * EB, ctx->w->in_c, &dr));
+    RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
+    uint8_t* dX = (uint8_t*)ctx->w->xbe.p;
+    uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
+    uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     const int64_t* hp = space == MPVSS_HOST ? positions + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
     if (two_streams && ctx->stream_b && fd_applies(t, hp, cnt)) {
       // Two streams: the forward-difference X path has long phases that occupy few CUs (inverting the
       // commitments, difference tables, stepping).  a2 = y^r Y^c does not depend on X, so it runs beside them:
       // its first half from the start, its second half once the seed launch (which wants the whole GPU) is done.
-      RET_IF(ensure(ctx, ctx->tab1, cnt * TABW * 4));     // no reallocation while two streams are live
-      RET_IF(ensure(ctx, ctx->tab2, cnt * TABW * 4));
-      RET_IF(ensure(ctx, ctx->tab3, cnt * TABW * 4));
-      RET_IF(ensure(ctx, ctx->gr_m, cnt * MODP_L * 4));
+      RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4));     // no reallocation while two streams are live
+      RET_IF(ensure(ctx, ctx->w->tab2, cnt * TABW * 4));
+      RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
+      RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
       // first part: what fits beside the (tiny) commitment inversion, so that the seed launch has the GPU to itself
       static const int h1_percent = fd_env("MPVSS_A2_FIRST_PERCENT", 40);
       const size_t h = ((cnt * (size_t)h1_percent / 100) / 64) * 64;
@@ -870,36 +908,36 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         Swap(mpvss_ctx* c_) : c(c_), a(c_->stream) { c->stream = c->stream_b; }
         ~Swap() { c->stream = a; }
       };
-      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
+      HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_fork, 0));
       {
         Swap sw(ctx);
         RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
                          0, c_windows, h, da2));
         // g^r_i needs only the responses: it runs here instead of after the stepping phase
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
-                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->gr_m.p, ctx->consts,
+                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
                                                              ctx->stream));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_gr, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
-      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, ctx->ev_seeds));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_seeds, 0));
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, ctx->w->ev_seeds));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_seeds, 0));
       {
         Swap sw(ctx);
         RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
                          (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_join, ctx->stream));
       }
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
         const uint32_t* tx;
-        RET_IF(number_tables(ctx, dX, cnt, ctx->tab3, &tx));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gr, 0));
+        RET_IF(number_tables(ctx, dX, cnt, ctx->w->tab3, &tx));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_gr, 0));
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0,
-                                                             c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->gr_m.p,
+                                                             c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                              ctx->consts, ctx->stream));
       }
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_join, 0));
     } else {
       // X_i                                                  participant.rs:423-434
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
@@ -1034,15 +1072,15 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
     for (size_t i = 0; i < cnt && small; ++i) small = fits_256_bits(hc.data() + i * EB);
     const int c_windows = small ? 64 : 512;
     const void *dpk, *ds, *dy, *dc, *dr;
-    RET_IF(stage_in(ctx, space, pk + off * EB, cnt * EB, ctx->in_a, &dpk));
-    RET_IF(stage_in(ctx, space, s + off * EB, cnt * EB, ctx->in_b, &ds));
-    RET_IF(stage_in(ctx, space, y + off * EB, cnt * EB, ctx->in_c, &dy));
-    RET_IF(stage_in(ctx, space, r + off * EB, cnt * EB, ctx->in_d, &dr));
-    RET_IF(stage_in(ctx, space, c + off * EB, cnt * EB, ctx->in_e, &dc));
-    RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-    RET_IF(ensure(ctx, ctx->out2, cnt * EB));
-    uint8_t* da1 = (uint8_t*)ctx->out1.p;
-    uint8_t* da2 = (uint8_t*)ctx->out2.p;
+    RET_IF(stage_in(ctx, space, pk + off * EB, cnt * EB, ctx->w->in_a, &dpk));
+    RET_IF(stage_in(ctx, space, s + off * EB, cnt * EB, ctx->w->in_b, &ds));
+    RET_IF(stage_in(ctx, space, y + off * EB, cnt * EB, ctx->w->in_c, &dy));
+    RET_IF(stage_in(ctx, space, r + off * EB, cnt * EB, ctx->w->in_d, &dr));
+    RET_IF(stage_in(ctx, space, c + off * EB, cnt * EB, ctx->w->in_e, &dc));
+    RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
+    uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
+    uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     // a1 = G^r * pk^c ; a2 = S^r * Y^c                       dleq.rs:66-84 via participant.rs:376-385
     RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB,
                      c_windows, cnt, da1, cG));
@@ -1094,24 +1132,24 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
       const int64_t* dpos;
       RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
       const void *dy, *dp, *dw;
-      RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->in_a, &dy));
-      RET_IF(stage_in(ctx, space, p_values + off * EB, cnt * EB, ctx->in_b, &dp));
-      RET_IF(stage_in(ctx, space, witnesses + off * EB, cnt * EB, ctx->in_c, &dw));
+      RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
+      RET_IF(stage_in(ctx, space, p_values + off * EB, cnt * EB, ctx->w->in_b, &dp));
+      RET_IF(stage_in(ctx, space, witnesses + off * EB, cnt * EB, ctx->w->in_c, &dw));
       uint8_t *dX = x_out + off * EB, *dY = y_out + off * EB, *da1 = a1_out + off * EB, *da2 = a2_out + off * EB;
       if (space == MPVSS_HOST) {
-        RET_IF(ensure(ctx, ctx->xbe, cnt * EB));
-        RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-        RET_IF(ensure(ctx, ctx->out2, cnt * EB));
-        RET_IF(ensure(ctx, ctx->in_d, cnt * EB));
-        dX = (uint8_t*)ctx->xbe.p;
-        dY = (uint8_t*)ctx->in_d.p;
-        da1 = (uint8_t*)ctx->out1.p;
-        da2 = (uint8_t*)ctx->out2.p;
+        RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
+        RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+        RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
+        RET_IF(ensure(ctx, ctx->w->in_d, cnt * EB));
+        dX = (uint8_t*)ctx->w->xbe.p;
+        dY = (uint8_t*)ctx->w->in_d.p;
+        da1 = (uint8_t*)ctx->w->out1.p;
+        da2 = (uint8_t*)ctx->w->out2.p;
       }
       RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions + off : nullptr, cnt, dX));
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:214-216)
       const uint32_t* ty;
-      RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->tab1, &ty));
+      RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->w->tab1, &ty));
       TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0,
                                                 (int)cnt, dY, ctx->consts, ctx->stream));
       TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
@@ -1169,18 +1207,18 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void *dy, *dxi, *dw;
-    RET_IF(stage_in(ctx, space, y + off * EB, cnt * EB, ctx->in_a, &dy));
-    RET_IF(stage_in(ctx, space, xinv + off * EB, cnt * EB, ctx->in_b, &dxi));
-    RET_IF(stage_in(ctx, space, w + off * EB, cnt * EB, ctx->in_c, &dw));
+    RET_IF(stage_in(ctx, space, y + off * EB, cnt * EB, ctx->w->in_a, &dy));
+    RET_IF(stage_in(ctx, space, xinv + off * EB, cnt * EB, ctx->w->in_b, &dxi));
+    RET_IF(stage_in(ctx, space, w + off * EB, cnt * EB, ctx->w->in_c, &dw));
     uint8_t* dS = s_out + off * EB;
     if (space == MPVSS_HOST) {
-      RET_IF(ensure(ctx, ctx->xbe, cnt * EB));
-      dS = (uint8_t*)ctx->xbe.p;
+      RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
+      dS = (uint8_t*)ctx->w->xbe.p;
     }
-    RET_IF(ensure(ctx, ctx->out1, cnt * EB));
-    RET_IF(ensure(ctx, ctx->out2, cnt * EB));
-    uint8_t* da1 = (uint8_t*)ctx->out1.p;
-    uint8_t* da2 = (uint8_t*)ctx->out2.p;
+    RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
+    uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
+    uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     RET_IF(exp_dev(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, cnt, dS));                       // S = Y^(1/x)
     TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
                                                    da1, ctx->consts, ctx->stream));                // a1 = G^w
