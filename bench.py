@@ -211,7 +211,7 @@ def main():
         raw = bytes(out.cpu().numpy().tobytes())
         return bool(raw[0]), raw[1:33]
 
-    def run_steps(k, depth=3):
+    def run_steps(k, depth=int(os.environ.get("MPVSS_BENCH_DEPTH", "3"))):
         """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
         enqueued while the host (and, on several GPUs, the rank-to-rank hash chain) finishes older ones."""
         results = []

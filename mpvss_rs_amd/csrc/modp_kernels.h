@@ -35,12 +35,14 @@ int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_t* cm_b, in
                                   hipStream_t s);
 int modp_fd_tpad(int t);
 int modp_launch_fd_check_positions(const int64_t* positions, int count, int* flag, hipStream_t s);
-int modp_launch_fd_seed_positions(const int64_t* positions, int chains, int chain_len, int t, int64_t* seedpos,
-                                  hipStream_t s);
-int modp_launch_fd_check_inverses(const uint32_t* cm, const uint32_t* cminv, int t, int* flag, uint8_t* scratch_be,
-                                  const void* cs, hipStream_t s);
-int modp_launch_fd_table(const uint32_t* seeds, int chains, int t, uint32_t* state, const int* gate, const void* cs,
-                         hipStream_t s);
+/* simultaneous inversion of m Montgomery-form numbers: one level up / down of the product tree (groups of G) */
+int modp_launch_binv_up(const uint32_t* a, int m, int G, uint32_t* prefix, uint32_t* totals, const int* gate,
+                        const void* cs, hipStream_t s);
+int modp_launch_binv_down(const uint32_t* a, const uint32_t* prefix, const uint32_t* tot_inv, int m, int G,
+                          uint32_t* a_inv, const int* gate, const void* cs, hipStream_t s);
+int modp_launch_fd_apply_ok(const int* ok, int* flag, hipStream_t s);
+int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state, const int* gate,
+                         const void* cs, hipStream_t s);
 int modp_launch_fd_step(const uint32_t* state, int chains, int t, int chain_len, int count, uint32_t* x_m,
                         const int* gate, const void* cs, hipStream_t s);
 int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,

@@ -317,43 +317,93 @@ extern "C" __global__ void k_modp_fd_check_positions(const int64_t* __restrict__
   if (!ok) atomicAnd(flag, 0);
 }
 
-// seedpos[(set * chains + s) * t + k] = positions[0] + s * chain_len + k
-extern "C" __global__ void k_modp_fd_seed_positions(const int64_t* __restrict__ positions, int chains, int chain_len,
-                                                     int t, int64_t* __restrict__ seedpos) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * chains * t) return;
-  const int k = i % t, s = (i / t) % chains;
-  seedpos[i] = positions[0] + (int64_t)s * chain_len + k;
-}
-
-// every commitment must be invertible: prod[j] = C_j * C_j^-1 must be 1, otherwise clear the flag
+// ---- simultaneous inversion (Montgomery's trick) of m numbers in Montgomery form ----------------------
+// One quad per group of G consecutive numbers.  up: prefix[i] = a[first] * .. * a[i] inside the group, the
+// group total goes to totals[g] (the next level's input).  down: given the inverse of the group total,
+//   inv(a[i]) = running * prefix[i-1],  running *= a[i]   for i = last .. first+1,   inv(a[first]) = running.
+// Three products per number; the single real inversion (of the root) is done by the host in stream order.
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
-k_modp_fd_check_inverses(const u32* __restrict__ cm, const u32* __restrict__ cminv, int t, int* __restrict__ flag,
-                         uint8_t* __restrict__ scratch_be, const ModpConsts* __restrict__ cs) {
+k_modp_binv_up(const u32* __restrict__ a, int m, int G, u32* __restrict__ prefix, u32* __restrict__ totals,
+               const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  if (*gate != 1) return;
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
-  const bool live = xi < t;
-  const int x = live ? xi : t - 1;
+  const int groups = (m + G - 1) / G;
+  const int gi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = gi < groups;
+  const int g = live ? gi : groups - 1;
+  const int first = g * G;
+  const int cnt = (m - first < G) ? m - first : G;
   u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
-  u32 n[LPL], a[LPL];
+  u32 n[LPL], acc[LPL], tmp[LPL];
   load_lane_limbs(n, cs->n, ln);
-  load_lane_limbs(a, cm + (size_t)x * L, ln);
-  slot_fill_from_global(slot, cminv + (size_t)x * L, ln);
-  __builtin_amdgcn_wave_barrier();
-  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);          // C * C^-1 in Montgomery form
-  __builtin_amdgcn_wave_barrier();
-  store_canonical_be256(scratch_be + (size_t)x * 256, a, true, slot, cs, n, ln, live);
-  if (live && ln.q == 0) {
-    bool one = scratch_be[(size_t)x * 256 + 255] == 1;
-    for (int i = 0; i < 255; ++i) one = one && (scratch_be[(size_t)x * 256 + i] == 0);
-    if (!one) atomicAnd(flag, 0);
+  load_lane_limbs(acc, a + (size_t)first * L, ln);
+  if (live) store_lane_limbs(prefix + (size_t)first * L, acc, ln);
+  for (int i = 1; i < G; ++i) {
+    const bool act = i < cnt;
+    const int idx = first + (act ? i : cnt - 1);
+    slot_fill_from_global(slot, a + (size_t)idx * L, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(tmp, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < LPL; ++k) acc[k] = tmp[k];
+      if (live) store_lane_limbs(prefix + (size_t)idx * L, acc, ln);
+    }
   }
+  if (live) store_lane_limbs(totals + (size_t)g * L, acc, ln);
 }
 
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_binv_down(const u32* __restrict__ a, const u32* __restrict__ prefix, const u32* __restrict__ tot_inv, int m,
+                 int G, u32* __restrict__ a_inv, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  if (*gate != 1) return;
+  const Lane ln = make_lane();
+  const int groups = (m + G - 1) / G;
+  const int gi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = gi < groups;
+  const int g = live ? gi : groups - 1;
+  const int first = g * G;
+  const int cnt = (m - first < G) ? m - first : G;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], run[LPL], tmp[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(run, tot_inv + (size_t)g * L, ln);
+  // 2 (G - 1) products through one site: odd steps emit inv(a[i]) = run * prefix[i-1], even steps do run *= a[i]
+  for (int s = 2 * (G - 1) - 1; s >= 0; --s) {
+    const int i = (s >> 1) + 1;
+    const bool emit = (s & 1) != 0;
+    const bool act = i < cnt;
+    const int ii = act ? i : (cnt > 1 ? cnt - 1 : 1);
+    const u32* src = emit ? prefix + (size_t)(first + ii - 1) * L : a + (size_t)(first + (cnt > 1 ? ii : 0)) * L;
+    slot_fill_from_global(slot, src, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(tmp, run, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+      if (emit) {
+        if (live) store_lane_limbs(a_inv + (size_t)(first + i) * L, tmp, ln);
+      } else {
+#pragma unroll
+        for (int k = 0; k < LPL; ++k) run[k] = tmp[k];
+      }
+    }
+  }
+  if (live) store_lane_limbs(a_inv + (size_t)first * L, run, ln);
+}
+
+// flag <- 0 when the host found the root of the inversion tree to be 0 mod q (some X is 0: no inverses)
+extern "C" __global__ void k_modp_fd_apply_ok(const int* __restrict__ ok, int* __restrict__ flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *ok != 1) *flag = 0;
+}
+
+// Chain c (of `chains`) owns the positions c, c + chains, c + 2 chains, ..: its seeds are x[c + chains k], k < t,
+// i.e. the first chains*t values of X are the seeds of all chains and are outputs at the same time.
 extern "C" __global__ void __launch_bounds__(FD_THREADS)
-k_modp_fd_table(const u32* __restrict__ seeds, int chains, int t, int tpad, u32* __restrict__ state,
-                const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
+k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int chains, int t, int tpad,
+                u32* __restrict__ state, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[2 * FD_QUADS * SLOT_WORDS];
   if (*gate != 1) return;
   const Lane ln = make_lane();
@@ -364,6 +414,7 @@ k_modp_fd_table(const u32* __restrict__ seeds, int chains, int t, int tpad, u32*
   const bool live = chain_i < chains && k < t;
   const int chain = chain_i < chains ? chain_i : chains - 1;
   const int kk = k < t ? k : t - 1;
+  const int wave_k0 = ((threadIdx.x & ~63) >> 2) % tpad;   // smallest k of this wave (tpad is a multiple of 16)
   u32* eslot = lds + qi * SLOT_WORDS;
   u32* fslot = lds + (FD_QUADS + qi) * SLOT_WORDS;
   const int nbq = (k + 1 < tpad) ? qi + 1 : qi;       // neighbour k+1 (values beyond the triangle are unused)
@@ -371,30 +422,37 @@ k_modp_fd_table(const u32* __restrict__ seeds, int chains, int t, int tpad, u32*
   const u32* fnb = lds + (FD_QUADS + nbq) * SLOT_WORDS;
   u32 n[LPL], E[LPL], F[LPL];
   load_lane_limbs(n, cs->n, ln);
-  load_lane_limbs(E, seeds + ((size_t)chain * t + kk) * L, ln);
-  load_lane_limbs(F, seeds + ((size_t)(chains + chain) * t + kk) * L, ln);
+  load_lane_limbs(E, x + ((size_t)chain + (size_t)chains * kk) * L, ln);
+  load_lane_limbs(F, x_inv + ((size_t)chain + (size_t)chains * kk) * L, ln);
   u32* st = state + (size_t)chain * t * L;
   if (live && k == 0) store_lane_limbs(st, E, ln);
-  // two levels per iteration: the register arrays swap roles (E' lands in F's registers and vice versa)
+  // two levels per iteration: the register arrays swap roles (E' lands in F's registers and vice versa).
+  // Level l only needs k <= t-1-l: waves wholly above that line skip the products (their values are dead).
   for (int lvl = 1; lvl < t; lvl += 2) {
     slot_store(eslot, E, ln);
     slot_store(fslot, F, ln);
     __syncthreads();
-    mont_mul<MODP_N0INV_C>(F, F, enb, n, ln);          // F regs <- E_l[k] = E_{l-1}[k+1] * F_{l-1}[k]
-    mont_mul<MODP_N0INV_C>(E, E, fnb, n, ln);          // E regs <- F_l[k] = F_{l-1}[k+1] * E_{l-1}[k]
+    if (wave_k0 <= t - 1 - lvl) {
+      mont_mul<MODP_N0INV_C>(F, F, enb, n, ln);          // F regs <- E_l[k] = E_{l-1}[k+1] * F_{l-1}[k]
+      mont_mul<MODP_N0INV_C>(E, E, fnb, n, ln);          // E regs <- F_l[k] = F_{l-1}[k+1] * E_{l-1}[k]
+    }
     __syncthreads();
     if (live && k == 0) store_lane_limbs(st + (size_t)lvl * L, F, ln);
     if (lvl + 1 >= t) break;
     slot_store(eslot, F, ln);                          // roles swapped
     slot_store(fslot, E, ln);
     __syncthreads();
-    mont_mul<MODP_N0INV_C>(E, E, enb, n, ln);          // E regs <- E_{l+1}[k]  (E regs held F_l[k])
-    mont_mul<MODP_N0INV_C>(F, F, fnb, n, ln);          // F regs <- F_{l+1}[k]  (F regs held E_l[k])
+    if (wave_k0 <= t - 2 - lvl) {
+      mont_mul<MODP_N0INV_C>(E, E, enb, n, ln);          // E regs <- E_{l+1}[k]  (E regs held F_l[k])
+      mont_mul<MODP_N0INV_C>(F, F, fnb, n, ln);          // F regs <- F_{l+1}[k]  (F regs held E_l[k])
+    }
     __syncthreads();
     if (live && k == 0) store_lane_limbs(st + (size_t)(lvl + 1) * L, E, ln);
   }
 }
 
+// x_m[c + chains j] = X at the j-th position of chain c; j < t are the seeds (already there), so the first
+// t - 1 steps only advance the table.
 extern "C" __global__ void __launch_bounds__(FD_THREADS)
 k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int chain_len, int count,
                u32* __restrict__ x_m, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
@@ -414,15 +472,14 @@ k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int c
   load_lane_limbs(n, cs->n, ln);
   if (threadIdx.x < 4) slot_fill_from_global(oneslot, cs->one_m, ln);
   if (k < t) load_lane_limbs(D, state + ((size_t)chain * t + k) * L, ln); else load_lane_limbs(D, cs->one_m, ln);
-  const size_t base = (size_t)chain * chain_len;
   const bool writer = live && k == 0;
-  if (writer && base < (size_t)count) store_lane_limbs(x_m + base * L, D, ln);
   for (int step = 1; step < chain_len; ++step) {
     slot_store(slot, D, ln);
     __syncthreads();
     mont_mul<MODP_N0INV_C>(D, D, bptr, n, ln);
     __syncthreads();
-    if (writer && base + step < (size_t)count) store_lane_limbs(x_m + (base + step) * L, D, ln);
+    const size_t idx = (size_t)chain + (size_t)chains * step;
+    if (writer && step >= t && idx < (size_t)count) store_lane_limbs(x_m + idx * L, D, ln);
   }
 }
 
@@ -747,24 +804,29 @@ extern "C" int modp_launch_fd_check_positions(const int64_t* positions, int coun
   hipLaunchKernelGGL(k_modp_fd_check_positions, dim3((count + 255) / 256), dim3(256), 0, s, positions, count, flag);
   return (int)hipGetLastError();
 }
-extern "C" int modp_launch_fd_seed_positions(const int64_t* positions, int chains, int chain_len, int t,
-                                             int64_t* seedpos, hipStream_t s) {
-  const int total = 2 * chains * t;
-  hipLaunchKernelGGL(k_modp_fd_seed_positions, dim3((total + 255) / 256), dim3(256), 0, s, positions, chains, chain_len,
-                     t, seedpos);
+extern "C" int modp_launch_binv_up(const uint32_t* a, int m, int G, uint32_t* prefix, uint32_t* totals, const int* gate,
+                                   const void* cs, hipStream_t s) {
+  const int groups = (m + G - 1) / G;
+  hipLaunchKernelGGL(k_modp_binv_up, dim3(grid_for(groups)), dim3(BLOCK_THREADS), 0, s, a, m, G, prefix, totals, gate,
+                     (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
-extern "C" int modp_launch_fd_check_inverses(const uint32_t* cm, const uint32_t* cminv, int t, int* flag,
-                                             uint8_t* scratch_be, const void* cs, hipStream_t s) {
-  hipLaunchKernelGGL(k_modp_fd_check_inverses, dim3(grid_for(t)), dim3(BLOCK_THREADS), 0, s, cm, cminv, t, flag,
-                     scratch_be, (const ModpConsts*)cs);
+extern "C" int modp_launch_binv_down(const uint32_t* a, const uint32_t* prefix, const uint32_t* tot_inv, int m, int G,
+                                     uint32_t* a_inv, const int* gate, const void* cs, hipStream_t s) {
+  const int groups = (m + G - 1) / G;
+  hipLaunchKernelGGL(k_modp_binv_down, dim3(grid_for(groups)), dim3(BLOCK_THREADS), 0, s, a, prefix, tot_inv, m, G,
+                     a_inv, gate, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
-extern "C" int modp_launch_fd_table(const uint32_t* seeds, int chains, int t, uint32_t* state, const int* gate,
-                                    const void* cs, hipStream_t s) {
+extern "C" int modp_launch_fd_apply_ok(const int* ok, int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_modp_fd_apply_ok, dim3(1), dim3(64), 0, s, ok, flag);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state,
+                                    const int* gate, const void* cs, hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
   const int cpw = FD_QUADS / tpad;
-  hipLaunchKernelGGL(k_modp_fd_table, dim3((chains + cpw - 1) / cpw), dim3(FD_THREADS), 0, s, seeds, chains, t, tpad,
+  hipLaunchKernelGGL(k_modp_fd_table, dim3((chains + cpw - 1) / cpw), dim3(FD_THREADS), 0, s, x, x_inv, chains, t, tpad,
                      state, gate, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }

@@ -57,18 +57,20 @@ struct mpvss_ctx {
   // flight on the GPU at once (the serial phases of one box overlap the wide phases of the next).
   struct Work {
     DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
-    DevBuf fd_flag, fd_seedpos, fd_cinv_be, fd_cinv_m, fd_seeds, fd_state, fd_xm;   // forward differences
+    DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root;   // forward differences
     DevBuf fd_tabc, tab3, gr_m;   // X tables of a1 in two-stream mode; gr_m: g^r_i in Montgomery form
     const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
-    const uint8_t* cm_src = nullptr;         // the caller's commitments (host or device, see cm_src_space)
-    int cm_src_space = MPVSS_HOST;
-    std::vector<uint8_t> cm_host, cinv_host; // commitments and their inverses on the host (forward differences)
+    struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
+      uint8_t in_be[256], out_be[256];
+      int ok;
+    };
+    RootJob* root = nullptr;
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
     hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr;
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
-              &fd_seedpos, &fd_cinv_be, &fd_cinv_m, &fd_seeds, &fd_state, &fd_xm, &fd_tabc, &tab3, &gr_m};
+              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_tabc, &tab3, &gr_m};
     }
   };
   Work work0;
@@ -374,6 +376,7 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
   HIPCHK(ctx, hipStreamCreateWithFlags(&w.sb, hipStreamNonBlocking));
   for (hipEvent_t* e : {&w.ev_fork, &w.ev_seeds, &w.ev_join, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  HIPCHK(ctx, hipHostMalloc((void**)&w.root, sizeof(*w.root), hipHostMallocDefault));
   w.ready = true;
   return 0;
 }
@@ -384,6 +387,7 @@ void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : {w.ev_fork, w.ev_seeds, w.ev_join, w.ev_gr})
     if (e) (void)hipEventDestroy(e);
+  if (w.root) (void)hipHostFree(w.root);
   if (w.sb) (void)hipStreamDestroy(w.sb);
   if (w.sa && owns_sa) (void)hipStreamDestroy(w.sa);
 }
@@ -573,8 +577,6 @@ int stage_commitments(mpvss_ctx* ctx, int space, const uint8_t* commitments, siz
   const void* dc;
   RET_IF(stage_in(ctx, space, commitments, t * EB, ctx->w->cbuf, &dc));
   ctx->w->cm_bytes_dev = (const uint8_t*)dc;
-  ctx->w->cm_src = commitments;
-  ctx->w->cm_src_space = space;
   RET_IF(ensure(ctx, ctx->w->cm, t * MODP_L * 4));
   LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)dc, (uint32_t*)ctx->w->cm.p, (int)t, ctx->consts, ctx->stream));
   return 0;
@@ -606,6 +608,24 @@ static int fd_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// stream callback: out = in^-1 mod q (canonical big-endian), ok = 0 when in is 0 mod q.  No HIP calls in here.
+void invert_root_on_host(void* p) {
+  static const hostq::Field* field = [] {
+    uint8_t qbe[EB];
+    for (size_t byte = 0; byte < EB; ++byte) {     // assemble q from its 28-bit limbs
+      unsigned v = 0;
+      for (int bit = 0; bit < 8; ++bit) {
+        const size_t b = byte * 8 + bit;
+        v |= ((MODP_N_LIMBS[b / 28] >> (b % 28)) & 1u) << bit;
+      }
+      qbe[EB - 1 - byte] = (uint8_t)v;
+    }
+    return new hostq::Field(qbe);
+  }();
+  auto* job = (mpvss_ctx::Work::RootJob*)p;
+  job->ok = hostq::batch_invert(*field, job->in_be, 1, job->out_be) ? 1 : 0;
+}
+
 // does the forward-difference path apply to this run of shares?  (host-side part of the decision)
 bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
   static const int fd_on = fd_env("MPVSS_FD", 1);
@@ -627,77 +647,77 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
                                                  ctx->consts, ctx->stream));
     return 0;
   }
-  // number of chains S: the seeds are 2*S*t Horner evaluations.  16384 of them are one wave per SIMD -- the
-  // cheapest the (latency-bound) seed launch gets -- and they must stay well below the cnt evaluations saved.
+  // number of chains S.  Chain c owns the positions c, c+S, c+2S, ..; the first S*t positions are the seeds of
+  // all chains (Horner, and outputs at the same time).  8192 seeds are half a wave per SIMD: the seed launch is
+  // latency-bound, so fewer would not finish sooner, and more would cost more than the steps they save.
   const int tpad = modp_fd_tpad((int)t);
   const int cpw = 256 / tpad;
-  int S = fd_chains_env > 0 ? fd_chains_env : (int)(16384 / (2 * t));
+  int S = fd_chains_env > 0 ? fd_chains_env : (int)(8192 / t);
   const int s_max = (int)(cnt / (4 * t));
   if (S > s_max) S = s_max;
   S = (S / (4 * cpw)) * (4 * cpw);        // whole workgroups of chains, S*t a multiple of the 64 numbers per block
   if (S < 4 * cpw) S = 4 * cpw;
   const int chain_len = (int)((cnt + S - 1) / S);
-  const size_t seeds = (size_t)2 * S * t;
+  const int m0 = (int)(S * t);
+  // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
+  constexpr int G = 16;
+  std::vector<int> ms{m0};
+  while (ms.back() > 1) ms.push_back((ms.back() + G - 1) / G);
+  const int nlev = (int)ms.size() - 1;
+  std::vector<size_t> pre_off(nlev + 1, 0), tot_off(nlev + 1, 0);
+  size_t pre_total = 0, tot_total = 0;
+  for (int l = 0; l < nlev; ++l) { pre_off[l] = pre_total; pre_total += (size_t)ms[l]; }
+  for (int l = 1; l <= nlev; ++l) { tot_off[l] = tot_total; tot_total += (size_t)ms[l]; }
 
-  RET_IF(ensure(ctx, ctx->w->fd_flag, 64));
-  RET_IF(ensure(ctx, ctx->w->fd_seedpos, seeds * 8));
-  RET_IF(ensure(ctx, ctx->w->fd_cinv_be, t * EB));
-  RET_IF(ensure(ctx, ctx->w->fd_cinv_m, t * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->w->fd_seeds, seeds * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->w->fd_state, (size_t)S * t * MODP_L * 4));
-  RET_IF(ensure(ctx, ctx->w->fd_xm, cnt * MODP_L * 4));
-  int* flag = (int*)ctx->w->fd_flag.p;
+  mpvss_ctx::Work& w = *ctx->w;
+  RET_IF(ensure(ctx, w.fd_flag, 64));
+  RET_IF(ensure(ctx, w.fd_root, 4 * EB));
+  RET_IF(ensure(ctx, w.fd_xm, cnt * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_xinv, (size_t)m0 * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_pre, pre_total * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_tot, tot_total * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_totinv, tot_total * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_state, (size_t)m0 * MODP_L * 4));
+  if (!w.root) return fail(ctx, MPVSS_E_DEVICE, "eval_x: workspace not initialised");
+  int* flag = (int*)w.fd_flag.p;
+  int* dok = flag + 1;
+  uint8_t* root_be = (uint8_t*)w.fd_root.p;
+  uint8_t* rootinv_be = root_be + EB;
+  uint32_t* xm = (uint32_t*)w.fd_xm.p;
+  auto level_in = [&](int l) { return l == 0 ? xm : (uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
+  auto level_inv = [&](int l) { return l == 0 ? (uint32_t*)w.fd_xinv.p : (uint32_t*)w.fd_totinv.p + tot_off[l] * MODP_L; };
   static const int one = 1;
   HIPCHK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
   if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions(dpos, (int)cnt, flag, ctx->stream));
-  // inverted commitments: Montgomery's batch trick on the host (about a millisecond for t = 256; the same job on
-  // the device is a latency-bound 2048-bit exponentiation of ~20 ms).  A commitment that is 0 mod q has no
-  // inverse: then X is 0 for every share and Horner's rule handles it.
-  {
-    static const hostq::Field* field = nullptr;
-    if (!field) {
-      uint8_t qbe[EB];
-      for (size_t byte = 0; byte < EB; ++byte) {     // assemble q from its 28-bit limbs
-        unsigned v = 0;
-        for (int bit = 0; bit < 8; ++bit) {
-          const size_t b = byte * 8 + bit;
-          v |= ((MODP_N_LIMBS[b / 28] >> (b % 28)) & 1u) << bit;
-        }
-        qbe[EB - 1 - byte] = (uint8_t)v;
-      }
-      field = new hostq::Field(qbe);
-    }
-    ctx->w->cinv_host.resize(t * EB);
-    const uint8_t* src = ctx->w->cm_src;
-    if (ctx->w->cm_src_space == MPVSS_DEVICE) {
-      ctx->w->cm_host.resize(t * EB);
-      HIPCHK(ctx, hipMemcpyAsync(ctx->w->cm_host.data(), ctx->w->cm_src, t * EB, hipMemcpyDeviceToHost, ctx->stream_c));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream_c));
-      src = ctx->w->cm_host.data();
-    }
-    if (!hostq::batch_invert(*field, src, t, ctx->w->cinv_host.data())) {
-      static const int zero = 0;
-      HIPCHK(ctx, hipMemcpyAsync(flag, &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->w->fd_cinv_be.p, ctx->w->cinv_host.data(), t * EB, hipMemcpyHostToDevice, ctx->stream));
-    LAUNCHCHK(ctx, modp_launch_to_mont((const uint8_t*)ctx->w->fd_cinv_be.p, (uint32_t*)ctx->w->fd_cinv_m.p, (int)t, ctx->consts,
-                                       ctx->stream));
-  }
-  // seeds, difference tables, stepping, conversion -- all gated on flag == 1
-  LAUNCHCHK(ctx, modp_launch_fd_seed_positions(dpos, S, chain_len, (int)t, (int64_t*)ctx->w->fd_seedpos.p, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->w->cm.p, (const uint32_t*)ctx->w->fd_cinv_m.p, (int)(S * t),
-                                               (int)t, (const int64_t*)ctx->w->fd_seedpos.p, (int)seeds,
-                                               (uint32_t*)ctx->w->fd_seeds.p, nullptr, flag, 1, ctx->consts, ctx->stream));
+  // seeds: X at the first S*t positions, kept in Montgomery form
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t, dpos,
+                                               m0, xm, nullptr, flag, 1, ctx->consts, ctx->stream));
   if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_table((const uint32_t*)ctx->w->fd_seeds.p, S, (int)t, (uint32_t*)ctx->w->fd_state.p, flag,
+  // their inverses: Montgomery's trick on the device, the single inversion of the root on the host, in stream
+  // order (no host synchronisation).  A root that is 0 mod q (some commitment is 0) clears the flag.
+  for (int l = 0; l < nlev; ++l)
+    LAUNCHCHK(ctx, modp_launch_binv_up(level_in(l), ms[l], G, (uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_in(l + 1),
+                                       flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_from_mont(level_in(nlev), 1, root_be, flag, ctx->consts, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(w.root->in_be, root_be, EB, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipLaunchHostFunc(ctx->stream, invert_root_on_host, w.root));
+  HIPCHK(ctx, hipMemcpyAsync(rootinv_be, w.root->out_be, EB, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dok, &w.root->ok, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_apply_ok(dok, flag, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_to_mont(rootinv_be, level_inv(nlev), 1, ctx->consts, ctx->stream));
+  for (int l = nlev - 1; l >= 0; --l)
+    LAUNCHCHK(ctx, modp_launch_binv_down(level_in(l), (const uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_inv(l + 1),
+                                         ms[l], G, level_inv(l), flag, ctx->consts, ctx->stream));
+  // difference tables, stepping, conversion -- all gated on flag == 1
+  LAUNCHCHK(ctx, modp_launch_fd_table(xm, (const uint32_t*)w.fd_xinv.p, S, (int)t, (uint32_t*)w.fd_state.p, flag,
                                       ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)ctx->w->fd_state.p, S, (int)t, chain_len, (int)cnt,
-                                     (uint32_t*)ctx->w->fd_xm.p, flag, ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_from_mont((const uint32_t*)ctx->w->fd_xm.p, (int)cnt, dX, flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)w.fd_state.p, S, (int)t, chain_len, (int)cnt, xm, flag, ctx->consts,
+                                     ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_from_mont(xm, (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)ctx->w->cm.p, (const uint32_t*)ctx->w->cm.p, 0x7fffffff, (int)t,
-                                               dpos, (int)cnt, nullptr, dX, flag, 0, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t, dpos,
+                                               (int)cnt, nullptr, dX, flag, 0, ctx->consts, ctx->stream));
   RET_IF(span_end(ctx));
   return 0;
 }

@@ -45,7 +45,8 @@ print(h)
 
 
 @pytest.mark.parametrize("t,n,p0,extra", [(16, 4096, 1, ""), (64, 8192, 1, ""), (33, 5000, 777, ""),
-                                           (256, 8192, 1, ""), (64, 8192, 1, "cm[5] = 0"), (64, 8192, 1, "cm[0] = Q")])
+                                           (256, 8192, 1, ""), (33, 9001, 777, ""), (17, 20011, 123456789, ""),
+                                           (100, 12345, 2, "cm[99] = Q - 1"), (64, 8192, 1, "cm[5] = 0"), (64, 8192, 1, "cm[0] = Q")])
 def test_fd_equals_horner(t, n, p0, extra):
     code = CODE % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), t * 1000 + n, t, n, p0, extra)
     a = run(code, {"MPVSS_FD": "1"}).strip()
