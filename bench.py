@@ -58,6 +58,9 @@ def keygen(rng: random.Random) -> int:
             return k
 
 
+PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "4"))   # boxes in flight (the engine has 8 block slots)
+
+
 def horner_modmuls(positions, t):
     """Montgomery products the commit_eval kernel executes for one 16-share wave (see
     k_modp_commit_eval): per Horner step (nb-1) squarings, one product per lower bit position at
@@ -211,7 +214,7 @@ def main():
         raw = bytes(out.cpu().numpy().tobytes())
         return bool(raw[0]), raw[1:33]
 
-    def run_steps(k, depth=int(os.environ.get("MPVSS_BENCH_DEPTH", "3"))):
+    def run_steps(k, depth=PIPE_DEPTH):
         """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
         enqueued while the host (and, on several GPUs, the rank-to-rank hash chain) finishes older ones."""
         results = []
@@ -259,11 +262,22 @@ def main():
     # work accounting: Montgomery products the kernels execute per step on this rank
     fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 256 and n >= 16 * t and n >= 8192
     if fd:
-        chains = max(4, min(16384 // (2 * t), n // (4 * t)))
+        tpad = 16
+        while tpad < t:
+            tpad *= 2
+        cpw = 256 // tpad
+        chains = min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or 8192 // t, n // (4 * t))
+        chains = max(4 * cpw, chains // (4 * cpw) * (4 * cpw))          # as eval_x() in mpvss_capi.cpp
         chain_len = -(-n // chains)
-        seed_pos = [positions[0] + s * chain_len + k for s in range(chains) for k in range(t)]
-        mm_x = 2 * horner_modmuls(seed_pos, t) + chains * t * (t - 1) + n * t + n
-        x_path = f"forward differences: {chains} chains, {2 * chains * t} Horner seeds, {chain_len} lock-step products per chain"
+        m0 = chains * t                                                  # the seeds: the first m0 positions, by Horner
+        inv_tree, m = 0, m0
+        while m > 1:                                                     # simultaneous inversion: 3 products per node
+            inv_tree += 3 * m
+            m = -(-m // 16)
+        mm_x = (horner_modmuls(positions[:m0], t) + inv_tree + chains * t * (t - 1)
+                + chains * t * (chain_len - 1) + n)
+        x_path = (f"forward differences: {chains} strided chains, {m0} Horner seeds (also outputs), inverses by "
+                  f"simultaneous inversion, {chain_len - 1} lock-step products per chain and level")
     else:
         mm_x = horner_modmuls(positions, t) + n
         x_path = "Horner in the exponent"
@@ -311,7 +325,8 @@ def main():
                                "note": "per-kind sums of launch durations; kinds overlap on two streams"},
         },
         "host": {"absorb_wait_plus_sha256_ms": 1e3 * sum(host_absorb_s) / max(len(host_absorb_s), 1), "setup_s": setup_s,
-                 "pipelining": "up to 3 verifications in flight: GPU work of i+1, i+2 enqueued while the host hashes i"},
+                 "pipelining": f"up to {PIPE_DEPTH} verifications in flight (one workspace and stream pair each): the GPU work "
+                               "of the next ones is enqueued while the host hashes the oldest"},
     }
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape

@@ -122,7 +122,7 @@ int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* com
  *   mpvss_modp_transcript_verdict(state, challenge, &verdict, digest);
  * `compute` only enqueues GPU work (kernels + device-to-host copies) and returns; `absorb` waits
  * for it, so the wait for the previous block's state overlaps this block's GPU work.
- * Up to four blocks may be in flight per engine (compute, compute, ..., absorb, absorb in FIFO order): the
+ * Up to eight blocks may be in flight per engine (compute, compute, ..., absorb, absorb in FIFO order): the
  * host hash of box k then overlaps the GPU work of boxes k+1.. (bench.py).
  * mpvss_modp_verify_distribution == init + compute + absorb + verdict on one engine. */
 #define MPVSS_TRANSCRIPT_STATE_BYTES 128

@@ -53,6 +53,7 @@ __device__ __forceinline__ u32 quad_from_prev(u32 v) {
 struct Lane {
   u32 q;         // lane index inside the quad, 0..3
   u32 not_top;   // all ones unless q == 3
+  u32 top28;     // 2^28 - 1 unless q == 3 (then 0): "take the low limb of the lane above"
   u32 low01;     // 1 iff q == 0, else 0
   u32 not_low;   // all ones unless q == 0
   u32 mask28;    // 2^28 - 1 in a VGPR (lets the compiler fuse "broadcast & mask" into one v_and_b32_dpp)
@@ -62,12 +63,13 @@ __device__ __forceinline__ Lane make_lane() {
   Lane ln;
   ln.q = threadIdx.x & 3;
   ln.not_top = (ln.q != 3) ? 0xffffffffu : 0u;
+  ln.top28 = (ln.q != 3) ? MASK : 0u;
   ln.low01 = (ln.q == 0) ? 1u : 0u;
   ln.not_low = (ln.q != 0) ? 0xffffffffu : 0u;
   // Opaque to the optimiser: otherwise `x & mask` becomes v_cndmask_b32 on an SGPR-pair condition,
   // which issues ~4x slower than v_and_b32 on gfx950 (profiles/r01_ubench_valu_issue_rates.txt).
   ln.mask28 = MASK;
-  asm volatile("" : "+v"(ln.not_top), "+v"(ln.low01), "+v"(ln.not_low), "+v"(ln.mask28));
+  asm volatile("" : "+v"(ln.not_top), "+v"(ln.top28), "+v"(ln.low01), "+v"(ln.not_low), "+v"(ln.mask28));
   return ln;
 }
 
@@ -78,9 +80,9 @@ __device__ __forceinline__ Lane make_lane() {
 // N0INV == 1 for the RFC 3526 prime (N = -1 mod 2^64), the multiply folds away.
 //
 // One step (one limb b_i of b), per lane: 19 mads a[k]*b_i, m from lane 0's lowest column,
-// 19 mads m*n[k]; lane 0's lowest column is then 0 mod 2^28: its upper bits are added to the
-// next column and the column is retired; every lane hands its lowest column to the lane below
-// (lane 3 starts a fresh zero column).  Column accumulators stay below 2^64 (76 steps x 2
+// 19 mads m*n[k]; lane 0's lowest column is then 0 mod 2^28 and retires.  Every lane carries the upper bits
+// of its lowest column into its next column and hands the low 28 bits to the lane below (lane 3 starts a
+// fresh zero column).  Column accumulators stay below 2^64 (76 steps x 2
 // products < 2^56.01 each, checked exhaustively for worst-case limbs in tests/test_limb_model.py).
 template <u32 N0INV>
 __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ b,
@@ -104,21 +106,14 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
       const u32 m = quad_bcast0((u32)T[rr] * N0INV) & ln.mask28;
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)m * n[k];
-      // lane 0: the lowest column is now 0 mod 2^28; move its upper bits (< 2^37) into the next
-      // column.  The multiplications by low01 (0/1) do the lane masking inside the adds.
+      // Every lane moves the upper bits of its lowest column into its next column (same weight) and hands the
+      // low 28 bits to the lane below, whose fresh top column they become; lane 0's lowest column is 0 mod 2^28
+      // by construction and retires.  No lane-dependent arithmetic: one shift, one 64-bit add, one v_and_b32_dpp.
       {
         const u64 ret = T[rr];
-        const u32 c_lo = (u32)(ret >> W);
-        const u32 c_hi = (u32)(ret >> 32) >> W;
-        u64& nx = T[(rr + 1) % LPL];
-        nx += (u64)c_lo * ln.low01;
-        const u32 nhi = __umul24(c_hi, ln.low01) + (u32)(nx >> 32);   // v_mad_u32_u24 on the high word
-        nx = ((u64)nhi << 32) | (u32)nx;
+        T[(rr + 1) % LPL] += ret >> W;
+        T[rr] = (u64)(quad_from_next((u32)ret) & ln.top28);
       }
-      // every lane hands its lowest column to the lane below; the top lane starts a fresh one
-      const u32 lo = quad_from_next((u32)T[rr]) & ln.not_top;
-      const u32 hi = quad_from_next((u32)(T[rr] >> 32)) & ln.not_top;
-      T[rr] = ((u64)hi << 32) | lo;
       // Pin the row-wise order: without this LLVM reassociates the 19-fold unrolled body into a
       // column-wise (product-scanning) form that keeps every b_i and m_i of the block live and
       // no longer fits 128 VGPRs (4 waves/SIMD).  The empty asm makes each accumulator opaque.

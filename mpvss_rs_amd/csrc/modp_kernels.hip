@@ -209,6 +209,7 @@ k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, i
   // gate: the forward-difference path (below) and this kernel exclude each other through a device flag,
   // so that the choice needs no host synchronisation
   if (gate != nullptr && *gate != gate_want) return;
+  if (gate != nullptr && x_m != nullptr) __builtin_amdgcn_s_setprio(3);   // seed launch of the forward-difference path
   const Lane ln = make_lane();
   const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   // numbers >= split evaluate the second commitment set (the inverted commitments of the seed phase)
@@ -302,10 +303,8 @@ k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, i
 //   table  : E_l[k] = E_{l-1}[k+1] F_{l-1}[k],  F_l[k] = F_{l-1}[k+1] E_{l-1}[k]  (E_0 = X, F_0 = X^-1); D_l = E_l[0]
 //   step   : D_k <- D_k * D_{k+1}, output D_0
 // Canonical results are identical to Horner's by uniqueness of the group element.
-// Chains of one workgroup: 1024 threads = 256 quads = 256 / tpad chains of tpad >= t numbers.
+// tpad = t rounded up to a power of two >= 16 (whole waves of 16 levels).
 // =======================================================================================
-constexpr int FD_QUADS = 256;
-constexpr int FD_THREADS = 4 * FD_QUADS;
 
 // flag = 1 iff positions[i] == positions[0] + i for all i (and no negative / overflowing value)
 extern "C" __global__ void k_modp_fd_check_positions(const int64_t* __restrict__ positions, int count,
@@ -327,6 +326,7 @@ k_modp_binv_up(const u32* __restrict__ a, int m, int G, u32* __restrict__ prefix
                const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   if (*gate != 1) return;
+  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
   const int groups = (m + G - 1) / G;
   const int gi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -360,6 +360,7 @@ k_modp_binv_down(const u32* __restrict__ a, const u32* __restrict__ prefix, cons
                  int G, u32* __restrict__ a_inv, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   if (*gate != 1) return;
+  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
   const int groups = (m + G - 1) / G;
   const int gi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -401,83 +402,181 @@ extern "C" __global__ void k_modp_fd_apply_ok(const int* __restrict__ ok, int* _
 
 // Chain c (of `chains`) owns the positions c, c + chains, c + 2 chains, ..: its seeds are x[c + chains k], k < t,
 // i.e. the first chains*t values of X are the seeds of all chains and are outputs at the same time.
-extern "C" __global__ void __launch_bounds__(FD_THREADS)
+//
+// Both kernels below are PIPELINES OF SINGLE-WAVE WORKGROUPS.  The t numbers of a chain (one per level k) are cut
+// into stages of 16 consecutive levels = one wave = one workgroup; level k only ever needs level k+1 of the previous
+// step, so a stage needs exactly one number per step from the stage above it and nothing from below.  That number
+// travels through HBM as self-validating words (bit 31 set on every limb word of a buffer zeroed before the
+// launch; limbs are < 2^29), written and polled with agent-scope relaxed atomics: no fences, no barriers, no
+// cross-workgroup synchronisation other than the data itself.  Stages above are dispatched first (lower block
+// index), so a waiting stage only ever waits for workgroups that are already resident or done.  A stage that
+// waits longer than FD_TIMEOUT_TICKS clears the device flag -- the gated Horner kernel then recomputes everything --
+// and poisons its own output so that the stages below give up at once.
+// One step then costs one Montgomery product of ONE wave per SIMD instead of four waves sharing a SIMD behind a
+// workgroup barrier, and the 128-register ceiling of 1024-thread workgroups is gone.
+constexpr u32 HAND_VALID = 0x80000000u;
+constexpr u32 HAND_POISON = 0x40000000u;
+constexpr long long FD_TIMEOUT_TICKS = 200000000LL;   // 2 s of the 100 MHz wall clock
+
+__device__ __forceinline__ void hand_publish(u32* __restrict__ dst, const u32 (&a)[LPL], const Lane& ln, u32 tag) {
+#pragma unroll
+  for (int k = 0; k < LPL; ++k)
+    __hip_atomic_store(dst + ln.q * LPL + k, a[k] | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one polling round: this lane's 19 words; returns HAND_VALID if all are valid, HAND_POISON if poisoned, else 0
+__device__ __forceinline__ u32 hand_poll(const u32* __restrict__ src, u32 (&v)[LPL], const Lane& ln) {
+  u32 all = 0xffffffffu, any = 0;
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) {
+    v[k] = __hip_atomic_load(src + ln.q * LPL + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    all &= v[k];
+    any |= v[k];
+  }
+  return (any & HAND_POISON) ? HAND_POISON : (all & HAND_VALID);
+}
+
+// The quad `is_reader` of the wave waits for one number from the stage above and puts it into the LDS slot `dst`.
+// Returns false (wave-uniform) when the wait failed: poisoned input or timeout.
+__device__ __forceinline__ bool hand_receive(const u32* __restrict__ src, u32* dst, bool is_reader, const Lane& ln) {
+  u32 v[LPL];
+  bool ok = true;
+  if (is_reader) {
+    const long long t0 = wall_clock64();
+    while (true) {
+      const u32 st = hand_poll(src, v, ln);
+      // all four lanes of the quad must agree (the reader quad is lanes 60..63)
+      const uint64_t good = __builtin_amdgcn_ballot_w64(st == HAND_VALID) >> 60;
+      const uint64_t bad = __builtin_amdgcn_ballot_w64(st == HAND_POISON) >> 60;
+      if (good == 0xf) break;
+      if (bad != 0 || wall_clock64() - t0 > FD_TIMEOUT_TICKS) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) dst[ln.q * LPL + k] = v[k] & 0x3fffffffu;
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
+
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
 k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int chains, int t, int tpad,
-                u32* __restrict__ state, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[2 * FD_QUADS * SLOT_WORDS];
+                u32* __restrict__ state, u32* __restrict__ hand, int* __restrict__ gate,
+                const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
+  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
-  const int qi = threadIdx.x >> 2;
-  const int cpw = FD_QUADS / tpad;
-  const int k = qi % tpad;
-  const int chain_i = blockIdx.x * cpw + qi / tpad;
-  const bool live = chain_i < chains && k < t;
-  const int chain = chain_i < chains ? chain_i : chains - 1;
+  const int quad = threadIdx.x >> 2;
+  const int stages = tpad / NUMS_PER_WAVE;
+  const int sidx = blockIdx.x / chains;                       // 0 = the top levels
+  const int chain = blockIdx.x % chains;
+  const int kbase = tpad - NUMS_PER_WAVE * (sidx + 1);
+  if (kbase >= t) return;                                     // nothing but padding in this stage
+  const int k = kbase + quad;
   const int kk = k < t ? k : t - 1;
-  const int wave_k0 = ((threadIdx.x & ~63) >> 2) % tpad;   // smallest k of this wave (tpad is a multiple of 16)
-  u32* eslot = lds + qi * SLOT_WORDS;
-  u32* fslot = lds + (FD_QUADS + qi) * SLOT_WORDS;
-  const int nbq = (k + 1 < tpad) ? qi + 1 : qi;       // neighbour k+1 (values beyond the triangle are unused)
-  const u32* enb = lds + nbq * SLOT_WORDS;
-  const u32* fnb = lds + (FD_QUADS + nbq) * SLOT_WORDS;
-  u32 n[LPL], E[LPL], F[LPL];
+  const bool has_up = kbase + NUMS_PER_WAVE < t;
+  const bool has_down = kbase > 0;
+  const int last_lvl = t - 1 - kbase;                         // level l needs k <= t-1-l
+  u32* eslot = lds + quad * SLOT_WORDS;
+  u32* fslot = lds + (NUMS_PER_WAVE + quad) * SLOT_WORDS;
+  u32* in_e = lds + 2 * NUMS_PER_WAVE * SLOT_WORDS;
+  u32* in_f = in_e + SLOT_WORDS;
+  const bool reader = quad == NUMS_PER_WAVE - 1;
+  const u32* enb = reader ? in_e : eslot + SLOT_WORDS;        // E_{l-1}[k+1]
+  const u32* fnb = reader ? in_f : fslot + SLOT_WORDS;        // F_{l-1}[k+1]
+  // handoff areas: [chain][stage][level][E,F]
+  u32* mine = hand + ((size_t)chain * stages + sidx) * (size_t)t * 2 * L;
+  const u32* up = hand + ((size_t)chain * stages + (sidx - 1)) * (size_t)t * 2 * L;
+  u32 n[LPL], E[LPL], F[LPL], T1[LPL];
   load_lane_limbs(n, cs->n, ln);
   load_lane_limbs(E, x + ((size_t)chain + (size_t)chains * kk) * L, ln);
   load_lane_limbs(F, x_inv + ((size_t)chain + (size_t)chains * kk) * L, ln);
   u32* st = state + (size_t)chain * t * L;
-  if (live && k == 0) store_lane_limbs(st, E, ln);
-  // two levels per iteration: the register arrays swap roles (E' lands in F's registers and vice versa).
-  // Level l only needs k <= t-1-l: waves wholly above that line skip the products (their values are dead).
-  for (int lvl = 1; lvl < t; lvl += 2) {
+  if (kbase == 0 && quad == 0) store_lane_limbs(st, E, ln);
+  if (has_up && reader) {                                     // level 0 of the stage above: its seeds
+    const size_t src = ((size_t)chain + (size_t)chains * (kbase + NUMS_PER_WAVE)) * L;
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) {
+      in_e[ln.q * LPL + i] = x[src + ln.q * LPL + i];
+      in_f[ln.q * LPL + i] = x_inv[src + ln.q * LPL + i];
+    }
+  }
+  for (int lvl = 1; lvl <= last_lvl; ++lvl) {
     slot_store(eslot, E, ln);
     slot_store(fslot, F, ln);
-    __syncthreads();
-    if (wave_k0 <= t - 1 - lvl) {
-      mont_mul<MODP_N0INV_C>(F, F, enb, n, ln);          // F regs <- E_l[k] = E_{l-1}[k+1] * F_{l-1}[k]
-      mont_mul<MODP_N0INV_C>(E, E, fnb, n, ln);          // E regs <- F_l[k] = F_{l-1}[k+1] * E_{l-1}[k]
+    const bool need_up = has_up && (kbase + NUMS_PER_WAVE - 1 <= t - 1 - lvl);
+    if (need_up && lvl > 1) {
+      const u32* src = up + (size_t)(lvl - 1) * 2 * L;
+      const bool ok = hand_receive(src, in_e, reader, ln) && hand_receive(src + L, in_f, reader, ln);
+      if (!ok) {
+        if (threadIdx.x == 0) *gate = 0;
+        if (has_down && quad == 0) hand_publish(mine + (size_t)lvl * 2 * L, E, ln, HAND_POISON);
+        return;
+      }
     }
-    __syncthreads();
-    if (live && k == 0) store_lane_limbs(st + (size_t)lvl * L, F, ln);
-    if (lvl + 1 >= t) break;
-    slot_store(eslot, F, ln);                          // roles swapped
-    slot_store(fslot, E, ln);
-    __syncthreads();
-    if (wave_k0 <= t - 2 - lvl) {
-      mont_mul<MODP_N0INV_C>(E, E, enb, n, ln);          // E regs <- E_{l+1}[k]  (E regs held F_l[k])
-      mont_mul<MODP_N0INV_C>(F, F, fnb, n, ln);          // F regs <- F_{l+1}[k]  (F regs held E_l[k])
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(T1, F, enb, n, ln);          // E_l[k] = E_{l-1}[k+1] * F_{l-1}[k]
+    mont_mul<MODP_N0INV_C>(F, E, fnb, n, ln);           // F_l[k] = F_{l-1}[k+1] * E_{l-1}[k]
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) E[i] = T1[i];
+    __builtin_amdgcn_wave_barrier();
+    if (has_down && quad == 0) {
+      hand_publish(mine + (size_t)lvl * 2 * L, E, ln, HAND_VALID);
+      hand_publish(mine + (size_t)lvl * 2 * L + L, F, ln, HAND_VALID);
     }
-    __syncthreads();
-    if (live && k == 0) store_lane_limbs(st + (size_t)(lvl + 1) * L, E, ln);
+    if (kbase == 0 && quad == 0) store_lane_limbs(st + (size_t)lvl * L, E, ln);   // D_l = E_l[0]
   }
 }
 
 // x_m[c + chains j] = X at the j-th position of chain c; j < t are the seeds (already there), so the first
-// t - 1 steps only advance the table.
-extern "C" __global__ void __launch_bounds__(FD_THREADS)
+// t - 1 steps only advance the table.  D_k <- D_k * D_{k+1}; D_{t-1} is constant.
+extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
 k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int chain_len, int count,
-               u32* __restrict__ x_m, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[(FD_QUADS + 1) * SLOT_WORDS];
+               u32* __restrict__ x_m, u32* __restrict__ hand, int* __restrict__ gate,
+               const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[(NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
+  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
-  const int qi = threadIdx.x >> 2;
-  const int cpw = FD_QUADS / tpad;
-  const int k = qi % tpad;
-  const int chain_i = blockIdx.x * cpw + qi / tpad;
-  const bool live = chain_i < chains && k < t;
-  const int chain = chain_i < chains ? chain_i : chains - 1;
-  u32* slot = lds + qi * SLOT_WORDS;
-  u32* oneslot = lds + FD_QUADS * SLOT_WORDS;
-  const u32* bptr = (k + 1 < t) ? lds + (qi + 1) * SLOT_WORDS : oneslot;   // D_{t-1} is constant
+  const int quad = threadIdx.x >> 2;
+  const int stages = tpad / NUMS_PER_WAVE;
+  const int sidx = blockIdx.x / chains;
+  const int chain = blockIdx.x % chains;
+  const int kbase = tpad - NUMS_PER_WAVE * (sidx + 1);
+  if (kbase >= t) return;
+  const int k = kbase + quad;
+  const bool has_up = kbase + NUMS_PER_WAVE < t;
+  const bool has_down = kbase > 0;
+  u32* slot = lds + quad * SLOT_WORDS;
+  u32* inslot = lds + NUMS_PER_WAVE * SLOT_WORDS;
+  u32* oneslot = inslot + SLOT_WORDS;
+  const bool reader = quad == NUMS_PER_WAVE - 1;
+  const u32* bptr = (k + 1 < t) ? (reader ? inslot : slot + SLOT_WORDS) : oneslot;
+  u32* mine = hand + ((size_t)chain * stages + sidx) * (size_t)chain_len * L;
+  const u32* up = hand + ((size_t)chain * stages + (sidx - 1)) * (size_t)chain_len * L;
   u32 n[LPL], D[LPL];
   load_lane_limbs(n, cs->n, ln);
   if (threadIdx.x < 4) slot_fill_from_global(oneslot, cs->one_m, ln);
   if (k < t) load_lane_limbs(D, state + ((size_t)chain * t + k) * L, ln); else load_lane_limbs(D, cs->one_m, ln);
-  const bool writer = live && k == 0;
+  if (has_up && reader) {                                     // step 0 of the stage above: its table entry
+    const size_t src = ((size_t)chain * t + kbase + NUMS_PER_WAVE) * L;
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) inslot[ln.q * LPL + i] = state[src + ln.q * LPL + i];
+  }
+  const bool writer = kbase == 0 && quad == 0;
   for (int step = 1; step < chain_len; ++step) {
     slot_store(slot, D, ln);
-    __syncthreads();
+    if (has_up && step > 1) {
+      if (!hand_receive(up + (size_t)(step - 1) * L, inslot, reader, ln)) {
+        if (threadIdx.x == 0) *gate = 0;
+        if (has_down && quad == 0) hand_publish(mine + (size_t)step * L, D, ln, HAND_POISON);
+        return;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
     mont_mul<MODP_N0INV_C>(D, D, bptr, n, ln);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    if (has_down && quad == 0) hand_publish(mine + (size_t)step * L, D, ln, HAND_VALID);
     const size_t idx = (size_t)chain + (size_t)chains * step;
     if (writer && step >= t && idx < (size_t)count) store_lane_limbs(x_m + idx * L, D, ln);
   }
@@ -676,42 +775,48 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
   }
   while (true) {
     const u32* bptr = slot;
+    const u32* fill = nullptr;     // global operand staged into `fill_to` (one staging site keeps the register use low)
+    u32* fill_to = slot;
     bool skip = false;
     if (phase == PH_A) {
       if (s == 5) { ++w; s = 0; }
       if (w == 512) {
         if (mode == 2) {                                 // multiply by the stored g^e1
-          slot_fill_from_global(pslot, p_m + (size_t)x * L, ln);
-          phase = PH_P;
+          fill = p_m + (size_t)x * L;
+          fill_to = pslot;
+          bptr = pslot;
+          phase = PH_F;
+        } else {
+          slot_store(pslot, acc, ln);                    // save B2^e2
+          phase = PH_B; k = 0;
           continue;
         }
-        slot_store(pslot, acc, ln);                      // save B2^e2
-        phase = PH_B; k = 0;
-        continue;
-      }
-      if (s < 4) {
-        slot_store(slot, acc, ln);
       } else {
-        const u32 byte = e2[w >> 1];
-        const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
-        slot_fill_from_global(slot, t2 + (size_t)d * L, ln);
+        if (s < 4) {
+          slot_store(slot, acc, ln);
+        } else {
+          const u32 byte = e2[w >> 1];
+          const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+          fill = t2 + (size_t)d * L;
+        }
+        ++s;
       }
-      ++s;
     } else if (phase == PH_B) {
       const u32 byte = e1[255 - (k >> 1)];
       const u32 d = (k & 1) ? (byte >> 4) : (byte & 15);
       const u32* entry = comb + ((size_t)k * 16 + d) * L;
       if (k == 0) { load_lane_limbs(acc, entry, ln); skip = true; }
-      else slot_fill_from_global(slot, entry, ln);
+      else fill = entry;
       ++k;
       if (k == 512) phase = (mode == 1) ? PH_F + 2 : (e2_windows > 0) ? PH_P : PH_F;
     } else if (phase == PH_P) {
       bptr = pslot;
       phase = PH_F;
     } else {
-      slot_fill_from_global(slot, cs->one, ln);
+      fill = cs->one;
       phase = PH_F + 1;
     }
+    if (fill != nullptr) slot_fill_from_global(fill_to, fill, ln);
     if (!skip) {
       __builtin_amdgcn_wave_barrier();
       mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
@@ -822,20 +927,25 @@ extern "C" int modp_launch_fd_apply_ok(const int* ok, int* flag, hipStream_t s) 
   hipLaunchKernelGGL(k_modp_fd_apply_ok, dim3(1), dim3(64), 0, s, ok, flag);
   return (int)hipGetLastError();
 }
+// words of the handoff buffers (zeroed by the caller before every launch)
+extern "C" size_t modp_fd_table_hand_words(int chains, int t) {
+  return (size_t)chains * (modp_fd_tpad(t) / NUMS_PER_WAVE) * (size_t)t * 2 * L;
+}
+extern "C" size_t modp_fd_step_hand_words(int chains, int t, int chain_len) {
+  return (size_t)chains * (modp_fd_tpad(t) / NUMS_PER_WAVE) * (size_t)chain_len * L;
+}
 extern "C" int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state,
-                                    const int* gate, const void* cs, hipStream_t s) {
+                                    uint32_t* hand, int* gate, const void* cs, hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
-  const int cpw = FD_QUADS / tpad;
-  hipLaunchKernelGGL(k_modp_fd_table, dim3((chains + cpw - 1) / cpw), dim3(FD_THREADS), 0, s, x, x_inv, chains, t, tpad,
-                     state, gate, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_fd_table, dim3(chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, x, x_inv, chains, t, tpad,
+                     state, hand, gate, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_fd_step(const uint32_t* state, int chains, int t, int chain_len, int count, uint32_t* x_m,
-                                   const int* gate, const void* cs, hipStream_t s) {
+                                   uint32_t* hand, int* gate, const void* cs, hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
-  const int cpw = FD_QUADS / tpad;
-  hipLaunchKernelGGL(k_modp_fd_step, dim3((chains + cpw - 1) / cpw), dim3(FD_THREADS), 0, s, state, chains, t, tpad,
-                     chain_len, count, x_m, gate, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_fd_step, dim3(chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, state, chains, t, tpad,
+                     chain_len, count, x_m, hand, gate, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,

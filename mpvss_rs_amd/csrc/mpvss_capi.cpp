@@ -57,7 +57,7 @@ struct mpvss_ctx {
   // flight on the GPU at once (the serial phases of one box overlap the wide phases of the next).
   struct Work {
     DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
-    DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root;   // forward differences
+    DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root, fd_hand_t, fd_hand_s;   // forward differences
     DevBuf fd_tabc, tab3, gr_m;   // X tables of a1 in two-stream mode; gr_m: g^r_i in Montgomery form
     const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
     struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
@@ -70,7 +70,7 @@ struct mpvss_ctx {
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
-              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_tabc, &tab3, &gr_m};
+              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &fd_tabc, &tab3, &gr_m};
     }
   };
   Work work0;
@@ -106,7 +106,7 @@ struct mpvss_ctx {
     double kernel_ms[4] = {0, 0, 0, 0};
     Work work;
   };
-  static constexpr unsigned NSLOT = 4;
+  static constexpr unsigned NSLOT = 8;
   BlockSlot slot[NSLOT];
   unsigned head = 0, tail = 0;   // next slot to fill / to absorb
   EcWork ecwork;
@@ -709,11 +709,17 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   for (int l = nlev - 1; l >= 0; --l)
     LAUNCHCHK(ctx, modp_launch_binv_down(level_in(l), (const uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_inv(l + 1),
                                          ms[l], G, level_inv(l), flag, ctx->consts, ctx->stream));
-  // difference tables, stepping, conversion -- all gated on flag == 1
-  LAUNCHCHK(ctx, modp_launch_fd_table(xm, (const uint32_t*)w.fd_xinv.p, S, (int)t, (uint32_t*)w.fd_state.p, flag,
-                                      ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)w.fd_state.p, S, (int)t, chain_len, (int)cnt, xm, flag, ctx->consts,
-                                     ctx->stream));
+  // difference tables, stepping, conversion -- all gated on flag == 1.  Both kernels are pipelines of single-wave
+  // stages that hand numbers down through zeroed buffers (see modp_kernels.hip).
+  const size_t hand_t = modp_fd_table_hand_words(S, (int)t) * 4, hand_s = modp_fd_step_hand_words(S, (int)t, chain_len) * 4;
+  RET_IF(ensure(ctx, w.fd_hand_t, hand_t));
+  RET_IF(ensure(ctx, w.fd_hand_s, hand_s));
+  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_t.p, 0, hand_t, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, hand_s, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_table(xm, (const uint32_t*)w.fd_xinv.p, S, (int)t, (uint32_t*)w.fd_state.p,
+                                      (uint32_t*)w.fd_hand_t.p, flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)w.fd_state.p, S, (int)t, chain_len, (int)cnt, xm,
+                                     (uint32_t*)w.fd_hand_s.p, flag, ctx->consts, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_from_mont(xm, (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
   LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t, dpos,
@@ -847,7 +853,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   if (n > 0 && (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff))
     return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1)");
   mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
-  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: four blocks already in flight, absorb one first");
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: eight blocks already in flight, absorb one first");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   sl.n = n;
@@ -913,15 +919,16 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     const int64_t* hp = space == MPVSS_HOST ? positions + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
     if (two_streams && ctx->stream_b && fd_applies(t, hp, cnt)) {
-      // Two streams: the forward-difference X path has long phases that occupy few CUs (inverting the
-      // commitments, difference tables, stepping).  a2 = y^r Y^c does not depend on X, so it runs beside them:
-      // its first half from the start, its second half once the seed launch (which wants the whole GPU) is done.
+      // Two streams: the forward-difference X path is a chain of latency-bound launches that occupy few wave
+      // slots (seeds, inversion tree, difference tables, stepping).  a2 = y^r Y^c and g^r do not depend on X, so
+      // they run beside it on the second stream.  With several boxes in flight (one workspace and stream pair per
+      // block slot) a single a2 launch is best; MPVSS_A2_FIRST_PERCENT < 100 splits it in two and
+      // MPVSS_A2_WAIT_SEEDS=1 holds the second part back until the seed launch is done (better for a lone box).
       RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4));     // no reallocation while two streams are live
       RET_IF(ensure(ctx, ctx->w->tab2, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
-      // first part: what fits beside the (tiny) commitment inversion, so that the seed launch has the GPU to itself
-      static const int h1_percent = fd_env("MPVSS_A2_FIRST_PERCENT", 40);
+      static const int h1_percent = fd_env("MPVSS_A2_FIRST_PERCENT", 100);
       const size_t h = ((cnt * (size_t)h1_percent / 100) / 64) * 64;
       struct Swap {
         mpvss_ctx* c; hipStream_t a;
@@ -941,11 +948,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, ctx->w->ev_seeds));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_seeds, 0));
+      static const int wait_seeds = fd_env("MPVSS_A2_WAIT_SEEDS", 0);
+      if (wait_seeds) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_seeds, 0));
       {
         Swap sw(ctx);
-        RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
-                         (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
+        if (cnt > h)
+          RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
+                           (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_join, ctx->stream));
       }
       // a1 = g^r * X^c: once X is known only X^c and one product remain

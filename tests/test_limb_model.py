@@ -25,12 +25,11 @@ def mont_mul_model(a, b, stats, bound_only=False):
         for j in range(L):
             T[j] += m * NL[j]
         assert T[0] & M == 0
-        c_lo = (T[0] >> W) & 0xFFFFFFFF
-        c_hi = (T[0] >> 32) >> W
-        assert (T[0] >> W) == c_lo + (c_hi << 32)
-        T[1] += c_lo
-        assert ((T[1] >> 32) + c_hi) < (1 << 32)          # the hi-word add cannot wrap
-        T[1] += c_hi << 32
+        stats["maxacc"] = max(stats["maxacc"], max(T))
+        for q in range(4):       # every lane: upper bits of its lowest column into its next column, low limb handed down
+            j = q * LPL
+            T[j + 1] += T[j] >> W
+            T[j] &= M
         stats["maxacc"] = max(stats["maxacc"], max(T))
         assert max(T) < (1 << 64)
         T = T[1:] + [0]
