@@ -281,7 +281,9 @@ def main():
     else:
         mm_x = horner_modmuls(positions, t) + n
         x_path = "Horner in the exponent"
-    mm_dual = n * ((2044 + 511 + 64 + 1) + (316 + 511 + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
+    comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
+    gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
+    mm_dual = n * ((2044 + 511 + 64 + 1) + (316 + gr + 2))    # a2: Straus chain; a1: comb for g^r + X^c windows
     mm_table = n * (3 * 15)                                   # three 16-entry tables per share (+1 conversion each)
     mm_total = mm_x + mm_dual + mm_table
     achieved_modmul = mm_total / (ms_per_step * 1e-3)         # against the step's wall time (kernels overlap)

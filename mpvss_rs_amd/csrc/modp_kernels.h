@@ -22,12 +22,14 @@ int modp_launch_dual_exp(const uint32_t* tab1, size_t tab1_stride, const uint32_
                          uint8_t* out, const void* cs, hipStream_t s);
 #define MODP_COMB_WORDS (512 * 16 * MODP_L)   /* fixed-base comb table, words */
 int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb, const void* cs, hipStream_t s);
+#define MODP_COMB16_WORDS ((size_t)128 * 65536 * MODP_L)   /* wide comb (16-bit windows): 2.5 GB */
+int modp_launch_comb16_build(const uint32_t* comb4, uint32_t* comb16, const void* cs, hipStream_t s);
 int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
                               const uint8_t* e2, size_t e2_stride, int e2_windows, int count, uint8_t* out,
-                              const void* cs, hipStream_t s);
+                              int comb_bits, const void* cs, hipStream_t s);
 int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
                                     const uint8_t* e2, size_t e2_stride, int e2_windows, int count, uint8_t* out, int mode,
-                                    uint32_t* p_m, const void* cs, hipStream_t s);
+                                    uint32_t* p_m, int comb_bits, const void* cs, hipStream_t s);
 int modp_occupancy_report(int* out5);
 /* forward-difference evaluation of X_i for consecutive positions (see modp_kernels.hip) */
 int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_t* cm_b, int split, int t, const int64_t* positions,

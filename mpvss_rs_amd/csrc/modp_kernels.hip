@@ -735,6 +735,44 @@ k_modp_comb_rows(u32* __restrict__ comb, const ModpConsts* __restrict__ cs) {
   }
 }
 
+// Wide comb (16-bit windows): comb16[k][d] = g^(d * 2^(16 k)), k < 128, d < 65536 -- 2.5 GB, sized for 288 GB of HBM.
+// Row bases come from the 4-bit comb (comb4[4k][1] = g^(2^(16k))); pass j = 1..15 doubles every row:
+//   p = entry[2^(j-1)]^2 = entry[2^j],   entry[2^j + i] = entry[i] * p   for i < 2^j.
+extern "C" __global__ void k_modp_comb16_init(const u32* __restrict__ comb4, u32* __restrict__ comb16,
+                                              const ModpConsts* __restrict__ cs) {
+  const int k = blockIdx.x;                    // 128 blocks of 76 threads
+  const int j = threadIdx.x;
+  if (j >= L) return;
+  comb16[((size_t)k * 65536 + 0) * L + j] = cs->one_m[j];
+  comb16[((size_t)k * 65536 + 1) * L + j] = comb4[((size_t)(4 * k) * 16 + 1) * L + j];
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_comb16_pass(u32* __restrict__ comb16, int j, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int half = 1 << j;
+  const int items = 128 * half;
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < items;
+  const int x = live ? xi : items - 1;
+  const int k = x >> j, i = x & (half - 1);
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32* row = comb16 + (size_t)k * 65536 * L;
+  u32 n[LPL], p[LPL], a[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(p, row + (size_t)(half >> 1) * L, ln);
+  slot_store(slot, p, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(p, p, slot, n, ln);           // p = entry[2^j]
+  __builtin_amdgcn_wave_barrier();
+  slot_store(slot, p, ln);
+  load_lane_limbs(a, row + (size_t)i * L, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);
+  if (live) store_lane_limbs(row + (size_t)(half + i) * L, a, ln);
+}
+
 // ---------------------------------------------------------------------------------------
 // out[x] = g^e1[x] * B2[x]^e2[x] with g given as a comb table (no squarings for the g part):
 //   phase A: acc = B2^e2 by 4-bit windows over tab2 (only the low e2_windows windows)
@@ -745,7 +783,9 @@ extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2, size_t tab2_stride,
                      const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride,
                      int e2_windows, int count, uint8_t* __restrict__ out_be, int mode, u32* __restrict__ p_m,
-                     const ModpConsts* __restrict__ cs) {
+                     int comb_bits, const ModpConsts* __restrict__ cs) {
+  // comb_bits: 4 = comb[k][d] = g^(d 16^k), 512 rows of 16; 16 = comb[k][d] = g^(d 65536^k), 128 rows of 65536
+  // (2.5 GB in HBM, a quarter of the products).
   // mode 0: the whole product.  mode 1: only g^e1 (needs nothing but the exponent, so it can run before B2 is
   // known), left in Montgomery form in p_m.  mode 2: B2^e2 times the stored p_m.
   __shared__ __attribute__((aligned(16))) u32 lds[2 * NUMS_PER_BLOCK * SLOT_WORDS];
@@ -761,6 +801,7 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
   const uint8_t* e1 = e1_be + (size_t)x * 256;
   const uint8_t* e2 = e2_be + (size_t)x * e2_stride;
   const int first_e2 = 512 - e2_windows;
+  const int comb_rows = comb_bits == 16 ? 128 : 512;
 
   // steps: A(w, s): w = first_e2..511, s = 0..3 square (w > first_e2), 4 = table product
   //        B(k):    k = 0..511 comb product (k = 0 loads), then P = product with phase-A value, F = final
@@ -802,13 +843,18 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
         ++s;
       }
     } else if (phase == PH_B) {
-      const u32 byte = e1[255 - (k >> 1)];
-      const u32 d = (k & 1) ? (byte >> 4) : (byte & 15);
-      const u32* entry = comb + ((size_t)k * 16 + d) * L;
+      size_t ent;
+      if (comb_bits == 16) {
+        ent = (size_t)k * 65536 + (((u32)e1[254 - 2 * k] << 8) | e1[255 - 2 * k]);
+      } else {
+        const u32 byte = e1[255 - (k >> 1)];
+        ent = (size_t)k * 16 + ((k & 1) ? (byte >> 4) : (byte & 15));
+      }
+      const u32* entry = comb + ent * L;
       if (k == 0) { load_lane_limbs(acc, entry, ln); skip = true; }
       else fill = entry;
       ++k;
-      if (k == 512) phase = (mode == 1) ? PH_F + 2 : (e2_windows > 0) ? PH_P : PH_F;
+      if (k == comb_rows) phase = (mode == 1) ? PH_F + 2 : (e2_windows > 0) ? PH_P : PH_F;
     } else if (phase == PH_P) {
       bptr = pslot;
       phase = PH_F;
@@ -979,22 +1025,31 @@ extern "C" int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb
   return (int)hipGetLastError();
 }
 
+// wide comb from the 4-bit comb of the same base (16 launches)
+extern "C" int modp_launch_comb16_build(const uint32_t* comb4, uint32_t* comb16, const void* cs, hipStream_t s) {
+  hipLaunchKernelGGL(k_modp_comb16_init, dim3(128), dim3(128), 0, s, comb4, comb16, (const ModpConsts*)cs);
+  for (int j = 1; j < 16; ++j)
+    hipLaunchKernelGGL(k_modp_comb16_pass, dim3(grid_for(128 << j)), dim3(BLOCK_THREADS), 0, s, comb16, j,
+                       (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
 extern "C" int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride,
                                          const uint8_t* e1, const uint8_t* e2, size_t e2_stride, int e2_windows,
-                                         int count, uint8_t* out, const void* cs, hipStream_t s) {
+                                         int count, uint8_t* out, int comb_bits, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
-                     e1, e2, e2_stride, e2_windows, count, out, 0, (uint32_t*)nullptr, (const ModpConsts*)cs);
+                     e1, e2, e2_stride, e2_windows, count, out, 0, (uint32_t*)nullptr, comb_bits, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 
 // the two halves of the same product: mode 1 = g^e1 into p_m (Montgomery form), mode 2 = B2^e2 * p_m
 extern "C" int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride,
                                                const uint8_t* e1, const uint8_t* e2, size_t e2_stride, int e2_windows,
-                                               int count, uint8_t* out, int mode, uint32_t* p_m, const void* cs,
-                                               hipStream_t s) {
+                                               int count, uint8_t* out, int mode, uint32_t* p_m, int comb_bits,
+                                               const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
-                     e1, e2, e2_stride, e2_windows, count, out, mode, p_m, (const ModpConsts*)cs);
+                     e1, e2, e2_stride, e2_windows, count, out, mode, p_m, comb_bits, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }

@@ -79,6 +79,8 @@ struct mpvss_ctx {
   hipStream_t stream_c = nullptr;                 // helper stream for small synchronous copies that must not wait for A/B
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
+  DevBuf comb16[2];          // their wide versions (16-bit windows, 2.5 GB each), built on first large batch
+  bool comb16_ready[2] = {false, false};
   // pinned host staging
   void* pin = nullptr;
   size_t pin_cap = 0;
@@ -113,6 +115,11 @@ struct mpvss_ctx {
 };
 
 namespace {
+
+int fd_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 int fail(mpvss_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
   if (ctx) {
@@ -304,8 +311,10 @@ int generator_id(const uint8_t* base_host) {
   return -1;
 }
 
-// fixed-base comb table of generator `gid` (modp.rs:64-66), built once per context (about 25 ms)
-int comb_table(mpvss_ctx* ctx, int gid, const uint32_t** comb) {
+// fixed-base comb table of generator `gid` (modp.rs:64-66), built once per context (about 25 ms).  Batches of
+// MPVSS_COMB16_MIN (default 8192) numbers or more use the wide comb instead: 16-bit windows, 128 products per
+// exponentiation instead of 512, 2.5 GB of HBM per generator, built once per context from the narrow one.
+int comb_table(mpvss_ctx* ctx, int gid, const uint32_t** comb, size_t batch = 0) {
   if (!ctx->comb_ready[gid]) {
     RET_IF(ensure(ctx, ctx->comb[gid], (size_t)MODP_COMB_WORDS * 4 + EB));
     uint8_t* dbase = (uint8_t*)ctx->comb[gid].p + (size_t)MODP_COMB_WORDS * 4;
@@ -315,7 +324,22 @@ int comb_table(mpvss_ctx* ctx, int gid, const uint32_t** comb) {
     ctx->comb_ready[gid] = true;
   }
   *comb = (const uint32_t*)ctx->comb[gid].p;
+  static const size_t wide_min = (size_t)fd_env("MPVSS_COMB16_MIN", 8192);
+  if (wide_min > 0 && batch >= wide_min) {
+    if (!ctx->comb16_ready[gid]) {
+      RET_IF(ensure(ctx, ctx->comb16[gid], MODP_COMB16_WORDS * 4));
+      LAUNCHCHK(ctx, modp_launch_comb16_build(*comb, (uint32_t*)ctx->comb16[gid].p, ctx->consts, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->comb16_ready[gid] = true;
+    }
+    *comb = (const uint32_t*)ctx->comb16[gid].p;
+  }
   return 0;
+}
+
+// window width of a table returned by comb_table()
+int comb_bits_of(const mpvss_ctx* ctx, const uint32_t* comb) {
+  return (comb != nullptr && (comb == ctx->comb16[0].p || comb == ctx->comb16[1].p)) ? 16 : 4;
 }
 
 // per-number tables of `count` bases (device bytes) into buf
@@ -421,7 +445,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto& sl : ctx->slot) work_destroy(sl.work, true);
   work_destroy(ctx->work0, ctx->own_stream);
-  for (DevBuf* b : {&ctx->comb[0], &ctx->comb[1]})
+  for (DevBuf* b : {&ctx->comb[0], &ctx->comb[1], &ctx->comb16[0], &ctx->comb16[1]})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&ctx->ecwork.a, &ctx->ecwork.b, &ctx->ecwork.c, &ctx->ecwork.d, &ctx->ecwork.e, &ctx->ecwork.pos,
                     &ctx->ecwork.cm, &ctx->ecwork.cmenc, &ctx->ecwork.x, &ctx->ecwork.o1, &ctx->ecwork.o2, &ctx->ecwork.ok,
@@ -545,7 +569,7 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
   const uint32_t* tg = nullptr;
   const uint32_t* cg = nullptr;
   if (generator_id(base_host) >= 0)
-    RET_IF(comb_table(ctx, generator_id(base_host), &cg));
+    RET_IF(comb_table(ctx, generator_id(base_host), &cg, n));
   else
     RET_IF(shared_table(ctx, base_host, &tg));
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
@@ -559,7 +583,7 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
     }
     if (cg)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
-                                                     dout, ctx->consts, ctx->stream));
+                                                     dout, comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     else
       TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
                                                 dout, ctx->consts, ctx->stream));
@@ -603,10 +627,6 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
 // share and coefficient.  Whether the path applies (consecutive positions, every commitment invertible) is
 // decided ON THE DEVICE through a flag that gates the kernels, so the pipelined callers never synchronise.
 // MPVSS_FD=0 disables the path, MPVSS_FD_CHAINS overrides the number of chains.
-static int fd_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 
 // stream callback: out = in^-1 mod q (canonical big-endian), ok = 0 when in is 0 mod q.  No HIP calls in here.
 void invert_root_on_host(void* p) {
@@ -765,7 +785,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
   RET_IF(number_tables(ctx, b2_dev, cnt, t2buf ? *t2buf : ctx->w->tab2, &t2));
   if (comb_b1) {   // B1 is a generator with a comb table: no squarings for B1^r
     TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(comb_b1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt,
-                                                   out_dev, ctx->consts, ctx->stream));
+                                                   out_dev, comb_bits_of(ctx, comb_b1), ctx->consts, ctx->stream));
     return 0;
   }
   if (shared_b1) {
@@ -793,7 +813,7 @@ extern "C" int mpvss_modp_dleq_commitments(mpvss_ctx* ctx, int space, const uint
   const uint32_t* tg = nullptr;
   const uint32_t* cg = nullptr;
   if (generator_id(g1_host) >= 0)
-    RET_IF(comb_table(ctx, generator_id(g1_host), &cg));
+    RET_IF(comb_table(ctx, generator_id(g1_host), &cg, n));
   else
     RET_IF(shared_table(ctx, g1_host, &tg));
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
@@ -886,7 +906,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   }
   RET_IF(stage_commitments(ctx, space, commitments, t));
   const uint32_t* cg;
-  RET_IF(comb_table(ctx, 0, &cg));
+  RET_IF(comb_table(ctx, 0, &cg, n));
   const void* dchal;
   RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->w->in_e, &dchal));
   const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
@@ -943,7 +963,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                          0, c_windows, h, da2));
         // g^r_i needs only the responses: it runs here instead of after the stepping phase
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
-                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
+                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
                                                              ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
@@ -964,7 +984,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_gr, 0));
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0,
                                                              c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
-                                                             ctx->consts, ctx->stream));
+                                                             comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_join, 0));
     } else {
@@ -1092,7 +1112,7 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
   HIPCHK(ctx, hipSetDevice(ctx->device));
   spans_reset(ctx);
   const uint32_t* cG;
-  RET_IF(comb_table(ctx, 1, &cG));
+  RET_IF(comb_table(ctx, 1, &cG, n));
   std::vector<uint8_t> hc, hpk, hy;
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
@@ -1155,7 +1175,7 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
   if (n > 0) {
     RET_IF(stage_commitments(ctx, space, commitments, t));
     const uint32_t* cg;
-    RET_IF(comb_table(ctx, 0, &cg));
+    RET_IF(comb_table(ctx, 0, &cg, n));
     for (size_t off = 0; off < n; off += MAX_CHUNK) {
       const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
       const int64_t* dpos;
@@ -1185,7 +1205,7 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
                                                 (int)cnt, da2, ctx->consts, ctx->stream));
       // a1 = g^w (dleq.rs:207-211)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
-                                                     da1, ctx->consts, ctx->stream));
+                                                     da1, comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       RET_IF(ensure_pinned(ctx, cnt * EB * 4));
       uint8_t* hX = (uint8_t*)ctx->pin;
       uint8_t* hY = hX + cnt * EB;
@@ -1231,7 +1251,7 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   spans_reset(ctx);
   const uint32_t* cG;
-  RET_IF(comb_table(ctx, 1, &cG));
+  RET_IF(comb_table(ctx, 1, &cG, n));
   std::vector<uint8_t> hpk, hy;
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
@@ -1250,7 +1270,7 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     RET_IF(exp_dev(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, cnt, dS));                       // S = Y^(1/x)
     TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
-                                                   da1, ctx->consts, ctx->stream));                // a1 = G^w
+                                                   da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));                // a1 = G^w
     RET_IF(exp_dev(ctx, dS, (const uint8_t*)dw, cnt, da2));                                        // a2 = S^w
     RET_IF(ensure_pinned(ctx, cnt * EB * 3));
     uint8_t* hS = (uint8_t*)ctx->pin;
