@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--participants", dest="n", type=int, default=65536, help="participants per GPU")
     ap.add_argument("--threshold", dest="t", type=int, default=256, help="threshold")
+    ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the CPU port (-1: 2 per core, 0: skip)")
     args = ap.parse_args()
 
@@ -383,6 +384,32 @@ def main():
                       f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
                       f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
         }
+    # ---------------- W_B: decrypted-share verifications (participant.rs:361-386), SURVEY 8(d) ----------------
+    # Secondary figure, rank 0 at N=1 only, outside the timed region above: a bounded batch of share boxes
+    # (built with the engine's own extract_shares), inputs resident in HBM, verdicts checked.
+    if rank == 0 and world == 1 and args.wb_shares != 0:
+        m = min(n, args.wb_shares if args.wb_shares > 0 else 16384)
+        sl = slice(0, m * EB)
+        rng_w = random.Random(SEED + 7)
+        wit_b = [keygen(rng_w) for _ in range(m)]
+        xinv = b"".join(fx(pow(x, -1, ORDER)) for x in privs[:m])
+        S, cb = eng.extract_shares(pubkeys[sl], shares[sl], xinv, b"".join(map(fx, wit_b)))
+        rb = b"".join(fx((w - x * int.from_bytes(cb[i * EB:(i + 1) * EB], "big")) % ORDER)
+                      for i, (w, x) in enumerate(zip(wit_b, privs[:m])))                      # dleq.rs:42-50
+        d_S, d_cb, d_rb = dev_u8(S), dev_u8(cb), dev_u8(rb)
+        verd = (C.c_uint8 * m)()
+        torch.cuda.synchronize()
+        reps = 3
+        for it in range(reps + 1):
+            if it == 1:
+                tw = time.perf_counter()
+            eng._check(lib.mpvss_modp_verify_shares(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb), vp(d_rb),
+                                                    m, verd), "verify_shares")
+        wb_s = (time.perf_counter() - tw) / reps
+        assert bytes(verd) == b"\x01" * m, "verify_share verdicts"
+        result["verify_share"] = {"value": m / wb_s, "unit": "share-box verifications/s", "batch": m,
+                                  "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c, per-share SHA-256 verdict on the host; "
+                                          "inputs resident in HBM, synchronous calls (no pipelining)"}
     if rank == 0:
         print(json.dumps(result))
     eng.close()
