@@ -122,7 +122,7 @@ int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* com
  *   mpvss_modp_transcript_verdict(state, challenge, &verdict, digest);
  * `compute` only enqueues GPU work (kernels + device-to-host copies) and returns; `absorb` waits
  * for it, so the wait for the previous block's state overlaps this block's GPU work.
- * Up to eight blocks may be in flight per engine (compute, compute, ..., absorb, absorb in FIFO order): the
+ * Up to sixteen blocks may be in flight per engine (compute, compute, ..., absorb, absorb in FIFO order): the
  * host hash of box k then overlaps the GPU work of boxes k+1.. (bench.py).
  * mpvss_modp_verify_distribution == init + compute + absorb + verdict on one engine. */
 #define MPVSS_TRANSCRIPT_STATE_BYTES 128
@@ -137,6 +137,24 @@ int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_ou
 int mpvss_modp_transcript_absorb(uint8_t* state, const uint8_t* elements, size_t count);
 int mpvss_modp_transcript_verdict(const uint8_t* state, const uint8_t* challenge_host, int* verdict,
                                   uint8_t* digest32_out);
+
+/* ---- registered public keys (opt-in) ---------------------------------------------------- */
+
+/* In a PVSS deployment the participants' public keys are long-lived: every dealer distributes to the same keys, so
+ * a verifier checks many boxes against one key set (src/participant.rs:399-455 takes the same `publickeys` each
+ * time).  A key set holds, in HBM, per-key tables for y_i^r (622 KB per key: 41 GB for 65536 keys) built once
+ * (about as much work as verifying 1.5 boxes); verify_block_compute_keyset then computes a2_i = y_i^r_i * Y_i^c with
+ * 571 products instead of 2 620.  Results are identical to mpvss_modp_verify_block_compute on the same keys.
+ * Shares i of the call use keys key_offset + i of the set.  Destroy a key set only after the blocks using it have
+ * been absorbed. */
+typedef struct mpvss_keyset mpvss_keyset;
+int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out);
+void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* keyset);
+size_t mpvss_modp_keyset_bytes(const mpvss_keyset* keyset);
+int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                           const int64_t* positions, const mpvss_keyset* keyset, size_t key_offset,
+                                           const uint8_t* shares, const uint8_t* responses, size_t n,
+                                           const uint8_t* challenge_host);
 
 /* ---- verify_share, batched -------------------------------------------------------------- */
 

@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
+    "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
+    "mpvss_modp_verify_block_compute_keyset",
 )
 
 GROUP_SECP256K1 = 1
@@ -58,6 +60,12 @@ def load_library() -> C.CDLL:
     lib.mpvss_last_error.restype = C.c_char_p
     lib.mpvss_ctx_set_stream.argtypes = [vp, vp]
     lib.mpvss_ctx_synchronize.argtypes = [vp]
+    lib.mpvss_modp_keyset_create.argtypes = [vp, ci, u8p, sz, C.POINTER(vp)]
+    lib.mpvss_modp_keyset_destroy.argtypes = [vp, vp]
+    lib.mpvss_modp_keyset_destroy.restype = None
+    lib.mpvss_modp_keyset_bytes.argtypes = [vp]
+    lib.mpvss_modp_keyset_bytes.restype = sz
+    lib.mpvss_modp_verify_block_compute_keyset.argtypes = [vp, ci, u8p, sz, i64p, vp, sz, u8p, u8p, sz, u8p]
     lib.mpvss_modp_batch_exp.argtypes = [vp, ci, u8p, u8p, sz, u8p]
     lib.mpvss_modp_batch_mul.argtypes = [vp, ci, u8p, u8p, sz, u8p]
     lib.mpvss_modp_batch_exp_fixed_base.argtypes = [vp, ci, u8p, u8p, sz, u8p]
@@ -215,6 +223,38 @@ class Engine:
         pos = (C.c_int64 * max(n, 1))(*positions)
         self._check(self.lib.mpvss_modp_verify_block_compute(self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p),
                                                              py, pY, pr, n, pch), "verify_block_compute")
+
+    # ---- registered public keys (per-key tables for y^r, reused by every box verified against the same keys)
+    def keyset_create(self, pubkeys: bytes):
+        kk, pk = _buf(pubkeys)
+        h = C.c_void_p()
+        self._check(self.lib.mpvss_modp_keyset_create(self.ctx, MPVSS_HOST, pk, len(pubkeys) // EB, C.byref(h)),
+                    "keyset_create")
+        return h
+
+    def keyset_destroy(self, keyset) -> None:
+        self.lib.mpvss_modp_keyset_destroy(self.ctx, keyset)
+
+    def keyset_bytes(self, keyset) -> int:
+        return int(self.lib.mpvss_modp_keyset_bytes(keyset))
+
+    def verify_block_compute_keyset(self, commitments: bytes, positions: Sequence[int], keyset, key_offset: int,
+                                    shares: bytes, responses: bytes, challenge: bytes) -> None:
+        t = len(commitments) // EB
+        n = len(positions)
+        kc, pc = _buf(commitments); kY, pY = _buf(shares); kr, pr = _buf(responses)
+        kch, pch = _buf(challenge)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        self._check(self.lib.mpvss_modp_verify_block_compute_keyset(self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p),
+                                                                    keyset, key_offset, pY, pr, n, pch),
+                    "verify_block_compute_keyset")
+
+    def verify_block_absorb_dump(self, state: bytes, n: int):
+        """absorb the oldest block and also return its X, a1, a2 arrays"""
+        ks, ps = _buf(state)
+        kx, px = _out(n * EB); k1, p1 = _out(n * EB); k2, p2 = _out(n * EB)
+        self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, px, p1, p2), "verify_block_absorb")
+        return bytes(ks), bytes(kx)[: n * EB], bytes(k1)[: n * EB], bytes(k2)[: n * EB]
 
     def verify_block_absorb(self, state: bytes) -> bytes:
         ks, ps = _buf(state)

@@ -878,6 +878,122 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
 }
 
 // ---------------------------------------------------------------------------------------
+// Registered public keys (opt-in): per-key tables for y^r, built once per key set and reused by every box that is
+// verified against it.  ks[key][j][d] = y^(d * 2^(256 j)), j < 8, d < 256 (Montgomery form; 8 x 256 x 304 B =
+// 622 KB per key, 41 GB for 65536 keys -- sized for 288 GB of HBM).  With r = sum_j r_j 2^(256 j):
+//   y^r * Y^c = prod_j (y^(2^(256 j)))^(r_j) * Y^c    -- Straus over 256-bit rows:
+// 252 squarings shared by all nine bases, 256 products from the key table (8-bit windows), 63 from Y's 4-bit
+// table: 571 products instead of 2 620.
+// ---------------------------------------------------------------------------------------
+constexpr int KS_SUB = 8;          // sub-bases per key
+constexpr int KS_ENT = 256;        // entries per sub-base (8-bit windows)
+
+// sub-bases: ks[key][j][1] = y^(2^(256 j)), ks[key][j][0] = 1   (one quad per key, 7 x 256 squarings)
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_keyset_bases(const uint8_t* __restrict__ pk_be, int count, u32* __restrict__ ks,
+                    const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL], one[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(one, cs->one_m, ln);
+  load_be256(acc, pk_be + (size_t)x * 256, ln);
+  u32* mine = ks + (size_t)x * KS_SUB * KS_ENT * L;
+  // op 0: to Montgomery form; then 256 squarings per further sub-base
+  for (int op = 0; op <= (KS_SUB - 1) * 256; ++op) {
+    if (op == 0) slot_fill_from_global(slot, cs->r2, ln); else slot_store(slot, acc, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    if (live && (op % 256) == 0) {
+      u32* row = mine + (size_t)(op / 256) * KS_ENT * L;
+      store_lane_limbs(row, one, ln);
+      store_lane_limbs(row + L, acc, ln);
+    }
+  }
+}
+
+// rows: ks[key][j][d] = ks[key][j][d-1] * ks[key][j][1], d = 2..255   (one quad per (key, j))
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_keyset_rows(u32* __restrict__ ks, int rows, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < rows;
+  const int x = live ? xi : rows - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32* row = ks + (size_t)x * KS_ENT * L;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(acc, row + L, ln);
+  slot_store(slot, acc, ln);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = 2; d < KS_ENT; ++d) {
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (live) store_lane_limbs(row + (size_t)d * L, acc, ln);
+  }
+}
+
+// out[x] = y_x^r_x * Y_x^c with y_x's registered table ks[x] and Y's 4-bit table tab2; c < 2^256 shared.
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_keyset_dual_exp(const u32* __restrict__ ks, const u32* __restrict__ tab2, const uint8_t* __restrict__ r_be,
+                       const uint8_t* __restrict__ c_be, int count, uint8_t* __restrict__ out_be,
+                       const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  const u32* kt = ks + (size_t)x * KS_SUB * KS_ENT * L;
+  const u32* t2 = tab2 + (size_t)x * 16 * L;
+  const uint8_t* r = r_be + (size_t)x * 256;
+  // Program, p = 0..31 (byte p of the 32-byte rows, most significant first):
+  //   [4 squarings] * Y[c hi nibble]   (p = 0: load)      steps 0..4
+  //   4 squarings   * Y[c lo nibble]                       steps 5..9
+  //   * ks[j][byte p of r_j], j = 0..7                     steps 10..17
+  {
+    const u32 d = c_be[224] >> 4;
+    load_lane_limbs(acc, t2 + (size_t)d * L, ln);
+  }
+  int p = 0, s = 5;
+  while (true) {
+    const u32* fill = nullptr;
+    if (s < 4 || (s >= 5 && s < 9)) {
+      slot_store(slot, acc, ln);                       // squaring
+    } else if (s == 4 || s == 9) {
+      const u32 byte = c_be[224 + p];
+      const u32 d = (s == 4) ? (byte >> 4) : (byte & 15);
+      fill = t2 + (size_t)d * L;
+    } else if (s < 10 + KS_SUB) {
+      const int j = s - 10;
+      const u32 d = r[224 - 32 * j + p];
+      fill = kt + ((size_t)j * KS_ENT + d) * L;
+    } else {
+      fill = cs->one;                                  // leave the Montgomery domain
+    }
+    if (fill != nullptr) slot_fill_from_global(slot, fill, ln);
+    __builtin_amdgcn_wave_barrier();
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    if (s == 10 + KS_SUB) break;
+    ++s;
+    if (s == 10 + KS_SUB) {
+      if (p == 31) continue;                           // final step
+      ++p;
+      s = 0;
+    }
+  }
+  store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
 // host-callable launchers (plain C linkage, used by mpvss_capi.cpp)
 // ---------------------------------------------------------------------------------------
 
@@ -1022,6 +1138,24 @@ extern "C" int modp_launch_dual_exp(const uint32_t* tab1, size_t tab1_stride, co
 extern "C" int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb, const void* cs, hipStream_t s) {
   hipLaunchKernelGGL(k_modp_comb_bases, dim3(1), dim3(BLOCK_THREADS), 0, s, base_be_dev, comb, (const ModpConsts*)cs);
   hipLaunchKernelGGL(k_modp_comb_rows, dim3(grid_for(512)), dim3(BLOCK_THREADS), 0, s, comb, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t modp_keyset_words_per_key() { return (size_t)KS_SUB * KS_ENT * L; }
+extern "C" int modp_launch_keyset_build(const uint8_t* pk_be, int count, uint32_t* ks, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_keyset_bases, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, pk_be, count, ks,
+                     (const ModpConsts*)cs);
+  const long long rows = (long long)count * KS_SUB;
+  hipLaunchKernelGGL(k_modp_keyset_rows, dim3((unsigned)((rows + NUMS_PER_BLOCK - 1) / NUMS_PER_BLOCK)), dim3(BLOCK_THREADS),
+                     0, s, ks, (int)rows, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_keyset_dual_exp(const uint32_t* ks, const uint32_t* tab2, const uint8_t* r, const uint8_t* c,
+                                           int count, uint8_t* out, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_keyset_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, ks, tab2, r, c, count, out,
+                     (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 

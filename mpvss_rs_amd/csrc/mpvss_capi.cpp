@@ -45,6 +45,12 @@ struct EcWork {   // device workspace of the elliptic-curve entry points
   DevBuf a, b, c, d, e, pos, cm, cmenc, x, o1, o2, ok, gen, chal;
 };
 
+// Registered public keys: per-key tables for y^r in HBM plus a device copy of the keys themselves.
+struct mpvss_keyset {
+  DevBuf table, keys;
+  size_t n = 0;
+};
+
 struct mpvss_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -108,7 +114,7 @@ struct mpvss_ctx {
     double kernel_ms[4] = {0, 0, 0, 0};
     Work work;
   };
-  static constexpr unsigned NSLOT = 8;
+  static constexpr unsigned NSLOT = 16;
   BlockSlot slot[NSLOT];
   unsigned head = 0, tail = 0;   // next slot to fill / to absorb
   EcWork ecwork;
@@ -868,12 +874,20 @@ static_assert(sizeof(mpvss::Sha256) <= MPVSS_TRANSCRIPT_STATE_BYTES, "transcript
 
 int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
-                                const uint8_t* responses, size_t n, const uint8_t* challenge_host) {
+                                const uint8_t* responses, size_t n, const uint8_t* challenge_host,
+                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0) {
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
-  if (n > 0 && (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff))
+  if (n > 0 && (!commitments || !positions || (!pubkeys && !ks) || !shares || !responses || t == 0 || t > 0x7fffffff))
     return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1)");
+  if (ks && (key_offset > ks->n || n > ks->n - key_offset))
+    return fail(ctx, MPVSS_E_INVALID, "verify: shares outside the registered key set");
+  int key_space = space;
+  if (ks) {          // the keys themselves come from the key set's device copy
+    pubkeys = (const uint8_t*)ks->keys.p + key_offset * EB;
+    key_space = MPVSS_DEVICE;
+  }
   mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
-  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: eight blocks already in flight, absorb one first");
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: sixteen blocks already in flight, absorb one first");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   sl.n = n;
@@ -927,7 +941,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       sl.check_positions = true;
     }
     const void *dy, *dY, *dr;
-    RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
+    RET_IF(stage_in(ctx, key_space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
     RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->w->in_b, &dY));
     RET_IF(stage_in(ctx, space, responses + off * EB, cnt * EB, ctx->w->in_c, &dr));
     RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
@@ -959,8 +973,17 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_fork, 0));
       {
         Swap sw(ctx);
-        RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
-                         0, c_windows, h, da2));
+        if (ks && c_windows == 64) {
+          // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
+          const uint32_t* t2;
+          RET_IF(number_tables(ctx, (const uint8_t*)dY, cnt, ctx->w->tab2, &t2));
+          const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
+          TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
+                                                           ctx->consts, ctx->stream));
+        } else {
+          RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
+                           0, c_windows, h, da2));
+        }
         // g^r_i needs only the responses: it runs here instead of after the stepping phase
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
                                                              (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
@@ -972,7 +995,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       if (wait_seeds) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_seeds, 0));
       {
         Swap sw(ctx);
-        if (cnt > h)
+        if (cnt > h && !(ks && c_windows == 64))
           RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
                            (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_join, ctx->stream));
@@ -1075,6 +1098,61 @@ extern "C" int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const 
   std::lock_guard<std::mutex> lk(ctx->mu);
   return verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
                                      challenge_host);
+}
+
+// ---- registered public keys -------------------------------------------------------------------------
+extern "C" int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out) {
+  if (!ctx || !out) return MPVSS_E_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!pubkeys || n == 0 || n > 0x7fffffff / 8) return fail(ctx, MPVSS_E_INVALID, "keyset_create: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  mpvss_keyset* ks = new mpvss_keyset();
+  ks->n = n;
+  auto cleanup = [&](int rc) {
+    if (ks->table.p) (void)hipFree(ks->table.p);
+    if (ks->keys.p) (void)hipFree(ks->keys.p);
+    delete ks;
+    return rc;
+  };
+  hipError_t e = hipMalloc(&ks->keys.p, n * EB);
+  if (e == hipSuccess) e = hipMalloc(&ks->table.p, n * modp_keyset_words_per_key() * 4);
+  if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_NOMEM, "keyset_create: hipMalloc", e));
+  e = hipMemcpyAsync(ks->keys.p, pubkeys, n * EB, space == MPVSS_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                     ctx->stream);
+  if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_DEVICE, "keyset_create: copy", e));
+  if (modp_launch_keyset_build((const uint8_t*)ks->keys.p, (int)n, (uint32_t*)ks->table.p, ctx->consts, ctx->stream) != 0)
+    return cleanup(fail(ctx, MPVSS_E_DEVICE, "keyset_create: launch"));
+  e = hipStreamSynchronize(ctx->stream);     // the tables are read from every stream afterwards
+  if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_DEVICE, "keyset_create: build", e));
+  *out = ks;
+  return MPVSS_OK;
+}
+
+extern "C" void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* ks) {
+  if (!ks) return;
+  if (ctx) {
+    (void)mpvss_ctx_synchronize(ctx);        // no launch may still read the tables
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (ks->table.p) (void)hipFree(ks->table.p);
+    if (ks->keys.p) (void)hipFree(ks->keys.p);
+  }
+  delete ks;
+}
+
+extern "C" size_t mpvss_modp_keyset_bytes(const mpvss_keyset* ks) {
+  return ks ? ks->n * (modp_keyset_words_per_key() * 4 + EB) : 0;
+}
+
+extern "C" int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                                      const int64_t* positions, const mpvss_keyset* keyset,
+                                                      size_t key_offset, const uint8_t* shares,
+                                                      const uint8_t* responses, size_t n, const uint8_t* challenge_host) {
+  if (!ctx || !keyset) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_block_compute_locked(ctx, space, commitments, t, positions, nullptr, shares, responses, n, challenge_host,
+                                     keyset, key_offset);
 }
 
 extern "C" int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host,

@@ -1,0 +1,64 @@
+"""Registered public keys: verify_block_compute_keyset must produce exactly the X, a1, a2 arrays and transcript
+state of verify_block_compute on the same keys (and a2 must be y^r * Y^c by the oracle's arithmetic)."""
+import random
+
+import pytest
+
+import mpvss_oracle as O
+from helpers import EB
+from mpvss_rs_amd import capi
+
+pytestmark = pytest.mark.gpu
+Q = O.ModpGroup().q
+
+
+def fx(v):
+    return v.to_bytes(EB, "big")
+
+
+@pytest.mark.parametrize("n,t,key_offset", [(8192, 16, 0), (8192, 32, 64)])
+def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
+    rng = random.Random(1000 * t + key_offset)
+    nk = n + key_offset + 3
+    keys = [pow(2, rng.randrange(Q - 1), Q) for _ in range(40)]
+    keys = [keys[rng.randrange(40)] * pow(2, i, Q) % Q for i in range(nk)]            # cheap distinct group elements
+    keys[key_offset + 5] = 1
+    keys[key_offset + 6] = Q - 1
+    pk = b"".join(map(fx, keys))
+    cm = b"".join(fx(pow(4, rng.randrange(Q - 1), Q)) for _ in range(t))
+    shares = rng.randbytes(EB * n)
+    resp = bytearray(rng.randbytes(EB * n))
+    resp[0:EB] = bytes(EB)                                   # r = 0
+    resp[EB:2 * EB] = b"\xff" * EB                           # r = 2^2048 - 1
+    resp = bytes(resp)
+    chal = fx(rng.randrange(1 << 256))
+    pos = list(range(1, n + 1))
+    sub = pk[key_offset * EB:(key_offset + n) * EB]
+
+    engine.verify_block_compute(cm, pos, sub, shares, resp, chal)
+    st0, X0, A10, A20 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
+
+    ks = engine.keyset_create(pk)
+    try:
+        assert engine.keyset_bytes(ks) == nk * (8 * 256 * 304 + 256)
+        engine.verify_block_compute_keyset(cm, pos, ks, key_offset, shares, resp, chal)
+        st1, X1, A11, A21 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
+        # a challenge that does not fit 256 bits takes the plain path inside the same entry point
+        big = fx((1 << 300) + 5)
+        engine.verify_block_compute_keyset(cm, pos, ks, key_offset, shares, resp, big)
+        st2, _, _, A22 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
+        engine.verify_block_compute(cm, pos, sub, shares, resp, big)
+        st3, _, _, A23 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
+        with pytest.raises(capi.EngineError):                # shares beyond the registered keys
+            engine.verify_block_compute_keyset(cm, pos, ks, key_offset + 4, shares, resp, chal)
+    finally:
+        engine.keyset_destroy(ks)
+    assert (X1, A11) == (X0, A10)
+    assert A21 == A20 and st1 == st0
+    assert A22 == A23 and st2 == st3
+    c = int.from_bytes(chal, "big")
+    for i in (0, 1, 2, 5, 6, n // 2, n - 1):
+        y = keys[key_offset + i]
+        Y = int.from_bytes(shares[i * EB:(i + 1) * EB], "big")
+        r = int.from_bytes(resp[i * EB:(i + 1) * EB], "big")
+        assert int.from_bytes(A21[i * EB:(i + 1) * EB], "big") == pow(y, r, Q) * pow(Y, c, Q) % Q, i
