@@ -22,6 +22,8 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import argparse
+import collections
+import concurrent.futures
 import ctypes as C
 import json
 import math
@@ -66,7 +68,8 @@ def keygen(rng: random.Random) -> int:
             return k
 
 
-PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "4"))   # boxes in flight (the engine has 8 block slots)
+PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "8"))   # boxes in flight (the engine has 16 block slots)
+HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "3"))   # host threads absorbing (hashing) boxes at N=1
 
 
 def horner_modmuls(positions, t):
@@ -89,8 +92,8 @@ def horner_modmuls(positions, t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--participants", dest="n", type=int, default=65536, help="participants per GPU")
     ap.add_argument("--threshold", dest="t", type=int, default=256, help="threshold")
     ap.add_argument("--registered-keys", type=int, default=1,
@@ -201,6 +204,7 @@ def main():
                                                         vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p))
         eng._check(rcode, "verify_block_compute")
 
+    hash_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(HASH_THREADS, 1))
     kernel_ms = {0: [], 1: [], 2: [], 3: []}
     a2_launches = []
     host_absorb_s = []
@@ -231,19 +235,31 @@ def main():
         raw = bytes(out.cpu().numpy().tobytes())
         return bool(raw[0]), raw[1:33]
 
-    def run_steps(k, depth=PIPE_DEPTH):
+    def run_steps(k, depth=None):
         """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
-        enqueued while the host (and, on several GPUs, the rank-to-rank hash chain) finishes older ones."""
+        enqueued while the host hashes the oldest ones.  On one GPU the boxes are independent transcripts, so
+        HASH_THREADS host threads absorb consecutive boxes side by side (the engine releases its lock while it
+        hashes); with several ranks the running hash state travels rank to rank per box, in order, on one thread."""
+        depth = depth or (PIPE_DEPTH if world == 1 else PIPE_DEPTH + world)
         results = []
         issued = 0
         while issued < min(depth, k):
             compute_block()
             issued += 1
-        for _ in range(k):
-            results.append(finish_block())
+        if world > 1 or HASH_THREADS <= 1:
+            for _ in range(k):
+                results.append(finish_block())
+                if issued < k:
+                    compute_block()
+                    issued += 1
+            return results
+        pending = collections.deque(hash_pool.submit(finish_block) for _ in range(issued))
+        while pending:
+            results.append(pending.popleft().result())
             if issued < k:
                 compute_block()
                 issued += 1
+                pending.append(hash_pool.submit(finish_block))
         return results
 
     def barrier():
@@ -283,18 +299,20 @@ def main():
         while tpad < t:
             tpad *= 2
         cpw = 256 // tpad
-        chains = min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or 8192 // t, n // (4 * t))
+        chains = min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or 4096 // t, n // (4 * t))
         chains = max(4 * cpw, chains // (4 * cpw) * (4 * cpw))          # as eval_x() in mpvss_capi.cpp
         chain_len = -(-n // chains)
-        m0 = chains * t                                                  # the seeds: the first m0 positions, by Horner
+        w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
+        m0 = chains * t                                                  # the seeds: m0 consecutive positions, by Horner
         inv_tree, m = 0, m0
         while m > 1:                                                     # simultaneous inversion: 3 products per node
             inv_tree += 3 * m
             m = -(-m // 16)
-        mm_x = (horner_modmuls(positions[:m0], t) + inv_tree + chains * t * (t - 1)
-                + chains * t * (chain_len - 1) + n)
-        x_path = (f"forward differences: {chains} strided chains, {m0} Horner seeds (also outputs), inverses by "
-                  f"simultaneous inversion, {chain_len - 1} lock-step products per chain and level")
+        steps = (chain_len - 1 - w0) + (w0 + t - 1)                      # forward + backward pipeline of every chain
+        mm_x = (horner_modmuls(positions[chains * w0:chains * w0 + m0], t) + inv_tree + chains * t * (t - 1)
+                + chains * t * steps + n)
+        x_path = (f"forward differences: {chains} strided chains stepping both ways from {m0} Horner seeds in their "
+                  f"middle (also outputs), inverses by simultaneous inversion, {steps} lock-step products per chain and level")
     else:
         mm_x = horner_modmuls(positions, t) + n
         x_path = "Horner in the exponent"
@@ -344,8 +362,9 @@ def main():
                                "note": "per-kind sums of launch durations; kinds overlap on two streams"},
         },
         "host": {"absorb_wait_plus_sha256_ms": 1e3 * sum(host_absorb_s) / max(len(host_absorb_s), 1), "setup_s": setup_s,
-                 "pipelining": f"up to {PIPE_DEPTH} verifications in flight (one workspace and stream pair each): the GPU work "
-                               "of the next ones is enqueued while the host hashes the oldest"},
+                 "pipelining": f"up to {PIPE_DEPTH if world == 1 else PIPE_DEPTH + world} verifications in flight (one "
+                               "workspace and stream pair each): the GPU work of the next ones is enqueued while "
+                               f"{HASH_THREADS if world == 1 else 1} host thread(s) hash the oldest"},
     }
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape

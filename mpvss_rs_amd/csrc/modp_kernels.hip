@@ -460,8 +460,12 @@ __device__ __forceinline__ bool hand_receive(const u32* __restrict__ src, u32* d
 
 extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
 k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int chains, int t, int tpad,
-                u32* __restrict__ state, u32* __restrict__ hand, int* __restrict__ gate,
+                u32* __restrict__ state, u32* __restrict__ state_back, u32* __restrict__ hand, int* __restrict__ gate,
                 const ModpConsts* __restrict__ cs) {
+  // state[c][l]      = E_l[0]                       = D_l at the first seed: the chain that steps forward
+  // state_back[c][l] = (l even ? E_l : F_l)[t-1-l]  = g^((-1)^l nabla^l P) at the last seed: with H_l(i-1) = H_l(i) H_{l+1}(i)
+  //                    the same recurrence steps BACKWARD from the last seed, H_0 being X (one seed window serves
+  //                    both directions, so half the seeds cover the same positions)
   __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
   __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
@@ -492,7 +496,9 @@ k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int ch
   load_lane_limbs(E, x + ((size_t)chain + (size_t)chains * kk) * L, ln);
   load_lane_limbs(F, x_inv + ((size_t)chain + (size_t)chains * kk) * L, ln);
   u32* st = state + (size_t)chain * t * L;
+  u32* sb = state_back + (size_t)chain * t * L;
   if (kbase == 0 && quad == 0) store_lane_limbs(st, E, ln);
+  if (k == t - 1) store_lane_limbs(sb, E, ln);
   if (has_up && reader) {                                     // level 0 of the stage above: its seeds
     const size_t src = ((size_t)chain + (size_t)chains * (kbase + NUMS_PER_WAVE)) * L;
 #pragma unroll
@@ -525,14 +531,18 @@ k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int ch
       hand_publish(mine + (size_t)lvl * 2 * L + L, F, ln, HAND_VALID);
     }
     if (kbase == 0 && quad == 0) store_lane_limbs(st + (size_t)lvl * L, E, ln);   // D_l = E_l[0]
+    if (k == t - 1 - lvl) {                                                        // the other diagonal
+      if (lvl & 1) store_lane_limbs(sb + (size_t)lvl * L, F, ln); else store_lane_limbs(sb + (size_t)lvl * L, E, ln);
+    }
   }
 }
 
-// x_m[c + chains j] = X at the j-th position of chain c; j < t are the seeds (already there), so the first
-// t - 1 steps only advance the table.  D_k <- D_k * D_{k+1}; D_{t-1} is constant.
+// Chain c owns x_m[c + chains j], j < chain_len; its seeds are j = w0 .. w0+t-1 (already in x_m).  Two pipelines per
+// chain: direction 0 steps forward from the first seed (after s steps its level 0 is X at j = w0 + s), direction 1
+// backward from the last seed (X at j = w0 + t - 1 - s).  The first t-1 steps of either only advance the table.
 extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
-k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int chain_len, int count,
-               u32* __restrict__ x_m, u32* __restrict__ hand, int* __restrict__ gate,
+k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back, int chains, int t, int tpad, int w0,
+               int chain_len, int count, u32* __restrict__ x_m, u32* __restrict__ hand, int* __restrict__ gate,
                const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[(NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
@@ -540,10 +550,14 @@ k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int c
   const Lane ln = make_lane();
   const int quad = threadIdx.x >> 2;
   const int stages = tpad / NUMS_PER_WAVE;
-  const int sidx = blockIdx.x / chains;
+  // block order: all stages of level group 0 (the top levels) of both directions first, then the next group, ..
+  const int sidx = blockIdx.x / (2 * chains);
+  const int dir = (blockIdx.x / chains) & 1;
   const int chain = blockIdx.x % chains;
   const int kbase = tpad - NUMS_PER_WAVE * (sidx + 1);
-  if (kbase >= t) return;
+  if (kbase >= t || (dir == 1 && w0 == 0)) return;                  // no positions before the seeds: nothing to do
+  const int steps = dir == 0 ? chain_len - 1 - w0 : w0 + t - 1;     // last forward j = chain_len-1, last backward j = 0
+  const int hand_len = chain_len + t;                               // room for either direction
   const int k = kbase + quad;
   const bool has_up = kbase + NUMS_PER_WAVE < t;
   const bool has_down = kbase > 0;
@@ -552,19 +566,21 @@ k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int c
   u32* oneslot = inslot + SLOT_WORDS;
   const bool reader = quad == NUMS_PER_WAVE - 1;
   const u32* bptr = (k + 1 < t) ? (reader ? inslot : slot + SLOT_WORDS) : oneslot;
-  u32* mine = hand + ((size_t)chain * stages + sidx) * (size_t)chain_len * L;
-  const u32* up = hand + ((size_t)chain * stages + (sidx - 1)) * (size_t)chain_len * L;
+  const size_t lane_area = ((size_t)dir * chains + chain) * stages;
+  u32* mine = hand + (lane_area + sidx) * (size_t)hand_len * L;
+  const u32* up = hand + (lane_area + sidx - 1) * (size_t)hand_len * L;
+  const u32* st = (dir == 0 ? state : state_back) + (size_t)chain * t * L;
   u32 n[LPL], D[LPL];
   load_lane_limbs(n, cs->n, ln);
   if (threadIdx.x < 4) slot_fill_from_global(oneslot, cs->one_m, ln);
-  if (k < t) load_lane_limbs(D, state + ((size_t)chain * t + k) * L, ln); else load_lane_limbs(D, cs->one_m, ln);
+  if (k < t) load_lane_limbs(D, st + (size_t)k * L, ln); else load_lane_limbs(D, cs->one_m, ln);
   if (has_up && reader) {                                     // step 0 of the stage above: its table entry
-    const size_t src = ((size_t)chain * t + kbase + NUMS_PER_WAVE) * L;
+    const u32* src = st + (size_t)(kbase + NUMS_PER_WAVE) * L;
 #pragma unroll
-    for (int i = 0; i < LPL; ++i) inslot[ln.q * LPL + i] = state[src + ln.q * LPL + i];
+    for (int i = 0; i < LPL; ++i) inslot[ln.q * LPL + i] = src[ln.q * LPL + i];
   }
   const bool writer = kbase == 0 && quad == 0;
-  for (int step = 1; step < chain_len; ++step) {
+  for (int step = 1; step <= steps; ++step) {
     slot_store(slot, D, ln);
     if (has_up && step > 1) {
       if (!hand_receive(up + (size_t)(step - 1) * L, inslot, reader, ln)) {
@@ -577,7 +593,8 @@ k_modp_fd_step(const u32* __restrict__ state, int chains, int t, int tpad, int c
     mont_mul<MODP_N0INV_C>(D, D, bptr, n, ln);
     __builtin_amdgcn_wave_barrier();
     if (has_down && quad == 0) hand_publish(mine + (size_t)step * L, D, ln, HAND_VALID);
-    const size_t idx = (size_t)chain + (size_t)chains * step;
+    const int j = dir == 0 ? w0 + step : w0 + t - 1 - step;
+    const size_t idx = (size_t)chain + (size_t)chains * j;
     if (writer && step >= t && idx < (size_t)count) store_lane_limbs(x_m + idx * L, D, ln);
   }
 }
@@ -1094,20 +1111,22 @@ extern "C" size_t modp_fd_table_hand_words(int chains, int t) {
   return (size_t)chains * (modp_fd_tpad(t) / NUMS_PER_WAVE) * (size_t)t * 2 * L;
 }
 extern "C" size_t modp_fd_step_hand_words(int chains, int t, int chain_len) {
-  return (size_t)chains * (modp_fd_tpad(t) / NUMS_PER_WAVE) * (size_t)chain_len * L;
+  return (size_t)2 * chains * (modp_fd_tpad(t) / NUMS_PER_WAVE) * (size_t)(chain_len + t) * L;
 }
 extern "C" int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state,
-                                    uint32_t* hand, int* gate, const void* cs, hipStream_t s) {
+                                    uint32_t* state_back, uint32_t* hand, int* gate, const void* cs, hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
   hipLaunchKernelGGL(k_modp_fd_table, dim3(chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, x, x_inv, chains, t, tpad,
-                     state, hand, gate, (const ModpConsts*)cs);
+                     state, state_back, hand, gate, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
-extern "C" int modp_launch_fd_step(const uint32_t* state, int chains, int t, int chain_len, int count, uint32_t* x_m,
-                                   uint32_t* hand, int* gate, const void* cs, hipStream_t s) {
+// x_m: base of the chains (position index 0); w0: index of the first seed inside every chain
+extern "C" int modp_launch_fd_step(const uint32_t* state, const uint32_t* state_back, int chains, int t, int w0,
+                                   int chain_len, int count, uint32_t* x_m, uint32_t* hand, int* gate, const void* cs,
+                                   hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
-  hipLaunchKernelGGL(k_modp_fd_step, dim3(chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, state, chains, t, tpad,
-                     chain_len, count, x_m, hand, gate, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_fd_step, dim3(2 * chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, state, state_back, chains,
+                     t, tpad, w0, chain_len, count, x_m, hand, gate, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,

@@ -12,6 +12,7 @@
 
 #include <mutex>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "host_modq.h"
@@ -72,7 +73,9 @@ struct mpvss_ctx {
     };
     RootJob* root = nullptr;
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
-    hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr, ev_join0 = nullptr;
+    static constexpr int MAXPARTS = 8;
+    hipEvent_t ev_part[MAXPARTS] = {};
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
@@ -82,7 +85,15 @@ struct mpvss_ctx {
   Work work0;
   Work* w = &work0;                               // workspace of the call being enqueued
   hipStream_t stream_b = nullptr;                 // second stream of the current workspace
-  hipStream_t stream_c = nullptr;                 // helper stream for small synchronous copies that must not wait for A/B
+  // Optional (MPVSS_WIDE_FIFO=1): a few context-wide low-priority streams carry the wide a2 launches of ALL blocks in
+  // flight, cut into parts that are dealt to the streams round-robin in block order, so that the oldest box finishes
+  // first instead of every box in flight sharing the multiplier.  Measured: better only for very short runs of a
+  // single-threaded host (boxes complete one by one, their hashes overlap the GPU work); the default gives every box
+  // its own low-priority stream and lets the boxes share the chip (10 % more throughput in steady state).
+  static constexpr int NWIDE = 4;
+  hipStream_t wide[NWIDE] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned wide_rr = 0;      // round-robin cursor over the wide streams
+  int prio_high = 0, prio_low = 0;
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
   DevBuf comb16[2];          // their wide versions (16-bit windows, 2.5 GB each), built on first large batch
@@ -108,6 +119,7 @@ struct mpvss_ctx {
     size_t cap = 0;
     size_t n = 0;
     bool busy = false;
+    bool absorbing = false;        // a host thread is waiting for / hashing this block (context lock released)
     bool check_positions = false;
     hipEvent_t done = nullptr;
     SpanSet spans;
@@ -162,6 +174,8 @@ int ensure(mpvss_ctx* ctx, DevBuf& b, size_t bytes) {
   if (b.p) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));
+    for (hipStream_t s : ctx->wide)
+      if (s) HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -400,12 +414,16 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
   if (w.ready) return 0;
   if (main_stream) {
     w.sa = main_stream;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&w.sb, hipStreamNonBlocking));
   } else {
-    HIPCHK(ctx, hipStreamCreateWithFlags(&w.sa, hipStreamNonBlocking));
+    // a block slot's stream carries the latency-bound chain of its box: highest priority, so that it never queues
+    // behind (or shares a hardware queue with) the wide launches on the low-priority context-wide streams
+    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, ctx->prio_high));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, ctx->prio_low));
   }
-  HIPCHK(ctx, hipStreamCreateWithFlags(&w.sb, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&w.ev_fork, &w.ev_seeds, &w.ev_join, &w.ev_gr})
+  for (hipEvent_t* e : {&w.ev_fork, &w.ev_seeds, &w.ev_join, &w.ev_gr, &w.ev_join0})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t& e : w.ev_part) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void**)&w.root, sizeof(*w.root), hipHostMallocDefault));
   w.ready = true;
   return 0;
@@ -415,7 +433,9 @@ void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
   if (w.sb) (void)hipStreamSynchronize(w.sb);
   for (DevBuf* b : w.all())
     if (b->p) (void)hipFree(b->p);
-  for (hipEvent_t e : {w.ev_fork, w.ev_seeds, w.ev_join, w.ev_gr})
+  for (hipEvent_t e : {w.ev_fork, w.ev_seeds, w.ev_join, w.ev_gr, w.ev_join0})
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : w.ev_part)
     if (e) (void)hipEventDestroy(e);
   if (w.root) (void)hipHostFree(w.root);
   if (w.sb) (void)hipStreamDestroy(w.sb);
@@ -436,7 +456,11 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
   }
   ctx->own_stream = true;
   if (work_init(ctx, ctx->work0, ctx->stream) != 0 ||
-      hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking) != hipSuccess ||
+      hipDeviceGetStreamPriorityRange(&ctx->prio_low, &ctx->prio_high) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->wide[0], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->wide[1], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->wide[2], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->wide[3], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
       modp_consts_upload(&ctx->consts) != 0) {
     delete ctx;
     return MPVSS_E_DEVICE;
@@ -465,7 +489,8 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
   }
-  if (ctx->stream_c) (void)hipStreamDestroy(ctx->stream_c);
+  for (hipStream_t s : ctx->wide)
+    if (s) (void)hipStreamDestroy(s);
   delete ctx;
 }
 
@@ -489,10 +514,11 @@ extern "C" int mpvss_ctx_synchronize(mpvss_ctx* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->work0.sb));
+  for (hipStream_t s : ctx->wide) HIPCHK(ctx, hipStreamSynchronize(s));
   for (auto& sl : ctx->slot)
     if (sl.work.ready) {
       HIPCHK(ctx, hipStreamSynchronize(sl.work.sa));
-      HIPCHK(ctx, hipStreamSynchronize(sl.work.sb));
+      if (sl.work.sb) HIPCHK(ctx, hipStreamSynchronize(sl.work.sb));
     }
   return MPVSS_OK;
 }
@@ -673,17 +699,21 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
                                                  ctx->consts, ctx->stream));
     return 0;
   }
-  // number of chains S.  Chain c owns the positions c, c+S, c+2S, ..; the first S*t positions are the seeds of
-  // all chains (Horner, and outputs at the same time).  8192 seeds are half a wave per SIMD: the seed launch is
-  // latency-bound, so fewer would not finish sooner, and more would cost more than the steps they save.
+  // number of chains S.  Chain c owns the positions c, c+S, c+2S, .. (index j inside the chain); its seeds are the t
+  // indices w0 .. w0+t-1 in the MIDDLE of the chain, from which one pipeline steps forward and one backward: the
+  // seeds of all chains together are the S*t consecutive positions from S*w0 (Horner, and outputs at the same time).
+  // 4096 seeds are a quarter of a wave per SIMD: the seed launch is latency-bound, so fewer would not finish
+  // sooner, and more would cost more than the steps they save.
   const int tpad = modp_fd_tpad((int)t);
   const int cpw = 256 / tpad;
-  int S = fd_chains_env > 0 ? fd_chains_env : (int)(8192 / t);
+  int S = fd_chains_env > 0 ? fd_chains_env : (int)(4096 / t);
   const int s_max = (int)(cnt / (4 * t));
   if (S > s_max) S = s_max;
-  S = (S / (4 * cpw)) * (4 * cpw);        // whole workgroups of chains, S*t a multiple of the 64 numbers per block
+  S = (S / (4 * cpw)) * (4 * cpw);        // S*t a multiple of the 64 numbers per block
   if (S < 4 * cpw) S = 4 * cpw;
   const int chain_len = (int)((cnt + S - 1) / S);
+  const int w0 = (chain_len - (int)t) / 2;
+  const size_t seed0 = (size_t)S * w0;    // index of the first seed position
   const int m0 = (int)(S * t);
   // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
   constexpr int G = 16;
@@ -703,22 +733,25 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   RET_IF(ensure(ctx, w.fd_pre, pre_total * MODP_L * 4));
   RET_IF(ensure(ctx, w.fd_tot, tot_total * MODP_L * 4));
   RET_IF(ensure(ctx, w.fd_totinv, tot_total * MODP_L * 4));
-  RET_IF(ensure(ctx, w.fd_state, (size_t)m0 * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_state, (size_t)2 * m0 * MODP_L * 4));
   if (!w.root) return fail(ctx, MPVSS_E_DEVICE, "eval_x: workspace not initialised");
   int* flag = (int*)w.fd_flag.p;
   int* dok = flag + 1;
   uint8_t* root_be = (uint8_t*)w.fd_root.p;
   uint8_t* rootinv_be = root_be + EB;
   uint32_t* xm = (uint32_t*)w.fd_xm.p;
-  auto level_in = [&](int l) { return l == 0 ? xm : (uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
+  uint32_t* xseed = xm + seed0 * MODP_L;
+  uint32_t* state_fwd = (uint32_t*)w.fd_state.p;
+  uint32_t* state_bwd = state_fwd + (size_t)m0 * MODP_L;
+  auto level_in = [&](int l) { return l == 0 ? xseed : (uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
   auto level_inv = [&](int l) { return l == 0 ? (uint32_t*)w.fd_xinv.p : (uint32_t*)w.fd_totinv.p + tot_off[l] * MODP_L; };
   static const int one = 1;
   HIPCHK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
   if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions(dpos, (int)cnt, flag, ctx->stream));
-  // seeds: X at the first S*t positions, kept in Montgomery form
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t, dpos,
-                                               m0, xm, nullptr, flag, 1, ctx->consts, ctx->stream));
+  // seeds: X at the S*t positions from seed0, kept in Montgomery form
+  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
+                                               dpos + seed0, m0, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
   if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
   // their inverses: Montgomery's trick on the device, the single inversion of the root on the host, in stream
   // order (no host synchronisation).  A root that is 0 mod q (some commitment is 0) clears the flag.
@@ -742,9 +775,9 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   RET_IF(ensure(ctx, w.fd_hand_s, hand_s));
   HIPCHK(ctx, hipMemsetAsync(w.fd_hand_t.p, 0, hand_t, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, hand_s, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_table(xm, (const uint32_t*)w.fd_xinv.p, S, (int)t, (uint32_t*)w.fd_state.p,
+  LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, S, (int)t, state_fwd, state_bwd,
                                       (uint32_t*)w.fd_hand_t.p, flag, ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_step((const uint32_t*)w.fd_state.p, S, (int)t, chain_len, (int)cnt, xm,
+  LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, S, (int)t, w0, chain_len, (int)cnt, xm,
                                      (uint32_t*)w.fd_hand_s.p, flag, ctx->consts, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_from_mont(xm, (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
@@ -952,54 +985,62 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     const int64_t* hp = space == MPVSS_HOST ? positions + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
-    if (two_streams && ctx->stream_b && fd_applies(t, hp, cnt)) {
-      // Two streams: the forward-difference X path is a chain of latency-bound launches that occupy few wave
-      // slots (seeds, inversion tree, difference tables, stepping).  a2 = y^r Y^c and g^r do not depend on X, so
-      // they run beside it on the second stream.  With several boxes in flight (one workspace and stream pair per
-      // block slot) a single a2 launch is best; MPVSS_A2_FIRST_PERCENT < 100 splits it in two and
-      // MPVSS_A2_WAIT_SEEDS=1 holds the second part back until the seed launch is done (better for a lone box).
+    if (two_streams && ctx->wide[0] && fd_applies(t, hp, cnt)) {
+      // The forward-difference X path is a chain of latency-bound launches that occupy few wave slots (seeds,
+      // inversion tree, difference tables, stepping) and runs on the block slot's own stream.  a2 = y^r Y^c and g^r
+      // do not depend on X: a2 goes in MPVSS_A2_PARTS parts to the context-wide streams, which serve the blocks in
+      // flight in order; g^r follows the last part.
       RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4));     // no reallocation while two streams are live
       RET_IF(ensure(ctx, ctx->w->tab2, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
-      static const int h1_percent = fd_env("MPVSS_A2_FIRST_PERCENT", 100);
-      const size_t h = ((cnt * (size_t)h1_percent / 100) / 64) * 64;
+      const bool use_keys = ks && c_windows == 64;
+      static const int wide_fifo = fd_env("MPVSS_WIDE_FIFO", 0);
+      static const int n_wide = std::min(std::max(fd_env("MPVSS_WIDE_STREAMS", 3), 1), (int)mpvss_ctx::NWIDE);
+      static const int n_parts = std::min(std::max(fd_env("MPVSS_A2_PARTS", 4), 1), (int)mpvss_ctx::Work::MAXPARTS);
       struct Swap {
         mpvss_ctx* c; hipStream_t a;
-        Swap(mpvss_ctx* c_) : c(c_), a(c_->stream) { c->stream = c->stream_b; }
+        Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
         ~Swap() { c->stream = a; }
       };
+      auto next_wide = [&]() {       // MPVSS_WIDE_FIFO=0: every box on its own low-priority stream, all boxes share the chip
+        return wide_fifo ? ctx->wide[ctx->wide_rr++ % n_wide] : ctx->w->sb;
+      };
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_fork, 0));
-      {
-        Swap sw(ctx);
-        if (ks && c_windows == 64) {
+      const int parts = use_keys ? 1 : (wide_fifo ? n_parts : 1);
+      hipStream_t last_wide = nullptr;
+      size_t lo = 0;
+      for (int part = 0; part < parts; ++part) {
+        const size_t hi = (part + 1 == parts) ? cnt : ((cnt * (size_t)(part + 1) / parts) / 64) * 64;
+        if (hi <= lo) continue;
+        last_wide = next_wide();
+        HIPCHK(ctx, hipStreamWaitEvent(last_wide, ctx->w->ev_fork, 0));
+        Swap sw(ctx, last_wide);
+        uint32_t* t2p = (uint32_t*)ctx->w->tab2.p + lo * TABW;      // the parts use disjoint ranges of the table buffers
+        TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY + lo * EB, (int)(hi - lo), t2p, ctx->consts, ctx->stream));
+        if (use_keys) {
           // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
-          const uint32_t* t2;
-          RET_IF(number_tables(ctx, (const uint8_t*)dY, cnt, ctx->w->tab2, &t2));
           const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
-          TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
+          TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
                                                            ctx->consts, ctx->stream));
         } else {
-          RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
-                           0, c_windows, h, da2));
+          uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * TABW;
+          TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy + lo * EB, (int)(hi - lo), t1p, ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1p, TABW, t2p, TABW, (const uint8_t*)dr + lo * EB, (const uint8_t*)dchal, 0,
+                                                    c_windows, (int)(hi - lo), da2 + lo * EB, ctx->consts, ctx->stream));
         }
-        // g^r_i needs only the responses: it runs here instead of after the stepping phase
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_part[part], ctx->stream));
+        lo = hi;
+      }
+      {
+        // g^r_i needs only the responses: it runs behind the last part instead of after the stepping phase
+        Swap sw(ctx, last_wide);
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
                                                              (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
                                                              ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
-      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, ctx->w->ev_seeds));
-      static const int wait_seeds = fd_env("MPVSS_A2_WAIT_SEEDS", 0);
-      if (wait_seeds) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_seeds, 0));
-      {
-        Swap sw(ctx);
-        if (cnt > h && !(ks && c_windows == 64))
-          RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy + h * EB, (const uint8_t*)dY + h * EB, (const uint8_t*)dr + h * EB,
-                           (const uint8_t*)dchal, 0, c_windows, cnt - h, da2 + h * EB));
-        HIPCHK(ctx, hipEventRecord(ctx->w->ev_join, ctx->stream));
-      }
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, nullptr));
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
         const uint32_t* tx;
@@ -1009,7 +1050,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                              c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                              comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_join, 0));
+      for (int part = 0; part < parts; ++part) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_part[part], 0));
     } else {
       // X_i                                                  participant.rs:423-434
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
@@ -1030,34 +1071,55 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   return MPVSS_OK;
 }
 
-int verify_block_absorb_locked(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out, uint8_t* a1_out, uint8_t* a2_out) {
+// Called with `lk` (the context lock) held.  The lock is RELEASED while this thread waits for the block's GPU work
+// and hashes it, so that other host threads can enqueue blocks or absorb the next ones meanwhile (every box has its
+// own transcript; a 65536-share box is 40 ms of SHA-256).  Blocks are handed out in FIFO order at entry.
+int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
+                               uint8_t* a1_out, uint8_t* a2_out) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
   mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
-  if (!sl.busy) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
+  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
   const size_t n = sl.n;
-  sl.busy = false;
   ++ctx->tail;
-  if (n == 0) return MPVSS_OK;
+  if (n == 0) {
+    sl.busy = false;
+    return MPVSS_OK;
+  }
+  sl.absorbing = true;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipEventSynchronize(sl.done));
-  RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
+  lk.unlock();
+  const hipError_t e = hipEventSynchronize(sl.done);
   const uint8_t* hX = (const uint8_t*)sl.pin;
   const uint8_t* hY = hX + n * EB;
   const uint8_t* h1 = hY + n * EB;
   const uint8_t* h2 = h1 + n * EB;
-  if (sl.check_positions) RET_IF(check_positions_host(ctx, (const int64_t*)(h2 + n * EB), n));
-  mpvss::Sha256 tr;
-  memcpy(&tr, state, sizeof(tr));
-  for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99, share order = array order
-    frame_update(tr, hX + i * EB);
-    frame_update(tr, hY + i * EB);
-    frame_update(tr, h1 + i * EB);
-    frame_update(tr, h2 + i * EB);
+  bool positions_ok = true;
+  if (e == hipSuccess) {
+    if (sl.check_positions) {
+      const int64_t* pos = (const int64_t*)(h2 + n * EB);
+      for (size_t i = 0; i < n && positions_ok; ++i) positions_ok = pos[i] >= 0;
+    }
+    if (positions_ok) {
+      mpvss::Sha256 tr;
+      memcpy(&tr, state, sizeof(tr));
+      for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99, share order = array order
+        frame_update(tr, hX + i * EB);
+        frame_update(tr, hY + i * EB);
+        frame_update(tr, h1 + i * EB);
+        frame_update(tr, h2 + i * EB);
+      }
+      memcpy(state, &tr, sizeof(tr));
+      if (x_out) memcpy(x_out, hX, n * EB);
+      if (a1_out) memcpy(a1_out, h1, n * EB);
+      if (a2_out) memcpy(a2_out, h2, n * EB);
+    }
   }
-  memcpy(state, &tr, sizeof(tr));
-  if (x_out) memcpy(x_out, hX, n * EB);
-  if (a1_out) memcpy(a1_out, h1, n * EB);
-  if (a2_out) memcpy(a2_out, h2, n * EB);
+  lk.lock();
+  sl.busy = false;
+  sl.absorbing = false;
+  if (e != hipSuccess) return fail(ctx, MPVSS_E_DEVICE, "absorb: hipEventSynchronize", e);
+  if (!positions_ok) return fail(ctx, MPVSS_E_INVALID, "negative position (the reference panics: negative exponent)");
+  RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
   return MPVSS_OK;
 }
 
@@ -1158,8 +1220,8 @@ extern "C" int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space,
 extern "C" int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host,
                                               uint8_t* a1_out_host, uint8_t* a2_out_host) {
   if (!ctx) return MPVSS_E_INVALID;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  return verify_block_absorb_locked(ctx, state, x_out_host, a1_out_host, a2_out_host);
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  return verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host);
 }
 
 extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
@@ -1168,14 +1230,16 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
                                               const uint8_t* challenge_host, int* verdict, uint8_t* digest32_out,
                                               uint8_t* x_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host) {
   if (!ctx) return MPVSS_E_INVALID;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::unique_lock<std::mutex> lk(ctx->mu);
   if (!verdict || !challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify_distribution: bad argument");
+  if (ctx->head != ctx->tail)
+    return fail(ctx, MPVSS_E_INVALID, "verify_distribution: blocks of the block API are in flight, absorb them first");
   *verdict = 0;
   uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
   mpvss_transcript_init(state);
   RET_IF(verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
                                      challenge_host));
-  RET_IF(verify_block_absorb_locked(ctx, state, x_out_host, a1_out_host, a2_out_host));
+  RET_IF(verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host));
   return mpvss_modp_transcript_verdict(state, challenge_host, verdict, digest32_out);
 }
 
