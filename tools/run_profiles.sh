@@ -11,7 +11,7 @@ mkdir -p $OUT
 ARGS="bench.py --cpu-sample 0 --wb-shares 0 --registered-keys 0"
 PMCARGS="bench.py --steps 2 --warmup 1 --cpu-sample 0 --wb-shares 0 --registered-keys 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
-tail -1 $OUT/trace.log > $OUT/bench_under_rocprof.json
+grep "^{\"metric\"" $OUT/trace.log > $OUT/bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $PMCARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $PMCARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $PMCARGS > $OUT/pmc_sq.log 2>&1
