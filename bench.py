@@ -123,7 +123,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    commdev = torch.device("cpu") if smoke_one_gpu else dev      # where the tiny exchange tensors live
+    # The running hash state (128 bytes per box and hop) is produced and consumed by host code: it travels over a
+    # gloo (CPU) group, so that a hop never waits for a free wave slot on a GPU that is saturated with long-running
+    # workgroups.  The barrier and the max-reduction of the timing stay on RCCL.
+    commdev = torch.device("cpu")
+    chain = dist.new_group(backend="gloo") if (world > 1 and not smoke_one_gpu) else None
 
     eng = capi.Engine(local_rank)     # raises if the HIP library or the GPU is missing
     lib, ctx = eng.lib, eng.ctx
@@ -161,16 +165,16 @@ def main():
             state = capi.transcript_init()
         else:
             buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
-            dist.recv(buf, src=rank - 1)
+            dist.recv(buf, src=rank - 1, group=chain)
             state = bytes(buf.cpu().numpy().tobytes())
         state = capi.transcript_absorb(state, bytes(inter))
         if rank + 1 < world:
-            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1)
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain)
             dg = torch.zeros(32, dtype=torch.uint8, device=commdev)
         else:
             _, digest = capi.transcript_verdict(state, bytes(EB))
             dg = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(commdev)
-        dist.broadcast(dg, src=world - 1)
+        dist.broadcast(dg, src=world - 1, group=chain)
         dealer_digest = bytes(dg.cpu().numpy().tobytes())
     else:
         state = capi.transcript_absorb(capi.transcript_init(), bytes(inter))
@@ -215,7 +219,7 @@ def main():
             state = capi.transcript_init()
         else:
             buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
-            dist.recv(buf, src=rank - 1)
+            dist.recv(buf, src=rank - 1, group=chain)
             state = bytes(buf.cpu().numpy().tobytes())
         t0 = time.perf_counter()
         state = eng.verify_block_absorb(state)          # waits for this block's GPU work, then hashes it
@@ -227,11 +231,11 @@ def main():
             return capi.transcript_verdict(state, challenge)
         out = torch.zeros(33, dtype=torch.uint8, device=commdev)
         if rank + 1 < world:
-            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1)
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain)
         else:
             verdict, digest = capi.transcript_verdict(state, challenge)
             out = torch.frombuffer(bytearray(bytes([int(verdict)]) + digest), dtype=torch.uint8).to(commdev)
-        dist.broadcast(out, src=world - 1)
+        dist.broadcast(out, src=world - 1, group=chain)
         raw = bytes(out.cpu().numpy().tobytes())
         return bool(raw[0]), raw[1:33]
 
@@ -280,7 +284,7 @@ def main():
     for verdict, digest in results:
         assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=commdev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=commdev if smoke_one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
