@@ -297,14 +297,9 @@ def main():
     shares_per_a2_launch = n / a2_n
 
     # work accounting: Montgomery products the kernels execute per step on this rank
-    fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 256 and n >= 16 * t and n >= 8192
+    fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "8192"))
     if fd:
-        tpad = 16
-        while tpad < t:
-            tpad *= 2
-        cpw = 256 // tpad
-        chains = min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or 4096 // t, n // (4 * t))
-        chains = max(4 * cpw, chains // (4 * cpw) * (4 * cpw))          # as eval_x() in mpvss_capi.cpp
+        chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or 4096 // t, n // (4 * t)))   # as eval_x()
         chain_len = -(-n // chains)
         w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
         m0 = chains * t                                                  # the seeds: m0 consecutive positions, by Horner

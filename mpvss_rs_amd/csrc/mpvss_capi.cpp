@@ -681,7 +681,8 @@ void invert_root_on_host(void* p) {
 // does the forward-difference path apply to this run of shares?  (host-side part of the decision)
 bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
   static const int fd_on = fd_env("MPVSS_FD", 1);
-  bool fd = fd_on && t >= 16 && t <= 256 && cnt >= 16 * t && cnt >= 8192;
+  static const size_t max_t = (size_t)fd_env("MPVSS_FD_MAX_T", 1024), min_shares = (size_t)fd_env("MPVSS_FD_MIN_SHARES", 8192);
+  bool fd = fd_on && t >= 16 && t <= max_t && cnt >= 16 * t && cnt >= min_shares;
   if (fd && hpos) {                       // host positions: decide here; device positions are checked by a kernel
     for (size_t i = 0; i < cnt && fd; ++i) fd = hpos[i] == hpos[0] + (int64_t)i;
     fd = fd && hpos[0] >= 0 && hpos[0] < ((int64_t)1 << 61);
@@ -704,13 +705,10 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // seeds of all chains together are the S*t consecutive positions from S*w0 (Horner, and outputs at the same time).
   // 4096 seeds are a quarter of a wave per SIMD: the seed launch is latency-bound, so fewer would not finish
   // sooner, and more would cost more than the steps they save.
-  const int tpad = modp_fd_tpad((int)t);
-  const int cpw = 256 / tpad;
   int S = fd_chains_env > 0 ? fd_chains_env : (int)(4096 / t);
-  const int s_max = (int)(cnt / (4 * t));
+  const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
   if (S > s_max) S = s_max;
-  S = (S / (4 * cpw)) * (4 * cpw);        // S*t a multiple of the 64 numbers per block
-  if (S < 4 * cpw) S = 4 * cpw;
+  if (S < 1) S = 1;
   const int chain_len = (int)((cnt + S - 1) / S);
   const int w0 = (chain_len - (int)t) / 2;
   const size_t seed0 = (size_t)S * w0;    // index of the first seed position

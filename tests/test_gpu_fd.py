@@ -38,7 +38,7 @@ pos = list(range(p0, p0 + n))
 out = eng.commit_eval(b"".join(map(fx, cm)), pos)
 h = hashlib.sha256(out).hexdigest()
 # spot-check against the oracle
-for i in (0, 1, t - 1, t, n // 2, n - 1):
+for i in ((0, 1, t - 1, t, n // 2, n - 1) if t < 512 else (0, n // 2 + 1, n - 1)):
     assert int.from_bytes(out[i * 256:(i + 1) * 256], "big") == O.commitment_eval(G, cm, pos[i]), i
 print(h)
 '''
@@ -46,9 +46,10 @@ print(h)
 
 @pytest.mark.parametrize("t,n,p0,extra", [(16, 4096, 1, ""), (64, 8192, 1, ""), (33, 5000, 777, ""),
                                            (256, 8192, 1, ""), (33, 9001, 777, ""), (17, 20011, 123456789, ""),
-                                           (100, 12345, 2, "cm[99] = Q - 1"), (64, 8192, 1, "cm[5] = 0"), (64, 8192, 1, "cm[0] = Q")])
+                                           (100, 12345, 2, "cm[99] = Q - 1"), (1024, 16384, 1, ""), (512, 9000, 40000, ""), (64, 2048, 1, ""),
+                                           (16, 2100, 7, ""), (257, 5000, 3, ""), (64, 8192, 1, "cm[5] = 0"), (64, 8192, 1, "cm[0] = Q")])
 def test_fd_equals_horner(t, n, p0, extra):
     code = CODE % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), t * 1000 + n, t, n, p0, extra)
-    a = run(code, {"MPVSS_FD": "1"}).strip()
+    a = run(code, {"MPVSS_FD": "1", "MPVSS_FD_MIN_SHARES": "2048"}).strip()
     b = run(code, {"MPVSS_FD": "0"}).strip()
     assert a == b and len(a) == 64
