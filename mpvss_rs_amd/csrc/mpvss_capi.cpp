@@ -65,7 +65,7 @@ struct mpvss_ctx {
   struct Work {
     DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
     DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root, fd_hand_t, fd_hand_s;   // forward differences
-    DevBuf fd_tabc, tab3, gr_m;   // X tables of a1 in two-stream mode; gr_m: g^r_i in Montgomery form
+    DevBuf tab3, gr_m;   // X tables of a1; gr_m: g^r_i in Montgomery form
     const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
     struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
       uint8_t in_be[256], out_be[256];
@@ -73,13 +73,13 @@ struct mpvss_ctx {
     };
     RootJob* root = nullptr;
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
-    hipEvent_t ev_fork = nullptr, ev_seeds = nullptr, ev_join = nullptr, ev_gr = nullptr, ev_join0 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_gr = nullptr;
     static constexpr int MAXPARTS = 8;
     hipEvent_t ev_part[MAXPARTS] = {};
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
-              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &fd_tabc, &tab3, &gr_m};
+              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &tab3, &gr_m};
     }
   };
   Work work0;
@@ -421,7 +421,7 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
     HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, ctx->prio_high));
     HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, ctx->prio_low));
   }
-  for (hipEvent_t* e : {&w.ev_fork, &w.ev_seeds, &w.ev_join, &w.ev_gr, &w.ev_join0})
+  for (hipEvent_t* e : {&w.ev_fork, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t& e : w.ev_part) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void**)&w.root, sizeof(*w.root), hipHostMallocDefault));
@@ -433,7 +433,7 @@ void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
   if (w.sb) (void)hipStreamSynchronize(w.sb);
   for (DevBuf* b : w.all())
     if (b->p) (void)hipFree(b->p);
-  for (hipEvent_t e : {w.ev_fork, w.ev_seeds, w.ev_join, w.ev_gr, w.ev_join0})
+  for (hipEvent_t e : {w.ev_fork, w.ev_gr})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : w.ev_part)
     if (e) (void)hipEventDestroy(e);
@@ -654,11 +654,12 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
 }
 
 // ---- X_i for a run of shares: Horner's rule, or forward differences when the positions are consecutive -------
-// Forward differences need t seed values X(c..c+t-1) and their inverses per chain (computed by the Horner kernel,
-// the inverses as the same polynomial over the inverted commitments) and then cost ONE Montgomery product per
-// share and coefficient.  Whether the path applies (consecutive positions, every commitment invertible) is
-// decided ON THE DEVICE through a flag that gates the kernels, so the pipelined callers never synchronise.
-// MPVSS_FD=0 disables the path, MPVSS_FD_CHAINS overrides the number of chains.
+// Forward differences need t seed values of X and their inverses per chain (the Horner kernel, then Montgomery's
+// simultaneous inversion) and then cost ONE Montgomery product per share and coefficient (modp_kernels.hip).
+// Whether the path applies (consecutive positions, no X that is 0 mod q) is decided ON THE DEVICE through a flag that
+// gates the kernels, so the pipelined callers never synchronise.
+// MPVSS_FD=0 disables the path, MPVSS_FD_CHAINS overrides the number of chains, MPVSS_FD_MAX_T / MPVSS_FD_MIN_SHARES
+// bound the thresholds and batch sizes it is used for.
 
 // stream callback: out = in^-1 mod q (canonical big-endian), ok = 0 when in is 0 mod q.  No HIP calls in here.
 void invert_root_on_host(void* p) {
@@ -690,12 +691,10 @@ bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
   return fd;
 }
 
-int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX,
-           hipEvent_t after_seeds = nullptr) {
+int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX) {
   static const int fd_chains_env = fd_env("MPVSS_FD_CHAINS", 0);
   const bool fd = fd_applies(t, hpos, cnt);
   if (!fd) {
-    if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
     TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->w->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
                                                  ctx->consts, ctx->stream));
     return 0;
@@ -750,7 +749,6 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // seeds: X at the S*t positions from seed0, kept in Montgomery form
   LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
                                                dpos + seed0, m0, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
-  if (after_seeds) HIPCHK(ctx, hipEventRecord(after_seeds, ctx->stream));
   // their inverses: Montgomery's trick on the device, the single inversion of the root on the host, in stream
   // order (no host synchronisation).  A root that is 0 mod q (some commitment is 0) clears the flag.
   for (int l = 0; l < nlev; ++l)
@@ -1038,7 +1036,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                              ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
-      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, nullptr));
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
         const uint32_t* tx;
