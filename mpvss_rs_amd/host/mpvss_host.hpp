@@ -7,6 +7,7 @@
 // binding).  Every group exponentiation goes to the GPU engine; the three loops of the hot path
 // (distribute_secret, verify_distribution_shares, verify_share) use the batched entry points.
 #pragma once
+#include <cstring>
 #include <map>
 #include <memory>
 #include <optional>
@@ -166,6 +167,75 @@ struct DistributionSharesBox {
   std::map<Bytes, BigUint> responses;
   BigUint U;
 };
+
+// ---- flat wire format (the reference has none; sharebox.rs:21-27,74-86 are HashMap-keyed in memory) ------
+// The positions-ordered structure-of-arrays the C ABI consumes, so a box can be streamed to the GPUs (or sharded by
+// byte ranges across ranks) without rebuilding maps:
+//   "MPVSSBX1" | u32 group (0 = MODP-2048) | u32 element bytes | u64 n | u64 t | u64 U bytes
+//   commitments [t][256] | positions i64-LE [n] | publickeys [n][256] | shares [n][256] | responses [n][256]
+//   challenge [256] | U (big-endian, U bytes)
+// Rows are in `publickeys` order (the order the reference iterates in, participant.rs:408-448).
+inline void put_u64(Bytes& b, uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+inline uint64_t get_u64(const uint8_t* p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v |= (uint64_t)p[i] << (8 * i); return v; }
+
+// false when an entry of the maps is missing (the box would not verify either, participant.rs:415-420)
+inline bool serialize_box(const DistributionSharesBox& box, const ModpGroup& group, Bytes& out) {
+  out.clear();
+  const Bytes ub = box.U.to_bytes_be();
+  const char magic[8] = {'M', 'P', 'V', 'S', 'S', 'B', 'X', '1'};
+  out.insert(out.end(), magic, magic + 8);
+  for (uint32_t v : {0u, (uint32_t)MPVSS_MODP_BYTES}) for (int i = 0; i < 4; ++i) out.push_back((uint8_t)(v >> (8 * i)));
+  put_u64(out, box.publickeys.size());
+  put_u64(out, box.commitments.size());
+  put_u64(out, ub.size());
+  for (auto& c : box.commitments) append(out, be256(c));
+  Bytes sh, rs;
+  for (auto& pk : box.publickeys) {
+    const Bytes key = group.element_to_bytes(pk);
+    const auto p = box.positions.find(key);
+    const auto s = box.shares.find(key);
+    const auto r = box.responses.find(key);
+    if (p == box.positions.end() || s == box.shares.end() || r == box.responses.end()) return false;
+    put_u64(out, (uint64_t)p->second);
+    append(sh, be256(s->second));
+    append(rs, be256(r->second));
+  }
+  for (auto& pk : box.publickeys) append(out, be256(pk));
+  append(out, sh);
+  append(out, rs);
+  append(out, be256(box.challenge));
+  append(out, ub);
+  return true;
+}
+
+inline bool parse_box(const Bytes& in, const ModpGroup& group, DistributionSharesBox& box) {
+  const size_t EBn = MPVSS_MODP_BYTES;
+  if (in.size() < 40 || memcmp(in.data(), "MPVSSBX1", 8) != 0) return false;
+  if (in[8] != 0 || in[9] != 0 || in[10] != 0 || in[11] != 0) return false;               // group: MODP-2048
+  if ((uint32_t)(in[12] | in[13] << 8 | in[14] << 16 | (uint32_t)in[15] << 24) != EBn) return false;
+  const uint64_t n = get_u64(&in[16]), t = get_u64(&in[24]), ulen = get_u64(&in[32]);
+  if (n > (1ull << 32) || t > (1ull << 32) || ulen > (1ull << 20)) return false;
+  const size_t need = 40 + t * EBn + n * 8 + 3 * n * EBn + EBn + ulen;
+  if (in.size() != need) return false;
+  const uint8_t* p = in.data() + 40;
+  box = DistributionSharesBox();
+  for (uint64_t j = 0; j < t; ++j, p += EBn) box.commitments.push_back(BigUint::from_bytes_be(p, EBn));
+  const uint8_t* pos = p;
+  const uint8_t* pk = pos + n * 8;
+  const uint8_t* sh = pk + n * EBn;
+  const uint8_t* rs = sh + n * EBn;
+  for (uint64_t i = 0; i < n; ++i) {
+    BigUint key = BigUint::from_bytes_be(pk + i * EBn, EBn);
+    const Bytes kb = group.element_to_bytes(key);
+    box.positions[kb] = (int64_t)get_u64(pos + i * 8);
+    box.shares[kb] = BigUint::from_bytes_be(sh + i * EBn, EBn);
+    box.responses[kb] = BigUint::from_bytes_be(rs + i * EBn, EBn);
+    box.publickeys.push_back(std::move(key));
+  }
+  box.challenge = BigUint::from_bytes_be(rs + n * EBn, EBn);
+  box.U = BigUint::from_bytes_be(rs + n * EBn + EBn, ulen);
+  return true;
+}
 
 // ---- DLEQ: src/dleq.rs:153-335 ----------------------------------------------------------------------------
 struct DLEQ {

@@ -107,8 +107,41 @@ static void test_group_basics(std::shared_ptr<ModpGroup> group) {          // mo
   CHECK(threw);
 }
 
+static void test_wire_format_round_trip(std::shared_ptr<ModpGroup> group) {
+  Rng rng(77);
+  Participant dealer = Participant::with_arc(group);
+  dealer.initialize(rng);
+  std::vector<Participant> ps;
+  std::vector<BigUint> keys;
+  for (int i = 0; i < 4; ++i) {
+    ps.push_back(Participant::with_arc(group));
+    ps.back().initialize(rng);
+    keys.push_back(ps.back().publickey);
+  }
+  const BigUint secret = BigUint::from_bytes_be(reinterpret_cast<const uint8_t*>("wire"), 4);
+  DistributionSharesBox box = dealer.distribute_secret(secret, keys, 3, rng);
+  Bytes flat;
+  CHECK(serialize_box(box, *group, flat));
+  CHECK(flat.size() == 40 + 3 * 256 + 4 * 8 + 3 * 4 * 256 + 256 + box.U.to_bytes_be().size());
+  DistributionSharesBox back;
+  CHECK(parse_box(flat, *group, back));
+  CHECK(back.commitments == box.commitments && back.publickeys == box.publickeys && back.positions == box.positions);
+  CHECK(back.shares == box.shares && back.responses == box.responses && back.challenge == box.challenge && back.U == box.U);
+  CHECK(ps[0].verify_distribution_shares(back));                 // the parsed box verifies on the GPU
+  Bytes again;
+  CHECK(serialize_box(back, *group, again) && again == flat);     // canonical: one encoding per box
+  flat[flat.size() - 1] ^= 1;                                     // U changes, the proofs still hold
+  CHECK(parse_box(flat, *group, back) && ps[0].verify_distribution_shares(back) && !(back.U == box.U));
+  flat.pop_back();
+  CHECK(!parse_box(flat, *group, back));                          // truncated
+  DistributionSharesBox missing = box;
+  missing.responses.erase(missing.responses.begin());
+  CHECK(!serialize_box(missing, *group, again));
+}
+
 int main() {
   auto group = ModpGroup::create();
+  test_wire_format_round_trip(group);
   test_group_basics(group);
   test_dleq_verify(group);
   test_end_to_end_modp(group);
