@@ -702,9 +702,9 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // number of chains S.  Chain c owns the positions c, c+S, c+2S, .. (index j inside the chain); its seeds are the t
   // indices w0 .. w0+t-1 in the MIDDLE of the chain, from which one pipeline steps forward and one backward: the
   // seeds of all chains together are the S*t consecutive positions from S*w0 (Horner, and outputs at the same time).
-  // 4096 seeds are a quarter of a wave per SIMD: the seed launch is latency-bound, so fewer would not finish
-  // sooner, and more would cost more than the steps they save.
-  int S = fd_chains_env > 0 ? fd_chains_env : (int)(4096 / t);
+  // The seed launch is latency-bound (2048 seeds are an eighth of a wave per SIMD), so fewer seeds would not finish
+  // sooner; more chains shorten the stepping but cost Horner work (measured optimum at n=65536, t=256: 8 chains).
+  int S = fd_chains_env > 0 ? fd_chains_env : std::max((int)(2048 / t), 4);
   const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
   if (S > s_max) S = s_max;
   if (S < 1) S = 1;
