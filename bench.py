@@ -317,8 +317,10 @@ def main():
         x_path = "Horner in the exponent"
     comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
     gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
-    mm_dual = n * ((2044 + 511 + 64 + 1) + (316 + gr + 2))    # a2: Straus chain; a1: comb for g^r + X^c windows
-    mm_table = n * (3 * 15)                                   # three 16-entry tables per share (+1 conversion each)
+    w6 = os.environ.get("MPVSS_A2_W6", "1") != "0"            # 6-bit windows for y^r (64-entry table) or 4-bit
+    a2_products = (2046 + 341 + 64 + 1) if w6 else (2044 + 511 + 64 + 1)
+    mm_dual = n * (a2_products + (316 + gr + 2))              # a2: Straus chain; a1: comb for g^r + X^c windows
+    mm_table = n * (2 * 15 + (63 if w6 else 15))              # window tables of X, Y (16 entries) and y (+1 conversion each)
     mm_total = mm_x + mm_dual + mm_table
     achieved_modmul = mm_total / (ms_per_step * 1e-3)         # against the step's wall time (kernels overlap)
     peak_modmul = PEAK_MODMUL_PER_S
@@ -441,7 +443,7 @@ def main():
         keyset[0] = None
         table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
         lib.mpvss_modp_keyset_destroy(ctx, h)
-        mm_k = mm_total - n * (2044 + 511 + 64 + 1) + n * (252 + 256 + 63 + 1)
+        mm_k = mm_total - n * a2_products - n * ((63 if w6 else 15) - 0) + n * (252 + 256 + 63 + 1)
         result["registered_keys"] = {
             "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
             "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,

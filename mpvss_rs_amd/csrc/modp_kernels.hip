@@ -895,6 +895,94 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
 }
 
 // ---------------------------------------------------------------------------------------
+// a2 = y^r * Y^c of the distribution check with a 6-bit window table for y (64 entries, 62 products to build,
+// 341 products instead of 511 for the 2047-bit r) and the 4-bit table for Y (c < 2^256): 2 046 squarings +
+// 341 + 64 products.  Windows of r are aligned at multiples of 6 bits, windows of c at multiples of 4.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_build_table64(const uint8_t* __restrict__ base_be, int count, u32* __restrict__ tab,
+                     const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], b[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(b, base_be + (size_t)x * 256, ln);
+  to_mont(b, slot, cs, n, ln);
+  u32* my = tab + (size_t)x * 64 * L;
+  load_lane_limbs(acc, cs->one_m, ln);
+  if (live) store_lane_limbs(my, acc, ln);
+  if (live) store_lane_limbs(my + L, b, ln);
+  slot_store(slot, b, ln);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) acc[k] = b[k];
+  for (int e = 2; e < 64; ++e) {
+    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (live) store_lane_limbs(my + (size_t)e * L, acc, ln);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
+                   const uint8_t* __restrict__ c_be, int count, uint8_t* __restrict__ out_be,
+                   const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  const u32* t1 = tab1 + (size_t)x * 64 * L;
+  const u32* t2 = tab2 + (size_t)x * 16 * L;
+  const uint8_t* e1 = e1_be + (size_t)x * 256;
+  // 6-bit window w of the 2048-bit exponent: bits 6w .. 6w+5 (little-endian byte k is e1[255 - k])
+  auto digit6 = [&](int w) -> u32 {
+    const int o = 6 * w, k = o >> 3;
+    const u32 lo = e1[255 - k];
+    const u32 hi = (k + 1 < 256) ? e1[254 - k] : 0u;
+    return ((lo | (hi << 8)) >> (o & 7)) & 63u;
+  };
+  // cur = weight (bit index) of the accumulator's unit.  Start with the top window (bits 2046, 2047).
+  load_lane_limbs(acc, t1 + (size_t)digit6(341) * L, ln);
+  int cur = 2046;
+  int s = 0;                       // 0: square (cur decreases), 1: product with tab1, 2: product with tab2, 3: final
+  while (true) {
+    const u32* fill = nullptr;
+    bool skip = false;
+    if (s == 0) {
+      slot_store(slot, acc, ln);
+      --cur;
+    } else if (s == 1) {
+      if (cur % 6 == 0) fill = t1 + (size_t)digit6(cur / 6) * L; else skip = true;
+    } else if (s == 2) {
+      if ((cur & 3) == 0 && cur < 256) {
+        const u32 byte = c_be[255 - (cur >> 3)];
+        fill = t2 + (size_t)((cur & 4) ? (byte >> 4) : (byte & 15)) * L;
+      } else {
+        skip = true;
+      }
+    } else {
+      fill = cs->one;              // leave the Montgomery domain
+    }
+    if (!skip) {
+      if (fill != nullptr) slot_fill_from_global(slot, fill, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (s == 3) break;
+    s = (s == 2) ? (cur == 0 ? 3 : 0) : s + 1;
+  }
+  store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
 // Registered public keys (opt-in): per-key tables for y^r, built once per key set and reused by every box that is
 // verified against it.  ks[key][j][d] = y^(d * 2^(256 j)), j < 8, d < 256 (Montgomery form; 8 x 256 x 304 B =
 // 622 KB per key, 41 GB for 65536 keys -- sized for 288 GB of HBM).  With r = sum_j r_j 2^(256 j):
@@ -1160,6 +1248,19 @@ extern "C" int modp_launch_comb_build(const uint8_t* base_be_dev, uint32_t* comb
   return (int)hipGetLastError();
 }
 
+extern "C" int modp_launch_build_table64(const uint8_t* base_be, int count, uint32_t* tab, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_build_table64, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, base_be, count, tab,
+                     (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
+                                       int count, uint8_t* out, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_dual_exp_w6, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab2, e1, c, count, out,
+                     (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
 extern "C" size_t modp_keyset_words_per_key() { return (size_t)KS_SUB * KS_ENT * L; }
 extern "C" int modp_launch_keyset_build(const uint8_t* pk_be, int count, uint32_t* ks, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;

@@ -986,7 +986,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       // inversion tree, difference tables, stepping) and runs on the block slot's own stream.  a2 = y^r Y^c and g^r
       // do not depend on X: a2 goes in MPVSS_A2_PARTS parts to the context-wide streams, which serve the blocks in
       // flight in order; g^r follows the last part.
-      RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4));     // no reallocation while two streams are live
+      static const int a2_w6 = fd_env("MPVSS_A2_W6", 1);
+      RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4 * (a2_w6 ? 4 : 1)));     // no reallocation while two streams are live
       RET_IF(ensure(ctx, ctx->w->tab2, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
@@ -1019,6 +1020,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
           TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
                                                            ctx->consts, ctx->stream));
+        } else if (a2_w6 && c_windows == 64) {
+          // 6-bit windows for y^r (64-entry tables, 19 KB per share): 341 products instead of 511
+          uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * 4 * TABW;
+          TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy + lo * EB, (int)(hi - lo), t1p, ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr + lo * EB, (const uint8_t*)dchal,
+                                                       (int)(hi - lo), da2 + lo * EB, ctx->consts, ctx->stream));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * TABW;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy + lo * EB, (int)(hi - lo), t1p, ctx->consts, ctx->stream));
