@@ -292,8 +292,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     avg = lambda xs: sum(xs) / max(len(xs), 1)
     x_ms, a1_ms, tb_ms, a2_ms = avg(kernel_ms[0]), avg(kernel_ms[1]), avg(kernel_ms[2]), avg(kernel_ms[3])
-    a2_n = avg(a2_launches)                      # k_modp_dual_exp launches per step (2 in two-stream mode)
-    a2_launch_ms = a2_ms / a2_n                  # average duration of one k_modp_dual_exp launch
+    a2_n = avg(a2_launches)                      # a2 launches per step (1 unless the box is split)
+    a2_launch_ms = a2_ms / a2_n                  # average duration of one a2 launch
+    a2_kernel = "k_modp_dual_exp_w6" if os.environ.get("MPVSS_A2_W6", "1") != "0" else "k_modp_dual_exp"
     shares_per_a2_launch = n / a2_n
 
     # work accounting: Montgomery products the kernels execute per step on this rank
@@ -343,7 +344,7 @@ def main():
                    "n_per_gpu": n, "t": t, "parallelism": f"participants sharded x{world}"},
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_modp_dual_exp",
+            "kernel": a2_kernel,
             "achieved": ALGO_BYTES_PER_SHARE * shares_per_a2_launch / (a2_launch_ms * 1e-3) / 1e9 if a2_launch_ms > 0 else None,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -370,7 +371,7 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape
         try:
-            result["roofline"]["traffic"] = json.load(open(traffic_file)).get("k_modp_dual_exp_bytes_per_launch")
+            result["roofline"]["traffic"] = json.load(open(traffic_file)).get(a2_kernel + "_bytes_per_launch")
         except Exception:
             pass
 

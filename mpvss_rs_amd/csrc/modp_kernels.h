@@ -58,7 +58,8 @@ size_t modp_fd_step_hand_words(int chains, int t, int chain_len);
 int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state,
                          uint32_t* state_back, uint32_t* hand, int* gate, const void* cs, hipStream_t s);
 int modp_launch_fd_step(const uint32_t* state, const uint32_t* state_back, int chains, int t, int w0, int chain_len,
-                        int count, uint32_t* x_m, uint32_t* hand, int* gate, const void* cs, hipStream_t s);
+                        int count, uint32_t* x_m, uint32_t* hand, int* gate, int inject_fault, const void* cs,
+                        hipStream_t s);
 int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,
                           hipStream_t s);
 #ifdef __cplusplus

@@ -543,7 +543,7 @@ k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int ch
 extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
 k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back, int chains, int t, int tpad, int w0,
                int chain_len, int count, u32* __restrict__ x_m, u32* __restrict__ hand, int* __restrict__ gate,
-               const ModpConsts* __restrict__ cs) {
+               int inject_fault, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[(NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
   __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
@@ -582,6 +582,12 @@ k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back
   const bool writer = kbase == 0 && quad == 0;
   for (int step = 1; step <= steps; ++step) {
     slot_store(slot, D, ln);
+    if (inject_fault && !has_up && dir == 0 && chain == 0 && step == 5) {
+      // test hook (MPVSS_FD_TEST_FAULT=1): behave like a stage whose wait timed out
+      if (threadIdx.x == 0) *gate = 0;
+      if (has_down && quad == 0) hand_publish(mine + (size_t)step * L, D, ln, HAND_POISON);
+      return;
+    }
     if (has_up && step > 1) {
       if (!hand_receive(up + (size_t)(step - 1) * L, inslot, reader, ln)) {
         if (threadIdx.x == 0) *gate = 0;
@@ -1210,11 +1216,11 @@ extern "C" int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, in
 }
 // x_m: base of the chains (position index 0); w0: index of the first seed inside every chain
 extern "C" int modp_launch_fd_step(const uint32_t* state, const uint32_t* state_back, int chains, int t, int w0,
-                                   int chain_len, int count, uint32_t* x_m, uint32_t* hand, int* gate, const void* cs,
-                                   hipStream_t s) {
+                                   int chain_len, int count, uint32_t* x_m, uint32_t* hand, int* gate, int inject_fault,
+                                   const void* cs, hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
   hipLaunchKernelGGL(k_modp_fd_step, dim3(2 * chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, state, state_back, chains,
-                     t, tpad, w0, chain_len, count, x_m, hand, gate, (const ModpConsts*)cs);
+                     t, tpad, w0, chain_len, count, x_m, hand, gate, inject_fault, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,

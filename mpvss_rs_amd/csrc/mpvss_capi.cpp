@@ -773,8 +773,9 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, hand_s, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, S, (int)t, state_fwd, state_bwd,
                                       (uint32_t*)w.fd_hand_t.p, flag, ctx->consts, ctx->stream));
+  static const int inject_fault = fd_env("MPVSS_FD_TEST_FAULT", 0);   // tests only: one stage gives up, the flag falls
   LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, S, (int)t, w0, chain_len, (int)cnt, xm,
-                                     (uint32_t*)w.fd_hand_s.p, flag, ctx->consts, ctx->stream));
+                                     (uint32_t*)w.fd_hand_s.p, flag, inject_fault, ctx->consts, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_from_mont(xm, (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
   LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t, dpos,

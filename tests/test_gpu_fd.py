@@ -53,3 +53,16 @@ def test_fd_equals_horner(t, n, p0, extra):
     a = run(code, {"MPVSS_FD": "1", "MPVSS_FD_MIN_SHARES": "2048"}).strip()
     b = run(code, {"MPVSS_FD": "0"}).strip()
     assert a == b and len(a) == 64
+
+
+def test_a_stage_that_gives_up_falls_back_to_horner():
+    """MPVSS_FD_TEST_FAULT=1 makes one pipeline stage behave as if its wait had timed out: it clears the device flag
+    and poisons its output; the stages below must give up at once and the gated Horner launch must produce every X."""
+    code = CODE % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), 4242, 64, 8192, 1, "")
+    import time
+    t0 = time.time()
+    a = run(code, {"MPVSS_FD": "1", "MPVSS_FD_TEST_FAULT": "1"}).strip()
+    took = time.time() - t0
+    b = run(code, {"MPVSS_FD": "0"}).strip()
+    assert a == b and len(a) == 64
+    assert took < 60, "poisoned stages must not wait for their timeouts one after the other"
