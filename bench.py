@@ -52,9 +52,9 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SHARE = 1536  # read y,Y,r + write X,a1,a2 (6 x 256 B)
 # measured sustained issue rate (tools/ubench_clock.hip, profiles/r01_ubench_sustained_mad_clock.txt): one
 # v_mad_u64_u32 wave-instruction per 2.07 ns per SIMD from 2 waves/SIMD up (~4.35 cycles at the ~2.1 GHz the
-# chip holds under this load); a 2048-bit Montgomery product = 2*76*76 lane-mads = 2888 wave-mads per 16 numbers
+# chip holds under this load); a 2048-bit Montgomery product = 2*72*72 lane-mads = 2592 wave-mads per 16 numbers
 MAD_NS_PER_SIMD = 2.07
-PEAK_MODMUL_PER_S = 1024 / (2 * 76 * 19 / 16 * MAD_NS_PER_SIMD * 1e-9)   # 256 CUs x 4 SIMDs -> 2.74e9
+PEAK_MODMUL_PER_S = 1024 / (2 * 72 * 18 / 16 * MAD_NS_PER_SIMD * 1e-9)   # 256 CUs x 4 SIMDs -> 3.05e9
 
 
 def fx(v: int) -> bytes:
@@ -337,7 +337,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 limbs (radix 2^28), u64 accumulators",
+        "dtype": "u32 limbs (radix 2^29), u64 accumulators",
         "data": "synthetic",
         "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n} t={t} per GPU "
                                f"({n_total} participants in the box), honest-dealer box, inputs resident in HBM",

@@ -2,18 +2,19 @@
 // four lanes of a DPP quad (16 numbers per 64-lane wavefront).
 //
 // Representation
-//   radix 2^28, L = 76 limbs (capacity 2128 bits, R = 2^2128), lane q of the quad owns limbs
-//   19q .. 19q+18 in registers.  Limbs are "almost normalised": every limb <= 2^28 - 1 + 2^9.
+//   radix 2^29, L = 72 limbs (capacity 2088 bits, R = 2^2088), lane q of the quad owns limbs
+//   18q .. 18q+17 in registers.  Limbs are "almost normalised": every limb <= 2^29 - 1 + 2^9.
 //   Values are kept in [0, 2N) (R > 4N, so no conditional subtraction inside a chain).
 //
 // Why this shape (measured on MI355X, profiles/r01_ubench_valu_issue_rates.txt):
-//   * v_mad_u64_u32 issues every ~3.4 cycles per SIMD with >= 4 waves resident but a
-//     carry-producing add (v_add_co/v_addc) costs the same, so a radix-2^32 schoolbook row
-//     (1 mad + 1 addc per product) is ~1.85x the cost of a radix-2^28 row whose products are
-//     accumulated carry-free in 64-bit column accumulators (1 mad per product).
-//   * one wave alone reaches only ~1/3 of the mad issue rate, so >= 4 waves per SIMD are
-//     needed, i.e. <= 128 VGPRs: a whole 2048-bit operand per lane (64+ VGPRs per operand)
-//     does not fit, a quarter of one (19 limbs) does.
+//   * v_mad_u64_u32 issues at one wave-instruction per ~2.07 ns per SIMD, but a carry-producing add
+//     (v_add_co/v_addc) costs the same, so a radix-2^32 schoolbook row (1 mad + 1 addc per product) is
+//     ~1.85x the cost of a row whose products are accumulated carry-free in 64-bit column accumulators
+//     (1 mad per product).  The radix is the largest for which that works: every column passes the lowest
+//     position of a lane every 18 rows and is carried there, so it collects at most 36 products < 2^58 in
+//     between (< 2^63.2, tests/test_limb_model.py); 2^30 would overflow.
+//   * a whole 2048-bit operand per lane (64+ VGPRs per operand, 3-4 live) does not fit 3 waves per SIMD,
+//     a quarter of one (18 limbs) does.
 //   * quad_perm DPP moves data between the four lanes at full VALU rate (no LDS round trip).
 //
 // Montgomery product (CIOS, one b-limb per step, accumulators shift one limb per step):
@@ -28,12 +29,12 @@ namespace bn {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-constexpr int W = 28;
-constexpr int L = 76;
-constexpr int LPL = 19;              // limbs per lane
+constexpr int W = 29;
+constexpr int L = 72;
+constexpr int LPL = 18;              // limbs per lane
 constexpr u32 MASK = (1u << W) - 1;
 constexpr int NUMS_PER_WAVE = 16;
-constexpr int SLOT_WORDS = 76;       // LDS words per number operand slot (304 B = 19 x 16 B)
+constexpr int SLOT_WORDS = 72;       // LDS words per number operand slot (288 B = 18 x 16 B)
 
 // quad_perm selectors: dpp_ctrl = p0 | p1<<2 | p2<<4 | p3<<6
 constexpr int QP_BCAST0 = 0x00;                          // every lane reads lane 0
@@ -53,10 +54,10 @@ __device__ __forceinline__ u32 quad_from_prev(u32 v) {
 struct Lane {
   u32 q;         // lane index inside the quad, 0..3
   u32 not_top;   // all ones unless q == 3
-  u32 top28;     // 2^28 - 1 unless q == 3 (then 0): "take the low limb of the lane above"
+  u32 top28;     // 2^W - 1 unless q == 3 (then 0): "take the low limb of the lane above"
   u32 low01;     // 1 iff q == 0, else 0
   u32 not_low;   // all ones unless q == 0
-  u32 mask28;    // 2^28 - 1 in a VGPR (lets the compiler fuse "broadcast & mask" into one v_and_b32_dpp)
+  u32 mask28;    // 2^W - 1 in a VGPR (lets the compiler fuse "broadcast & mask" into one v_and_b32_dpp)
 };
 
 __device__ __forceinline__ Lane make_lane() {
@@ -74,16 +75,16 @@ __device__ __forceinline__ Lane make_lane() {
 }
 
 // r = a * b * R^-1 (mod N), result almost normalised and < 2N when a, b < 2N.
-//   a   : this lane's 19 limbs of the first operand (registers)
-//   b   : LDS pointer to the 76 limbs of the second operand of THIS number
-//   n   : this lane's 19 limbs of the modulus (registers)
+//   a   : this lane's 18 limbs of the first operand (registers)
+//   b   : LDS pointer to the 72 limbs of the second operand of THIS number
+//   n   : this lane's 18 limbs of the modulus (registers)
 // N0INV == 1 for the RFC 3526 prime (N = -1 mod 2^64), the multiply folds away.
 //
-// One step (one limb b_i of b), per lane: 19 mads a[k]*b_i, m from lane 0's lowest column,
-// 19 mads m*n[k]; lane 0's lowest column is then 0 mod 2^28 and retires.  Every lane carries the upper bits
-// of its lowest column into its next column and hands the low 28 bits to the lane below (lane 3 starts a
-// fresh zero column).  Column accumulators stay below 2^64 (76 steps x 2
-// products < 2^56.01 each, checked exhaustively for worst-case limbs in tests/test_limb_model.py).
+// One step (one limb b_i of b), per lane: 18 mads a[k]*b_i, m from lane 0's lowest column,
+// 18 mads m*n[k]; lane 0's lowest column is then 0 mod 2^29 and retires.  Every lane carries the upper bits
+// of its lowest column into its next column and hands the low 29 bits to the lane below (lane 3 starts a
+// fresh zero column).  Column accumulators stay below 2^64 (at most 18 steps x 2 products < 2^58.01 between two
+// carries of a column, checked for worst-case limbs in tests/test_limb_model.py).
 template <u32 N0INV>
 __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ b,
                                          const u32 (&n)[LPL], const Lane& ln) {
@@ -107,7 +108,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)m * n[k];
       // Every lane moves the upper bits of its lowest column into its next column (same weight) and hands the
-      // low 28 bits to the lane below, whose fresh top column they become; lane 0's lowest column is 0 mod 2^28
+      // low 28 bits to the lane below, whose fresh top column they become; lane 0's lowest column is 0 mod 2^W
       // by construction and retires.  No lane-dependent arithmetic: one shift, one 64-bit add, one v_and_b32_dpp.
       {
         const u64 ret = T[rr];
@@ -160,7 +161,7 @@ __device__ __forceinline__ void slot_fill_from_global(u32* slot, const u32* __re
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     const int idx = c * 4 + (int)ln.q;
-    if (idx < 19) s4[idx] = g4[idx];
+    if (idx < SLOT_WORDS / 4) s4[idx] = g4[idx];
   }
 }
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ void slot_spill_to_global(u32* __restrict__ g, const 
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     const int idx = c * 4 + (int)ln.q;
-    if (idx < 19) g4[idx] = s4[idx];
+    if (idx < SLOT_WORDS / 4) g4[idx] = s4[idx];
   }
 }
 

@@ -4,13 +4,13 @@
 //   Participant<ModpGroup>::verify_distribution_shares  (src/participant.rs:399-455)
 //   DLEQ verifier commitments                            (src/dleq.rs:66-84)
 //   ModpGroup::exp / ModpGroup::mul                      (src/groups/modp.rs:122-132)
-// re-designed for CDNA4: one number per DPP quad, radix-2^28 carry-free column
-// accumulation (see bn_quad28.h), one wavefront (16 numbers) per workgroup so that waves
+// re-designed for CDNA4: one number per DPP quad, radix-2^29 carry-free column
+// accumulation (see bn_quad.h), one wavefront (16 numbers) per workgroup so that waves
 // never synchronise with each other, window tables in an HBM workspace, second operand of
 // every product staged in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "bn_quad28.h"
+#include "bn_quad.h"
 #include "modp_kernels.h"
 
 // Occupancy target.  Measured on MI355X (n=65536, t=256): 3 waves/SIMD without spills (135 VGPRs) beats
@@ -53,17 +53,17 @@ __device__ __forceinline__ void store_lane_limbs(u32* __restrict__ g, const u32 
   for (int k = 0; k < LPL; ++k) g[ln.q * LPL + k] = a[k];
 }
 
-// limb j (28 bits at bit offset 28 j) of a 256-byte big-endian integer
+// limb j (W bits at bit offset W j) of a 256-byte big-endian integer
 __device__ __forceinline__ u32 be256_limb(const uint8_t* __restrict__ be, int j) {
   const int o = W * j;
   const int p = o >> 3, s = o & 7;
-  u32 w = 0;
+  u64 w = 0;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < 5; ++t) {                // W + 7 <= 40 bits
     const int idx = 255 - (p + t);
-    if (idx >= 0) w |= (u32)be[idx] << (8 * t);
+    if (idx >= 0) w |= (u64)be[idx] << (8 * t);
   }
-  return (w >> s) & MASK;
+  return (u32)(w >> s) & MASK;
 }
 
 __device__ __forceinline__ void load_be256(u32 (&a)[LPL], const uint8_t* __restrict__ be, const Lane& ln) {
@@ -114,7 +114,7 @@ __device__ __forceinline__ void store_canonical_be256(uint8_t* __restrict__ out,
 #pragma nounroll
       for (int j = 0; j < L; ++j) {
         const u32 d = slot[j] - cs->n[j] - borrow;
-        borrow = (d >> 31) & 1;  // operands < 2^28, so a wrap sets the top bit
+        borrow = (d >> 31) & 1;  // operands < 2^W, so a wrap sets the top bit
         slot[j] = d & MASK;
       }
     }
@@ -128,8 +128,11 @@ __device__ __forceinline__ void store_canonical_be256(uint8_t* __restrict__ out,
       const int wd = (int)ln.q * 16 + i;
       const int bit = 32 * wd;
       const int j = bit / W, s = bit % W;
-      const u64 two = (u64)slot[j] | ((u64)(j + 1 < L ? slot[j + 1] : 0u) << W);
-      const u32 v = (u32)(two >> s);
+      // 32 bits starting at bit s of limb j: up to three limbs (s + 32 can exceed 2 W)
+      u64 two = (u64)slot[j] | ((u64)(j + 1 < L ? slot[j + 1] : 0u) << W);
+      two >>= s;
+      if (2 * W - s < 32) two |= (u64)(j + 2 < L ? slot[j + 2] : 0u) << (2 * W - s);
+      const u32 v = (u32)two;
       out32[63 - wd] = __builtin_bswap32(v);
     }
   }
@@ -763,7 +766,7 @@ k_modp_comb_rows(u32* __restrict__ comb, const ModpConsts* __restrict__ cs) {
 //   p = entry[2^(j-1)]^2 = entry[2^j],   entry[2^j + i] = entry[i] * p   for i < 2^j.
 extern "C" __global__ void k_modp_comb16_init(const u32* __restrict__ comb4, u32* __restrict__ comb16,
                                               const ModpConsts* __restrict__ cs) {
-  const int k = blockIdx.x;                    // 128 blocks of 76 threads
+  const int k = blockIdx.x;                    // 128 blocks, one thread per limb
   const int j = threadIdx.x;
   if (j >= L) return;
   comb16[((size_t)k * 65536 + 0) * L + j] = cs->one_m[j];

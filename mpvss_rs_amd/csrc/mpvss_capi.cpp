@@ -665,11 +665,11 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
 void invert_root_on_host(void* p) {
   static const hostq::Field* field = [] {
     uint8_t qbe[EB];
-    for (size_t byte = 0; byte < EB; ++byte) {     // assemble q from its 28-bit limbs
+    for (size_t byte = 0; byte < EB; ++byte) {     // assemble q from its limbs
       unsigned v = 0;
       for (int bit = 0; bit < 8; ++bit) {
         const size_t b = byte * 8 + bit;
-        v |= ((MODP_N_LIMBS[b / 28] >> (b % 28)) & 1u) << bit;
+        v |= ((MODP_N_LIMBS[b / MODP_W] >> (b % MODP_W)) & 1u) << bit;
       }
       qbe[EB - 1 - byte] = (uint8_t)v;
     }

@@ -1,4 +1,4 @@
-"""Integer model of the kernels' quad-lane radix-2^28 Montgomery product (mpvss_rs_amd/csrc/bn_quad28.h):
+"""Integer model of the kernels' quad-lane radix-2^29 Montgomery product (mpvss_rs_amd/csrc/bn_quad.h):
 same step order, same lazy carries, same two-pass normalisation.  Checks (a) the result, (b) that no
 64-bit column accumulator can overflow even for worst-case "almost normalised" limbs, (c) the limb
 bound the next product relies on."""
@@ -7,7 +7,7 @@ import random
 import mpvss_oracle as O
 
 N = O.ModpGroup().q
-W, L, LPL = 28, 76, 19
+W, L, LPL = 29, 72, 18
 M = (1 << W) - 1
 R = 1 << (W * L)
 NL = [(N >> (W * j)) & M for j in range(L)]
