@@ -72,11 +72,14 @@ PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "8"))   # boxes in flight (
 HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "3"))   # host threads absorbing (hashing) boxes at N=1
 
 
+SQ_COST = (72 * (9.5 + 18)) / (72 * 36)      # mads of a dedicated squaring relative to a general product (0.764)
+
+
 def horner_modmuls(positions, t):
-    """Montgomery products the commit_eval kernel executes for one 16-share wave (see
-    k_modp_commit_eval): per Horner step (nb-1) squarings, one product per lower bit position at
-    which any share of the wave has the bit set, plus the product with C_j."""
-    total = 0
+    """Work of the commit_eval kernel in full-product equivalents (a squaring counts SQ_COST), per 16-share wave
+    (see k_modp_commit_eval): per Horner step (nb-1) squarings, one product per lower bit position at which any
+    share of the wave has the bit set, plus the product with C_j."""
+    total = 0.0
     for w in range(0, len(positions), 16):
         grp = positions[w:w + 16]
         nb = max(grp).bit_length()
@@ -84,7 +87,7 @@ def horner_modmuls(positions, t):
         for p in grp:
             anyset |= p
         mults = bin(anyset & ((1 << max(nb - 1, 0)) - 1)).count("1")
-        per_step = max(nb - 1, 0) + mults + 1
+        per_step = max(nb - 1, 0) * SQ_COST + mults + 1
         total += len(grp) * per_step * (t - 1)
     return total
 
@@ -319,8 +322,9 @@ def main():
     comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
     gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
     w6 = os.environ.get("MPVSS_A2_W6", "1") != "0"            # 6-bit windows for y^r (64-entry table) or 4-bit
-    a2_products = (2046 + 341 + 64 + 1) if w6 else (2044 + 511 + 64 + 1)
-    mm_dual = n * (a2_products + (316 + gr + 2))              # a2: Straus chain; a1: comb for g^r + X^c windows
+    # full-product equivalents: squarings weigh SQ_COST
+    a2_products = (2046 * SQ_COST + 341 + 64 + 1) if w6 else (2044 * SQ_COST + 511 + 64 + 1)
+    mm_dual = n * (a2_products + (252 * SQ_COST + 64 + gr + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
     mm_table = n * (2 * 15 + (63 if w6 else 15))              # window tables of X, Y (16 entries) and y (+1 conversion each)
     mm_total = mm_x + mm_dual + mm_table
     achieved_modmul = mm_total / (ms_per_step * 1e-3)         # against the step's wall time (kernels overlap)
@@ -356,7 +360,7 @@ def main():
         },
         "compute": {
             "bound": "valu v_mad_u64_u32 issue",
-            "achieved": achieved_modmul, "peak": peak_modmul, "unit": "2048-bit Montgomery products/s (all kernels / step wall time)",
+            "achieved": achieved_modmul, "peak": peak_modmul, "unit": "2048-bit Montgomery products/s (all kernels / step wall time; a squaring counts 0.764 of a product, its share of the mads)",
             "frac": achieved_modmul / peak_modmul,
             "modmul_per_share": mm_total / n,
             "x_path": x_path,
@@ -444,7 +448,7 @@ def main():
         keyset[0] = None
         table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
         lib.mpvss_modp_keyset_destroy(ctx, h)
-        mm_k = mm_total - n * a2_products - n * ((63 if w6 else 15) - 0) + n * (252 + 256 + 63 + 1)
+        mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 256 + 63 + 1)
         result["registered_keys"] = {
             "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
             "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,

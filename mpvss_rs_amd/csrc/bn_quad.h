@@ -85,7 +85,14 @@ __device__ __forceinline__ Lane make_lane() {
 // of its lowest column into its next column and hands the low 29 bits to the lane below (lane 3 starts a
 // fresh zero column).  Column accumulators stay below 2^64 (at most 18 steps x 2 products < 2^58.01 between two
 // carries of a column, checked for worst-case limbs in tests/test_limb_model.py).
-template <u32 N0INV>
+//
+// SQ = true: b must be (an LDS copy of) a itself.  Row r = 18 o + rr then only visits the local positions k >= rr:
+// k > rr with the doubled limb 2 a_r, k == rr with a_r itself.  Every pair {r, j}, r != j, is then counted exactly
+// twice -- once doubled in the row of the limb with the smaller local index, or once in each of the two rows when the
+// local indices are equal -- and every square once, in all four lanes by the same instructions: 9.5 instead of 18
+// mads per row for the a*a half, 24 % fewer mads per squaring.  (Needs an even number of limbs per lane only in
+// the sense that the rule is lane-independent; bounds: tests/test_limb_model.py.)
+template <u32 N0INV, bool SQ = false>
 __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ b,
                                          const u32 (&n)[LPL], const Lane& ln) {
   u64 T[LPL];
@@ -102,8 +109,14 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
         const int nxt = o * LPL + rr + 1;
         bnext = b[nxt < L ? nxt : L - 1];
       }
+      if (SQ) {
+        const u32 bi2 = bi << 1;
 #pragma unroll
-      for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)a[k] * bi;
+        for (int k = rr; k < LPL; ++k) T[(k + rr) % LPL] += (u64)a[k] * (k > rr ? bi2 : bi);
+      } else {
+#pragma unroll
+        for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)a[k] * bi;
+      }
       const u32 m = quad_bcast0((u32)T[rr] * N0INV) & ln.mask28;
 #pragma unroll
       for (int k = 0; k < LPL; ++k) T[(k + rr) % LPL] += (u64)m * n[k];
@@ -139,6 +152,13 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
   const u64 v = (u64)r[0] + (((u64)ch << 32) | cl);
   r[0] = (u32)v & MASK;
   r[1] += (u32)(v >> W);
+}
+
+// r = a^2 R^-1 (mod N); `self` = LDS slot holding a copy of a
+template <u32 N0INV>
+__device__ __forceinline__ void mont_sqr(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ self,
+                                         const u32 (&n)[LPL], const Lane& ln) {
+  mont_mul<N0INV, true>(r, a, self, n, ln);
 }
 
 // ---- operand slot helpers (one wave = 16 numbers, slot = 76 words per number) -------------

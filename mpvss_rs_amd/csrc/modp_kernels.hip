@@ -142,7 +142,7 @@ __device__ __forceinline__ void store_canonical_be256(uint8_t* __restrict__ out,
 __device__ __forceinline__ void square_into(u32 (&a)[LPL], u32* slot, const u32 (&n)[LPL], const Lane& ln) {
   slot_store(slot, a, ln);
   __builtin_amdgcn_wave_barrier();
-  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);
+  mont_sqr<MODP_N0INV_C>(a, a, slot, n, ln);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -273,7 +273,8 @@ k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, i
     }
     if (!skip) {
       __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
+      if (kind == K_SQUARE) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      else mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
       __builtin_amdgcn_wave_barrier();
     }
     if (kind == K_FINAL) break;
@@ -694,6 +695,7 @@ k_modp_dual_exp(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __r
   while (true) {
     if (s == 6) { ++w; s = 0; }
     const bool final_step = (w == 512);
+    const bool sq = !final_step && s < 4;
     if (final_step) {
       slot_fill_from_global(slot, cs->one, ln);
     } else if (s < 4) {
@@ -705,7 +707,7 @@ k_modp_dual_exp(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __r
       slot_fill_from_global(slot, ((s == 4) ? t1 : t2) + (size_t)d * L, ln);
     }
     __builtin_amdgcn_wave_barrier();
-    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (sq) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
     __builtin_amdgcn_wave_barrier();
     if (final_step) break;
     ++s;
@@ -733,7 +735,7 @@ k_modp_comb_bases(const uint8_t* __restrict__ base_be, u32* __restrict__ comb, c
   for (int op = 0; op <= 511 * 4; ++op) {
     if (op == 0) slot_fill_from_global(slot, cs->r2, ln); else slot_store(slot, acc, ln);
     __builtin_amdgcn_wave_barrier();
-    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (op == 0) mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln);
     __builtin_amdgcn_wave_barrier();
     if (writer && (op % 4) == 0) store_lane_limbs(comb + ((size_t)(op / 4) * 16 + 1) * L, acc, ln);
   }
@@ -844,7 +846,7 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
     const u32* bptr = slot;
     const u32* fill = nullptr;     // global operand staged into `fill_to` (one staging site keeps the register use low)
     u32* fill_to = slot;
-    bool skip = false;
+    bool skip = false, sq = false;
     if (phase == PH_A) {
       if (s == 5) { ++w; s = 0; }
       if (w == 512) {
@@ -861,6 +863,7 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
       } else {
         if (s < 4) {
           slot_store(slot, acc, ln);
+          sq = true;
         } else {
           const u32 byte = e2[w >> 1];
           const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
@@ -891,7 +894,7 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
     if (fill != nullptr) slot_fill_from_global(fill_to, fill, ln);
     if (!skip) {
       __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
+      if (sq) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, bptr, n, ln);
       __builtin_amdgcn_wave_barrier();
     }
     if (phase >= PH_F + 1) break;
@@ -982,7 +985,7 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
     if (!skip) {
       if (fill != nullptr) slot_fill_from_global(slot, fill, ln);
       __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      if (s == 0) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
       __builtin_amdgcn_wave_barrier();
     }
     if (s == 3) break;
@@ -1021,7 +1024,7 @@ k_modp_keyset_bases(const uint8_t* __restrict__ pk_be, int count, u32* __restric
   for (int op = 0; op <= (KS_SUB - 1) * 256; ++op) {
     if (op == 0) slot_fill_from_global(slot, cs->r2, ln); else slot_store(slot, acc, ln);
     __builtin_amdgcn_wave_barrier();
-    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (op == 0) mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln);
     __builtin_amdgcn_wave_barrier();
     if (live && (op % 256) == 0) {
       u32* row = mine + (size_t)(op / 256) * KS_ENT * L;
@@ -1079,7 +1082,8 @@ k_modp_keyset_dual_exp(const u32* __restrict__ ks, const u32* __restrict__ tab2,
   int p = 0, s = 5;
   while (true) {
     const u32* fill = nullptr;
-    if (s < 4 || (s >= 5 && s < 9)) {
+    const bool sq = s < 4 || (s >= 5 && s < 9);
+    if (sq) {
       slot_store(slot, acc, ln);                       // squaring
     } else if (s == 4 || s == 9) {
       const u32 byte = c_be[224 + p];
@@ -1094,7 +1098,7 @@ k_modp_keyset_dual_exp(const u32* __restrict__ ks, const u32* __restrict__ tab2,
     }
     if (fill != nullptr) slot_fill_from_global(slot, fill, ln);
     __builtin_amdgcn_wave_barrier();
-    mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    if (sq) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
     __builtin_amdgcn_wave_barrier();
     if (s == 10 + KS_SUB) break;
     ++s;

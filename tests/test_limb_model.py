@@ -15,12 +15,19 @@ N0INV = (-pow(N, -1, 1 << W)) % (1 << W)
 LIMB_BOUND = M + 512
 
 
-def mont_mul_model(a, b, stats, bound_only=False):
+def mont_mul_model(a, b, stats, bound_only=False, square=False):
+    """square=True: the dedicated squaring (b is a): row r = 18 o + rr visits only the local positions k >= rr of
+    every lane, k > rr with the doubled limb."""
     T = [0] * L
     for i in range(L):
         bi = b[i]
+        rr = i % LPL
         for j in range(L):
-            T[j] += a[j] * bi
+            k = j % LPL
+            if not square:
+                T[j] += a[j] * bi
+            elif k >= rr:
+                T[j] += a[j] * (2 * bi if k > rr else bi)
         m = ((T[0] & 0xFFFFFFFF) * N0INV) & M
         for j in range(L):
             T[j] += m * NL[j]
@@ -75,6 +82,22 @@ def test_model_matches_montgomery_product_and_bounds():
         assert v % N == (a * b * rinv) % N and v < 2 * N
         assert max(r) <= LIMB_BOUND
     assert stats["maxacc"] < (1 << 64)
+
+
+def test_dedicated_squaring_matches_and_stays_in_bounds():
+    rng = random.Random(6)
+    rinv = pow(R, -1, N)
+    stats = {"maxacc": 0}
+    for it in range(40):
+        a = rng.randrange(2 * N)
+        if it < 3:
+            a = 2 * N - 1
+        r = mont_mul_model(tolimbs(a), tolimbs(a), stats, square=True)
+        v = val(r)
+        assert v % N == (a * a * rinv) % N and v < 2 * N
+        assert max(r) <= LIMB_BOUND
+    mont_mul_model([LIMB_BOUND] * L, [LIMB_BOUND] * L, stats, bound_only=True, square=True)
+    assert stats["maxacc"].bit_length() <= 64
 
 
 def test_worst_case_limbs_do_not_overflow():
