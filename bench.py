@@ -212,6 +212,7 @@ def main():
         eng._check(rcode, "verify_block_compute")
 
     hash_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(HASH_THREADS, 1))
+    pending_send = [None, None]     # outstanding isend of the hash state to the next rank
     kernel_ms = {0: [], 1: [], 2: [], 3: []}
     a2_launches = []
     host_absorb_s = []
@@ -232,15 +233,17 @@ def main():
         a2_launches.append(max(eng.kernel_launches(3), 1))
         if world == 1:
             return capi.transcript_verdict(state, challenge)
-        out = torch.zeros(33, dtype=torch.uint8, device=commdev)
+        # Several ranks: hand the state on and return at once -- the ranks form a pipeline over the boxes (rank r hashes
+        # box b while rank r+1 hashes box b-1).  Only the last rank knows the verdicts; they are broadcast once, at the
+        # end of run_steps(), not per box (a per-box broadcast would hold every rank until the last one is done).
         if rank + 1 < world:
-            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain)
-        else:
-            verdict, digest = capi.transcript_verdict(state, challenge)
-            out = torch.frombuffer(bytearray(bytes([int(verdict)]) + digest), dtype=torch.uint8).to(commdev)
-        dist.broadcast(out, src=world - 1, group=chain)
-        raw = bytes(out.cpu().numpy().tobytes())
-        return bool(raw[0]), raw[1:33]
+            if pending_send[0] is not None:
+                pending_send[0].wait()
+            msg = torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev)
+            pending_send[0] = dist.isend(msg, dst=rank + 1, group=chain)
+            pending_send[1] = msg                               # keep the buffer alive until the send completes
+            return None
+        return capi.transcript_verdict(state, challenge)
 
     def run_steps(k, depth=None):
         """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
@@ -259,6 +262,18 @@ def main():
                 if issued < k:
                     compute_block()
                     issued += 1
+            if world > 1:                      # one broadcast of all k verdicts and digests from the last rank
+                if pending_send[0] is not None:
+                    pending_send[0].wait()
+                    pending_send[0] = None
+                if rank == world - 1:
+                    flat = b"".join(bytes([int(v)]) + d for v, d in results)
+                    out = torch.frombuffer(bytearray(flat), dtype=torch.uint8).to(commdev)
+                else:
+                    out = torch.zeros(33 * k, dtype=torch.uint8, device=commdev)
+                dist.broadcast(out, src=world - 1, group=chain)
+                raw = bytes(out.cpu().numpy().tobytes())
+                results = [(bool(raw[33 * i]), raw[33 * i + 1:33 * i + 33]) for i in range(k)]
             return results
         pending = collections.deque(hash_pool.submit(finish_block) for _ in range(issued))
         while pending:
