@@ -135,3 +135,29 @@ def test_caller_provided_stream(engine):
     assert out == [35, 35, 35]
     assert eng.lib.mpvss_ctx_synchronize(eng.ctx) == 0
     eng.close()
+
+
+def test_blocks_absorbed_by_several_host_threads(engine):
+    """Several host threads may absorb consecutive blocks side by side (the engine releases its lock while it waits
+    and hashes): every block must come out with its own, correct transcript."""
+    import concurrent.futures
+    g, privs, pks, coeffs, ws, box = make_modp_instance(12, 4, 21)
+    flat = O.box_to_flat(g, box)
+    tampered = bytearray(flat["responses"]); tampered[700] ^= 4
+    kinds = [flat["responses"], bytes(tampered)] * 4                 # 8 blocks, alternately honest and tampered
+    for resp in kinds:
+        engine.verify_block_compute(flat["commitments"], flat["positions"], flat["publickeys"], flat["shares"], resp,
+                                    flat["challenge"])
+
+    def absorb(_):
+        st = engine.verify_block_absorb(capi.transcript_init())
+        return capi.transcript_verdict(st, flat["challenge"])
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
+        out = list(pool.map(absorb, range(len(kinds))))
+    # blocks are handed out in FIFO order at entry, but the threads enter in any order: compare as multisets
+    assert sorted(v for v, _ in out) == [False] * 4 + [True] * 4
+    assert all(d == box["_digest"] for v, d in out if v)
+    assert all(d != box["_digest"] for v, d in out if not v)
+    with pytest.raises(capi.EngineError):
+        engine.verify_block_absorb(capi.transcript_init())
