@@ -91,6 +91,110 @@ __device__ __forceinline__ void add_body(const uint8_t* __restrict__ a_enc, cons
   ok[x] = (g1 && g2) ? 1 : 0;
 }
 
+// ---- forward differences for consecutive positions (additive version of modp_kernels.hip's) ---------------------
+// X(i) = sum_j i^j C_j is a polynomial of degree t-1 in i, so with D_0 = X, D_k(i) = D_{k-1}(i+1) - D_{k-1}(i) the level
+// D_{t-1} is constant and D_k(i+1) = D_k(i) + D_{k+1}(i): one point addition per share and coefficient instead of
+// ~35 point operations for Horner's rule.  Negation is free, so there is no inversion step.  Chain c of `chains`
+// owns the positions c, c+S, c+2S, ..; its seeds are t consecutive members in its middle (Horner), from which it is
+// stepped both ways (forward with D_l = E_l[0], backward with H_l = (-1)^l E_l[t-1-l], same recurrence).
+// One workgroup = one chain, one lane = one level; neighbours talk through LDS.  Results are the same group
+// elements, hence the same canonical encodings.
+
+// seeds: Horner as above, but the points stay in internal coordinates (array of structs)
+template <class C>
+__device__ __forceinline__ void seeds_body(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions,
+                                           int count, u32* __restrict__ pts) {
+  const int xi = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  const uint64_t pos = (uint64_t)positions[x];
+  int nb = (pos == 0) ? 0 : 64 - __builtin_clzll(pos);
+  typename C::Point acc, cj, r;
+  load_point_aos<C>(acc, cm + (size_t)(t - 1) * C::POINT_WORDS);
+  for (int j = t - 2; j >= 0; --j) {
+    small_scalar_mul<C>(r, acc, pos, nb);
+    load_point_aos<C>(cj, cm + (size_t)j * C::POINT_WORDS);
+    C::add(acc, r, cj);
+  }
+  if (live) store_point_aos<C>(pts + (size_t)x * C::POINT_WORDS, acc);
+}
+
+template <class C>
+__device__ __forceinline__ void lds_put(u32* lds, int k, const typename C::Point& p) {
+  const u32* w = reinterpret_cast<const u32*>(&p);
+#pragma unroll
+  for (int i = 0; i < C::POINT_WORDS; ++i) lds[i * blockDim.x + k] = w[i];     // word-major: conflict-free
+}
+template <class C>
+__device__ __forceinline__ void lds_get(typename C::Point& p, const u32* lds, int k) {
+  u32* w = reinterpret_cast<u32*>(&p);
+#pragma unroll
+  for (int i = 0; i < C::POINT_WORDS; ++i) w[i] = lds[i * blockDim.x + k];
+}
+
+// difference tables: E_l[k] = E_{l-1}[k+1] - E_{l-1}[k];  seeds of chain c are pts[c + chains k]
+template <class C>
+__device__ __forceinline__ void fd_table_body(const u32* __restrict__ seeds, int chains, int t, u32* __restrict__ fwd,
+                                              u32* __restrict__ bwd) {
+  extern __shared__ u32 lds[];
+  const int chain = blockIdx.x, k = threadIdx.x;
+  typename C::Point E, nb, neg;
+  if (k < t) load_point_aos<C>(E, seeds + ((size_t)chain + (size_t)chains * k) * C::POINT_WORDS); else C::identity(E);
+  u32* f = fwd + (size_t)chain * t * C::POINT_WORDS;
+  u32* b = bwd + (size_t)chain * t * C::POINT_WORDS;
+  if (k == 0) store_point_aos<C>(f, E);
+  if (k == t - 1) store_point_aos<C>(b, E);
+  for (int lvl = 1; lvl < t; ++lvl) {
+    lds_put<C>(lds, k, E);
+    __syncthreads();
+    if (k <= t - 1 - lvl) {
+      lds_get<C>(nb, lds, k + 1);
+      C::neg(neg, E);
+      C::add(E, nb, neg);
+    }
+    __syncthreads();
+    if (k == 0) store_point_aos<C>(f + (size_t)lvl * C::POINT_WORDS, E);
+    if (k == t - 1 - lvl) {
+      if (lvl & 1) { C::neg(neg, E); store_point_aos<C>(b + (size_t)lvl * C::POINT_WORDS, neg); }
+      else store_point_aos<C>(b + (size_t)lvl * C::POINT_WORDS, E);
+    }
+  }
+}
+
+// stepping: D_k <- D_k + D_{k+1}; block = (direction, chain); pts[c + chains j] = X at index j of chain c
+template <class C>
+__device__ __forceinline__ void fd_step_body(const u32* __restrict__ fwd, const u32* __restrict__ bwd, int chains, int t,
+                                             int w0, int chain_len, int count, u32* __restrict__ pts) {
+  extern __shared__ u32 lds[];
+  const int dir = blockIdx.x / chains, chain = blockIdx.x % chains, k = threadIdx.x;
+  if (dir == 1 && w0 == 0) return;
+  const int steps = dir == 0 ? chain_len - 1 - w0 : w0 + t - 1;
+  const u32* st = (dir == 0 ? fwd : bwd) + (size_t)chain * t * C::POINT_WORDS;
+  typename C::Point D, nb;
+  if (k < t) load_point_aos<C>(D, st + (size_t)k * C::POINT_WORDS); else C::identity(D);
+  for (int step = 1; step <= steps; ++step) {
+    lds_put<C>(lds, k, D);
+    __syncthreads();
+    if (k + 1 < t) {
+      lds_get<C>(nb, lds, k + 1);
+      C::add(D, D, nb);
+    }
+    __syncthreads();
+    const int j = dir == 0 ? w0 + step : w0 + t - 1 - step;
+    const size_t idx = (size_t)chain + (size_t)chains * j;
+    if (k == 0 && step >= t && idx < (size_t)count) store_point_aos<C>(pts + idx * C::POINT_WORDS, D);
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int count, uint8_t* __restrict__ enc) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= count) return;
+  typename C::Point p;
+  load_point_aos<C>(p, pts + (size_t)x * C::POINT_WORDS);
+  C::encode(enc + (size_t)x * C::ENC_LEN, p);
+}
+
 }  // namespace
 
 #define EC_KERNELS(NAME, CURVE)                                                                                        \
@@ -110,6 +214,22 @@ __device__ __forceinline__ void add_body(const uint8_t* __restrict__ a_enc, cons
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_add(const uint8_t* a, const uint8_t* b, int count,       \
                                                                   uint8_t* out, uint8_t* ok) {                         \
     add_body<CURVE>(a, b, count, out, ok);                                                                             \
+  }                                                                                                                    \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds(const u32* cm, int t, const int64_t* pos,       \
+                                                                       int count, u32* pts) {                          \
+    seeds_body<CURVE>(cm, t, pos, count, pts);                                                                         \
+  }                                                                                                                    \
+  extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_table(const u32* seeds, int chains, int t, u32* fwd, \
+                                                                        u32* bwd) {                                    \
+    fd_table_body<CURVE>(seeds, chains, t, fwd, bwd);                                                                  \
+  }                                                                                                                    \
+  extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_step(const u32* fwd, const u32* bwd, int chains,     \
+                                                                       int t, int w0, int chain_len, int count,        \
+                                                                       u32* pts) {                                     \
+    fd_step_body<CURVE>(fwd, bwd, chains, t, w0, chain_len, count, pts);                                               \
+  }                                                                                                                    \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_encode(const u32* pts, int count, uint8_t* enc) {        \
+    encode_body<CURVE>(pts, count, enc);                                                                               \
   }
 
 EC_KERNELS(secp, Secp)
@@ -148,5 +268,32 @@ extern "C" int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int 
   if (count <= 0) return 0;
   if (group == 1) hipLaunchKernelGGL(k_secp_add, dim3(blocks_for(count)), dim3(64), 0, s, a, b, count, out, ok);
   else hipLaunchKernelGGL(k_rist_add, dim3(blocks_for(count)), dim3(64), 0, s, a, b, count, out, ok);
+  return (int)hipGetLastError();
+}
+
+// ---- forward differences: seeds (m0 positions from `positions`), tables, stepping, encoding -------------------------
+// pts: [count][point words] internal points, index 0 = first position of the batch; seeds go to pts + seed0.
+extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                            int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc,
+                            hipStream_t s) {
+  const int m0 = chains * t;
+  const size_t seed0 = (size_t)chains * w0;
+  const int pw = ec_point_words(group);
+  uint32_t* seeds = pts + seed0 * pw;
+  const int lanes = ((t + 63) / 64) * 64;                       // one lane per level
+  const size_t lds = (size_t)lanes * pw * 4;
+  if (group == 1) {
+    hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
+    hipLaunchKernelGGL(k_secp_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd);
+    hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
+                       count, pts);
+    hipLaunchKernelGGL(k_secp_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, x_enc);
+  } else {
+    hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
+    hipLaunchKernelGGL(k_rist_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd);
+    hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
+                       count, pts);
+    hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, x_enc);
+  }
   return (int)hipGetLastError();
 }

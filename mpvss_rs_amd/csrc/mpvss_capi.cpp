@@ -43,7 +43,8 @@ struct DevBuf {
 }  // namespace
 
 struct EcWork {   // device workspace of the elliptic-curve entry points
-  DevBuf a, b, c, d, e, pos, cm, cmenc, x, o1, o2, ok, gen, chal;
+  DevBuf a, b, c, d, e, pos, cm, cmenc, x, o1, o2, ok, gen, chal, pts, fdst;
+  std::vector<int64_t> hpos;     // host copy of device-resident positions (forward-difference decision)
 };
 
 // Registered public keys: per-key tables for y^r in HBM plus a device copy of the keys themselves.
@@ -479,7 +480,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&ctx->ecwork.a, &ctx->ecwork.b, &ctx->ecwork.c, &ctx->ecwork.d, &ctx->ecwork.e, &ctx->ecwork.pos,
                     &ctx->ecwork.cm, &ctx->ecwork.cmenc, &ctx->ecwork.x, &ctx->ecwork.o1, &ctx->ecwork.o2, &ctx->ecwork.ok,
-                    &ctx->ecwork.gen, &ctx->ecwork.chal})
+                    &ctx->ecwork.gen, &ctx->ecwork.chal, &ctx->ecwork.pts, &ctx->ecwork.fdst})
     if (b->p) (void)hipFree(b->p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
@@ -1631,6 +1632,44 @@ extern "C" int mpvss_ec_batch_mul(mpvss_ctx* ctx, int group, int space, const ui
   return MPVSS_OK;
 }
 
+// X_i for n shares into dX (encoded): forward differences (ec_kernels.hip) when the positions are consecutive and the
+// batch is large enough -- one point addition per share and coefficient -- otherwise Horner's rule.
+// MPVSS_EC_FD=0 disables the path, MPVSS_EC_FD_CHAINS overrides the number of chains.
+int ec_eval_x(mpvss_ctx* ctx, const EcInfo* gi, int group, EcWork& w, int space, size_t t, const int64_t* positions,
+              const int64_t* dpos, size_t n, uint8_t* dX) {
+  static const int fd_on = fd_env("MPVSS_EC_FD", 1), chains_env = fd_env("MPVSS_EC_FD_CHAINS", 0);
+  bool fd = fd_on && t >= 16 && t <= 256 && n >= 16 * t && n >= 4096;
+  if (fd) {
+    const int64_t* hp = positions;
+    if (space == MPVSS_DEVICE) {
+      w.hpos.resize(n);
+      HIPCHK(ctx, hipMemcpyAsync(w.hpos.data(), positions, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      hp = w.hpos.data();
+    }
+    fd = hp[0] >= 0 && hp[0] < ((int64_t)1 << 61);
+    for (size_t i = 1; i < n && fd; ++i) fd = hp[i] == hp[0] + (int64_t)i;
+  }
+  if (!fd) {
+    TIMED_LAUNCH(ctx, 0, ec_launch_commit_eval(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, dX, ctx->stream));
+    return 0;
+  }
+  int S = chains_env > 0 ? chains_env : std::max((int)(4096 / t), 4);
+  const int s_max = (int)(n / (4 * t));
+  if (S > s_max) S = s_max;
+  if (S < 1) S = 1;
+  const int chain_len = (int)((n + S - 1) / S);
+  const int w0 = (chain_len - (int)t) / 2;
+  const size_t pw = (size_t)ec_point_words(group);
+  RET_IF(ensure(ctx, w.pts, n * pw * 4));
+  RET_IF(ensure(ctx, w.fdst, (size_t)2 * S * t * pw * 4));
+  uint32_t* st = (uint32_t*)w.fdst.p;
+  (void)gi;
+  TIMED_LAUNCH(ctx, 0, ec_launch_fd(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, S, w0, chain_len, (uint32_t*)w.pts.p,
+                                    st, st + (size_t)S * t * pw, dX, ctx->stream));
+  return 0;
+}
+
 // ---- X_i = sum_j i^j C_j ------------------------------------------------------------------------------
 extern "C" int mpvss_ec_commit_eval(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
                                     const int64_t* positions, size_t n, uint8_t* x_out) {
@@ -1643,7 +1682,7 @@ extern "C" int mpvss_ec_commit_eval(mpvss_ctx* ctx, int group, int space, const 
   RET_IF(stage_positions(ctx, space, positions, n, &dpos));
   uint8_t* dout = x_out;
   if (space == MPVSS_HOST) { RET_IF(ensure(ctx, w.x, n * gi->enc)); dout = (uint8_t*)w.x.p; }
-  TIMED_LAUNCH(ctx, 0, ec_launch_commit_eval(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, dout, ctx->stream));
+  RET_IF(ec_eval_x(ctx, gi, group, w, space, t, positions, dpos, n, dout));
   if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, x_out, dout, n * gi->enc));
   RET_IF(spans_collect(ctx));
   return MPVSS_OK;
@@ -1717,7 +1756,7 @@ extern "C" int mpvss_ec_verify_distribution(mpvss_ctx* ctx, int group, int space
     RET_IF(ensure(ctx, w.o2, n * gi->enc));
     RET_IF(ensure(ctx, w.ok, 2 * (n > 4096 ? n : 4096)));
     uint8_t *dX = (uint8_t*)w.x.p, *d1 = (uint8_t*)w.o1.p, *d2 = (uint8_t*)w.o2.p;
-    TIMED_LAUNCH(ctx, 0, ec_launch_commit_eval(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, dX, ctx->stream));
+    RET_IF(ec_eval_x(ctx, gi, group, w, space, t, positions, dpos, n, dX));
     // a1 = r*G + c*X, a2 = r*y + c*Y   (dleq.rs:66-84)
     TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dr, dX, (const uint8_t*)dc, 0, (int)n, d1,
                                             (uint8_t*)w.ok.p, ctx->stream));
@@ -1835,7 +1874,7 @@ extern "C" int mpvss_ec_distribute(mpvss_ctx* ctx, int group, int space, const u
     }
     RET_IF(ensure(ctx, w.ok, 3 * (n > 4096 ? n : 4096)));
     uint8_t* ok = (uint8_t*)w.ok.p;
-    TIMED_LAUNCH(ctx, 0, ec_launch_commit_eval(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, dX, ctx->stream));
+    RET_IF(ec_eval_x(ctx, gi, group, w, space, t, positions, dpos, n, dX));
     TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dy, gi->enc, (const uint8_t*)dp, nullptr, nullptr, 0, (int)n,
                                             dY, ok, ctx->stream));                      // Y = p * y
     TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n, d1, ok + n,
