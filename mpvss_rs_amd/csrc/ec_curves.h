@@ -441,6 +441,19 @@ EC_HD void dual_mul(typename C::Point& r, const typename C::Point& p1, const uin
   }
 }
 
+// r = k * p for a 256-bit scalar given as 8 little-endian 32-bit words (double and always-add, branch-free)
+template <class C>
+EC_HD void limb_scalar_mul(typename C::Point& r, const typename C::Point& p, const u32 (&k)[8]) {
+  C::identity(r);
+  for (int i = 255; i >= 0; --i) {
+    C::dbl(r, r);
+    typename C::Point sel;
+    C::identity(sel);
+    C::cmov(sel, p, (k[i >> 5] >> (i & 31)) & 1);
+    C::add(r, r, sel);
+  }
+}
+
 // 32-byte scalar in the curve's byte order -> little-endian words
 template <class C>
 EC_HD void scalar_words(u32 (&w)[8], const uint8_t* k) {

@@ -17,7 +17,8 @@ int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uin
 /* forward differences for consecutive positions: seeds at chain indices w0..w0+t-1, tables, stepping both ways,
  * encoding; pts [count][point words], state_fwd / state_bwd [chains*t][point words] */
 int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
-                 int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc, hipStream_t s);
+                 int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc, int split_seeds,
+                 hipStream_t s);
 int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
 #ifdef __cplusplus
 }

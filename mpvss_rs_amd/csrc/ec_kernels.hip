@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "ec_curves.h"
+#include "ec_scalar.h"
 #include "ec_kernels.h"
 
 using namespace ec;
@@ -120,6 +121,64 @@ __device__ __forceinline__ void seeds_body(const u32* __restrict__ cm, int t, co
 }
 
 template <class C>
+__device__ __forceinline__ void lds_put_raw(u32* lds, int k, const typename C::Point& p) {
+  const u32* w = reinterpret_cast<const u32*>(&p);
+#pragma unroll
+  for (int i = 0; i < C::POINT_WORDS; ++i) lds[i * blockDim.x + k] = w[i];
+}
+template <class C>
+__device__ __forceinline__ void lds_get_raw(typename C::Point& p, const u32* lds, int k) {
+  u32* w = reinterpret_cast<u32*>(&p);
+#pragma unroll
+  for (int i = 0; i < C::POINT_WORDS; ++i) w[i] = lds[i * blockDim.x + k];
+}
+
+// The same seeds with the polynomial cut into PARTS pieces evaluated by PARTS adjacent lanes:
+//   X(x) = sum_p x^(lo_p) * Piece_p(x),   Piece_p(x) = sum_{j < len_p} x^j C_{lo_p + j}   (Horner, len_p = t/PARTS),
+// the factor x^(lo_p) mod the group order by 256-bit Montgomery arithmetic, applied as one full-width scalar
+// multiplication; the pieces are added up through LDS.  The sequential depth of a seed drops from (t-1) Horner steps
+// to t/PARTS steps + one scalar multiplication (about five-fold for t = 256): the seed launch bounds a box's latency.
+template <class C, class O, int PARTS>
+__device__ __forceinline__ void seeds_split_body(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions,
+                                                 int count, u32* __restrict__ pts) {
+  extern __shared__ u32 lds[];
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int xi = gi / PARTS, part = gi % PARTS;
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  const uint64_t pos = (uint64_t)positions[x];
+  const int nb = (pos == 0) ? 0 : 64 - __builtin_clzll(pos);
+  const int len = (t + PARTS - 1) / PARTS;
+  const int lo = part * len;
+  const int hi = (lo + len < t) ? lo + len : t;            // coefficients lo .. hi-1 (empty when lo >= t)
+  typename C::Point acc, cj, r;
+  C::identity(acc);
+  for (int j = hi - 1; j >= lo; --j) {
+    small_scalar_mul<C>(r, acc, pos, nb);
+    load_point_aos<C>(cj, cm + (size_t)j * C::POINT_WORDS);
+    C::add(acc, r, cj);
+  }
+  if (part > 0) {                                          // times x^lo
+    Sc s;
+    ScalarField<O>::pow_u64(s, pos, (u32)lo);
+    limb_scalar_mul<C>(r, acc, s.v);
+    acc = r;
+  }
+  // sum of the PARTS pieces: tree through LDS (pieces of one seed sit in adjacent lanes)
+  const int k = threadIdx.x;
+  for (int d = PARTS / 2; d >= 1; d >>= 1) {
+    lds_put_raw<C>(lds, k, acc);
+    __syncthreads();
+    if (part < d) {
+      lds_get_raw<C>(cj, lds, k + d);
+      C::add(acc, acc, cj);
+    }
+    __syncthreads();
+  }
+  if (live && part == 0) store_point_aos<C>(pts + (size_t)x * C::POINT_WORDS, acc);
+}
+
+template <class C>
 __device__ __forceinline__ void lds_put(u32* lds, int k, const typename C::Point& p) {
   const u32* w = reinterpret_cast<const u32*>(&p);
 #pragma unroll
@@ -197,7 +256,7 @@ __device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int cou
 
 }  // namespace
 
-#define EC_KERNELS(NAME, CURVE)                                                                                        \
+#define EC_KERNELS(NAME, CURVE, ORDER)                                                                                        \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_decode(const uint8_t* enc, int count, u32* pts,          \
                                                                      uint8_t* ok) {                                    \
     decode_body<CURVE>(enc, count, pts, ok);                                                                           \
@@ -219,6 +278,10 @@ __device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int cou
                                                                        int count, u32* pts) {                          \
     seeds_body<CURVE>(cm, t, pos, count, pts);                                                                         \
   }                                                                                                                    \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds_split(const u32* cm, int t, const int64_t* pos, \
+                                                                             int count, u32* pts) {                    \
+    seeds_split_body<CURVE, ORDER, 8>(cm, t, pos, count, pts);                                                         \
+  }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_table(const u32* seeds, int chains, int t, u32* fwd, \
                                                                         u32* bwd) {                                    \
     fd_table_body<CURVE>(seeds, chains, t, fwd, bwd);                                                                  \
@@ -232,8 +295,8 @@ __device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int cou
     encode_body<CURVE>(pts, count, enc);                                                                               \
   }
 
-EC_KERNELS(secp, Secp)
-EC_KERNELS(rist, Ristretto)
+EC_KERNELS(secp, Secp, OrderSecp)
+EC_KERNELS(rist, Ristretto, OrderEd)
 
 // ---- launchers ---------------------------------------------------------------------------------------
 static inline int blocks_for(int count) { return (count + 63) / 64; }
@@ -275,21 +338,31 @@ extern "C" int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int 
 // pts: [count][point words] internal points, index 0 = first position of the batch; seeds go to pts + seed0.
 extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
                             int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc,
-                            hipStream_t s) {
+                            int split_seeds, hipStream_t s) {
   const int m0 = chains * t;
   const size_t seed0 = (size_t)chains * w0;
   const int pw = ec_point_words(group);
   uint32_t* seeds = pts + seed0 * pw;
   const int lanes = ((t + 63) / 64) * 64;                       // one lane per level
   const size_t lds = (size_t)lanes * pw * 4;
+  const bool split = split_seeds && t >= 64;                    // 8 lanes per seed
+  const size_t lds_seed = (size_t)64 * pw * 4;
+  if (split) {
+    if (group == 1)
+      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
+                         seeds);
+    else
+      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
+                         seeds);
+  }
   if (group == 1) {
-    hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
+    if (!split) hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
     hipLaunchKernelGGL(k_secp_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd);
     hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
                        count, pts);
     hipLaunchKernelGGL(k_secp_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, x_enc);
   } else {
-    hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
+    if (!split) hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
     hipLaunchKernelGGL(k_rist_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd);
     hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
                        count, pts);

@@ -1638,6 +1638,7 @@ extern "C" int mpvss_ec_batch_mul(mpvss_ctx* ctx, int group, int space, const ui
 int ec_eval_x(mpvss_ctx* ctx, const EcInfo* gi, int group, EcWork& w, int space, size_t t, const int64_t* positions,
               const int64_t* dpos, size_t n, uint8_t* dX) {
   static const int fd_on = fd_env("MPVSS_EC_FD", 1), chains_env = fd_env("MPVSS_EC_FD_CHAINS", 0);
+  static const int split_seeds = fd_env("MPVSS_EC_FD_SPLIT", 1);     // every seed evaluated by 8 lanes (shorter latency)
   bool fd = fd_on && t >= 16 && t <= 256 && n >= 16 * t && n >= 4096;
   if (fd) {
     const int64_t* hp = positions;
@@ -1666,7 +1667,7 @@ int ec_eval_x(mpvss_ctx* ctx, const EcInfo* gi, int group, EcWork& w, int space,
   uint32_t* st = (uint32_t*)w.fdst.p;
   (void)gi;
   TIMED_LAUNCH(ctx, 0, ec_launch_fd(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, S, w0, chain_len, (uint32_t*)w.pts.p,
-                                    st, st + (size_t)S * t * pw, dX, ctx->stream));
+                                    st, st + (size_t)S * t * pw, dX, split_seeds, ctx->stream));
   return 0;
 }
 
