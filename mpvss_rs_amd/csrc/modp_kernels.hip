@@ -23,10 +23,12 @@
 #define MODP_WAVES_PER_EU_MAX MODP_WAVES_PER_EU
 #endif
 #define WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MODP_WAVES_PER_EU, MODP_WAVES_PER_EU_MAX)))
-// Waves per workgroup.  Waves never talk to each other; 4-wave workgroups only exist because a CU
-// admits more resident waves that way than as single-wave workgroups.
+// Waves per workgroup.  Waves never talk to each other, so a workgroup is ONE wave: a single-wave workgroup fits any
+// free wave slot, whereas a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once -- and the
+// single-wave stages of the forward-difference pipelines, which sit on their SIMDs for tens of milliseconds, leave
+// the slots of a CU unevenly filled (measured: +6 % for the whole verification with 1 instead of 4).
 #ifndef MODP_WPB
-#define MODP_WPB 4
+#define MODP_WPB 1
 #endif
 #define BLOCK_THREADS (64 * MODP_WPB)
 #define NUMS_PER_BLOCK (NUMS_PER_WAVE * MODP_WPB)
