@@ -30,10 +30,10 @@ int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* tab2, size_t
 int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
                                     const uint8_t* e2, size_t e2_stride, int e2_windows, int count, uint8_t* out, int mode,
                                     uint32_t* p_m, int comb_bits, const void* cs, hipStream_t s);
-/* a2 = y^r Y^c with a 64-entry (6-bit window) table for y: tab1 [count][64][76], tab2 [count][16][76], c < 2^256 shared */
+/* a2 = y^r Y^c with a 64-entry (6-bit window) table for y: tab1 [count][64][72], tab2 [count][16][72]; every c < 2^256, c_stride 0 = one c for all */
 int modp_launch_build_table64(const uint8_t* base_be, int count, uint32_t* tab, const void* cs, hipStream_t s);
-int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c, int count,
-                            uint8_t* out, const void* cs, hipStream_t s);
+int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
+                            size_t c_stride, int count, uint8_t* out, const void* cs, hipStream_t s);
 /* registered public keys: per-key tables for y^r (see modp_kernels.hip) */
 size_t modp_keyset_words_per_key(void);
 int modp_launch_keyset_build(const uint8_t* pk_be, int count, uint32_t* ks, const void* cs, hipStream_t s);

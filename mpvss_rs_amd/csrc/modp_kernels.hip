@@ -942,7 +942,7 @@ k_modp_build_table64(const uint8_t* __restrict__ base_be, int count, u32* __rest
 
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
-                   const uint8_t* __restrict__ c_be, int count, uint8_t* __restrict__ out_be,
+                   const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
                    const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
@@ -955,6 +955,7 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
   const u32* t1 = tab1 + (size_t)x * 64 * L;
   const u32* t2 = tab2 + (size_t)x * 16 * L;
   const uint8_t* e1 = e1_be + (size_t)x * 256;
+  const uint8_t* c_be = c_all + (size_t)x * c_stride;      // stride 0: one challenge for all shares
   // 6-bit window w of the 2048-bit exponent: bits 6w .. 6w+5 (little-endian byte k is e1[255 - k])
   auto digit6 = [&](int w) -> u32 {
     const int o = 6 * w, k = o >> 3;
@@ -1270,10 +1271,10 @@ extern "C" int modp_launch_build_table64(const uint8_t* base_be, int count, uint
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
-                                       int count, uint8_t* out, const void* cs, hipStream_t s) {
+                                       size_t c_stride, int count, uint8_t* out, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_dual_exp_w6, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab2, e1, c, count, out,
-                     (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_dual_exp_w6, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab2, e1, c, c_stride, count,
+                     out, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 extern "C" size_t modp_keyset_words_per_key() { return (size_t)KS_SUB * KS_ENT * L; }

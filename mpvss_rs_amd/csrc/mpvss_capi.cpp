@@ -825,6 +825,15 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
                                                    out_dev, comb_bits_of(ctx, comb_b1), ctx->consts, ctx->stream));
     return 0;
   }
+  static const int w6 = fd_env("MPVSS_A2_W6", 1);
+  if (!shared_b1 && w6 && c_windows == 64 && cnt >= 1024) {
+    // per-share base with a full-width exponent and 256-bit second exponent(s): 6-bit windows for B1^r
+    RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
+    TIMED_LAUNCH(ctx, 2, modp_launch_build_table64(b1_dev, (int)cnt, (uint32_t*)ctx->w->tab1.p, ctx->consts, ctx->stream));
+    TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6((const uint32_t*)ctx->w->tab1.p, t2, r_dev, c_dev, c_stride, (int)cnt, out_dev,
+                                                 ctx->consts, ctx->stream));
+    return 0;
+  }
   if (shared_b1) {
     t1 = shared_b1;
     s1 = 0;
@@ -1026,7 +1035,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           // 6-bit windows for y^r (64-entry tables, 19 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * 4 * TABW;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy + lo * EB, (int)(hi - lo), t1p, ctx->consts, ctx->stream));
-          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr + lo * EB, (const uint8_t*)dchal,
+          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr + lo * EB, (const uint8_t*)dchal, 0,
                                                        (int)(hi - lo), da2 + lo * EB, ctx->consts, ctx->stream));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * TABW;

@@ -49,3 +49,30 @@ def test_ec_extract_shares(engine, name):
     assert c == sc([e["challenge"] for e in exp])
     r = [O.dleq_response(G, w, x, e["challenge"]) for w, x, e in zip(wit, privs, exp)]
     assert list(engine.ec_verify_shares(gid, enc(pks), S, enc(Y), c, sc(r))) == [1] * n
+
+
+def test_modp_verify_shares_large_batch_uses_wide_windows(engine):
+    """Batches of 1024 share boxes and more take the 6-bit-window path for S^r (per-share challenges): honest proofs
+    built with the engine's own extract_shares must verify, tampered ones must not."""
+    g = O.ModpGroup()
+    rng = random.Random(91)
+    n = 1100
+    order = g.group_order_int()
+    privs = [modp_keygen(g, rng) for _ in range(8)]
+    privs = [privs[i % 8] for i in range(n)]                           # few distinct keys (Python pow is slow)
+    pk_of = {x: g.generate_public_key(x) for x in set(privs)}
+    pks = [pk_of[x] for x in privs]
+    ps = [rng.randrange(order) for _ in range(16)]
+    Y_of = {(x, p): pow(pk_of[x], p, g.q) for x in set(privs) for p in ps}
+    pvals = [ps[i % 16] for i in range(n)]
+    Y = [Y_of[(x, p)] for x, p in zip(privs, pvals)]
+    wit = [rng.randrange(1, order) for _ in range(n)]
+    xinv_of = {x: O.mod_inverse(x, order) for x in set(privs)}
+    S, c = engine.extract_shares(cat(g, pks), cat(g, Y), cat(g, [xinv_of[x] for x in privs]), cat(g, wit))
+    assert split(S)[:3] == [pow(2, p, g.q) for p in pvals[:3]]         # S_i = Y_i^(1/x_i) = G^p_i
+    r = [O.dleq_response(g, w, x, ci) for w, x, ci in zip(wit, privs, split(c))]
+    rb = bytearray(cat(g, r))
+    for i in (5, 600, 1099):
+        rb[i * 256 + 200] ^= 1
+    verdicts = list(engine.verify_shares(cat(g, pks), S, cat(g, Y), c, bytes(rb)))
+    assert verdicts == [0 if i in (5, 600, 1099) else 1 for i in range(n)]
