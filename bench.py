@@ -69,7 +69,7 @@ def keygen(rng: random.Random) -> int:
 
 
 PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "8"))   # boxes in flight (the engine has 16 block slots)
-HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "3"))   # host threads absorbing (hashing) boxes at N=1
+HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "4"))   # host threads absorbing (hashing) boxes at N=1
 
 
 SQ_COST = (72 * (9.5 + 18)) / (72 * 36)      # mads of a dedicated squaring relative to a general product (0.764)
