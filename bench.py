@@ -251,6 +251,8 @@ def main():
         HASH_THREADS host threads absorb consecutive boxes side by side (the engine releases its lock while it
         hashes); with several ranks the running hash state travels rank to rank per box, in order, on one thread."""
         depth = depth or (PIPE_DEPTH if world == 1 else PIPE_DEPTH + world)
+        # the engine has 16 block slots; absorbing threads take the oldest blocks in any order, so leave them slack
+        depth = min(depth, 16 - (HASH_THREADS if world == 1 else 0))
         results = []
         issued = 0
         while issued < min(depth, k):
