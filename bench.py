@@ -523,6 +523,9 @@ def main():
                                   "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c, per-share SHA-256 verdict on the host; "
                                           "inputs resident in HBM; `value`: synchronous calls on one context, "
                                           "`value_3_contexts`: three contexts and host threads side by side"}
+    fd_blocks, fd_fallbacks = eng.fd_stats()
+    result["compute"]["fd_blocks"] = fd_blocks
+    result["compute"]["fd_fallbacks"] = fd_fallbacks          # boxes whose pipeline gave up and were recomputed by Horner
     if rank == 0:
         print(json.dumps(result))
     eng.close()

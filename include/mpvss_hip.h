@@ -252,6 +252,10 @@ void mpvss_modp_hash_to_scalar(const uint8_t* data, size_t len, uint8_t out256[2
  * mpvss_last_kernel_launches gives the number of launches behind each sum.  Negative when unavailable. */
 double mpvss_last_kernel_ms(const mpvss_ctx* ctx, int kernel_id);
 int mpvss_last_kernel_launches(const mpvss_ctx* ctx, int kernel_id);
+/* Absorbed verify blocks whose X_i went through the forward-difference path, and how many of those fell back to
+ * Horner's rule on the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up):
+ * same results either way, the fall-back is just slower -- a counter for operators and tests. */
+int mpvss_modp_fd_stats(mpvss_ctx* ctx, unsigned long long* blocks, unsigned long long* fallbacks);
 
 #ifdef __cplusplus
 }

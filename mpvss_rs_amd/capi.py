@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
-    "mpvss_modp_verify_block_compute_keyset",
+    "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
 )
 
 GROUP_SECP256K1 = 1
@@ -60,6 +60,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_last_error.restype = C.c_char_p
     lib.mpvss_ctx_set_stream.argtypes = [vp, vp]
     lib.mpvss_ctx_synchronize.argtypes = [vp]
+    lib.mpvss_modp_fd_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.mpvss_modp_keyset_create.argtypes = [vp, ci, u8p, sz, C.POINTER(vp)]
     lib.mpvss_modp_keyset_destroy.argtypes = [vp, vp]
     lib.mpvss_modp_keyset_destroy.restype = None
@@ -255,6 +256,12 @@ class Engine:
         kx, px = _out(n * EB); k1, p1 = _out(n * EB); k2, p2 = _out(n * EB)
         self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, px, p1, p2), "verify_block_absorb")
         return bytes(ks), bytes(kx)[: n * EB], bytes(k1)[: n * EB], bytes(k2)[: n * EB]
+
+    def fd_stats(self) -> Tuple[int, int]:
+        """(blocks absorbed through the forward-difference path, of those: fell back to Horner on the device)"""
+        b, f = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self.lib.mpvss_modp_fd_stats(self.ctx, C.byref(b), C.byref(f)), "fd_stats")
+        return int(b.value), int(f.value)
 
     def verify_block_absorb(self, state: bytes) -> bytes:
         ks, ps = _buf(state)

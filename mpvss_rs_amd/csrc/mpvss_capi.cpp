@@ -73,6 +73,7 @@ struct mpvss_ctx {
       int ok;
     };
     RootJob* root = nullptr;
+    bool fd_used = false;                    // eval_x took the forward-difference path in the call being enqueued
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
     hipEvent_t ev_fork = nullptr, ev_gr = nullptr;
     static constexpr int MAXPARTS = 8;
@@ -121,6 +122,7 @@ struct mpvss_ctx {
     size_t n = 0;
     bool busy = false;
     bool absorbing = false;        // a host thread is waiting for / hashing this block (context lock released)
+    bool fd_used = false;          // the block's X path was the forward-difference one: its final flag is in the staging
     bool check_positions = false;
     hipEvent_t done = nullptr;
     SpanSet spans;
@@ -130,6 +132,9 @@ struct mpvss_ctx {
   static constexpr unsigned NSLOT = 16;
   BlockSlot slot[NSLOT];
   unsigned head = 0, tail = 0;   // next slot to fill / to absorb
+  // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
+  // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
+  unsigned long long fd_blocks = 0, fd_fallbacks = 0;
   EcWork ecwork;
 };
 
@@ -534,6 +539,14 @@ extern "C" int mpvss_last_kernel_launches(const mpvss_ctx* ctx, int kernel_id) {
   return ctx->kernel_launches[kernel_id];
 }
 
+extern "C" int mpvss_modp_fd_stats(mpvss_ctx* ctx, unsigned long long* blocks, unsigned long long* fallbacks) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (blocks) *blocks = ctx->fd_blocks;
+  if (fallbacks) *fallbacks = ctx->fd_fallbacks;
+  return MPVSS_OK;
+}
+
 extern "C" void mpvss_sha256(const uint8_t* data, size_t len, uint8_t out32[32]) { mpvss::sha256(data, len, out32); }
 
 extern "C" void mpvss_modp_hash_to_scalar(const uint8_t* data, size_t len, uint8_t out256[256]) {
@@ -724,6 +737,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   for (int l = 1; l <= nlev; ++l) { tot_off[l] = tot_total; tot_total += (size_t)ms[l]; }
 
   mpvss_ctx::Work& w = *ctx->w;
+  w.fd_used = true;
   RET_IF(ensure(ctx, w.fd_flag, 64));
   RET_IF(ensure(ctx, w.fd_root, 4 * EB));
   RET_IF(ensure(ctx, w.fd_xm, cnt * MODP_L * 4));
@@ -945,11 +959,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
   } restore{ctx, ctx->stream, ctx->stream_b};
   ctx->w = &sl.work;
+  sl.work.fd_used = false;
   ctx->stream = sl.work.sa;
   ctx->stream_b = sl.work.sb;
   ctx->sp = &sl.spans;
   spans_reset(ctx);
-  const size_t need = n * EB * 4 + n * 8;
+  const size_t need = n * EB * 4 + n * 8 + 8;
   if (need > sl.cap) {
     if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
     sl.pin = nullptr;
@@ -1079,6 +1094,9 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
+  sl.fd_used = sl.work.fd_used;
+  if (sl.fd_used)      // the device's decision (1 = forward differences held, 0 = fell back), for the statistics
+    HIPCHK(ctx, hipMemcpyAsync((uint8_t*)sl.pin + n * EB * 4 + n * 8, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
   ++ctx->head;
@@ -1131,6 +1149,12 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   lk.lock();
   sl.busy = false;
   sl.absorbing = false;
+  if (e == hipSuccess && sl.fd_used) {
+    int flag = 1;
+    memcpy(&flag, h2 + n * EB + n * 8, sizeof(flag));
+    ++ctx->fd_blocks;
+    if (flag != 1) ++ctx->fd_fallbacks;
+  }
   if (e != hipSuccess) return fail(ctx, MPVSS_E_DEVICE, "absorb: hipEventSynchronize", e);
   if (!positions_ok) return fail(ctx, MPVSS_E_INVALID, "negative position (the reference panics: negative exponent)");
   RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));

@@ -35,8 +35,10 @@ def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
     pos = list(range(1, n + 1))
     sub = pk[key_offset * EB:(key_offset + n) * EB]
 
+    blocks0, fallbacks0 = engine.fd_stats()
     engine.verify_block_compute(cm, pos, sub, shares, resp, chal)
     st0, X0, A10, A20 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
+    assert engine.fd_stats() == (blocks0 + 1, fallbacks0)      # forward differences were used and held
 
     ks = engine.keyset_create(pk)
     try:
