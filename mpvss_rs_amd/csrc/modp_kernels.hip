@@ -22,6 +22,9 @@
 #ifndef MODP_WAVES_PER_EU_MAX
 #define MODP_WAVES_PER_EU_MAX MODP_WAVES_PER_EU
 #endif
+#ifndef MODP_SETPRIO
+#define MODP_SETPRIO 3          // wave priority of the latency-bound launches (seeds, inversion tree, pipeline stages)
+#endif
 #define WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MODP_WAVES_PER_EU, MODP_WAVES_PER_EU_MAX)))
 // Waves per workgroup.  Waves never talk to each other, so a workgroup is ONE wave: a single-wave workgroup fits any
 // free wave slot, whereas a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once -- and the
@@ -214,7 +217,7 @@ k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, i
   // gate: the forward-difference path (below) and this kernel exclude each other through a device flag,
   // so that the choice needs no host synchronisation
   if (gate != nullptr && *gate != gate_want) return;
-  if (gate != nullptr && x_m != nullptr) __builtin_amdgcn_s_setprio(3);   // seed launch of the forward-difference path
+  if (gate != nullptr && x_m != nullptr) __builtin_amdgcn_s_setprio(MODP_SETPRIO);   // seed launch of the forward-difference path
   const Lane ln = make_lane();
   const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
   // numbers >= split evaluate the second commitment set (the inverted commitments of the seed phase)
@@ -332,7 +335,7 @@ k_modp_binv_up(const u32* __restrict__ a, int m, int G, u32* __restrict__ prefix
                const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   if (*gate != 1) return;
-  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
+  __builtin_amdgcn_s_setprio(MODP_SETPRIO);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
   const int groups = (m + G - 1) / G;
   const int gi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -366,7 +369,7 @@ k_modp_binv_down(const u32* __restrict__ a, const u32* __restrict__ prefix, cons
                  int G, u32* __restrict__ a_inv, const int* __restrict__ gate, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   if (*gate != 1) return;
-  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
+  __builtin_amdgcn_s_setprio(MODP_SETPRIO);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
   const int groups = (m + G - 1) / G;
   const int gi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -474,7 +477,7 @@ k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int ch
   //                    both directions, so half the seeds cover the same positions)
   __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
-  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
+  __builtin_amdgcn_s_setprio(MODP_SETPRIO);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
   const int quad = threadIdx.x >> 2;
   const int stages = tpad / NUMS_PER_WAVE;
@@ -552,7 +555,7 @@ k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back
                int inject_fault, const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[(NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
-  __builtin_amdgcn_s_setprio(3);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
+  __builtin_amdgcn_s_setprio(MODP_SETPRIO);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
   const Lane ln = make_lane();
   const int quad = threadIdx.x >> 2;
   const int stages = tpad / NUMS_PER_WAVE;

@@ -424,8 +424,9 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
   } else {
     // a block slot's stream carries the latency-bound chain of its box: highest priority, so that it never queues
     // behind (or shares a hardware queue with) the wide launches on the low-priority context-wide streams
-    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, ctx->prio_high));
-    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, ctx->prio_low));
+    static const int use_prio = fd_env("MPVSS_STREAM_PRIO", 1);
+    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, use_prio ? ctx->prio_high : 0));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, use_prio ? ctx->prio_low : 0));
   }
   for (hipEvent_t* e : {&w.ev_fork, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
