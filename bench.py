@@ -446,32 +446,42 @@ def main():
     # NOT the headline: `value` above recomputes y_i^r_i from the bare keys in every step.  Here the per-key tables
     # are built once (timed separately) and the same K steps are repeated against them -- the situation of a verifier
     # that checks many dealers' boxes against one set of long-lived participant keys.
+    keyset_ok = False
     if world == 1 and args.registered_keys:
         tk = time.perf_counter()
         h = C.c_void_p()
-        eng._check(lib.mpvss_modp_keyset_create(ctx, capi.MPVSS_DEVICE, vp(d_pk), n, C.byref(h)), "keyset_create")
-        torch.cuda.synchronize()
-        build_s = time.perf_counter() - tk
-        keyset[0] = h
-        for verdict, digest in run_steps(min(args.warmup, 2)) if args.warmup > 0 else []:
-            assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys, warm-up)"
-        barrier()
-        t1 = time.perf_counter()
-        res_k = run_steps(args.steps)
-        barrier()
-        el_k = time.perf_counter() - t1
-        for verdict, digest in res_k:
-            assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys)"
-        keyset[0] = None
-        table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
-        lib.mpvss_modp_keyset_destroy(ctx, h)
-        mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 256 + 63 + 1)
-        result["registered_keys"] = {
-            "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
-            "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
-            "compute_frac": mm_k / (el_k / args.steps) / PEAK_MODMUL_PER_S,
-            "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)) in HBM, built once per key set, "
-                    "a2 = y^r Y^c in 571 products instead of 2620; same verdict and transcript digest; not the headline"}
+        try:
+            eng._check(lib.mpvss_modp_keyset_create(ctx, capi.MPVSS_DEVICE, vp(d_pk), n, C.byref(h)), "keyset_create")
+            keyset_ok = True
+        except capi.EngineError as err:      # 622 KB per key: very large key sets do not fit beside the workspaces
+            result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
+    if keyset_ok:
+        try:
+            torch.cuda.synchronize()
+            build_s = time.perf_counter() - tk
+            keyset[0] = h
+            for verdict, digest in run_steps(min(args.warmup, 2)) if args.warmup > 0 else []:
+                assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys, warm-up)"
+            barrier()
+            t1 = time.perf_counter()
+            res_k = run_steps(args.steps)
+            barrier()
+            el_k = time.perf_counter() - t1
+            for verdict, digest in res_k:
+                assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys)"
+            keyset[0] = None
+            table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
+            lib.mpvss_modp_keyset_destroy(ctx, h)
+            mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 256 + 63 + 1)
+            result["registered_keys"] = {
+                "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
+                "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
+                "compute_frac": mm_k / (el_k / args.steps) / PEAK_MODMUL_PER_S,
+                "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)) in HBM, built once per key set, "
+                        "a2 = y^r Y^c in 571 products instead of 2620; same verdict and transcript digest; not the headline"}
+        except capi.EngineError as err:
+            keyset[0] = None
+            result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
 
     # ---------------- W_B: decrypted-share verifications (participant.rs:361-386), SURVEY 8(d) ----------------
     # Secondary figure, rank 0 at N=1 only, outside the timed region above: a bounded batch of share boxes
