@@ -76,8 +76,7 @@ struct mpvss_ctx {
     bool fd_used = false;                    // eval_x took the forward-difference path in the call being enqueued
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
     hipEvent_t ev_fork = nullptr, ev_gr = nullptr;
-    static constexpr int MAXPARTS = 8;
-    hipEvent_t ev_part[MAXPARTS] = {};
+    hipEvent_t ev_a2 = nullptr;
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
@@ -87,14 +86,6 @@ struct mpvss_ctx {
   Work work0;
   Work* w = &work0;                               // workspace of the call being enqueued
   hipStream_t stream_b = nullptr;                 // second stream of the current workspace
-  // Optional (MPVSS_WIDE_FIFO=1): a few context-wide low-priority streams carry the wide a2 launches of ALL blocks in
-  // flight, cut into parts that are dealt to the streams round-robin in block order, so that the oldest box finishes
-  // first instead of every box in flight sharing the multiplier.  Measured: better only for very short runs of a
-  // single-threaded host (boxes complete one by one, their hashes overlap the GPU work); the default gives every box
-  // its own low-priority stream and lets the boxes share the chip (10 % more throughput in steady state).
-  static constexpr int NWIDE = 4;
-  hipStream_t wide[NWIDE] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned wide_rr = 0;      // round-robin cursor over the wide streams
   int prio_high = 0, prio_low = 0;
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
@@ -180,8 +171,6 @@ int ensure(mpvss_ctx* ctx, DevBuf& b, size_t bytes) {
   if (b.p) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));
-    for (hipStream_t s : ctx->wide)
-      if (s) HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -423,14 +412,14 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
     HIPCHK(ctx, hipStreamCreateWithFlags(&w.sb, hipStreamNonBlocking));
   } else {
     // a block slot's stream carries the latency-bound chain of its box: highest priority, so that it never queues
-    // behind (or shares a hardware queue with) the wide launches on the low-priority context-wide streams
+    // behind (or shares a hardware queue with) the wide launches, which go to the slot's low-priority second stream
     static const int use_prio = fd_env("MPVSS_STREAM_PRIO", 1);
     HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, use_prio ? ctx->prio_high : 0));
     HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, use_prio ? ctx->prio_low : 0));
   }
   for (hipEvent_t* e : {&w.ev_fork, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
-  for (hipEvent_t& e : w.ev_part) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_a2, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void**)&w.root, sizeof(*w.root), hipHostMallocDefault));
   w.ready = true;
   return 0;
@@ -442,8 +431,7 @@ void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : {w.ev_fork, w.ev_gr})
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : w.ev_part)
-    if (e) (void)hipEventDestroy(e);
+  if (w.ev_a2) (void)hipEventDestroy(w.ev_a2);
   if (w.root) (void)hipHostFree(w.root);
   if (w.sb) (void)hipStreamDestroy(w.sb);
   if (w.sa && owns_sa) (void)hipStreamDestroy(w.sa);
@@ -464,10 +452,6 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
   ctx->own_stream = true;
   if (work_init(ctx, ctx->work0, ctx->stream) != 0 ||
       hipDeviceGetStreamPriorityRange(&ctx->prio_low, &ctx->prio_high) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->wide[0], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->wide[1], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->wide[2], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->wide[3], hipStreamNonBlocking, ctx->prio_low) != hipSuccess ||
       modp_consts_upload(&ctx->consts) != 0) {
     delete ctx;
     return MPVSS_E_DEVICE;
@@ -496,8 +480,6 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
   }
-  for (hipStream_t s : ctx->wide)
-    if (s) (void)hipStreamDestroy(s);
   delete ctx;
 }
 
@@ -521,7 +503,6 @@ extern "C" int mpvss_ctx_synchronize(mpvss_ctx* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->work0.sb));
-  for (hipStream_t s : ctx->wide) HIPCHK(ctx, hipStreamSynchronize(s));
   for (auto& sl : ctx->slot)
     if (sl.work.ready) {
       HIPCHK(ctx, hipStreamSynchronize(sl.work.sa));
@@ -1008,63 +989,46 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     const int64_t* hp = space == MPVSS_HOST ? positions + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
-    if (two_streams && ctx->wide[0] && fd_applies(t, hp, cnt)) {
+    if (two_streams && ctx->w->sb && fd_applies(t, hp, cnt)) {
       // The forward-difference X path is a chain of latency-bound launches that occupy few wave slots (seeds,
-      // inversion tree, difference tables, stepping) and runs on the block slot's own stream.  a2 = y^r Y^c and g^r
-      // do not depend on X: a2 goes in MPVSS_A2_PARTS parts to the context-wide streams, which serve the blocks in
-      // flight in order; g^r follows the last part.
+      // inversion tree, difference tables, stepping) and runs on the block slot's high-priority stream.  a2 = y^r Y^c
+      // and g^r do not depend on X: they run beside it on the slot's low-priority stream.
       static const int a2_w6 = fd_env("MPVSS_A2_W6", 1);
       RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4 * (a2_w6 ? 4 : 1)));     // no reallocation while two streams are live
       RET_IF(ensure(ctx, ctx->w->tab2, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
       const bool use_keys = ks && c_windows == 64;
-      static const int wide_fifo = fd_env("MPVSS_WIDE_FIFO", 0);
-      static const int n_wide = std::min(std::max(fd_env("MPVSS_WIDE_STREAMS", 3), 1), (int)mpvss_ctx::NWIDE);
-      static const int n_parts = std::min(std::max(fd_env("MPVSS_A2_PARTS", 4), 1), (int)mpvss_ctx::Work::MAXPARTS);
       struct Swap {
         mpvss_ctx* c; hipStream_t a;
         Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
         ~Swap() { c->stream = a; }
       };
-      auto next_wide = [&]() {       // MPVSS_WIDE_FIFO=0: every box on its own low-priority stream, all boxes share the chip
-        return wide_fifo ? ctx->wide[ctx->wide_rr++ % n_wide] : ctx->w->sb;
-      };
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
-      const int parts = use_keys ? 1 : (wide_fifo ? n_parts : 1);
-      hipStream_t last_wide = nullptr;
-      size_t lo = 0;
-      for (int part = 0; part < parts; ++part) {
-        const size_t hi = (part + 1 == parts) ? cnt : ((cnt * (size_t)(part + 1) / parts) / 64) * 64;
-        if (hi <= lo) continue;
-        last_wide = next_wide();
-        HIPCHK(ctx, hipStreamWaitEvent(last_wide, ctx->w->ev_fork, 0));
-        Swap sw(ctx, last_wide);
-        uint32_t* t2p = (uint32_t*)ctx->w->tab2.p + lo * TABW;      // the parts use disjoint ranges of the table buffers
-        TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY + lo * EB, (int)(hi - lo), t2p, ctx->consts, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
+      {
+        Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
+        uint32_t* t2p = (uint32_t*)ctx->w->tab2.p;
+        TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
         if (use_keys) {
           // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
           const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
           TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
                                                            ctx->consts, ctx->stream));
         } else if (a2_w6 && c_windows == 64) {
-          // 6-bit windows for y^r (64-entry tables, 19 KB per share): 341 products instead of 511
-          uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * 4 * TABW;
-          TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy + lo * EB, (int)(hi - lo), t1p, ctx->consts, ctx->stream));
-          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr + lo * EB, (const uint8_t*)dchal, 0,
-                                                       (int)(hi - lo), da2 + lo * EB, ctx->consts, ctx->stream));
+          // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
+          uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
+          TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, (int)cnt, da2,
+                                                       ctx->consts, ctx->stream));
         } else {
-          uint32_t* t1p = (uint32_t*)ctx->w->tab1.p + lo * TABW;
-          TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy + lo * EB, (int)(hi - lo), t1p, ctx->consts, ctx->stream));
-          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1p, TABW, t2p, TABW, (const uint8_t*)dr + lo * EB, (const uint8_t*)dchal, 0,
-                                                    c_windows, (int)(hi - lo), da2 + lo * EB, ctx->consts, ctx->stream));
+          uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
+          TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1p, TABW, t2p, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows,
+                                                    (int)cnt, da2, ctx->consts, ctx->stream));
         }
-        HIPCHK(ctx, hipEventRecord(ctx->w->ev_part[part], ctx->stream));
-        lo = hi;
-      }
-      {
-        // g^r_i needs only the responses: it runs behind the last part instead of after the stepping phase
-        Swap sw(ctx, last_wide);
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
+        // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
                                                              (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
                                                              ctx->stream));
@@ -1080,7 +1044,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                              c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                              comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
-      for (int part = 0; part < parts; ++part) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_part[part], 0));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
     } else {
       // X_i                                                  participant.rs:423-434
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
