@@ -320,7 +320,8 @@ def main():
     # work accounting: Montgomery products the kernels execute per step on this rank
     fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "8192"))
     if fd:
-        chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(2048 // t, 4), n // (4 * t)))   # as eval_x()
+        chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(min(2048 // t, n // 8192), n // 16384, 4),
+                            n // (4 * t)))                                   # as eval_x() in mpvss_capi.cpp
         chain_len = -(-n // chains)
         w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
         m0 = chains * t                                                  # the seeds: m0 consecutive positions, by Horner

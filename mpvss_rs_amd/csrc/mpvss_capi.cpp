@@ -699,8 +699,11 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // indices w0 .. w0+t-1 in the MIDDLE of the chain, from which one pipeline steps forward and one backward: the
   // seeds of all chains together are the S*t consecutive positions from S*w0 (Horner, and outputs at the same time).
   // The seed launch is latency-bound (2048 seeds are an eighth of a wave per SIMD), so fewer seeds would not finish
-  // sooner; more chains shorten the stepping but cost Horner work (measured optimum at n=65536, t=256: 8 chains).
-  int S = fd_chains_env > 0 ? fd_chains_env : std::max((int)(2048 / t), 4);
+  // sooner; more chains shorten the stepping but cost Horner work.
+  // measured optima on MI355X: chains of about 8192 members (n=65536: 8 chains for t = 16..256), fewer when the
+  // seeds are dear (t = 512: 4), never longer than 16384 members (n=131072, t=1024: 8)
+  int S = fd_chains_env > 0 ? fd_chains_env
+                            : (int)std::max<size_t>(std::max<size_t>(std::min<size_t>(2048 / t, cnt / 8192), cnt / 16384), 4);
   const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
   if (S > s_max) S = s_max;
   if (S < 1) S = 1;

@@ -61,8 +61,11 @@ def test_a_stage_that_gives_up_falls_back_to_horner():
     code = CODE % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), 4242, 64, 8192, 1, "")
     import time
     t0 = time.time()
+    b = run(code, {"MPVSS_FD": "0"}).strip()
+    ref = time.time() - t0
+    t0 = time.time()
     a = run(code, {"MPVSS_FD": "1", "MPVSS_FD_TEST_FAULT": "1"}).strip()
     took = time.time() - t0
-    b = run(code, {"MPVSS_FD": "0"}).strip()
     assert a == b and len(a) == 64
-    assert took < 60, "poisoned stages must not wait for their timeouts one after the other"
+    # poisoned stages must give up at once, not wait for their 2 s timeouts one after the other (16 stages per chain)
+    assert took < ref + 20, (took, ref)
