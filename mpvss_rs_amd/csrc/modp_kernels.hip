@@ -958,7 +958,7 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
   const u32* t1 = tab1 + (size_t)x * 64 * L;
   const u32* t2 = tab2 + (size_t)x * 16 * L;
   const uint8_t* e1 = e1_be + (size_t)x * 256;
-  const uint8_t* c_be = c_all + (size_t)x * c_stride;      // stride 0: one challenge for all shares
+  const uint8_t* c_be = c_all + (size_t)x * c_stride;      // stride 0: one challenge for all shares; c_all null: y^r only
   // 6-bit window w of the 2048-bit exponent: bits 6w .. 6w+5 (little-endian byte k is e1[255 - k])
   auto digit6 = [&](int w) -> u32 {
     const int o = 6 * w, k = o >> 3;
@@ -979,7 +979,7 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
     } else if (s == 1) {
       if (cur % 6 == 0) fill = t1 + (size_t)digit6(cur / 6) * L; else skip = true;
     } else if (s == 2) {
-      if ((cur & 3) == 0 && cur < 256) {
+      if ((cur & 3) == 0 && cur < 256 && c_all != nullptr) {
         const u32 byte = c_be[255 - (cur >> 3)];
         fill = t2 + (size_t)((cur & 4) ? (byte >> 4) : (byte & 15)) * L;
       } else {

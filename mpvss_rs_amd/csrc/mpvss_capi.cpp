@@ -1345,12 +1345,21 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
       }
       RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions + off : nullptr, cnt, dX));
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:214-216)
-      const uint32_t* ty;
-      RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->w->tab1, &ty));
-      TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0,
-                                                (int)cnt, dY, ctx->consts, ctx->stream));
-      TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
-                                                (int)cnt, da2, ctx->consts, ctx->stream));
+      static const int w6 = fd_env("MPVSS_A2_W6", 1);
+      if (w6 && cnt >= 1024) {          // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
+        RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
+        uint32_t* ty = (uint32_t*)ctx->w->tab1.p;
+        TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dp, nullptr, 0, (int)cnt, dY, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dw, nullptr, 0, (int)cnt, da2, ctx->consts, ctx->stream));
+      } else {
+        const uint32_t* ty;
+        RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->w->tab1, &ty));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0,
+                                                  (int)cnt, dY, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
+                                                  (int)cnt, da2, ctx->consts, ctx->stream));
+      }
       // a1 = g^w (dleq.rs:207-211)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
                                                      da1, comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
