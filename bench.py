@@ -55,6 +55,8 @@ ALGO_BYTES_PER_SHARE = 1536  # read y,Y,r + write X,a1,a2 (6 x 256 
 # chip holds under this load); a 2048-bit Montgomery product = 2*72*72 lane-mads = 2592 wave-mads per 16 numbers
 MAD_NS_PER_SIMD = 2.07
 PEAK_MODMUL_PER_S = 1024 / (2 * 72 * 18 / 16 * MAD_NS_PER_SIMD * 1e-9)   # 256 CUs x 4 SIMDs -> 3.05e9
+# the same 4.35 cycles per wave-mad at the nominal 2.4 GHz instead of the ~2.1 GHz the chip holds at its power cap
+PEAK_MODMUL_NOMINAL = 1024 / (2 * 72 * 18 / 16 * (4.35 / 2.4) * 1e-9)   # 3.49e9
 
 
 def fx(v: int) -> bytes:
@@ -70,6 +72,7 @@ def keygen(rng: random.Random) -> int:
 
 PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "8"))   # boxes in flight (the engine has 16 block slots)
 HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "4"))   # host threads absorbing (hashing) boxes at N=1
+USE_VERIFY_MANY = os.environ.get("MPVSS_BENCH_VERIFY_MANY", "1") != "0"   # N=1: the library's own pipeline (0: Python threads)
 
 
 SQ_COST = (72 * (9.5 + 18)) / (72 * 36)      # mads of a dedicated squaring relative to a general product (0.764)
@@ -102,6 +105,8 @@ def main():
     ap.add_argument("--registered-keys", type=int, default=1,
                     help="also time the opt-in registered-key variant at N=1 (0: skip)")
     ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
+    ap.add_argument("--lone-boxes", type=int, default=2, help="boxes verified one at a time after the timed region "
+                                                              "(isolated kernel durations for the roofline; 0: skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the CPU port (-1: 2 per core, 0: skip)")
     args = ap.parse_args()
 
@@ -217,9 +222,6 @@ def main():
 
     hash_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(HASH_THREADS, 1))
     pending_send = [None, None]     # outstanding isend of the hash state to the next rank
-    kernel_ms = {0: [], 1: [], 2: [], 3: []}
-    a2_launches = []
-    host_absorb_s = []
 
     def finish_block():
         """absorb the oldest in-flight block into the (chained) transcript; returns (verdict, digest)"""
@@ -229,12 +231,7 @@ def main():
             buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
             dist.recv(buf, src=rank - 1, group=chain)
             state = bytes(buf.cpu().numpy().tobytes())
-        t0 = time.perf_counter()
         state = eng.verify_block_absorb(state)          # waits for this block's GPU work, then hashes it
-        host_absorb_s.append(time.perf_counter() - t0)
-        for k in kernel_ms:
-            kernel_ms[k].append(eng.kernel_ms(k))
-        a2_launches.append(max(eng.kernel_launches(3), 1))
         if world == 1:
             return capi.transcript_verdict(state, challenge)
         # Several ranks: hand the state on and return at once -- the ranks form a pipeline over the boxes (rank r hashes
@@ -249,11 +246,28 @@ def main():
             return None
         return capi.transcript_verdict(state, challenge)
 
+    def run_steps_many(k, depth):
+        """N = 1: k complete verifications of the box in ONE library call (mpvss_modp_verify_many): the calling thread
+        enqueues the GPU work of up to `depth` boxes ahead, HASH_THREADS library threads absorb (wait for and hash)
+        the boxes in order.  No Python in the loop."""
+        ks = keyset[0]
+        box = capi.ModpBox(d_cm.data_ptr(), t, d_pos.data_ptr(), None if ks is not None else d_pk.data_ptr(),
+                           d_sh.data_ptr(), d_rs.data_ptr(), n, C.cast(ch_buf, C.c_void_p), ks, 0)
+        arr = (capi.ModpBox * k)(*([box] * k))
+        verdicts = (C.c_int * k)()
+        digests = (C.c_uint8 * (32 * k))()
+        eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_DEVICE, arr, k, depth, max(HASH_THREADS, 1), verdicts,
+                                              C.cast(digests, C.c_void_p)), "verify_many")
+        raw = bytes(digests)
+        return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(k)]
+
     def run_steps(k, depth=None):
         """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
-        enqueued while the host hashes the oldest ones.  On one GPU the boxes are independent transcripts, so
-        HASH_THREADS host threads absorb consecutive boxes side by side (the engine releases its lock while it
-        hashes); with several ranks the running hash state travels rank to rank per box, in order, on one thread."""
+        enqueued while the host hashes the oldest ones.  On one GPU the boxes are independent transcripts and the
+        whole pipeline runs inside the library (run_steps_many); with several ranks the running hash state travels
+        rank to rank per box, in order, on one thread."""
+        if world == 1 and USE_VERIFY_MANY and k > 0:
+            return run_steps_many(k, min(depth or PIPE_DEPTH, 16 - max(HASH_THREADS, 1)))
         depth = depth or (PIPE_DEPTH if world == 1 else PIPE_DEPTH + world)
         # the engine has 16 block slots; absorbing threads take the oldest blocks in any order, so leave them slack
         depth = min(depth, 16 - (HASH_THREADS if world == 1 else 0))
@@ -297,14 +311,13 @@ def main():
 
     for verdict, digest in run_steps(args.warmup) if args.warmup > 0 else []:
         assert verdict is True and digest == dealer_digest, "parity gate failed in warm-up"
-    for k in kernel_ms:
-        kernel_ms[k].clear()
-    host_absorb_s.clear()
+    eng.pipeline_stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     results = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    pst = eng.pipeline_stats(reset=True)          # host and kernel accounting of exactly the timed steps
     for verdict, digest in results:
         assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
     if world > 1:
@@ -314,12 +327,26 @@ def main():
 
     value = n_total * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    avg = lambda xs: sum(xs) / max(len(xs), 1)
-    x_ms, a1_ms, tb_ms, a2_ms = avg(kernel_ms[0]), avg(kernel_ms[1]), avg(kernel_ms[2]), avg(kernel_ms[3])
-    a2_n = avg(a2_launches)                      # a2 launches per step (1 unless the box is split)
-    a2_launch_ms = a2_ms / a2_n                  # average duration of one a2 launch
+    nb = max(pst["blocks"], 1)
+    x_ms, a1_ms, tb_ms, a2_ms = (pst["kernel_ms"][k] / nb for k in (0, 1, 2, 3))    # overlapped: boxes share the chip
+    a2_n = max(pst["kernel_launches"][3] / nb, 1.0)   # a2 launches per step (1 unless the box is split)
     a2_kernel = "k_modp_dual_exp_w6" if os.environ.get("MPVSS_A2_W6", "1") != "0" else "k_modp_dual_exp"
     shares_per_a2_launch = n / a2_n
+    # Isolated launches: the same box verified alone (one box in flight, nothing else on the GPU) after the timed
+    # region -- the duration of a launch that has the chip to itself is what a roofline can be read from; in the timed
+    # region up to PIPE_DEPTH boxes share the chip and a launch's wall duration exceeds the step time.
+    lone = None
+    if world == 1 and args.lone_boxes > 0:
+        torch.cuda.synchronize()
+        for verdict, digest in run_steps(args.lone_boxes, depth=1):
+            assert verdict is True and digest == dealer_digest, "parity gate failed (lone box)"
+        lst = eng.pipeline_stats(reset=True)
+        lb = max(lst["blocks"], 1)
+        lone = {"x_path": lst["kernel_ms"][0] / lb, "a1_comb_dual_exp": lst["kernel_ms"][1] / lb,
+                "tables": lst["kernel_ms"][2] / lb, "a2_dual_exp": lst["kernel_ms"][3] / lb,
+                "a2_launches": max(lst["kernel_launches"][3] / lb, 1.0), "boxes": lb}
+    a2_launch_ms_overlapped = a2_ms / a2_n
+    a2_launch_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else a2_launch_ms_overlapped
 
     # work accounting: Montgomery products the kernels execute per step on this rank
     fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "8192"))
@@ -377,6 +404,9 @@ def main():
             "frac": (ALGO_BYTES_PER_SHARE * shares_per_a2_launch / (a2_launch_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if a2_launch_ms > 0 else None,
             "traffic": None,
             "kernel_ms": a2_launch_ms,
+            "kernel_ms_is": ("isolated launch (one box in flight, measured live after the timed region)" if lone
+                             else "overlapped launch (timed region)"),
+            "kernel_ms_overlapped": a2_launch_ms_overlapped,
             "launches_per_step": a2_n,
             "shares_per_launch": shares_per_a2_launch,
         },
@@ -386,13 +416,21 @@ def main():
             "frac": achieved_modmul / peak_modmul,
             "modmul_per_share": mm_total / n,
             "x_path": x_path,
+            "peak_nominal_clock": PEAK_MODMUL_NOMINAL,
+            "frac_of_nominal_clock_peak": achieved_modmul / PEAK_MODMUL_NOMINAL,
             "kernel_ms_sums": {"x_path": x_ms, "a1_comb_dual_exp": a1_ms, "a2_dual_exp": a2_ms, "tables": tb_ms,
-                               "note": "per-kind sums of launch durations; kinds overlap on two streams"},
+                               "note": "per-kind sums of launch durations per step in the timed region; boxes and kinds "
+                                       "overlap, so the sums exceed the step time"},
+            "kernel_ms_isolated": lone,
         },
-        "host": {"absorb_wait_plus_sha256_ms": 1e3 * sum(host_absorb_s) / max(len(host_absorb_s), 1), "setup_s": setup_s,
-                 "pipelining": f"up to {PIPE_DEPTH if world == 1 else PIPE_DEPTH + world} verifications in flight (one "
-                               "workspace and stream pair each): the GPU work of the next ones is enqueued while "
-                               f"{HASH_THREADS if world == 1 else 1} host thread(s) hash the oldest"},
+        "host": {"sha_ni": bool(lib.mpvss_sha256_uses_shani()),
+                 "per_box_ms": {"enqueue": pst["enqueue_ms"] / nb, "wait_for_gpu": pst["wait_ms"] / nb,
+                                "sha256_transcript": pst["hash_ms"] / nb},
+                 "hash_threads": HASH_THREADS if world == 1 else 1,
+                 "boxes_in_flight": PIPE_DEPTH if world == 1 else PIPE_DEPTH + world,
+                 "pipeline": ("mpvss_modp_verify_many (library threads)" if (world == 1 and USE_VERIFY_MANY)
+                              else "verify_block_compute/absorb driven from Python"),
+                 "setup_s": setup_s},
     }
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape

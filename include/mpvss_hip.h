@@ -138,6 +138,24 @@ int mpvss_modp_transcript_absorb(uint8_t* state, const uint8_t* elements, size_t
 int mpvss_modp_transcript_verdict(const uint8_t* state, const uint8_t* challenge_host, int* verdict,
                                   uint8_t* digest32_out);
 
+/* Many boxes at once -- the situation of a participant that checks every dealer's box (each call of
+ * src/participant.rs:399-455 is independent of the others).  The library pipelines them itself: the calling thread
+ * enqueues the GPU work of up to `depth` boxes (1..16) ahead while `hash_threads` (1..8) library threads wait for the
+ * boxes in order and hash their transcripts.  verdicts[i] / digests32[32 i .. 32 i + 31] (optional) belong to
+ * boxes[i]; all array pointers of a box live in `space`, the challenge is a host pointer; `keyset` may be NULL
+ * (registered keys: then `pubkeys` may be NULL, see below).  Equivalent to count calls of
+ * mpvss_modp_verify_distribution. */
+typedef struct mpvss_keyset mpvss_keyset;
+typedef struct mpvss_modp_box {
+  const uint8_t* commitments; size_t t;
+  const int64_t* positions;
+  const uint8_t* pubkeys; const uint8_t* shares; const uint8_t* responses; size_t n;
+  const uint8_t* challenge_host;
+  const mpvss_keyset* keyset; size_t key_offset;
+} mpvss_modp_box;
+int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
+                           int hash_threads, int* verdicts, uint8_t* digests32);
+
 /* ---- registered public keys (opt-in) ---------------------------------------------------- */
 
 /* In a PVSS deployment the participants' public keys are long-lived: every dealer distributes to the same keys, so
@@ -147,7 +165,6 @@ int mpvss_modp_transcript_verdict(const uint8_t* state, const uint8_t* challenge
  * 571 products instead of 2 620.  Results are identical to mpvss_modp_verify_block_compute on the same keys.
  * Shares i of the call use keys key_offset + i of the set.  Destroy a key set only after the blocks using it have
  * been absorbed. */
-typedef struct mpvss_keyset mpvss_keyset;
 int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out);
 void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* keyset);
 size_t mpvss_modp_keyset_bytes(const mpvss_keyset* keyset);
@@ -256,6 +273,19 @@ int mpvss_last_kernel_launches(const mpvss_ctx* ctx, int kernel_id);
  * Horner's rule on the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up):
  * same results either way, the fall-back is just slower -- a counter for operators and tests. */
 int mpvss_modp_fd_stats(mpvss_ctx* ctx, unsigned long long* blocks, unsigned long long* fallbacks);
+
+/* Host-side accounting of the block pipeline (verify_block_compute / _absorb / verify_many), sums over the blocks
+ * absorbed since the last reset: time the calling threads spent enqueueing GPU work, waiting for the GPU and
+ * hashing transcripts, and the per-kind kernel durations of mpvss_last_kernel_ms summed over those blocks. */
+typedef struct mpvss_pipeline_stats {
+  double enqueue_ms, wait_ms, hash_ms;
+  double kernel_ms[4];
+  unsigned long long kernel_launches[4];
+  unsigned long long blocks;
+} mpvss_pipeline_stats;
+int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* out, int reset);
+/* 1 when the transcript hash uses the CPU's SHA extensions (about 1.7 GB/s per thread), 0 for the portable code */
+int mpvss_sha256_uses_shani(void);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
+    "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_sha256_uses_shani",
 )
 
 GROUP_SECP256K1 = 1
@@ -43,6 +44,19 @@ TRANSCRIPT_STATE_BYTES = 128
 
 class EngineError(RuntimeError):
     pass
+
+
+class ModpBox(C.Structure):
+    """struct mpvss_modp_box (include/mpvss_hip.h)"""
+    _fields_ = [("commitments", C.c_void_p), ("t", C.c_size_t), ("positions", C.c_void_p), ("pubkeys", C.c_void_p),
+                ("shares", C.c_void_p), ("responses", C.c_void_p), ("n", C.c_size_t), ("challenge_host", C.c_void_p),
+                ("keyset", C.c_void_p), ("key_offset", C.c_size_t)]
+
+
+class PipelineStats(C.Structure):
+    """struct mpvss_pipeline_stats"""
+    _fields_ = [("enqueue_ms", C.c_double), ("wait_ms", C.c_double), ("hash_ms", C.c_double),
+                ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_ulonglong * 4), ("blocks", C.c_ulonglong)]
 
 
 def load_library() -> C.CDLL:
@@ -98,6 +112,9 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_verify_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
+    lib.mpvss_modp_verify_many.argtypes = [vp, ci, C.POINTER(ModpBox), sz, ci, ci, C.POINTER(ci), u8p]
+    lib.mpvss_pipeline_stats_get.argtypes = [vp, C.POINTER(PipelineStats), ci]
+    lib.mpvss_sha256_uses_shani.restype = ci
     lib.mpvss_modp_extract_shares.argtypes = [vp, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
     lib.mpvss_ec_extract_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
     return lib
@@ -256,6 +273,30 @@ class Engine:
         kx, px = _out(n * EB); k1, p1 = _out(n * EB); k2, p2 = _out(n * EB)
         self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, px, p1, p2), "verify_block_absorb")
         return bytes(ks), bytes(kx)[: n * EB], bytes(k1)[: n * EB], bytes(k2)[: n * EB]
+
+    def verify_many(self, boxes: Sequence[dict], depth: int = 8, hash_threads: int = 4):
+        """boxes: dicts with commitments, positions, pubkeys, shares, responses, challenge (host bytes).
+        Returns [(verdict, digest)] in box order."""
+        keep, arr = [], (ModpBox * max(len(boxes), 1))()
+        for i, b in enumerate(boxes):
+            n = len(b["positions"])
+            pos = (C.c_int64 * max(n, 1))(*b["positions"])
+            bufs = [_buf(b[k]) for k in ("commitments", "pubkeys", "shares", "responses", "challenge")]
+            keep.append((pos, bufs))
+            arr[i] = ModpBox(bufs[0][1], len(b["commitments"]) // EB, C.cast(pos, C.c_void_p), bufs[1][1], bufs[2][1],
+                             bufs[3][1], n, bufs[4][1], None, 0)
+        verdicts = (C.c_int * max(len(boxes), 1))()
+        kd, pd = _out(32 * len(boxes))
+        self._check(self.lib.mpvss_modp_verify_many(self.ctx, MPVSS_HOST, arr, len(boxes), depth, hash_threads, verdicts, pd),
+                    "verify_many")
+        raw = bytes(kd)
+        return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(len(boxes))]
+
+    def pipeline_stats(self, reset: bool = False) -> dict:
+        st = PipelineStats()
+        self._check(self.lib.mpvss_pipeline_stats_get(self.ctx, C.byref(st), int(reset)), "pipeline_stats_get")
+        return {"enqueue_ms": st.enqueue_ms, "wait_ms": st.wait_ms, "hash_ms": st.hash_ms,
+                "kernel_ms": list(st.kernel_ms), "kernel_launches": list(st.kernel_launches), "blocks": int(st.blocks)}
 
     def fd_stats(self) -> Tuple[int, int]:
         """(blocks absorbed through the forward-difference path, of those: fell back to Horner on the device)"""

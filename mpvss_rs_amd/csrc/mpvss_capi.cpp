@@ -10,9 +10,13 @@
 
 #include <math.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
-#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "host_modq.h"
@@ -59,6 +63,7 @@ struct mpvss_ctx {
   bool own_stream = false;
   void* consts = nullptr;
   std::string err;
+  mutable std::mutex err_mu;     // guards `err` alone: mpvss_last_error may run beside calls of other threads
   std::mutex mu;
   // Device workspace of one call in flight (grow-only buffers, the stream pair and the events that order them).
   // work0 serves the ordinary entry points; every verify-block slot has its own, so that several boxes can be in
@@ -71,6 +76,8 @@ struct mpvss_ctx {
     struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
       uint8_t in_be[256], out_be[256];
       int ok;
+      int one;                               // pinned constant 1 (initial value of the forward-difference flag)
+      uint8_t challenge[256];                // pinned copy of the call's challenge (the caller's buffer is not kept)
     };
     RootJob* root = nullptr;
     bool fd_used = false;                    // eval_x took the forward-difference path in the call being enqueued
@@ -113,8 +120,10 @@ struct mpvss_ctx {
     size_t n = 0;
     bool busy = false;
     bool absorbing = false;        // a host thread is waiting for / hashing this block (context lock released)
-    bool fd_used = false;          // the block's X path was the forward-difference one: its final flag is in the staging
+    bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
+    unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
+    double enqueue_ms = 0;         // host time spent enqueueing this block's GPU work
     hipEvent_t done = nullptr;
     SpanSet spans;
     double kernel_ms[4] = {0, 0, 0, 0};
@@ -126,6 +135,13 @@ struct mpvss_ctx {
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
+  // host-side accounting of the block pipeline (mpvss_pipeline_stats_get): sums over absorbed blocks
+  struct PipeStats {
+    double enqueue_ms = 0, wait_ms = 0, hash_ms = 0;
+    double kernel_ms[4] = {0, 0, 0, 0};
+    unsigned long long kernel_launches[4] = {0, 0, 0, 0};
+    unsigned long long blocks = 0;
+  } pstats;
   EcWork ecwork;
 };
 
@@ -143,6 +159,7 @@ int fail(mpvss_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) 
       snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
     else
       snprintf(buf, sizeof(buf), "%s", what);
+    std::lock_guard<std::mutex> g(ctx->err_mu);
     ctx->err = buf;
   }
   return code;
@@ -421,6 +438,7 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_a2, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void**)&w.root, sizeof(*w.root), hipHostMallocDefault));
+  w.root->one = 1;
   w.ready = true;
   return 0;
 }
@@ -483,7 +501,16 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   delete ctx;
 }
 
-extern "C" const char* mpvss_last_error(const mpvss_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" const char* mpvss_last_error(const mpvss_ctx* ctx) {
+  if (!ctx) return "null context";
+  // a copy per calling thread: the context's string may be reassigned by another thread's failing call
+  static thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    copy = ctx->err;
+  }
+  return copy.c_str();
+}
 
 extern "C" int mpvss_ctx_set_stream(mpvss_ctx* ctx, void* hip_stream) {
   if (!ctx) return MPVSS_E_INVALID;
@@ -742,8 +769,8 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   uint32_t* state_bwd = state_fwd + (size_t)m0 * MODP_L;
   auto level_in = [&](int l) { return l == 0 ? xseed : (uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
   auto level_inv = [&](int l) { return l == 0 ? (uint32_t*)w.fd_xinv.p : (uint32_t*)w.fd_totinv.p + tot_off[l] * MODP_L; };
-  static const int one = 1;
-  HIPCHK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  w.root->one = 1;     // pinned: the copy below is asynchronous and reads it in stream order
+  HIPCHK(ctx, hipMemcpyAsync(flag, &w.root->one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
   if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions(dpos, (int)cnt, flag, ctx->stream));
   // seeds: X at the S*t positions from seed0, kept in Montgomery form
@@ -927,15 +954,24 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   }
   mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: sixteen blocks already in flight, absorb one first");
+  const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  if (!sl.done) {
+    // blocking wait by default: threads that absorb blocks sleep until the GPU is done instead of spinning
+    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+  }
   sl.n = n;
   sl.check_positions = false;
+  sl.fd_used = false;
+  sl.fd_chunks = 0;
+  sl.enqueue_ms = 0;
   if (n == 0) {
     sl.busy = true;
     ++ctx->head;
     return MPVSS_OK;
   }
+  if (space == MPVSS_HOST) RET_IF(check_positions_host(ctx, positions, n));
   // this block runs in its slot's own workspace and stream pair, so that boxes overlap on the GPU
   RET_IF(work_init(ctx, sl.work, nullptr));
   struct Restore {
@@ -949,7 +985,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   ctx->stream_b = sl.work.sb;
   ctx->sp = &sl.spans;
   spans_reset(ctx);
-  const size_t need = n * EB * 4 + n * 8 + 8;
+  // Pinned staging of the slot: the outputs X, Y, a1, a2, the positions, one forward-difference flag per chunk and --
+  // for callers that hand over host memory -- a copy of the inputs, so that every transfer is asynchronous and
+  // nothing of the caller's is referenced after this call returns.
+  constexpr size_t FLAGS = 64;                 // chunks per block whose flags are kept (the rest count as held)
+  const size_t out_bytes = n * EB * 4 + n * 8 + FLAGS * 4;
+  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + t * EB : 0);
   if (need > sl.cap) {
     if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
     sl.pin = nullptr;
@@ -958,22 +999,39 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(block staging)", e);
     sl.cap = need;
   }
-  RET_IF(stage_commitments(ctx, space, commitments, t));
-  const uint32_t* cg;
-  RET_IF(comb_table(ctx, 0, &cg, n));
-  const void* dchal;
-  RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, EB, ctx->w->in_e, &dchal));
-  const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
   uint8_t* hX = (uint8_t*)sl.pin;
   uint8_t* hY = hX + n * EB;
   uint8_t* h1 = hY + n * EB;
   uint8_t* h2 = h1 + n * EB;
   int64_t* hpos = (int64_t*)(h2 + n * EB);
+  int* hflags = (int*)((uint8_t*)sl.pin + n * EB * 4 + n * 8);
+  if (space == MPVSS_HOST) {
+    uint8_t* in = (uint8_t*)sl.pin + out_bytes;
+    if (!ks) memcpy(in, pubkeys, n * EB);
+    memcpy(in + n * EB, shares, n * EB);
+    memcpy(in + 2 * n * EB, responses, n * EB);
+    memcpy(in + 3 * n * EB, commitments, t * EB);
+    memcpy(hpos, positions, n * 8);
+    if (!ks) pubkeys = in;
+    shares = in + n * EB;
+    responses = in + 2 * n * EB;
+    commitments = in + 3 * n * EB;
+  }
+  memcpy(sl.work.root->challenge, challenge_host, EB);
+  RET_IF(stage_commitments(ctx, space, commitments, t));
+  const uint32_t* cg;
+  RET_IF(comb_table(ctx, 0, &cg, n));
+  RET_IF(ensure(ctx, ctx->w->in_e, EB));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->w->in_e.p, sl.work.root->challenge, EB, hipMemcpyHostToDevice, ctx->stream));
+  const void* dchal = ctx->w->in_e.p;
+  const int c_windows = fits_256_bits(challenge_host) ? 64 : 512;
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const int64_t* dpos;
     if (space == MPVSS_HOST) {
-      RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
+      const void* d;
+      RET_IF(stage_in(ctx, space, hpos + off, cnt * 8, ctx->w->pos, &d));      // from the pinned copy
+      dpos = (const int64_t*)d;
     } else {
       // device-resident positions are validated when the block is absorbed (no host sync here)
       dpos = positions + off;
@@ -990,7 +1048,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* dX = (uint8_t*)ctx->w->xbe.p;
     uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
-    const int64_t* hp = space == MPVSS_HOST ? positions + off : nullptr;
+    sl.work.fd_used = false;
+    const int64_t* hp = space == MPVSS_HOST ? hpos + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
     if (two_streams && ctx->w->sb && fd_applies(t, hp, cnt)) {
       // The forward-difference X path is a chain of latency-bound launches that occupy few wave slots (seeds,
@@ -1060,13 +1119,17 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    if (sl.work.fd_used) {     // the device's decision for this chunk (1 = forward differences held, 0 = fell back)
+      sl.fd_used = true;
+      if (sl.fd_chunks < FLAGS)
+        HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+      ++sl.fd_chunks;
+    }
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
-  sl.fd_used = sl.work.fd_used;
-  if (sl.fd_used)      // the device's decision (1 = forward differences held, 0 = fell back), for the statistics
-    HIPCHK(ctx, hipMemcpyAsync((uint8_t*)sl.pin + n * EB * 4 + n * 8, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
+  sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
   ++ctx->head;
   return MPVSS_OK;
 }
@@ -1088,7 +1151,9 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   sl.absorbing = true;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   lk.unlock();
+  const auto t_w0 = std::chrono::steady_clock::now();
   const hipError_t e = hipEventSynchronize(sl.done);
+  const auto t_w1 = std::chrono::steady_clock::now();
   const uint8_t* hX = (const uint8_t*)sl.pin;
   const uint8_t* hY = hX + n * EB;
   const uint8_t* h1 = hY + n * EB;
@@ -1114,18 +1179,31 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
       if (a2_out) memcpy(a2_out, h2, n * EB);
     }
   }
+  const auto t_h1 = std::chrono::steady_clock::now();
   lk.lock();
   sl.busy = false;
   sl.absorbing = false;
   if (e == hipSuccess && sl.fd_used) {
-    int flag = 1;
-    memcpy(&flag, h2 + n * EB + n * 8, sizeof(flag));
+    const int* hflags = (const int*)(h2 + n * EB + n * 8);
+    bool held = true;
+    for (unsigned k = 0; k < sl.fd_chunks && k < 64; ++k) held = held && hflags[k] == 1;
     ++ctx->fd_blocks;
-    if (flag != 1) ++ctx->fd_fallbacks;
+    if (!held) ++ctx->fd_fallbacks;
   }
   if (e != hipSuccess) return fail(ctx, MPVSS_E_DEVICE, "absorb: hipEventSynchronize", e);
   if (!positions_ok) return fail(ctx, MPVSS_E_INVALID, "negative position (the reference panics: negative exponent)");
   RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
+  {
+    mpvss_ctx::PipeStats& ps = ctx->pstats;
+    ps.enqueue_ms += sl.enqueue_ms;
+    ps.wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count();
+    ps.hash_ms += std::chrono::duration<double, std::milli>(t_h1 - t_w1).count();
+    for (int k = 0; k < 4; ++k) {
+      ps.kernel_ms[k] += ctx->kernel_ms[k];
+      ps.kernel_launches[k] += (unsigned long long)ctx->kernel_launches[k];
+    }
+    ++ps.blocks;
+  }
   return MPVSS_OK;
 }
 
@@ -1248,6 +1326,117 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   RET_IF(verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host));
   return mpvss_modp_transcript_verdict(state, challenge_host, verdict, digest32_out);
 }
+
+// ---- many boxes, pipelined inside the library -------------------------------------------------------------
+// The calling thread enqueues the GPU work of up to `depth` boxes ahead; `hash_threads` library threads wait for the
+// boxes in FIFO order and hash them (every box has its own transcript, so the hashes of consecutive boxes run side
+// by side).  Nothing of this depends on the caller's scheduler.
+extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
+                                      int hash_threads, int* verdicts, uint8_t* digests32) {
+  if (!ctx) return MPVSS_E_INVALID;
+  if (count == 0) return MPVSS_OK;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!boxes || !verdicts) return fail(ctx, MPVSS_E_INVALID, "verify_many: bad argument");
+    if (ctx->head != ctx->tail)
+      return fail(ctx, MPVSS_E_INVALID, "verify_many: blocks of the block API are in flight, absorb them first");
+  }
+  if (hash_threads < 1) hash_threads = 1;
+  if (hash_threads > 8) hash_threads = 8;
+  if (depth < 1) depth = 1;
+  if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
+  for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
+
+  struct Shared {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t issued = 0, claimed = 0, done = 0;
+    bool stop = false;          // no more boxes will be issued
+    int rc = MPVSS_OK;
+  } sh;
+  const unsigned base_tail = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->tail; }();
+
+  auto worker = [&]() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(sh.m);
+        sh.cv.wait(l, [&] { return sh.claimed < sh.issued || sh.stop; });
+        if (sh.claimed >= sh.issued) return;       // stop and nothing left
+        ++sh.claimed;
+      }
+      uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
+      mpvss_transcript_init(state);
+      size_t idx;
+      int rc;
+      {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        idx = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
+        rc = verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
+      }
+      if (rc == MPVSS_OK && idx < count)
+        rc = mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],
+                                           digests32 ? digests32 + 32 * idx : nullptr);
+      {
+        std::lock_guard<std::mutex> l(sh.m);
+        ++sh.done;
+        if (rc != MPVSS_OK && sh.rc == MPVSS_OK) sh.rc = rc;
+      }
+      sh.cv.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)hash_threads);
+  for (int i = 0; i < hash_threads; ++i) pool.emplace_back(worker);
+
+  for (size_t b = 0; b < count; ++b) {
+    {
+      std::unique_lock<std::mutex> l(sh.m);
+      sh.cv.wait(l, [&] { return sh.issued - sh.done < (size_t)depth || sh.rc != MPVSS_OK; });
+      if (sh.rc != MPVSS_OK) break;
+    }
+    const mpvss_modp_box& bx = boxes[b];
+    int rc;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
+                                       bx.n, bx.challenge_host, bx.keyset, bx.key_offset);
+    }
+    {
+      std::lock_guard<std::mutex> l(sh.m);
+      if (rc != MPVSS_OK) {
+        if (sh.rc == MPVSS_OK) sh.rc = rc;
+      } else {
+        ++sh.issued;
+      }
+    }
+    sh.cv.notify_all();
+    if (rc != MPVSS_OK) break;
+  }
+  {
+    std::lock_guard<std::mutex> l(sh.m);
+    sh.stop = true;
+  }
+  sh.cv.notify_all();
+  for (auto& th : pool) th.join();     // the workers drain every issued block, so no slot stays busy
+  return sh.rc;
+}
+
+extern "C" int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* out, int reset) {
+  if (!ctx || !out) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  out->enqueue_ms = ctx->pstats.enqueue_ms;
+  out->wait_ms = ctx->pstats.wait_ms;
+  out->hash_ms = ctx->pstats.hash_ms;
+  for (int k = 0; k < 4; ++k) {
+    out->kernel_ms[k] = ctx->pstats.kernel_ms[k];
+    out->kernel_launches[k] = ctx->pstats.kernel_launches[k];
+  }
+  out->blocks = ctx->pstats.blocks;
+  if (reset) ctx->pstats = mpvss_ctx::PipeStats();
+  return MPVSS_OK;
+}
+
+extern "C" int mpvss_sha256_uses_shani(void) { return mpvss::sha256_uses_shani() ? 1 : 0; }
 
 // ---- verify_share, batched ----------------------------------------------------------------------------
 extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s,

@@ -32,3 +32,81 @@ def cat(g, elems):
 
 def split(b):
     return [int.from_bytes(b[i:i + EB], "big") for i in range(0, len(b), EB)]
+
+
+# ---- full-size boxes and parallel oracle work (tests/test_gpu_configs.py) ---------------------------------------
+import concurrent.futures  # noqa: E402
+import multiprocessing  # noqa: E402
+import os  # noqa: E402
+
+MODP_Q = O.ModpGroup().q
+MODP_ORDER = MODP_Q - 1
+
+
+def _poly_chunk(args):
+    coeffs_rev, positions, order = args
+    out = []
+    for i in positions:
+        acc = 0
+        for a in coeffs_rev:
+            acc = (acc * i + a) % order
+        out.append(acc)
+    return out
+
+
+def worker_count(limit=40):
+    try:
+        return max(1, min(limit, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(limit, os.cpu_count() or 1))
+
+
+def parallel_map(fn, items, procs=None):
+    """fn(item) for every item on freshly spawned oracle-only worker processes (never forked from a process that
+    holds a GPU context)."""
+    items = list(items)
+    procs = min(procs or worker_count(), max(1, len(items)))
+    if procs == 1:
+        return [fn(x) for x in items]
+    ctx = multiprocessing.get_context("spawn")
+    with concurrent.futures.ProcessPoolExecutor(max_workers=procs, mp_context=ctx) as ex:
+        return list(ex.map(fn, items))
+
+
+def poly_values(coeffs, positions, order):
+    """P(i) mod order for every position (polynomial.rs:50-58 followed by the caller's `% order`,
+    participant.rs:202); big shapes are cut over worker processes."""
+    rc = list(reversed(coeffs))
+    if len(coeffs) * len(positions) < (1 << 22):
+        return _poly_chunk((rc, positions, order))
+    w = worker_count()
+    step = -(-len(positions) // (4 * w))
+    chunks = [(rc, positions[k:k + step], order) for k in range(0, len(positions), step)]
+    return [v for part in parallel_map(_poly_chunk, chunks) for v in part]
+
+
+def ec_reference_share(args):
+    """One share of verify_distribution_shares in the REFERENCE operation order (participant.rs:1404-1430 /
+    1847-1873 via oracle/mpvss_oracle.py): returns the encodings of X_i, a1_i, a2_i."""
+    name, cm_enc, position, y, Y, r, c = args
+    G = O.GROUPS[name]()
+    L = G.elem_len
+    cm = [G.element_from_fixed(cm_enc[k:k + L]) for k in range(0, len(cm_enc), L)]
+    X = O.commitment_eval(G, cm, position)
+    a1, a2 = O.dleq_verifier_commitments(G, G.subgroup_generator(), X, G.element_from_fixed(y), G.element_from_fixed(Y),
+                                         G.scalar_from_fixed(r), G.scalar_from_fixed(c))
+    return G.element_to_bytes(X), G.element_to_bytes(a1), G.element_to_bytes(a2)
+
+
+def ec_reference_x(args):
+    name, cm_enc, position = args
+    G = O.GROUPS[name]()
+    L = G.elem_len
+    cm = [G.element_from_fixed(cm_enc[k:k + L]) for k in range(0, len(cm_enc), L)]
+    return G.element_to_bytes(O.commitment_eval(G, cm, position))
+
+
+def modp_reference_x(args):
+    cm, position = args
+    G = O.ModpGroup()
+    return O.commitment_eval(G, cm, position)

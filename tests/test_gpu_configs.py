@@ -1,0 +1,175 @@
+"""BASELINE.json configs at their full sizes on the GPU: C2 (MODP n=4096 t=64, every share against the C port),
+the headline shape (MODP n=65536 t=256, a seeded 1 % sample), C3 / C4 (secp256k1 / ristretto255 n=65536 t=256) and
+one GPU's slice of C5 (MODP n=131072 t=1024).  Size-independent properties: a box produced by the engine's dealer
+path must verify with the dealer's transcript digest; one flipped bit anywhere must be rejected; sampled shares must
+equal the oracle evaluated in the REFERENCE operation order (src/participant.rs:399-455, 1384-1442, 1827-1885)."""
+import concurrent.futures
+import hashlib
+import math
+import random
+
+import pytest
+
+import mpvss_oracle as O
+from helpers import (EB, MODP_ORDER as ORDER, MODP_Q as Q, ec_reference_share, ec_reference_x, parallel_map, poly_values,
+                     worker_count)
+from mpvss_rs_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def fx(v):
+    return v.to_bytes(EB, "big")
+
+
+def keygen(rng):
+    while True:                                   # modp.rs:162-174
+        k = rng.randrange(Q)
+        if math.gcd(k, ORDER) == 1:
+            return k
+
+
+def make_modp_box(engine, n, t, seed):
+    rng = random.Random(seed)
+    coeffs = [rng.randrange(ORDER) for _ in range(t)]
+    privs = [keygen(rng) for _ in range(n)]
+    wits = [keygen(rng) for _ in range(n)]
+    positions = list(range(1, n + 1))
+    pvals = poly_values(coeffs, positions, ORDER)
+    cm = engine.batch_exp_fixed_base(fx(4), b"".join(map(fx, coeffs)))
+    pks = engine.batch_exp_fixed_base(fx(2), b"".join(map(fx, privs)))
+    d = engine.distribute(cm, positions, pks, b"".join(map(fx, pvals)), b"".join(map(fx, wits)))
+    c = int.from_bytes(hashlib.sha256(d["digest"]).digest(), "big") % ((Q - 1) // 2)
+    responses = b"".join(fx((w - p * c) % ORDER) for w, p in zip(wits, pvals))
+    return {"cm": cm, "pos": positions, "pk": pks, "Y": d["Y"], "r": responses, "c": fx(c), "d": d}
+
+
+def check_modp_box(engine, box, sample_idx):
+    """round trip, three tampers, and the C port (reference operation sequence) on the sampled shares"""
+    n = len(box["pos"])
+    res = engine.verify_distribution(box["cm"], box["pos"], box["pk"], box["Y"], box["r"], box["c"], dump=True)
+    assert res["verdict"] is True
+    assert res["digest"] == box["d"]["digest"]            # verifier transcript == dealer transcript
+    assert res["X"] == box["d"]["X"] and res["a1"] == box["d"]["a1"] and res["a2"] == box["d"]["a2"]
+    rng = random.Random(5)
+    for field in ("r", "Y", "cm"):
+        buf = bytearray(box[field])
+        buf[rng.randrange(len(buf))] ^= 1 << rng.randrange(8)
+        args = dict(box)
+        args[field] = bytes(buf)
+        bad = engine.verify_distribution(args["cm"], args["pos"], args["pk"], args["Y"], args["r"], args["c"])
+        assert bad["verdict"] is False and bad["digest"] != box["d"]["digest"]
+    from modp_ref import ModpRef
+    ref = ModpRef()
+
+    def work(i):
+        s = slice(i * EB, (i + 1) * EB)
+        return ref.share_work(box["cm"], box["pos"][i], box["pk"][s], box["Y"][s], box["r"][s], box["c"])
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=worker_count(64)) as ex:     # ctypes releases the GIL
+        outs = list(ex.map(work, sample_idx))
+    for i, (x, a1, a2) in zip(sample_idx, outs):
+        s = slice(i * EB, (i + 1) * EB)
+        assert (x, a1, a2) == (res["X"][s], res["a1"][s], res["a2"][s]), f"share {i} of {n}"
+
+
+def test_c2_every_share_against_the_c_port(engine):
+    """BASELINE config C2: n=4096, t=64 -- all 4096 shares' X, a1, a2 against oracle/modp_ref.c."""
+    box = make_modp_box(engine, 4096, 64, seed=4096 + 64)
+    check_modp_box(engine, box, list(range(4096)))
+
+
+def test_headline_shape_seeded_one_percent_sample(engine):
+    """n=65536, t=256 (the metric's shape): 656 seeded shares (1 %) against the C port, plus the first and last."""
+    n = 65536
+    box = make_modp_box(engine, n, 256, seed=n + 256)
+    idx = sorted(set(random.Random(99).sample(range(n), 656)) | {0, 1, n - 2, n - 1})
+    check_modp_box(engine, box, idx)
+
+
+def test_c5_slice_of_one_gpu(engine):
+    """BASELINE config C5 is n=2^20, t=1024 over 8 GPUs: this is ONE GPU's block (131072 consecutive positions, the
+    block of rank 3, so positions start at 393217) -- multi-GPU run itself is the driver's.  48 seeded shares against
+    the C port (a share costs the reference sequence ~30 core-seconds at t=1024)."""
+    n, t, lo = 131072, 1024, 3 * 131072
+    rng = random.Random(1024 + n)
+    coeffs = [rng.randrange(ORDER) for _ in range(t)]
+    privs = [keygen(rng) for _ in range(n)]
+    wits = [keygen(rng) for _ in range(n)]
+    positions = list(range(lo + 1, lo + n + 1))
+    pvals = poly_values(coeffs, positions, ORDER)
+    cm = engine.batch_exp_fixed_base(fx(4), b"".join(map(fx, coeffs)))
+    pks = engine.batch_exp_fixed_base(fx(2), b"".join(map(fx, privs)))
+    d = engine.distribute(cm, positions, pks, b"".join(map(fx, pvals)), b"".join(map(fx, wits)))
+    c = int.from_bytes(hashlib.sha256(d["digest"]).digest(), "big") % ((Q - 1) // 2)
+    responses = b"".join(fx((w - p * c) % ORDER) for w, p in zip(wits, pvals))
+    box = {"cm": cm, "pos": positions, "pk": pks, "Y": d["Y"], "r": responses, "c": fx(c), "d": d}
+    idx = sorted(set(random.Random(7).sample(range(n), 46)) | {0, n - 1})
+    blocks0, fallbacks0 = engine.fd_stats()
+    check_modp_box(engine, box, idx)
+    blocks1, fallbacks1 = engine.fd_stats()
+    assert blocks1 > blocks0 and fallbacks1 == fallbacks0      # the forward-difference path ran and held
+
+
+GID = {"secp256k1": capi.GROUP_SECP256K1, "ristretto255": capi.GROUP_RISTRETTO255}
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_c3_c4_curve_groups_full_size(engine, name):
+    """BASELINE configs C3 (secp256k1) and C4 (ristretto255): n=65536, t=256.  Engine dealer box -> verify, digest
+    equality, three tamper cases, 64 seeded positions of X / a1 / a2 against oracle/mpvss_oracle.py in the reference
+    operation order, and X over doctored commitments (a duplicate and the identity) at 16 positions."""
+    n, t = 65536, 256
+    G = O.GROUPS[name]()
+    gid = GID[name]
+    order = G.group_order_int()
+    L = G.elem_len
+    sb = G.scalar_to_fixed
+    rng = random.Random(0xC3C4 + gid)
+    coeffs = [rng.randrange(order) for _ in range(t)]
+    privs = [rng.randrange(1, order) for _ in range(n)]
+    wits = [rng.randrange(1, order) for _ in range(n)]
+    positions = list(range(1, n + 1))
+    pvals = poly_values(coeffs, positions, order)
+    gen = G.element_to_bytes(G.generator())
+    cm = engine.ec_batch_exp(gid, gen * t, b"".join(map(sb, coeffs)))
+    pks = engine.ec_batch_exp(gid, gen * n, b"".join(map(sb, privs)))
+    d = engine.ec_distribute(gid, cm, positions, pks, b"".join(map(sb, pvals)), b"".join(map(sb, wits)))
+    c = G.hash_to_scalar(d["digest"])                        # secp256k1.rs:121-131 / ristretto255.rs:196-205
+    assert sb(c) == capi.ec_hash_to_scalar(gid, d["digest"])
+    responses = b"".join(sb((w - p * c) % order) for w, p in zip(wits, pvals))     # dleq.rs:42-50
+    res = engine.ec_verify_distribution(gid, cm, positions, pks, d["Y"], responses, sb(c), dump=True)
+    assert res["verdict"] is True and res["digest"] == d["digest"]
+    assert res["X"] == d["X"] and res["a1"] == d["a1"] and res["a2"] == d["a2"]
+    trng = random.Random(5)
+    for field in ("r", "Y", "cm"):
+        args = {"cm": cm, "Y": d["Y"], "r": responses}
+        buf = bytearray(args[field])
+        if field == "r":                                     # stay below the group order: flip a low bit of a response
+            k = trng.randrange(n)
+            buf[k * 32 + (31 if name == "secp256k1" else 0)] ^= 1
+        elif field == "Y":                                   # another valid point in place of one share
+            k = trng.randrange(n)
+            buf[k * L:(k + 1) * L] = pks[((k + 1) % n) * L:((k + 1) % n + 1) * L]
+        else:
+            k = trng.randrange(t)
+            buf[k * L:(k + 1) * L] = pks[k * L:(k + 1) * L]
+        args[field] = bytes(buf)
+        bad = engine.ec_verify_distribution(gid, args["cm"], positions, pks, args["Y"], args["r"], sb(c))
+        assert bad["verdict"] is False and bad["digest"] != d["digest"], field
+    idx = sorted(set(random.Random(11).sample(range(n), 62)) | {0, n - 1})
+    jobs = [(name, cm, positions[i], pks[i * L:(i + 1) * L], d["Y"][i * L:(i + 1) * L], responses[i * 32:(i + 1) * 32], sb(c))
+            for i in idx]
+    for i, (x, a1, a2) in zip(idx, parallel_map(ec_reference_share, jobs)):
+        s = slice(i * L, (i + 1) * L)
+        assert (x, a1, a2) == (res["X"][s], res["a1"][s], res["a2"][s]), f"{name} share {i}"
+    # adversarial commitments: a duplicate and the identity (X accumulation starts from the identity and meets P + P)
+    ident = G.element_to_bytes(G.identity())
+    doctored = bytearray(cm)
+    doctored[3 * L:4 * L] = cm[2 * L:3 * L]
+    doctored[5 * L:6 * L] = ident
+    doctored = bytes(doctored)
+    xs = engine.ec_commit_eval(gid, doctored, positions)
+    idx2 = sorted(set(random.Random(12).sample(range(n), 14)) | {0, n - 1})
+    for i, x in zip(idx2, parallel_map(ec_reference_x, [(name, doctored, positions[i]) for i in idx2])):
+        assert x == xs[i * L:(i + 1) * L], f"{name} doctored X {i}"

@@ -1,7 +1,7 @@
 """Full-size GPU checks through size-independent properties: an honest box produced by the engine's own dealer
 path must verify with the dealer's transcript digest; one flipped bit anywhere must be rejected; a sample of
-shares must equal the C restatement (reference operation order).  BASELINE configs C2 (n=4096, t=64) and the
-headline shape (n=65536, t=256)."""
+shares must equal the C restatement (reference operation order).  The BASELINE configs at their full sizes are in
+tests/test_gpu_configs.py; this file keeps a quick mid-size case and the homomorphic property."""
 import hashlib
 import math
 import random
@@ -50,7 +50,7 @@ def make_box(engine, n, t, seed):
     return {"cm": cm, "pos": positions, "pk": pks, "Y": d["Y"], "r": responses, "c": fx(c), "d": d}
 
 
-@pytest.mark.parametrize("n,t,sample", [(4096, 64, 6), (65536, 256, 4)])
+@pytest.mark.parametrize("n,t,sample", [(2048, 32, 6)])
 def test_round_trip_and_tamper(engine, n, t, sample):
     box = make_box(engine, n, t, seed=n + t)
     res = engine.verify_distribution(box["cm"], box["pos"], box["pk"], box["Y"], box["r"], box["c"], dump=True)

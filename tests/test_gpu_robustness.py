@@ -161,3 +161,34 @@ def test_blocks_absorbed_by_several_host_threads(engine):
     assert all(d != box["_digest"] for v, d in out if not v)
     with pytest.raises(capi.EngineError):
         engine.verify_block_absorb(capi.transcript_init())
+
+
+def test_verify_many_pipelines_boxes_inside_the_library(engine):
+    """mpvss_modp_verify_many == one verify_distribution per box, in box order: honest, tampered, empty and
+    different-sized boxes mixed; more boxes than block slots; an invalid box aborts the call with its error."""
+    g, privs, pks, coeffs, ws, box = make_modp_instance(12, 4, 21)
+    flat = O.box_to_flat(g, box)
+    g2, _, _, _, _, box2 = make_modp_instance(5, 3, 22)
+    flat2 = O.box_to_flat(g2, box2)
+    as_box = lambda f, **kw: dict({"commitments": f["commitments"], "positions": f["positions"], "pubkeys": f["publickeys"],
+                                   "shares": f["shares"], "responses": f["responses"], "challenge": f["challenge"]}, **kw)
+    tampered = bytearray(flat["responses"]); tampered[700] ^= 4
+    empty = as_box(flat, positions=[], pubkeys=b"", shares=b"", responses=b"")
+    boxes = ([as_box(flat), as_box(flat, responses=bytes(tampered)), as_box(flat2), empty] * 6)[:21]
+    want = []
+    for b in boxes:
+        r = engine.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"],
+                                       b["challenge"])
+        want.append((r["verdict"], r["digest"]))
+    assert want[0] == (True, box["_digest"]) and want[1][0] is False and want[2] == (True, box2["_digest"])
+    engine.pipeline_stats(reset=True)
+    for depth, threads in ((1, 1), (3, 2), (16, 8)):
+        assert engine.verify_many(boxes, depth=depth, hash_threads=threads) == want
+    st = engine.pipeline_stats()
+    assert st["blocks"] == 3 * sum(1 for b in boxes if b["positions"])
+    assert st["hash_ms"] > 0 and st["enqueue_ms"] > 0
+    bad = as_box(flat, positions=[-1] + flat["positions"][1:])
+    with pytest.raises(capi.EngineError):
+        engine.verify_many([as_box(flat)] * 3 + [bad] + [as_box(flat)] * 3, depth=4, hash_threads=2)
+    # the engine is usable afterwards (no slot left busy)
+    assert engine.verify_many([as_box(flat)], depth=1, hash_threads=1) == [want[0]]
