@@ -71,7 +71,7 @@ def keygen(rng: random.Random) -> int:
 
 
 PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "8"))   # boxes in flight (the engine has 16 block slots)
-HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "4"))   # host threads absorbing (hashing) boxes at N=1
+HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "6"))   # host threads absorbing (hashing) boxes at N=1
 USE_VERIFY_MANY = os.environ.get("MPVSS_BENCH_VERIFY_MANY", "1") != "0"   # N=1: the library's own pipeline (0: Python threads)
 
 
@@ -356,15 +356,24 @@ def main():
         chain_len = -(-n // chains)
         w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
         m0 = chains * t                                                  # the seeds: m0 consecutive positions, by Horner
-        inv_tree, m = 0, m0
-        while m > 1:                                                     # simultaneous inversion: 3 products per node
-            inv_tree += 3 * m
-            m = -(-m // 16)
+        def inv_tree_products(m):                                         # simultaneous inversion: 3 products per node
+            total = 0
+            while m > 1:
+                total += 3 * m
+                m = -(-m // 16)
+            return total
         steps = (chain_len - 1 - w0) + (w0 + t - 1)                      # forward + backward pipeline of every chain
-        mm_x = (horner_modmuls(positions[chains * w0:chains * w0 + m0], t) + inv_tree + chains * t * (t - 1)
-                + chains * t * steps + n)
-        x_path = (f"forward differences: {chains} strided chains stepping both ways from {m0} Horner seeds in their "
-                  f"middle (also outputs), inverses by simultaneous inversion, {steps} lock-step products per chain and level")
+        two_level = os.environ.get("MPVSS_FD_L1", "1") != "0" and chains > 1
+        if two_level:     # Horner for t seeds only; a stride-1 chain steps through the other (chains-1)*t seed positions
+            seed_work = (horner_modmuls(positions[chains * w0:chains * w0 + t], t) + inv_tree_products(t) + t * (t - 1)
+                         + t * (m0 - 1))
+            seed_txt = f"{t} Horner seeds, a stride-1 chain through the other {m0 - t} seed positions"
+        else:
+            seed_work = horner_modmuls(positions[chains * w0:chains * w0 + m0], t)
+            seed_txt = f"{m0} Horner seeds"
+        mm_x = seed_work + inv_tree_products(m0) + chains * t * (t - 1) + chains * t * steps + n
+        x_path = (f"forward differences: {chains} strided chains stepping both ways from {m0} seeds in their middle "
+                  f"(also outputs; {seed_txt}), inverses by simultaneous inversion, {steps} lock-step products per chain and level")
     else:
         mm_x = horner_modmuls(positions, t) + n
         x_path = "Horner in the exponent"

@@ -178,10 +178,18 @@ int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space, const uint
 /* n independent share-box proofs, src/participant.rs:361-386 -> src/dleq.rs:275-302:
  *   a1 = G^r_i * pk_i^c_i, a2 = S_i^r_i * Y_i^c_i,
  *   verdicts[i] = ( hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1) framed(a2))) == c_i ).
- * pk, s (decrypted shares S_i), y (encrypted shares Y_i), c, r: n x 256 in `space`;
- * verdicts: n bytes, host. */
+ * Everything runs on the device, the hashing too (one lane per share, verdict_kernels.hip); only the n verdict bytes
+ * come back.  pk, s (decrypted shares S_i), y (encrypted shares Y_i), c, r: n x 256 in `space`; verdicts: n bytes, host. */
 int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
                              const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_host);
+/* The same in two steps, so that several batches are in flight (they share the sixteen block slots and the FIFO order
+ * of mpvss_modp_verify_block_compute / _absorb): `compute` only enqueues GPU work and returns; `absorb` waits for the
+ * oldest batch and hands out its verdict bytes.  verdicts_dev_out (optional, device memory, n bytes) receives the
+ * verdicts in stream order as well -- the tensor a multi-GPU caller all-gathers over RCCL without a host round trip
+ * (valid once the batch has been absorbed or mpvss_ctx_synchronize has returned). */
+int mpvss_modp_verify_shares_compute(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
+                                     const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_dev_out);
+int mpvss_modp_verify_shares_absorb(mpvss_ctx* ctx, uint8_t* verdicts_host);
 
 /* ---- distribute_secret, group part ------------------------------------------------------ */
 

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
     "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_sha256_uses_shani",
+    "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
 )
 
 GROUP_SECP256K1 = 1
@@ -89,6 +90,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_verify_distribution.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p,
                                                    C.POINTER(ci), u8p, u8p, u8p, u8p]
     lib.mpvss_modp_verify_shares.argtypes = [vp, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_verify_shares_compute.argtypes = [vp, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_modp_verify_shares_absorb.argtypes = [vp, u8p]
     lib.mpvss_modp_distribute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_sha256.argtypes = [u8p, sz, u8p]
     lib.mpvss_sha256.restype = None
@@ -407,6 +410,21 @@ class Engine:
         kv, pv = _out(n)
         self._check(self.lib.mpvss_modp_verify_shares(self.ctx, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
                                                       k[4][1], n, pv), "verify_shares")
+        return bytes(kv)[:n]
+
+    def verify_shares_compute(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes, verdicts_dev_ptr: int = 0) -> int:
+        """Enqueue one batch of share-box proofs (returns its size); verdicts_dev_ptr: optional device address that
+        receives the n verdict bytes in stream order (e.g. a torch uint8 tensor's data_ptr())."""
+        n = len(pk) // EB
+        k = [_buf(x) for x in (pk, s, y, c, r)]
+        self._check(self.lib.mpvss_modp_verify_shares_compute(self.ctx, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                              k[4][1], n, C.c_void_p(verdicts_dev_ptr or None)),
+                    "verify_shares_compute")
+        return n
+
+    def verify_shares_absorb(self, n: int) -> bytes:
+        kv, pv = _out(n)
+        self._check(self.lib.mpvss_modp_verify_shares_absorb(self.ctx, pv), "verify_shares_absorb")
         return bytes(kv)[:n]
 
     def distribute(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, p_values: bytes,

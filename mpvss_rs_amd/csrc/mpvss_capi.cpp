@@ -22,6 +22,7 @@
 #include "host_modq.h"
 #include "modp_kernels.h"
 #include "sha256.h"
+#include "verdict_kernels.h"
 
 namespace {
 
@@ -72,6 +73,7 @@ struct mpvss_ctx {
     DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
     DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root, fd_hand_t, fd_hand_s;   // forward differences
     DevBuf tab3, gr_m;   // X tables of a1; gr_m: g^r_i in Montgomery form
+    DevBuf verd;         // per-share verdict bytes of verify_share batches (K7)
     const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
     struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
       uint8_t in_be[256], out_be[256];
@@ -87,7 +89,7 @@ struct mpvss_ctx {
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
-              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &tab3, &gr_m};
+              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &tab3, &gr_m, &verd};
     }
   };
   Work work0;
@@ -123,6 +125,7 @@ struct mpvss_ctx {
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
+    int kind = 0;                  // 0: block of verify_distribution_shares, 1: batch of verify_share proofs (W_B)
     double enqueue_ms = 0;         // host time spent enqueueing this block's GPU work
     hipEvent_t done = nullptr;
     SpanSet spans;
@@ -437,8 +440,8 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
   for (hipEvent_t* e : {&w.ev_fork, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_a2, hipEventDisableTiming));
-  HIPCHK(ctx, hipHostMalloc((void**)&w.root, sizeof(*w.root), hipHostMallocDefault));
-  w.root->one = 1;
+  HIPCHK(ctx, hipHostMalloc((void**)&w.root, 2 * sizeof(*w.root), hipHostMallocDefault));   // one mailbox per seeding level
+  w.root[0].one = 1;
   w.ready = true;
   return 0;
 }
@@ -738,15 +741,23 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   const int w0 = (chain_len - (int)t) / 2;
   const size_t seed0 = (size_t)S * w0;    // index of the first seed position
   const int m0 = (int)(S * t);
+  // Two-level seeding (MPVSS_FD_L1, default on): Horner's rule -- about 7 000 products per seed at (65536, 256) -- only
+  // for the first t of the S*t seed positions; a stride-1 forward-difference chain built from those t values steps
+  // through the remaining (S-1)*t seed positions at t products each.  Same values (uniqueness of the group element);
+  // 180 products per share fewer at (65536, 256), for about 15 ms more latency of the box's chain.
+  static const int two_level_env = fd_env("MPVSS_FD_L1", 1);
+  const bool two_level = two_level_env && S > 1;
   // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
   constexpr int G = 16;
-  std::vector<int> ms{m0};
-  while (ms.back() > 1) ms.push_back((ms.back() + G - 1) / G);
-  const int nlev = (int)ms.size() - 1;
-  std::vector<size_t> pre_off(nlev + 1, 0), tot_off(nlev + 1, 0);
+  auto tree_sizes = [&](int m) {
+    std::vector<int> ms{m};
+    while (ms.back() > 1) ms.push_back((ms.back() + G - 1) / G);
+    return ms;
+  };
+  const std::vector<int> ms_all = tree_sizes(m0);
   size_t pre_total = 0, tot_total = 0;
-  for (int l = 0; l < nlev; ++l) { pre_off[l] = pre_total; pre_total += (size_t)ms[l]; }
-  for (int l = 1; l <= nlev; ++l) { tot_off[l] = tot_total; tot_total += (size_t)ms[l]; }
+  for (size_t l = 0; l + 1 < ms_all.size(); ++l) pre_total += (size_t)ms_all[l];
+  for (size_t l = 1; l < ms_all.size(); ++l) tot_total += (size_t)ms_all[l];
 
   mpvss_ctx::Work& w = *ctx->w;
   w.fd_used = true;
@@ -767,37 +778,63 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   uint32_t* xseed = xm + seed0 * MODP_L;
   uint32_t* state_fwd = (uint32_t*)w.fd_state.p;
   uint32_t* state_bwd = state_fwd + (size_t)m0 * MODP_L;
-  auto level_in = [&](int l) { return l == 0 ? xseed : (uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
-  auto level_inv = [&](int l) { return l == 0 ? (uint32_t*)w.fd_xinv.p : (uint32_t*)w.fd_totinv.p + tot_off[l] * MODP_L; };
-  w.root->one = 1;     // pinned: the copy below is asynchronous and reads it in stream order
-  HIPCHK(ctx, hipMemcpyAsync(flag, &w.root->one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  // inverses of the m Montgomery-form numbers at `in` into `inv_out`: Montgomery's trick on the device (3 products per
+  // number), the single inversion of the root on the host, in stream order (no host synchronisation).  A root that
+  // is 0 mod q (some X is 0: a commitment was) clears the flag.  `job`: pinned mailbox of the host callback.
+  auto invert_batch = [&](const uint32_t* in, int m, uint32_t* inv_out, mpvss_ctx::Work::RootJob* job) -> int {
+    const std::vector<int> ms = tree_sizes(m);
+    const int nlev = (int)ms.size() - 1;
+    std::vector<size_t> pre_off(nlev + 1, 0), tot_off(nlev + 1, 0);
+    size_t po = 0, to = 0;
+    for (int l = 0; l < nlev; ++l) { pre_off[l] = po; po += (size_t)ms[l]; }
+    for (int l = 1; l <= nlev; ++l) { tot_off[l] = to; to += (size_t)ms[l]; }
+    auto level_in = [&](int l) { return l == 0 ? in : (const uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
+    auto level_out = [&](int l) { return (uint32_t*)w.fd_tot.p + tot_off[l] * MODP_L; };
+    auto level_inv = [&](int l) { return l == 0 ? inv_out : (uint32_t*)w.fd_totinv.p + tot_off[l] * MODP_L; };
+    for (int l = 0; l < nlev; ++l)
+      LAUNCHCHK(ctx, modp_launch_binv_up(level_in(l), ms[l], G, (uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_out(l + 1),
+                                         flag, ctx->consts, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_from_mont(level_in(nlev), 1, root_be, flag, ctx->consts, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(job->in_be, root_be, EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipLaunchHostFunc(ctx->stream, invert_root_on_host, job));
+    HIPCHK(ctx, hipMemcpyAsync(rootinv_be, job->out_be, EB, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dok, &job->ok, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_fd_apply_ok(dok, flag, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_to_mont(rootinv_be, level_inv(nlev), 1, ctx->consts, ctx->stream));
+    for (int l = nlev - 1; l >= 0; --l)
+      LAUNCHCHK(ctx, modp_launch_binv_down(level_in(l), (const uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_inv(l + 1),
+                                           ms[l], G, level_inv(l), flag, ctx->consts, ctx->stream));
+    return 0;
+  };
+  // handoff buffers of the pipelined kernels (zeroed per call): [tables L2][stepping L2][tables L1][stepping L1]
+  const size_t hand_t = modp_fd_table_hand_words(S, (int)t) * 4, hand_s = modp_fd_step_hand_words(S, (int)t, chain_len) * 4;
+  const size_t hand_t1 = two_level ? modp_fd_table_hand_words(1, (int)t) * 4 : 0;
+  const size_t hand_s1 = two_level ? modp_fd_step_hand_words(1, (int)t, m0) * 4 : 0;
+  RET_IF(ensure(ctx, w.fd_hand_t, hand_t + hand_t1));
+  RET_IF(ensure(ctx, w.fd_hand_s, hand_s + hand_s1));
+  w.root[0].one = 1;     // pinned: the copy below is asynchronous and reads it in stream order
+  HIPCHK(ctx, hipMemcpyAsync(flag, &w.root[0].one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
   if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions(dpos, (int)cnt, flag, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_t.p, 0, hand_t + hand_t1, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, hand_s + hand_s1, ctx->stream));
   // seeds: X at the S*t positions from seed0, kept in Montgomery form
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
-                                               dpos + seed0, m0, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
-  // their inverses: Montgomery's trick on the device, the single inversion of the root on the host, in stream
-  // order (no host synchronisation).  A root that is 0 mod q (some commitment is 0) clears the flag.
-  for (int l = 0; l < nlev; ++l)
-    LAUNCHCHK(ctx, modp_launch_binv_up(level_in(l), ms[l], G, (uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_in(l + 1),
-                                       flag, ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_from_mont(level_in(nlev), 1, root_be, flag, ctx->consts, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(w.root->in_be, root_be, EB, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipLaunchHostFunc(ctx->stream, invert_root_on_host, w.root));
-  HIPCHK(ctx, hipMemcpyAsync(rootinv_be, w.root->out_be, EB, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(dok, &w.root->ok, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_apply_ok(dok, flag, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_to_mont(rootinv_be, level_inv(nlev), 1, ctx->consts, ctx->stream));
-  for (int l = nlev - 1; l >= 0; --l)
-    LAUNCHCHK(ctx, modp_launch_binv_down(level_in(l), (const uint32_t*)w.fd_pre.p + pre_off[l] * MODP_L, level_inv(l + 1),
-                                         ms[l], G, level_inv(l), flag, ctx->consts, ctx->stream));
+  if (two_level) {
+    LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
+                                                 dpos + seed0, (int)t, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
+    RET_IF(invert_batch(xseed, (int)t, (uint32_t*)w.fd_xinv.p, &w.root[1]));
+    // one chain of stride 1 over the seed window: tables from its first t values, then m0 - 1 steps forward
+    LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, 1, (int)t, state_fwd, state_bwd,
+                                        (uint32_t*)((uint8_t*)w.fd_hand_t.p + hand_t), flag, ctx->consts, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, 1, (int)t, 0, m0, m0, xseed,
+                                       (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), flag, 0, ctx->consts, ctx->stream));
+  } else {
+    LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
+                                                 dpos + seed0, m0, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
+  }
+  RET_IF(invert_batch(xseed, m0, (uint32_t*)w.fd_xinv.p, &w.root[0]));
   // difference tables, stepping, conversion -- all gated on flag == 1.  Both kernels are pipelines of single-wave
   // stages that hand numbers down through zeroed buffers (see modp_kernels.hip).
-  const size_t hand_t = modp_fd_table_hand_words(S, (int)t) * 4, hand_s = modp_fd_step_hand_words(S, (int)t, chain_len) * 4;
-  RET_IF(ensure(ctx, w.fd_hand_t, hand_t));
-  RET_IF(ensure(ctx, w.fd_hand_s, hand_s));
-  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_t.p, 0, hand_t, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, hand_s, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, S, (int)t, state_fwd, state_bwd,
                                       (uint32_t*)w.fd_hand_t.p, flag, ctx->consts, ctx->stream));
   static const int inject_fault = fd_env("MPVSS_FD_TEST_FAULT", 0);   // tests only: one stage gives up, the flag falls
@@ -962,6 +999,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
   }
   sl.n = n;
+  sl.kind = 0;
   sl.check_positions = false;
   sl.fd_used = false;
   sl.fd_chunks = 0;
@@ -1142,6 +1180,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
   mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
   if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
+  if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the oldest block in flight is a verify_share batch");
   const size_t n = sl.n;
   ++ctx->tail;
   if (n == 0) {
@@ -1350,10 +1389,12 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    size_t issued = 0, claimed = 0, done = 0;
+    size_t issued = 0, claimed = 0, low = 0;   // low: boxes 0 .. low-1 are finished (their block slots are free)
+    std::vector<char> finished;
     bool stop = false;          // no more boxes will be issued
     int rc = MPVSS_OK;
   } sh;
+  sh.finished.assign(count, 0);
   const unsigned base_tail = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->tail; }();
 
   auto worker = [&]() {
@@ -1378,7 +1419,8 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
                                            digests32 ? digests32 + 32 * idx : nullptr);
       {
         std::lock_guard<std::mutex> l(sh.m);
-        ++sh.done;
+        if (idx < count) sh.finished[idx] = 1;
+        while (sh.low < count && sh.finished[sh.low]) ++sh.low;
         if (rc != MPVSS_OK && sh.rc == MPVSS_OK) sh.rc = rc;
       }
       sh.cv.notify_all();
@@ -1391,7 +1433,8 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   for (size_t b = 0; b < count; ++b) {
     {
       std::unique_lock<std::mutex> l(sh.m);
-      sh.cv.wait(l, [&] { return sh.issued - sh.done < (size_t)depth || sh.rc != MPVSS_OK; });
+      // slots are a ring: box b may be enqueued once box b - depth has been absorbed (the threads finish in any order)
+      sh.cv.wait(l, [&] { return sh.issued - sh.low < (size_t)depth || sh.rc != MPVSS_OK; });
       if (sh.rc != MPVSS_OK) break;
     }
     const mpvss_modp_box& bx = boxes[b];
@@ -1439,24 +1482,68 @@ extern "C" int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* ou
 extern "C" int mpvss_sha256_uses_shani(void) { return mpvss::sha256_uses_shani() ? 1 : 0; }
 
 // ---- verify_share, batched ----------------------------------------------------------------------------
-extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s,
-                                        const uint8_t* y, const uint8_t* c, const uint8_t* r, size_t n,
-                                        uint8_t* verdicts_host) {
-  if (!ctx) return MPVSS_E_INVALID;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  if (n == 0) return MPVSS_OK;
-  if (!pk || !s || !y || !c || !r || !verdicts_host) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
+// n independent share-box proofs (participant.rs:361-386 -> dleq.rs:275-302).  Everything runs on the device: the two
+// double exponentiations, then K7 (verdict_kernels.hip): one lane per share hashes the four framed elements, applies
+// hash_to_scalar and compares with c_i -- a verdict byte per share in HBM.  Batches go through the same block slots
+// as the boxes of verify_distribution_shares (own workspace and stream pair each), so several are in flight at once.
+namespace {
+
+int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
+                                 const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_dev_out) {
+  if (n > 0 && (!pk || !s || !y || !c || !r)) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify_shares: sixteen blocks already in flight, absorb one first");
+  const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!sl.done) {
+    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+  }
+  sl.n = n;
+  sl.kind = 1;
+  sl.check_positions = false;
+  sl.fd_used = false;
+  sl.fd_chunks = 0;
+  sl.enqueue_ms = 0;
+  if (n == 0) {
+    sl.busy = true;
+    ++ctx->head;
+    return MPVSS_OK;
+  }
+  RET_IF(work_init(ctx, sl.work, nullptr));
+  struct Restore {
+    mpvss_ctx* c;
+    hipStream_t a, b;
+    ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
+  } restore{ctx, ctx->stream, ctx->stream_b};
+  ctx->w = &sl.work;
+  ctx->stream = sl.work.sa;
+  ctx->stream_b = sl.work.sb;
+  ctx->sp = &sl.spans;
   spans_reset(ctx);
+  // pinned staging: the verdict bytes and, for host callers, a copy of the five input arrays
+  const size_t need = n + (space == MPVSS_HOST ? 5 * n * EB : 0);
+  if (need > sl.cap) {
+    if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
+    sl.pin = nullptr;
+    sl.cap = 0;
+    hipError_t e = hipHostMalloc(&sl.pin, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(block staging)", e);
+    sl.cap = need;
+  }
+  uint8_t* hv = (uint8_t*)sl.pin;
+  if (space == MPVSS_HOST) {
+    uint8_t* in = hv + n;
+    const uint8_t* src[5] = {pk, s, y, c, r};
+    for (int k = 0; k < 5; ++k) memcpy(in + (size_t)k * n * EB, src[k], n * EB);
+    pk = in; s = in + n * EB; y = in + 2 * n * EB; c = in + 3 * n * EB; r = in + 4 * n * EB;
+  }
   const uint32_t* cG;
   RET_IF(comb_table(ctx, 1, &cG, n));
-  std::vector<uint8_t> hc, hpk, hy;
+  RET_IF(ensure(ctx, ctx->w->verd, n));
+  uint8_t* dv = (uint8_t*)ctx->w->verd.p;
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
-    RET_IF(small_vec_to_host(ctx, space, c + off * EB, cnt * EB, hc));
-    bool small = true;
-    for (size_t i = 0; i < cnt && small; ++i) small = fits_256_bits(hc.data() + i * EB);
-    const int c_windows = small ? 64 : 512;
     const void *dpk, *ds, *dy, *dc, *dr;
     RET_IF(stage_in(ctx, space, pk + off * EB, cnt * EB, ctx->w->in_a, &dpk));
     RET_IF(stage_in(ctx, space, s + off * EB, cnt * EB, ctx->w->in_b, &ds));
@@ -1468,31 +1555,83 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
     uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     // a1 = G^r * pk^c ; a2 = S^r * Y^c                       dleq.rs:66-84 via participant.rs:376-385
-    RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB,
-                     c_windows, cnt, da1, cG));
-    RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)ds, (const uint8_t*)dy, (const uint8_t*)dr, (const uint8_t*)dc, EB,
-                     c_windows, cnt, da2));
-    RET_IF(ensure_pinned(ctx, cnt * EB * 2));
-    uint8_t* h1 = (uint8_t*)ctx->pin;
-    uint8_t* h2 = h1 + cnt * EB;
-    HIPCHK(ctx, hipMemcpyAsync(h1, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h2, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    RET_IF(small_vec_to_host(ctx, space, pk + off * EB, cnt * EB, hpk));
-    RET_IF(small_vec_to_host(ctx, space, y + off * EB, cnt * EB, hy));
-    for (size_t i = 0; i < cnt; ++i) {
-      mpvss::Sha256 h;                                      // dleq.rs:289 fresh hasher per proof
-      frame_update(h, hpk.data() + i * EB);
-      frame_update(h, hy.data() + i * EB);
-      frame_update(h, h1 + i * EB);
-      frame_update(h, h2 + i * EB);
-      uint8_t digest[32];
-      h.final(digest);
-      verdicts_host[off + i] = challenge_matches(digest, hc.data() + i * EB) ? 1 : 0;
-    }
+    // Only the low 256 bits of c_i enter the exponentiations: a challenge >= 2^256 can never equal the 256-bit hash,
+    // and K7 gives such a share the verdict 0 whatever a1, a2 are.
+    RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64, cnt, da1, cG));
+    RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)ds, (const uint8_t*)dy, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64,
+                     cnt, da2));
+    TIMED_LAUNCH(ctx, 0, verdict_launch_modp((const uint8_t*)dpk, (const uint8_t*)dy, da1, da2, (const uint8_t*)dc, (int)cnt,
+                                             dv + off, ctx->stream));
+    if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
-  RET_IF(spans_collect(ctx));
+  HIPCHK(ctx, hipMemcpyAsync(hv, dv, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (verdicts_dev_out) HIPCHK(ctx, hipMemcpyAsync(verdicts_dev_out, dv, n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+  sl.busy = true;
+  sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
+  ++ctx->head;
   return MPVSS_OK;
+}
+
+int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* verdicts_host) {
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
+  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "verify_shares_absorb: no batch in flight");
+  if (sl.kind != 1) return fail(ctx, MPVSS_E_INVALID, "verify_shares_absorb: the oldest block in flight is a verify_distribution block");
+  const size_t n = sl.n;
+  ++ctx->tail;
+  if (n == 0) {
+    sl.busy = false;
+    return MPVSS_OK;
+  }
+  sl.absorbing = true;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  lk.unlock();
+  const auto t_w0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipEventSynchronize(sl.done);
+  const auto t_w1 = std::chrono::steady_clock::now();
+  if (e == hipSuccess && verdicts_host) memcpy(verdicts_host, sl.pin, n);
+  lk.lock();
+  sl.busy = false;
+  sl.absorbing = false;
+  if (e != hipSuccess) return fail(ctx, MPVSS_E_DEVICE, "verify_shares_absorb: hipEventSynchronize", e);
+  RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
+  ctx->pstats.enqueue_ms += sl.enqueue_ms;
+  ctx->pstats.wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count();
+  for (int k = 0; k < 4; ++k) {
+    ctx->pstats.kernel_ms[k] += ctx->kernel_ms[k];
+    ctx->pstats.kernel_launches[k] += (unsigned long long)ctx->kernel_launches[k];
+  }
+  ++ctx->pstats.blocks;
+  return MPVSS_OK;
+}
+
+}  // namespace
+
+extern "C" int mpvss_modp_verify_shares_compute(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s,
+                                                const uint8_t* y, const uint8_t* c, const uint8_t* r, size_t n,
+                                                uint8_t* verdicts_dev_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_shares_compute_locked(ctx, space, pk, s, y, c, r, n, verdicts_dev_out);
+}
+
+extern "C" int mpvss_modp_verify_shares_absorb(mpvss_ctx* ctx, uint8_t* verdicts_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  return verify_shares_absorb_locked(ctx, lk, verdicts_host);
+}
+
+extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s,
+                                        const uint8_t* y, const uint8_t* c, const uint8_t* r, size_t n,
+                                        uint8_t* verdicts_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  if (n == 0) return MPVSS_OK;
+  if (!pk || !s || !y || !c || !r || !verdicts_host) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
+  if (ctx->head != ctx->tail)
+    return fail(ctx, MPVSS_E_INVALID, "verify_shares: blocks of the block API are in flight, absorb them first");
+  RET_IF(verify_shares_compute_locked(ctx, space, pk, s, y, c, r, n, nullptr));
+  return verify_shares_absorb_locked(ctx, lk, verdicts_host);
 }
 
 // ---- distribute_secret, group part ---------------------------------------------------------------------
@@ -1999,8 +2138,6 @@ extern "C" int mpvss_ec_verify_shares(mpvss_ctx* ctx, int group, int space, cons
   if (n == 0) return MPVSS_OK;
   if (!pk || !s || !y || !c || !r || !verdicts_host || n > 0x7fffffff)
     return fail(ctx, MPVSS_E_INVALID, "ec_verify_shares: bad argument");
-  RET_IF(ec_check_scalars(ctx, gi, space, r, n, "responses"));
-  RET_IF(ec_check_scalars(ctx, gi, space, c, n, "challenges"));
   const uint8_t* dg;
   RET_IF(ec_generator_dev(ctx, gi, w, nullptr, &dg));
   const void *dpk, *ds, *dy, *dc, *dr;
@@ -2011,34 +2148,36 @@ extern "C" int mpvss_ec_verify_shares(mpvss_ctx* ctx, int group, int space, cons
   RET_IF(stage_in(ctx, space, c, n * 32, w.e, &dc));
   RET_IF(ensure(ctx, w.o1, n * gi->enc));
   RET_IF(ensure(ctx, w.o2, n * gi->enc));
-  RET_IF(ensure(ctx, w.ok, 2 * (n > 4096 ? n : 4096)));
+  const size_t okn = n > 4096 ? n : 4096;
+  RET_IF(ensure(ctx, w.ok, 4 * okn));          // decode flags of a1's and a2's inputs, scalar flags, verdicts
   uint8_t *d1 = (uint8_t*)w.o1.p, *d2 = (uint8_t*)w.o2.p;
+  uint8_t *ok = (uint8_t*)w.ok.p, *dv = ok + 3 * okn;
   // a1 = r*G + c*pk ; a2 = r*S + c*Y
   TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dr, (const uint8_t*)dpk, (const uint8_t*)dc, 32, (int)n,
-                                          d1, (uint8_t*)w.ok.p, ctx->stream));
+                                          d1, ok, ctx->stream));
   TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)ds, gi->enc, (const uint8_t*)dr, (const uint8_t*)dy,
-                                          (const uint8_t*)dc, 32, (int)n, d2, (uint8_t*)w.ok.p + n, ctx->stream));
-  RET_IF(ensure_pinned(ctx, n * gi->enc * 2));
-  uint8_t* h1 = (uint8_t*)ctx->pin;
-  uint8_t* h2 = h1 + n * gi->enc;
-  HIPCHK(ctx, hipMemcpyAsync(h1, d1, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h2, d2, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-  RET_IF(ec_check_ok(ctx, (const uint8_t*)w.ok.p, 2 * n, "share boxes"));
-  std::vector<uint8_t> hpk, hy, hc;
-  RET_IF(small_vec_to_host(ctx, space, pk, n * gi->enc, hpk));
-  RET_IF(small_vec_to_host(ctx, space, y, n * gi->enc, hy));
-  RET_IF(small_vec_to_host(ctx, space, c, n * 32, hc));
-  for (size_t i = 0; i < n; ++i) {
-    mpvss::Sha256 h;
-    ec_frame_update(h, hpk.data() + i * gi->enc, gi->enc);
-    ec_frame_update(h, hy.data() + i * gi->enc, gi->enc);
-    ec_frame_update(h, h1 + i * gi->enc, gi->enc);
-    ec_frame_update(h, h2 + i * gi->enc, gi->enc);
-    uint8_t digest[32], hs[32];
-    h.final(digest);
-    ec_hash_to_scalar(gi, digest, hs);
-    verdicts_host[i] = memcmp(hs, hc.data() + i * 32, 32) == 0 ? 1 : 0;
-  }
+                                          (const uint8_t*)dc, 32, (int)n, d2, ok + n, ctx->stream));
+  // K7: per-share SHA-256 of the framed elements, hash_to_scalar, comparison with c_i -- on the device
+  TIMED_LAUNCH(ctx, 0, verdict_launch_ec(group, (const uint8_t*)dpk, (const uint8_t*)dy, d1, d2, (const uint8_t*)dc,
+                                         (const uint8_t*)dr, (int)n, dv, ok + 2 * n, ctx->stream));
+  RET_IF(ensure_pinned(ctx, 4 * n));
+  uint8_t* hok = (uint8_t*)ctx->pin;
+  HIPCHK(ctx, hipMemcpyAsync(hok, ok, 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(hok + 3 * n, dv, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i)
+    if (!hok[2 * n + i]) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "ec_verify_shares: response or challenge %zu is not below the group order (the reference cannot represent it)", i);
+      return fail(ctx, MPVSS_E_INVALID, buf);
+    }
+  for (size_t i = 0; i < 2 * n; ++i)
+    if (!hok[i]) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "share boxes: element %zu is not a valid group-element encoding", i % n);
+      return fail(ctx, MPVSS_E_INVALID, buf);
+    }
+  memcpy(verdicts_host, hok + 3 * n, n);
   RET_IF(spans_collect(ctx));
   return MPVSS_OK;
 }

@@ -1,0 +1,18 @@
+// Internal launch interface of the per-share verdict kernels (verdict_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* verdict[i] = hash_to_scalar(SHA256(framed(h1_i) framed(h2_i) framed(a1_i) framed(a2_i))) == c_i; all arrays [count][256] */
+int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2, const uint8_t* c,
+                        int count, uint8_t* verdict, hipStream_t s);
+/* group 1 = secp256k1 (33-byte elements), 2 = ristretto255 (32-byte); c, r: [count][32] in the group's byte order;
+ * ok[i] = 0 when c_i or r_i is not below the group order */
+int verdict_launch_ec(int group, const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,
+                      const uint8_t* c, const uint8_t* r, int count, uint8_t* verdict, uint8_t* ok, hipStream_t s);
+#ifdef __cplusplus
+}
+#endif

@@ -40,9 +40,20 @@ def _comm_device(group=None) -> torch.device:
     return torch.device("cpu")
 
 
+class ShardError(capi.EngineError):
+    """Raised on EVERY rank, after the collectives of the call have completed, when some rank's engine failed."""
+
+
+STATE = capi.TRANSCRIPT_STATE_BYTES
+
+
 class ShardedVerifier:
     """Runs one box over all ranks.  `engine` is anything with the block interface of
-    mpvss_rs_amd.capi.Engine (verify_block_compute / verify_block_absorb / verify_shares)."""
+    mpvss_rs_amd.capi.Engine (verify_block_compute / verify_block_absorb / verify_shares).
+
+    A rank whose engine fails (a negative position in its block, an allocation failure, ...) still takes part in
+    the chain and in every collective: it forwards the hash state marked as poisoned, so no other rank is left
+    waiting; afterwards all ranks raise ShardError together (the reference panics on such a box)."""
 
     def __init__(self, engine, group=None):
         self.engine = engine
@@ -51,50 +62,80 @@ class ShardedVerifier:
         self.world = dist.get_world_size(group)
         self.dev = _comm_device(group)
 
+    def _gather_status(self, count: int, failed: bool):
+        mine = torch.tensor([count, int(failed)], dtype=torch.int64, device=self.dev)
+        gathered = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(gathered, mine, group=self.group)
+        rows = [[int(v) for v in g.cpu().tolist()] for g in gathered]
+        return [r[0] for r in rows], [k for k, r in enumerate(rows) if r[1]]
+
     # -- verify_distribution_shares ---------------------------------------------------------
     def verify_distribution(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, shares: bytes,
                             responses: bytes, challenge: bytes):
         """Arguments are THIS rank's block (commitments and challenge are replicated).
-        Returns (verdict, digest, statuses) on every rank."""
+        Returns (verdict, digest, counts) on every rank; raises ShardError on every rank if any rank failed."""
         eng, rank, world = self.engine, self.rank, self.world
-        eng.verify_block_compute(commitments, positions, pubkeys, shares, responses, challenge)
+        error: Optional[Exception] = None
+        enqueued = False
+        try:
+            eng.verify_block_compute(commitments, positions, pubkeys, shares, responses, challenge)
+            enqueued = True
+        except Exception as exc:      # still join the chain below
+            error = exc
+        poisoned = False
         if rank == 0:
             state = capi.transcript_init()
         else:
-            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=self.dev)
+            buf = torch.empty(STATE + 1, dtype=torch.uint8, device=self.dev)
             dist.recv(buf, src=rank - 1, group=self.group)
-            state = bytes(buf.cpu().numpy().tobytes())
-        state = eng.verify_block_absorb(state)
-        out = torch.zeros(33, dtype=torch.uint8, device=self.dev)
+            raw = bytes(buf.cpu().numpy().tobytes())
+            state, poisoned = raw[:STATE], bool(raw[STATE])
+        if enqueued:
+            try:
+                state = eng.verify_block_absorb(state)          # also frees the block slot when the chain is poisoned
+            except Exception as exc:
+                error = error or exc
+        poisoned = poisoned or error is not None
+        out = torch.zeros(34, dtype=torch.uint8, device=self.dev)
         if rank + 1 < world:
-            msg = torch.frombuffer(bytearray(state), dtype=torch.uint8).to(self.dev)
+            msg = torch.frombuffer(bytearray(state + bytes([int(poisoned)])), dtype=torch.uint8).to(self.dev)
             dist.send(msg, dst=rank + 1, group=self.group)
         else:
-            verdict, digest = capi.transcript_verdict(state, challenge)
-            out = torch.frombuffer(bytearray(bytes([int(verdict)]) + digest), dtype=torch.uint8).to(self.dev)
+            if poisoned:
+                verdict, digest = False, bytes(32)
+            else:
+                verdict, digest = capi.transcript_verdict(state, challenge)
+            out = torch.frombuffer(bytearray(bytes([int(verdict), int(poisoned)]) + digest), dtype=torch.uint8).to(self.dev)
         dist.broadcast(out, src=world - 1, group=self.group)
         raw = bytes(out.cpu().numpy().tobytes())
-        # per-rank status record: (shares in block); one small all-gather per box
-        mine = torch.tensor([len(positions)], dtype=torch.int64, device=self.dev)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=self.group)
-        return bool(raw[0]), raw[1:33], [int(g.item()) for g in gathered]
+        counts, failed = self._gather_status(len(positions), error is not None)   # one small all-gather per box
+        if failed:
+            raise ShardError(f"verify_distribution failed on rank(s) {failed}" + (f": {error}" if error else "")) from error
+        return bool(raw[0]), raw[2:34], counts
 
     # -- verify_share, batched ------------------------------------------------------------------
     def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes, block: int) -> bytes:
         """Arguments are this rank's block of share boxes; `block` is the (equal) padded block
-        length.  Returns the verdict bytes of ALL ranks, in rank order, padding removed by the
-        caller via the returned per-rank counts."""
+        length.  Returns the verdict bytes of ALL ranks, in rank order, padding removed.
+
+        With RCCL ("nccl" group) the engine writes its verdict bytes straight into the device tensor that is
+        all-gathered: the per-share verdicts never visit the host before the collective."""
         n = len(pk) // EB
-        mine = self.engine.verify_shares(pk, s, y, c, r) if n else b""
         t = torch.zeros(block, dtype=torch.uint8, device=self.dev)
-        if n:
-            t[:n] = torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(self.dev)
+        error: Optional[Exception] = None
+        try:
+            if n and self.dev.type == "cuda" and hasattr(self.engine, "verify_shares_compute"):
+                self.engine.verify_shares_compute(pk, s, y, c, r, verdicts_dev_ptr=t.data_ptr())
+                self.engine.verify_shares_absorb(n)             # waits for the batch: t[:n] is final
+            elif n:
+                mine = self.engine.verify_shares(pk, s, y, c, r)
+                t[:n] = torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(self.dev)
+        except Exception as exc:
+            error = exc
         allv = torch.zeros(block * self.world, dtype=torch.uint8, device=self.dev)
         dist.all_gather_into_tensor(allv, t, group=self.group)   # RCCL all-gather of per-share verdicts
-        counts = torch.tensor([n], dtype=torch.int64, device=self.dev)
-        gathered = [torch.zeros_like(counts) for _ in range(self.world)]
-        dist.all_gather(gathered, counts, group=self.group)
+        counts, failed = self._gather_status(n, error is not None)
+        if failed:
+            raise ShardError(f"verify_shares failed on rank(s) {failed}" + (f": {error}" if error else "")) from error
         raw = bytes(allv.cpu().numpy().tobytes())
-        out = b"".join(raw[k * block: k * block + int(g.item())] for k, g in enumerate(gathered))
-        return out
+        return b"".join(raw[k * block: k * block + cnt] for k, cnt in enumerate(counts))

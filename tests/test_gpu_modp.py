@@ -6,6 +6,7 @@ import pytest
 
 import mpvss_oracle as O
 from helpers import EB, cat, make_modp_instance, modp_keygen, split
+from mpvss_rs_amd import capi
 
 pytestmark = pytest.mark.gpu
 
@@ -171,6 +172,85 @@ def test_verify_shares_batch(engine):
     exp = [O.dleq_verify(g, g.generator(), pks[i], S[i], Y[i], c[i], r[i]) for i in range(9)]   # participant.rs:361-386
     assert list(verdicts) == [int(v) for v in exp]
     assert exp == [True, True, False, True, True, False, True, False, True]
+
+
+def test_verify_shares_device_hash_framing_edge_cases(engine):
+    """K7 hashes on the device: elements with leading zero bytes are framed with their minimal length (255 bytes,
+    1 byte, zero as one 0x00 byte -- modp.rs:150-152), elements above q as given, and a challenge >= 2^256 never
+    verifies even when its low 256 bits equal the hash."""
+    rng = random.Random(77)
+    pk = [5, 0, 1 << 2039, (1 << 2040) - 1, rng.randrange(Q), Q + 3, (1 << 2048) - 1, 255, 256, rng.randrange(Q)]
+    Y = [1 << 2039, 7, 0, rng.randrange(1 << 2033), 1, rng.randrange(Q), 2, (1 << 2047), 65535, rng.randrange(Q)]
+    n = len(pk)
+    S = [rng.randrange(Q) for _ in range(n)]
+    r = [rng.randrange(Q - 1) for _ in range(n)]
+    r[3] = 0
+    c = [rng.randrange(1 << 256) for _ in range(n)]
+    exp = [O.dleq_verify(G, G.generator(), pk[i], S[i], Y[i], c[i], r[i]) for i in range(n)]
+    got = engine.verify_shares(cat(G, pk), cat(G, S), cat(G, Y), cat(G, c), cat(G, r))
+    assert list(got) == [int(v) for v in exp] and not any(exp)
+    # honest proofs, then two challenges lifted above 2^256: their low 256 bits still equal the hash
+    g, privs, pks, coeffs, ws, box = make_modp_instance(6, 3, 23)
+    sbs = [O.extract_secret_share(g, box, k, modp_keygen(g, rng)) for k in privs]
+    keys = [g.element_to_bytes(p) for p in pks]
+    Yh = [box["shares"][k] for k in keys]
+    Sh = [sb["share"] for sb in sbs]
+    ch = [sb["challenge"] for sb in sbs]
+    rh = [sb["response"] for sb in sbs]
+    ch[1] += 1 << 256
+    ch[4] += 1 << 2047
+    got = engine.verify_shares(cat(g, pks), cat(g, Sh), cat(g, Yh), cat(g, ch), cat(g, rh))
+    assert list(got) == [1, 0, 1, 1, 0, 1]
+    assert [O.dleq_verify(g, g.generator(), pks[i], Sh[i], Yh[i], ch[i], rh[i]) for i in range(6)] == \
+        [True, False, True, True, False, True]
+
+
+def test_verify_shares_transcript_with_short_elements_verifies(engine):
+    """Share boxes whose pk and Y have one-byte encodings (0 and 1) and whose c IS the hash of the resulting transcript
+    -- possible because 0^c and 1^c do not depend on c: the verdict must be 1, i.e. the device frames short elements
+    exactly as the reference does (a wrong length prefix or padding would change the hash)."""
+    rng = random.Random(78)
+    pk, Y, S, r, c = [], [], [], [], []
+    for p, y in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        s_, r_ = rng.randrange(Q), rng.randrange(1, Q - 1)
+        a1 = pow(2, r_, Q) * p % Q              # G^r * pk^c with pk in {0, 1} and c > 0
+        a2 = pow(s_, r_, Q) * y % Q
+        c_ = G.hash_to_scalar(O.sha256(O.append_transcript(G, p, y, a1, a2)))
+        assert c_ > 0 and O.dleq_verify(G, G.generator(), p, s_, y, c_, r_) is True
+        pk.append(p); Y.append(y); S.append(s_); r.append(r_); c.append(c_)
+    pk += [5, 1 << 2039]; Y += [1 << 2039, 3]; S += [7, 9]; r += [11, 13]; c += [rng.randrange(1 << 256)] * 2
+    got = engine.verify_shares(cat(G, pk), cat(G, S), cat(G, Y), cat(G, c), cat(G, r))
+    assert list(got) == [1, 1, 1, 1, 0, 0]
+
+
+def test_verify_shares_block_api_keeps_batches_in_flight(engine):
+    """verify_shares_compute / _absorb: several batches enqueued, absorbed in FIFO order; a device buffer receives the
+    same verdict bytes; the two block kinds do not mix."""
+    import torch
+    g, privs, pks, coeffs, ws, box = make_modp_instance(9, 3, 21)
+    rng = random.Random(5)
+    sbs = [O.extract_secret_share(g, box, k, modp_keygen(g, rng)) for k in privs]
+    keys = [g.element_to_bytes(p) for p in pks]
+    Y = [box["shares"][k] for k in keys]
+    S = [sb["share"] for sb in sbs]
+    c = [sb["challenge"] for sb in sbs]
+    rs = [sb["response"] for sb in sbs]
+    batches, want = [], []
+    for k in range(5):
+        r = list(rs)
+        r[k] ^= 1                                  # batch k: share k tampered
+        batches.append((cat(g, pks), cat(g, S), cat(g, Y), cat(g, c), cat(g, r)))
+        want.append(bytes(0 if i == k else 1 for i in range(9)))
+    dev = [torch.zeros(9, dtype=torch.uint8, device="cuda") for _ in batches]
+    for b, d in zip(batches, dev):
+        engine.verify_shares_compute(*b, verdicts_dev_ptr=d.data_ptr())
+    with pytest.raises(capi.EngineError):          # the oldest block is a verify_share batch
+        engine.verify_block_absorb(capi.transcript_init())
+    got = [engine.verify_shares_absorb(9) for _ in batches]
+    assert got == want
+    assert [bytes(d.cpu().numpy().tobytes()) for d in dev] == want
+    with pytest.raises(capi.EngineError):
+        engine.verify_shares_absorb(9)
 
 
 def test_distribute_group_part(engine):

@@ -21,6 +21,9 @@ class OracleBlockEngine:
 
     def verify_block_compute(self, commitments, positions, pubkeys, shares, responses, challenge):
         O, G = self.O, self.G
+        if any(p < 0 for p in positions):       # the engine's MPVSS_E_INVALID (the reference panics: negative exponent)
+            from mpvss_rs_amd import capi
+            raise capi.EngineError("verify_block_compute failed: rc=-1 negative position")
         sp = lambda b: [int.from_bytes(b[i:i + 256], "big") for i in range(0, len(b), 256)]
         cm, pk, sh, rs = sp(commitments), sp(pubkeys), sp(shares), sp(responses)
         c = int.from_bytes(challenge, "big")
@@ -83,6 +86,60 @@ def _worker(rank, world, port, tamper, q):
         q.put((rank, verdict, digest, counts, list(allv)))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_bad_block(rank, world, port, bad_rank, q):
+    """one rank's block holds a negative position: its engine fails, nobody may hang, every rank raises"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import mpvss_oracle as O
+    from helpers import make_modp_instance
+    from mpvss_rs_amd.sharding import ShardedVerifier, ShardError, block_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, t = 7, 3
+        g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, seed=77)
+        flat = O.box_to_flat(g, box)
+        lo, hi = block_range(n, world, rank)
+        sl = slice(lo * 256, hi * 256)
+        pos = list(flat["positions"][lo:hi])
+        if rank == bad_rank:
+            pos[1] = -pos[1]
+        sv = ShardedVerifier(OracleBlockEngine())
+        try:
+            sv.verify_distribution(flat["commitments"], pos, flat["publickeys"][sl], flat["shares"][sl],
+                                   flat["responses"][sl], flat["challenge"])
+            q.put((rank, "no error"))
+        except ShardError as err:
+            q.put((rank, str(err)))
+        # the group is still usable: the honest box verifies afterwards
+        verdict, digest, counts = sv.verify_distribution(flat["commitments"], flat["positions"][lo:hi], flat["publickeys"][sl],
+                                                         flat["shares"][sl], flat["responses"][sl], flat["challenge"])
+        q.put((rank, verdict))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_a_failing_rank_does_not_hang_the_group(bad_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bad_block, args=(r, 2, port, bad_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    errors = [m for _, m in results if isinstance(m, str)]
+    assert len(errors) == 2 and all(f"rank(s) [{bad_rank}]" in m for m in errors), results
+    assert sorted(m for _, m in results if isinstance(m, bool)) == [True, True]
 
 
 def _free_port():
