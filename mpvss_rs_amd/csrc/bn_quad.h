@@ -24,6 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MODP_RETIRE_MAD
+#define MODP_RETIRE_MAD 1
+#endif
+
 namespace bn {
 
 typedef uint32_t u32;
@@ -58,6 +62,8 @@ struct Lane {
   u32 low01;     // 1 iff q == 0, else 0
   u32 not_low;   // all ones unless q == 0
   u32 mask28;    // 2^W - 1 in a VGPR (lets the compiler fuse "broadcast & mask" into one v_and_b32_dpp)
+  u32 one;       // 1 in a VGPR, opaque: "x * one" stays a v_mad_u64_u32 (a 64-bit add would be two carry instructions)
+  u32 eight;     // 8 likewise: "hi * eight" must not become a 64-bit shift-and-add
 };
 
 __device__ __forceinline__ Lane make_lane() {
@@ -70,7 +76,10 @@ __device__ __forceinline__ Lane make_lane() {
   // Opaque to the optimiser: otherwise `x & mask` becomes v_cndmask_b32 on an SGPR-pair condition,
   // which issues ~4x slower than v_and_b32 on gfx950 (profiles/r01_ubench_valu_issue_rates.txt).
   ln.mask28 = MASK;
-  asm volatile("" : "+v"(ln.not_top), "+v"(ln.top28), "+v"(ln.low01), "+v"(ln.not_low), "+v"(ln.mask28));
+  ln.one = 1u;
+  ln.eight = 8u;
+  asm volatile("" : "+v"(ln.not_top), "+v"(ln.top28), "+v"(ln.low01), "+v"(ln.not_low), "+v"(ln.mask28), "+v"(ln.one),
+               "+v"(ln.eight));
   return ln;
 }
 
@@ -125,7 +134,14 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
       // by construction and retires.  No lane-dependent arithmetic: one shift, one 64-bit add, one v_and_b32_dpp.
       {
         const u64 ret = T[rr];
+#if MODP_RETIRE_MAD
+        // ret >> 29 = hi * 8 + (lo >> 29), added with two mads and a 32-bit shift: v_lshrrev_b64 + v_lshl_add_u64 (the
+        // 64-bit shift and add) cost about 9 ns per wave and SIMD, this form about 6 (profiles/r01_ubench_valu_issue_rates.txt)
+        T[(rr + 1) % LPL] += (u64)(u32)(ret >> 32) * ln.eight;
+        T[(rr + 1) % LPL] += (u64)((u32)ret >> W) * ln.one;
+#else
         T[(rr + 1) % LPL] += ret >> W;
+#endif
         T[rr] = (u64)(quad_from_next((u32)ret) & ln.top28);
       }
       // Pin the row-wise order: without this LLVM reassociates the 19-fold unrolled body into a

@@ -163,6 +163,19 @@ def test_c3_c4_curve_groups_full_size(engine, name):
     for i, (x, a1, a2) in zip(idx, parallel_map(ec_reference_share, jobs)):
         s = slice(i * L, (i + 1) * L)
         assert (x, a1, a2) == (res["X"][s], res["a1"][s], res["a2"][s]), f"{name} share {i}"
+    # a seeded 1 % sample (656 shares) against the independent C restatement (oracle/ec_ref.c, reference order)
+    from ec_ref import EcRef
+    ref = EcRef()
+    idx3 = sorted(set(random.Random(13).sample(range(n), 656)))
+
+    def work(i):
+        return ref.share_work(gid, cm, positions[i], pks[i * L:(i + 1) * L], d["Y"][i * L:(i + 1) * L],
+                              responses[i * 32:(i + 1) * 32], sb(c))
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=worker_count(64)) as ex:
+        for i, (x, a1, a2) in zip(idx3, ex.map(work, idx3)):
+            s = slice(i * L, (i + 1) * L)
+            assert (x, a1, a2) == (res["X"][s], res["a1"][s], res["a2"][s]), f"{name} share {i} (C port)"
     # adversarial commitments: a duplicate and the identity (X accumulation starts from the identity and meets P + P)
     ident = G.element_to_bytes(G.identity())
     doctored = bytearray(cm)

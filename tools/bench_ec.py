@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--t", type=int, default=256)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--groups", default="secp256k1,ristretto255")
-    ap.add_argument("--threads", type=lambda s: [int(x) for x in s.split(",")], default=[2, 3, 4],
+    ap.add_argument("--threads", type=lambda s: [int(x) for x in s.split(",")], default=[],
                     help="also measure with this many contexts / host threads verifying boxes side by side")
     args = ap.parse_args()
     eng = capi.Engine(0)
