@@ -25,7 +25,7 @@
 #include <stdint.h>
 
 #ifndef MODP_RETIRE_MAD
-#define MODP_RETIRE_MAD 1
+#define MODP_RETIRE_MAD 0
 #endif
 
 namespace bn {
@@ -135,8 +135,11 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
       {
         const u64 ret = T[rr];
 #if MODP_RETIRE_MAD
-        // ret >> 29 = hi * 8 + (lo >> 29), added with two mads and a 32-bit shift: v_lshrrev_b64 + v_lshl_add_u64 (the
-        // 64-bit shift and add) cost about 9 ns per wave and SIMD, this form about 6 (profiles/r01_ubench_valu_issue_rates.txt)
+        // Experiment (off by default): ret >> 29 = hi * 8 + (lo >> 29) added with two mads and a 32-bit shift instead of
+        // v_lshrrev_b64 + v_lshl_add_u64 -- 42 instead of 41 VALU instructions per row but no double-cost 64-bit ones.
+        // Measured on MI355X (profiles/r02_retire_step_ab.txt): 917.7 / 913.5 k share verifications/s against
+        // 916.7 / 930.0 k for the shift-and-add form -- the board runs at its power cap and the two extra multiplier
+        // passes cost what the cheaper issue slots save.
         T[(rr + 1) % LPL] += (u64)(u32)(ret >> 32) * ln.eight;
         T[(rr + 1) % LPL] += (u64)((u32)ret >> W) * ln.one;
 #else

@@ -7,10 +7,35 @@
 //   Point, identity(), add(), dbl(), decode(bytes)->ok, encode(bytes), scalar byte order,
 // and the generic routines at the bottom (scalar_mul, dual_mul, horner step) are templates over it.
 #pragma once
+#include <stddef.h>
+
 #include "ec_consts.h"
 #include "ec_field.h"
 
 namespace ec {
+
+// canonical field element (limbs < 2^26, value < p) <-> 8 little-endian 32-bit words
+EC_HD void pack_fe(u32* w, const Fe& a) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int bit = 32 * i;
+    const int j = bit / 26, sft = bit % 26;
+    u64 v = (u64)a.v[j] >> sft;
+    if (j + 1 < 10) v |= (u64)a.v[j + 1] << (26 - sft);
+    if (j + 2 < 10 && 52 - sft < 32) v |= (u64)a.v[j + 2] << (52 - sft);
+    w[i] = (u32)v;
+  }
+}
+EC_HD void unpack_fe(Fe& a, const u32* w) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int bit = 26 * i;
+    const int j = bit / 32, sft = bit % 32;
+    u64 v = (u64)w[j] >> sft;
+    if (j + 1 < 8) v |= (u64)w[j + 1] << (32 - sft);
+    a.v[i] = (u32)v & M26;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // secp256k1: y^2 = x^3 + 7, homogeneous projective (X:Y:Z), identity (0:1:0).
@@ -188,6 +213,122 @@ struct Secp {
     Fp::to_le32(le, x);
     out[0] = 2 + (y.v[0] & 1);
     for (int i = 0; i < 32; ++i) out[1 + i] = le[31 - i];
+  }
+
+  // ---- window tables (ec_kernels.hip: signed 4-bit Straus, fixed-base comb for G) ---------------------------------
+  // per-share table entry: the projective point itself; the negative digit negates Y
+  typedef Point Cached;
+  static constexpr int CACHED_WORDS = 30;
+  static EC_HD void to_cached(Cached& r, const Point& p) { r = p; }
+  static EC_HD void add_cached(Point& r, const Point& p, const Cached& q, bool negate) {
+    Point t = q;
+    Fe ny;
+    Fp::neg(ny, q.Y);
+    Fp::cmov(t.Y, ny, negate);
+    add(r, p, t);
+  }
+  // comb entry: an affine point (never the identity), coordinates canonical and packed 8 x 32 bit
+  struct Affine {
+    Fe x, y;
+  };
+  static constexpr int AFFINE_PACKED_WORDS = 16;
+  // mixed addition, Renes-Costello-Batina Algorithm 8 (a = 0, b3 = 21): complete for every P, Q = (x2, y2) affine
+  static EC_HD void add_affine(Point& r, const Point& p, const Affine& q, bool negate) {
+    Fe y2 = q.y, ny;
+    Fp::neg(ny, q.y);
+    Fp::cmov(y2, ny, negate);
+    Fe t0, t1, t2, t3, t4, x3, y3, z3;
+    Fp::mul(t0, p.X, q.x);
+    Fp::mul(t1, p.Y, y2);
+    Fp::add(t3, q.x, y2);
+    Fp::add(t4, p.X, p.Y);
+    Fp::mul(t3, t3, t4);
+    Fp::add(t4, t0, t1);
+    Fp::sub(t3, t3, t4);               // X1 y2 + x2 Y1
+    Fp::mul(t4, y2, p.Z);
+    Fp::addc(t4, t4, p.Y);             // Y1 + y2 Z1
+    Fp::mul(y3, q.x, p.Z);
+    Fp::addc(y3, y3, p.X);             // X1 + x2 Z1
+    Fp::add(x3, t0, t0);
+    Fp::addc(t0, x3, t0);              // 3 X1 x2
+    Fp::mul_small(t2, p.Z, 21);        // b3 Z1
+    Fp::addc(z3, t1, t2);
+    Fp::sub(t1, t1, t2);
+    Fp::mul_small(y3, y3, 21);
+    Fp::mul(x3, t4, y3);
+    Fp::mul(t2, t3, t1);
+    Fp::sub(x3, t2, x3);
+    Fp::mul(y3, y3, t0);
+    Fp::mul(t1, t1, z3);
+    Fp::addc(y3, t1, y3);
+    Fp::mul(t0, t0, t3);
+    Fp::mul(z3, z3, t4);
+    Fp::addc(z3, z3, t0);
+    r.X = x3;
+    r.Y = y3;
+    r.Z = z3;
+  }
+  // affine form of a point that is not the identity (one inversion): comb construction only
+  static EC_HD void to_affine(Affine& r, const Point& p) {
+    Fe zi;
+    invert(zi, p.Z);
+    Fp::mul(r.x, p.X, zi);
+    Fp::mul(r.y, p.Y, zi);
+    Fp::canon(r.x);
+    Fp::canon(r.y);
+  }
+  static EC_HD void pack_affine(u32* w, const Affine& a) {
+    pack_fe(w, a.x);
+    pack_fe(w + 8, a.y);
+  }
+  static EC_HD void unpack_affine(Affine& a, const u32* w) {
+    unpack_fe(a.x, w);
+    unpack_fe(a.y, w + 8);
+  }
+  // B points to SEC1 bytes with ONE shared inversion (Montgomery's trick): 5 products per point + 1/B inversion.
+  // `load(i, P)` fetches point i (called twice per point, so that only the prefix products stay live),
+  // `live(i)` says whether output i is written.
+  template <int B, class Load, class Live>
+  static EC_HD void encode_batch(uint8_t* out, size_t out_stride, Load load, Live live) {
+    Fe pre[B], acc, zi, one;
+    Fp::one(one);
+    acc = one;
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      Point p;
+      load(i, p);
+      Fe z = p.Z;
+      Fp::cmov(z, one, Fp::is_zero(p.Z));   // the identity does not enter the product
+      pre[i] = acc;
+      Fp::mul(acc, acc, z);
+    }
+    invert(acc, acc);
+#pragma unroll
+    for (int i = B - 1; i >= 0; --i) {
+      Point p;
+      load(i, p);
+      const bool inf = Fp::is_zero(p.Z);
+      Fe z = p.Z;
+      Fp::cmov(z, one, inf);
+      Fp::mul(zi, acc, pre[i]);        // 1 / Z_i
+      Fp::mul(acc, acc, z);
+      Fe x, y;
+      Fp::mul(x, p.X, zi);
+      Fp::mul(y, p.Y, zi);
+      Fp::canon(x);
+      Fp::canon(y);
+      if (live(i)) {
+        uint8_t* o = out + (size_t)i * out_stride;
+        if (inf) {
+          for (int k = 0; k < 33; ++k) o[k] = 0;
+        } else {
+          uint8_t le[32];
+          Fp::to_le32(le, x);
+          o[0] = 2 + (y.v[0] & 1);
+          for (int k = 0; k < 32; ++k) o[1 + k] = le[31 - k];
+        }
+      }
+    }
   }
 };
 
@@ -397,6 +538,104 @@ struct Ristretto {
     Fp::canon(s);
     Fp::to_le32(out, s);
   }
+
+  // ---- window tables (ec_kernels.hip) -----------------------------------------------------------------------------
+  // per-share table entry in "cached" form (Y+X, Y-X, Z, 2dT): addition costs 8 products; the negative digit swaps
+  // the first two and negates the last
+  struct Cached {
+    Fe YpX, YmX, Z, T2d;
+  };
+  static constexpr int CACHED_WORDS = 40;
+  static EC_HD void to_cached(Cached& r, const Point& p) {
+    const Fe d2 = {EC_ED_2D_INIT};
+    Fp::addc(r.YpX, p.Y, p.X);
+    Fp::sub(r.YmX, p.Y, p.X);
+    r.Z = p.Z;
+    Fp::mul(r.T2d, p.T, d2);
+  }
+  static EC_HD void add_cached(Point& r, const Point& p, const Cached& q, bool negate) {
+    Fe qa = q.YmX, qb = q.YpX, qc = q.T2d, nc;
+    Fp::cmov(qa, q.YpX, negate);
+    Fp::cmov(qb, q.YmX, negate);
+    Fp::neg(nc, q.T2d);
+    Fp::cmov(qc, nc, negate);
+    Fe a, b, c, d, e, f, g, h;
+    Fp::sub(a, p.Y, p.X);
+    Fp::mul(a, a, qa);
+    Fp::addc(b, p.Y, p.X);
+    Fp::mul(b, b, qb);
+    Fp::mul(c, p.T, qc);
+    Fp::mul(d, p.Z, q.Z);
+    Fp::addc(d, d, d);
+    Fp::sub(e, b, a);
+    Fp::sub(f, d, c);
+    Fp::addc(g, d, c);
+    Fp::addc(h, b, a);
+    Fp::mul(r.X, e, f);
+    Fp::mul(r.Y, g, h);
+    Fp::mul(r.T, e, h);
+    Fp::mul(r.Z, f, g);
+  }
+  // comb entry: affine Niels form (y+x, y-x, 2dxy) of a point with Z = 1, canonical, packed 8 x 32 bit each
+  struct Affine {
+    Fe ypx, ymx, xy2d;
+  };
+  static constexpr int AFFINE_PACKED_WORDS = 24;
+  static EC_HD void add_affine(Point& r, const Point& p, const Affine& q, bool negate) {   // 7 products
+    Fe qa = q.ymx, qb = q.ypx, qc = q.xy2d, nc;
+    Fp::cmov(qa, q.ypx, negate);
+    Fp::cmov(qb, q.ymx, negate);
+    Fp::neg(nc, q.xy2d);
+    Fp::cmov(qc, nc, negate);
+    Fe a, b, c, d, e, f, g, h;
+    Fp::sub(a, p.Y, p.X);
+    Fp::mul(a, a, qa);
+    Fp::addc(b, p.Y, p.X);
+    Fp::mul(b, b, qb);
+    Fp::mul(c, p.T, qc);
+    Fp::addc(d, p.Z, p.Z);
+    Fp::sub(e, b, a);
+    Fp::sub(f, d, c);
+    Fp::addc(g, d, c);
+    Fp::addc(h, b, a);
+    Fp::mul(r.X, e, f);
+    Fp::mul(r.Y, g, h);
+    Fp::mul(r.T, e, h);
+    Fp::mul(r.Z, f, g);
+  }
+  // 1 / z = z^(p-2) = (z^(2^252 - 3))^8 * z^3
+  static EC_HD void invert(Fe& r, const Fe& z) {
+    Fe t, z2, z3;
+    pow22523(t, z);
+    Fp::sqrn(t, t, 3);
+    Fp::sqr(z2, z);
+    Fp::mul(z3, z2, z);
+    Fp::mul(r, t, z3);
+  }
+  static EC_HD void to_affine(Affine& r, const Point& p) {       // comb construction only
+    const Fe d2 = {EC_ED_2D_INIT};
+    Fe zi, x, y, t;
+    invert(zi, p.Z);
+    Fp::mul(x, p.X, zi);
+    Fp::mul(y, p.Y, zi);
+    Fp::addc(r.ypx, y, x);
+    Fp::sub(r.ymx, y, x);
+    Fp::mul(t, x, y);
+    Fp::mul(r.xy2d, t, d2);
+    Fp::canon(r.ypx);
+    Fp::canon(r.ymx);
+    Fp::canon(r.xy2d);
+  }
+  static EC_HD void pack_affine(u32* w, const Affine& a) {
+    pack_fe(w, a.ypx);
+    pack_fe(w + 8, a.ymx);
+    pack_fe(w + 16, a.xy2d);
+  }
+  static EC_HD void unpack_affine(Affine& a, const u32* w) {
+    unpack_fe(a.ypx, w);
+    unpack_fe(a.ymx, w + 8);
+    unpack_fe(a.xy2d, w + 16);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -467,6 +706,80 @@ EC_HD void scalar_words(u32 (&w)[8], const uint8_t* k) {
     }
     w[i] = v;
   }
+}
+
+
+// ---- signed 4-bit windows ---------------------------------------------------------------------------------------
+// k' = k + sum_{w < 64} 8 * 16^w  (257 bits, 9 words): nibble w of k' minus 8 is the signed digit d_w in [-8, 7] for
+// w < 64, nibble 64 (0 or 1) is the top digit; sum d_w 16^w = k.  No carry chain between digits at use.
+template <class C>
+EC_HD void recode_signed4(u32 (&kp)[9], const uint8_t* k) {
+  u32 w[8];
+  scalar_words<C>(w, k);
+  u64 carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    carry += (u64)w[i] + 0x88888888u;
+    kp[i] = (u32)carry;
+    carry >>= 32;
+  }
+  kp[8] = (u32)carry;
+}
+// signed digit w (0..64) from the word holding its nibble
+EC_HD int signed_digit4(u32 word, int w) {
+  const int nib = (int)((word >> (4 * (w & 7))) & 15u);
+  return w == 64 ? nib : nib - 8;
+}
+
+// table of one point: entries (i + 1) * P, i < 8, in cached form (4 doublings, 3 additions)
+template <class C>
+EC_HD void build_cached_table(typename C::Cached (&tab)[8], const typename C::Point& p) {
+  typename C::Point m[8];
+  m[0] = p;
+  C::dbl(m[1], m[0]);
+  C::add(m[2], m[1], m[0]);
+  C::dbl(m[3], m[1]);
+  C::add(m[4], m[3], m[0]);
+  C::dbl(m[5], m[2]);
+  C::add(m[6], m[5], m[0]);
+  C::dbl(m[7], m[3]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) C::to_cached(tab[i], m[i]);
+}
+
+// the same, handing each entry to `store(i, cached)` as soon as it exists (three points live at a time)
+template <class C, class Store>
+EC_HD void build_cached_table_streamed(const typename C::Point& p, Store store) {
+  typename C::Point a, b, c;
+  typename C::Cached e;
+  C::to_cached(e, p); store(0, e);
+  C::dbl(a, p);       C::to_cached(e, a); store(1, e);      // 2P
+  C::add(b, a, p);    C::to_cached(e, b); store(2, e);      // 3P
+  C::dbl(a, a);       C::to_cached(e, a); store(3, e);      // 4P
+  C::add(c, a, p);    C::to_cached(e, c); store(4, e);      // 5P
+  C::dbl(b, b);       C::to_cached(e, b); store(5, e);      // 6P
+  C::add(c, b, p);    C::to_cached(e, c); store(6, e);      // 7P
+  C::dbl(a, a);       C::to_cached(e, a); store(7, e);      // 8P
+}
+
+// acc += d * P with P's table entry for |d| supplied by `load(index 0..7)`; d == 0 leaves acc alone
+template <class C, class Load>
+EC_HD void add_signed_digit(typename C::Point& acc, int d, Load load) {
+  const int mag = d < 0 ? -d : d;
+  typename C::Cached e;
+  load(e, mag > 0 ? mag - 1 : 0);
+  typename C::Point sum;
+  C::add_cached(sum, acc, e, d < 0);
+  C::cmov(acc, sum, mag != 0);
+}
+template <class C, class Load>
+EC_HD void add_signed_digit_affine(typename C::Point& acc, int d, Load load) {
+  const int mag = d < 0 ? -d : d;
+  typename C::Affine e;
+  load(e, mag > 0 ? mag - 1 : 0);
+  typename C::Point sum;
+  C::add_affine(sum, acc, e, d < 0);
+  C::cmov(acc, sum, mag != 0);
 }
 
 }  // namespace ec

@@ -20,6 +20,18 @@ int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions,
                  int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc, int split_seeds,
                  hipStream_t s);
 int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
+/* windowed double-scalar multiplication (signed 4-bit windows; see ec_kernels.hip):
+ *   comb: 65 x 8 packed affine multiples of the generator (ec_comb_words() words, built once by ec_launch_comb_build)
+ *   tables: [count][8][ec_cached_words()] multiples P .. 8P of per-share bases, from encodings or internal points
+ *   dual_win: out_pts[x] = k1[x] * (G | P1[x]) + k2[x] * P2[x] in internal coordinates; encode: -> canonical bytes */
+int ec_cached_words(int group);
+int ec_comb_words(int group);
+int ec_launch_comb_build(int group, uint32_t* comb, hipStream_t s);
+int ec_launch_build_tables(int group, const uint8_t* enc, size_t enc_stride, const uint32_t* pts, int count, uint32_t* tab,
+                           uint8_t* ok, hipStream_t s);
+int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_t* tab1, const uint8_t* k1, size_t k1_stride,
+                       const uint32_t* tab2, const uint8_t* k2, size_t k2_stride, int count, uint32_t* out_pts, hipStream_t s);
+int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

@@ -254,6 +254,148 @@ __device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int cou
   C::encode(enc + (size_t)x * C::ENC_LEN, p);
 }
 
+
+// ---- windowed double-scalar multiplication (signed 4-bit Straus) ---------------------------------------------------
+// out = k1 * P1 + k2 * P2   (dleq.rs:66-84; Group::exp is the k2-less case).  k256 and curve25519-dalek, which the
+// reference delegates to (secp256k1.rs:91-100, ristretto255.rs:161-170), use 4-bit signed windows as well.
+//   * a per-share base comes with a table of its multiples P .. 8P in cached form, built once per base by
+//     k_*_build_tables into HBM (960 / 1280 B per share, array of structs: a lane reads ITS entry |d| contiguously);
+//   * the group generator comes as a fixed-base comb  comb[w][i] = (i+1) 16^w G  (65 windows x 8 affine entries,
+//     packed canonical coordinates, 33 KB / 49 KB) staged in LDS by every workgroup: r G costs 64 mixed additions
+//     and NO doublings;
+//   * signed digits d_w = nibble_w(k + 0x88..8) - 8 need no carry between windows; the recoded scalars sit in LDS
+//     (word-major across the lanes), the loop fetches one word per eight windows.
+// One share per lane, 256 lanes per workgroup; 256 doublings + 128 (two tables) or 64 + 64 (comb + table) additions
+// instead of 256 + 256.  The result leaves in internal coordinates (array of structs) for the encoding kernels.
+constexpr int DW_THREADS = 256;
+
+template <class C>
+__device__ __forceinline__ void store_cached(u32* __restrict__ dst, const typename C::Cached& e) {
+  const u32* w = reinterpret_cast<const u32*>(&e);
+#pragma unroll
+  for (int i = 0; i < C::CACHED_WORDS; ++i) dst[i] = w[i];
+}
+template <class C>
+__device__ __forceinline__ void load_cached(typename C::Cached& e, const u32* __restrict__ src) {
+  u32* w = reinterpret_cast<u32*>(&e);
+#pragma unroll
+  for (int i = 0; i < C::CACHED_WORDS; ++i) w[i] = src[i];
+}
+
+// tab[x][i] = (i + 1) * P_x, i < 8.  P_x from its encoding (enc != null: decoded here, ok[x] = validity) or from
+// internal coordinates (pts).
+template <class C>
+__device__ __forceinline__ void build_tables_body(const uint8_t* __restrict__ enc, size_t enc_stride,
+                                                  const u32* __restrict__ pts, int count, u32* __restrict__ tab,
+                                                  uint8_t* __restrict__ ok) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= count) return;
+  typename C::Point p;
+  if (enc != nullptr) {
+    const bool good = C::decode(p, enc + (size_t)x * enc_stride);
+    if (ok != nullptr) ok[x] = good ? 1 : 0;
+  } else {
+    load_point_aos<C>(p, pts + (size_t)x * C::POINT_WORDS);
+  }
+  u32* mine = tab + (size_t)x * 8 * C::CACHED_WORDS;
+  build_cached_table_streamed<C>(p, [&](int i, const typename C::Cached& e) { store_cached<C>(mine + i * C::CACHED_WORDS, e); });
+}
+
+// comb[w][i] = (i + 1) * 16^w * G, packed affine -- once per context and group
+template <class C>
+__device__ __forceinline__ void comb_build_body(u32* __restrict__ comb) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= 65) return;
+  typename C::Point base, m;
+  C::generator(base);
+  for (int i = 0; i < 4 * w; ++i) C::dbl(base, base);
+  m = base;
+  for (int i = 0; i < 8; ++i) {
+    typename C::Affine a;
+    C::to_affine(a, m);
+    C::pack_affine(comb + (size_t)(w * 8 + i) * C::AFFINE_PACKED_WORDS, a);
+    C::add(m, m, base);
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void dual_win_body(const u32* __restrict__ comb, const u32* __restrict__ tab1,
+                                              const uint8_t* __restrict__ k1, size_t k1_stride, const u32* __restrict__ tab2,
+                                              const uint8_t* __restrict__ k2, size_t k2_stride, int count,
+                                              u32* __restrict__ out_pts, u32* lds) {
+  constexpr int AW = C::AFFINE_PACKED_WORDS;
+  u32* lds_comb = lds;                                           // [65 * 8 * AW]        (only when comb != null)
+  u32* lds_k = lds + (comb != nullptr ? 65 * 8 * AW : 0);        // [2][9][DW_THREADS]   recoded scalars
+  const int xi = blockIdx.x * DW_THREADS + threadIdx.x;
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  if (comb != nullptr) {
+    for (int i = threadIdx.x; i < 65 * 8 * AW; i += DW_THREADS) lds_comb[i] = comb[i];
+  }
+  {
+    u32 kp[9];
+    recode_signed4<C>(kp, k1 + (size_t)x * k1_stride);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) lds_k[j * DW_THREADS + threadIdx.x] = kp[j];
+    if (tab2 != nullptr) {
+      recode_signed4<C>(kp, k2 + (size_t)x * k2_stride);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) lds_k[(9 + j) * DW_THREADS + threadIdx.x] = kp[j];
+    }
+  }
+  __syncthreads();
+  const u32* t1 = tab1 != nullptr ? tab1 + (size_t)x * 8 * C::CACHED_WORDS : nullptr;
+  const u32* t2 = tab2 != nullptr ? tab2 + (size_t)x * 8 * C::CACHED_WORDS : nullptr;
+  typename C::Point acc;
+  C::identity(acc);
+  if (t1 != nullptr || t2 != nullptr) {
+    u32 w1 = 0, w2 = 0;
+    for (int w = 64; w >= 0; --w) {
+      if ((w & 7) == 7 || w == 64) {
+        w1 = lds_k[(w >> 3) * DW_THREADS + threadIdx.x];
+        if (t2 != nullptr) w2 = lds_k[(9 + (w >> 3)) * DW_THREADS + threadIdx.x];
+      }
+      if (w != 64) {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) C::dbl(acc, acc);
+      }
+      if (t1 != nullptr)
+        add_signed_digit<C>(acc, signed_digit4(w1, w), [&](typename C::Cached& e, int i) { load_cached<C>(e, t1 + i * C::CACHED_WORDS); });
+      if (t2 != nullptr) {
+        // with a comb for the first scalar the table belongs to the SECOND scalar; without, to the second as well
+        const u32 word = (t1 != nullptr || comb != nullptr) ? w2 : w1;
+        add_signed_digit<C>(acc, signed_digit4(word, w), [&](typename C::Cached& e, int i) { load_cached<C>(e, t2 + i * C::CACHED_WORDS); });
+      }
+    }
+  }
+  if (comb != nullptr) {     // k1 * G from the comb in LDS: one mixed addition per window, no doublings
+    typename C::Point g;
+    C::identity(g);
+    u32 w1 = 0;
+    for (int w = 0; w < 65; ++w) {
+      if ((w & 7) == 0) w1 = lds_k[(w >> 3) * DW_THREADS + threadIdx.x];
+      add_signed_digit_affine<C>(g, signed_digit4(w1, w),
+                                 [&](typename C::Affine& e, int i) { C::unpack_affine(e, lds_comb + (w * 8 + i) * AW); });
+    }
+    C::add(acc, acc, g);
+  }
+  if (live) store_point_aos<C>(out_pts + (size_t)x * C::POINT_WORDS, acc);
+}
+
+// secp256k1: eight points per lane share one field inversion (Montgomery's trick)
+__device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ pts, int count, uint8_t* __restrict__ enc) {
+  constexpr int B = 8;
+  const int first = (blockIdx.x * blockDim.x + threadIdx.x) * B;
+  if (first >= count) return;
+  Secp::encode_batch<B>(
+      enc + (size_t)first * 33, 33,
+      [&](int i, Secp::Point& p) {
+        const int idx = first + i < count ? first + i : count - 1;
+        load_point_aos<Secp>(p, pts + (size_t)idx * Secp::POINT_WORDS);
+      },
+      [&](int i) { return first + i < count; });
+}
+
 }  // namespace
 
 #define EC_KERNELS(NAME, CURVE, ORDER)                                                                                        \
@@ -297,6 +439,24 @@ __device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int cou
 
 EC_KERNELS(secp, Secp, OrderSecp)
 EC_KERNELS(rist, Ristretto, OrderEd)
+
+#define EC_WIN_KERNELS(NAME, CURVE)                                                                                          \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_build_tables(const uint8_t* enc, size_t enc_stride,            \
+                                                                           const u32* pts, int count, u32* tab, uint8_t* ok) { \
+    build_tables_body<CURVE>(enc, enc_stride, pts, count, tab, ok);                                                          \
+  }                                                                                                                          \
+  extern "C" __global__ void __launch_bounds__(128) k_##NAME##_comb_build(u32* comb) { comb_build_body<CURVE>(comb); }       \
+  extern "C" __global__ void __launch_bounds__(DW_THREADS) k_##NAME##_dual_win(                                              \
+      const u32* comb, const u32* tab1, const uint8_t* k1, size_t k1_stride, const u32* tab2, const uint8_t* k2,             \
+      size_t k2_stride, int count, u32* out_pts) {                                                                           \
+    extern __shared__ u32 lds[];                                                                                             \
+    dual_win_body<CURVE>(comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts, lds);                               \
+  }
+EC_WIN_KERNELS(secp, Secp)
+EC_WIN_KERNELS(rist, Ristretto)
+extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc) {
+  secp_encode_batch_body(pts, count, enc);
+}
 
 // ---- launchers ---------------------------------------------------------------------------------------
 static inline int blocks_for(int count) { return (count + 63) / 64; }
@@ -368,5 +528,44 @@ extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t*
                        count, pts);
     hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, x_enc);
   }
+  return (int)hipGetLastError();
+}
+
+// ---- windowed path ---------------------------------------------------------------------------------------------------
+extern "C" int ec_cached_words(int group) { return group == 1 ? Secp::CACHED_WORDS : Ristretto::CACHED_WORDS; }
+extern "C" int ec_comb_words(int group) { return 65 * 8 * (group == 1 ? Secp::AFFINE_PACKED_WORDS : Ristretto::AFFINE_PACKED_WORDS); }
+
+extern "C" int ec_launch_comb_build(int group, uint32_t* comb, hipStream_t s) {
+  if (group == 1) hipLaunchKernelGGL(k_secp_comb_build, dim3(1), dim3(128), 0, s, comb);
+  else hipLaunchKernelGGL(k_rist_comb_build, dim3(1), dim3(128), 0, s, comb);
+  return (int)hipGetLastError();
+}
+// tables of `count` bases: from encodings (enc, stride 0 = one shared base; ok receives the validity flags) or from
+// internal points (pts)
+extern "C" int ec_launch_build_tables(int group, const uint8_t* enc, size_t enc_stride, const uint32_t* pts, int count,
+                                      uint32_t* tab, uint8_t* ok, hipStream_t s) {
+  if (count <= 0) return 0;
+  if (group == 1) hipLaunchKernelGGL(k_secp_build_tables, dim3(blocks_for(count)), dim3(64), 0, s, enc, enc_stride, pts, count, tab, ok);
+  else hipLaunchKernelGGL(k_rist_build_tables, dim3(blocks_for(count)), dim3(64), 0, s, enc, enc_stride, pts, count, tab, ok);
+  return (int)hipGetLastError();
+}
+// out_pts[x] = k1[x] * (G if comb else P1[x]) + k2[x] * P2[x]; tab2 may be null (single multiplication)
+extern "C" int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_t* tab1, const uint8_t* k1, size_t k1_stride,
+                                  const uint32_t* tab2, const uint8_t* k2, size_t k2_stride, int count, uint32_t* out_pts,
+                                  hipStream_t s) {
+  if (count <= 0) return 0;
+  const size_t lds = ((comb != nullptr ? (size_t)ec_comb_words(group) : 0) + (size_t)2 * 9 * DW_THREADS) * 4;
+  const dim3 grid((count + DW_THREADS - 1) / DW_THREADS);
+  if (group == 1)
+    hipLaunchKernelGGL(k_secp_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);
+  else
+    hipLaunchKernelGGL(k_rist_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);
+  return (int)hipGetLastError();
+}
+// internal points -> canonical encodings (secp256k1: eight points per lane share an inversion)
+extern "C" int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s) {
+  if (count <= 0) return 0;
+  if (group == 1) hipLaunchKernelGGL(k_secp_encode_batch, dim3(blocks_for((count + 7) / 8)), dim3(64), 0, s, pts, count, enc);
+  else hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, enc);
   return (int)hipGetLastError();
 }

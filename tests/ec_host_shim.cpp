@@ -40,7 +40,77 @@ static int t_gen(uint8_t* out) {
   return 0;
 }
 
+// the windowed paths of ec_kernels.hip: signed 4-bit Straus over per-point cached tables, fixed-base comb for the
+// generator (65 windows x 8 packed affine entries), batched SEC1 encoding
+template <class C>
+static int t_dual_win(const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, uint8_t* out) {
+  typename C::Point a, b, r;
+  if (!C::decode(a, p1)) return -1;
+  if (p2) { if (!C::decode(b, p2)) return -2; } else C::identity(b);
+  typename C::Cached t1[8], t2[8];
+  build_cached_table<C>(t1, a);
+  build_cached_table_streamed<C>(b, [&](int i, const typename C::Cached& e) { t2[i] = e; });
+  u32 kp1[9], kp2[9];
+  recode_signed4<C>(kp1, k1);
+  if (p2) recode_signed4<C>(kp2, k2);
+  C::identity(r);
+  for (int w = 64; w >= 0; --w) {
+    if (w != 64) for (int i = 0; i < 4; ++i) C::dbl(r, r);
+    add_signed_digit<C>(r, signed_digit4(kp1[w >> 3], w), [&](typename C::Cached& e, int i) { e = t1[i]; });
+    if (p2) add_signed_digit<C>(r, signed_digit4(kp2[w >> 3], w), [&](typename C::Cached& e, int i) { e = t2[i]; });
+  }
+  C::encode(out, r);
+  return 0;
+}
+// comb[w][i] = (i + 1) * 16^w * G, packed affine; returns k * G
+template <class C>
+static int t_comb(const uint8_t* k, uint8_t* out) {
+  static u32* comb = nullptr;
+  constexpr int AW = C::AFFINE_PACKED_WORDS;
+  if (!comb) {
+    comb = new u32[65 * 8 * AW];
+    typename C::Point base, m;
+    C::generator(base);
+    for (int w = 0; w < 65; ++w) {
+      m = base;
+      for (int i = 0; i < 8; ++i) {
+        typename C::Affine a;
+        C::to_affine(a, m);
+        C::pack_affine(comb + (w * 8 + i) * AW, a);
+        C::add(m, m, base);
+      }
+      for (int i = 0; i < 4; ++i) C::dbl(base, base);
+    }
+  }
+  u32 kp[9];
+  recode_signed4<C>(kp, k);
+  typename C::Point r;
+  C::identity(r);
+  for (int w = 0; w < 65; ++w)
+    add_signed_digit_affine<C>(r, signed_digit4(kp[w >> 3], w),
+                               [&](typename C::Affine& e, int i) { C::unpack_affine(e, comb + (w * 8 + i) * AW); });
+  C::encode(out, r);
+  return 0;
+}
+
 extern "C" {
+int ec_dual_win(int curve, const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, uint8_t* out) {
+  return curve == 0 ? t_dual_win<Secp>(p1, k1, p2, k2, out) : t_dual_win<Ristretto>(p1, k1, p2, k2, out);
+}
+int ec_comb(int curve, const uint8_t* k, uint8_t* out) { return curve == 0 ? t_comb<Secp>(k, out) : t_comb<Ristretto>(k, out); }
+// four SEC1 points (33 zero bytes = identity) re-encoded through the shared-inversion path
+int secp_encode_batch4(const uint8_t* in, uint8_t* out) {
+  Secp::Point p[4];
+  bool live[4] = {true, true, true, true};
+  for (int i = 0; i < 4; ++i) {
+    if (!Secp::decode(p[i], in + 33 * i)) return -1;
+    Secp::Point t;                       // de-normalise: multiply by something so that Z != 1
+    Secp::dbl(t, p[i]);
+    Secp::add(p[i], t, p[i]);            // 3 P
+  }
+  Secp::encode_batch<4>(out, 33, [&](int i, Secp::Point& q) { q = p[i]; }, [&](int i) { return live[i]; });
+  return 0;
+}
 int ec_dual(int curve, const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, uint8_t* out) {
   return curve == 0 ? t_dual<Secp>(p1, k1, p2, k2, out) : t_dual<Ristretto>(p1, k1, p2, k2, out);
 }

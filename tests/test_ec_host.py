@@ -84,3 +84,39 @@ def test_group_law_and_encodings(shim, curve, name):
           [bytes.fromhex("01" + "00" * 31), bytes.fromhex("ed" + "ff" * 30 + "7f")]
     for x in bad:
         assert shim.ec_decode_ok(curve, buf(x)) == 0
+
+
+@pytest.mark.parametrize("curve,name", [(0, "secp256k1"), (1, "ristretto255")])
+def test_windowed_paths(shim, curve, name):
+    """The signed-4-bit Straus routine over cached tables, the fixed-base comb of the generator and the batched SEC1
+    encoding (the routines the windowed kernels run) against the oracle, incl. scalars 0, 1, order - 1, digits that
+    hit -8 / +8 and the identity as a base."""
+    G = O.GROUPS[name]()
+    rng = random.Random(17 + curve)
+    order = G.group_order_int()
+    e, s = G.element_to_bytes, G.scalar_to_bytes
+    B = G.generator()
+    P, Q = G.exp(B, rng.randrange(1, order)), G.exp(B, rng.randrange(1, order))
+    out = (C.c_uint8 * G.elem_len)()
+    special = [0, 1, 2, 7, 8, 9, 15, 16, 0x88888888, 0x77777777, 0x8 << 252, order - 1, order - 2,
+               int("8" * 62, 16), int("7" * 63, 16) % order, int("f" * 63, 16) % order]
+    ks = special + [rng.randrange(order) for _ in range(6)]
+    for k in ks:
+        assert shim.ec_comb(curve, buf(s(k)), out) == 0
+        assert bytes(out) == e(G.exp(B, k)), hex(k)
+        assert shim.ec_dual_win(curve, buf(e(P)), buf(s(k)), None, None, out) == 0
+        assert bytes(out) == e(G.exp(P, k)), hex(k)
+    for k1, k2 in zip(ks, reversed(ks)):
+        assert shim.ec_dual_win(curve, buf(e(P)), buf(s(k1)), buf(e(Q)), buf(s(k2)), out) == 0
+        assert bytes(out) == e(G.mul(G.exp(P, k1), G.exp(Q, k2)))
+    ident = G.identity()
+    k1, k2 = rng.randrange(order), rng.randrange(order)
+    assert shim.ec_dual_win(curve, buf(e(ident)), buf(s(k1)), buf(e(Q)), buf(s(k2)), out) == 0
+    assert bytes(out) == e(G.exp(Q, k2))
+    assert shim.ec_dual_win(curve, buf(e(P)), buf(s(k1)), buf(e(G.element_inverse(P))), buf(s(k1)), out) == 0
+    assert bytes(out) == e(ident)
+    if curve == 0:
+        pts = [P, ident, Q, G.exp(B, 5)]
+        out4 = (C.c_uint8 * (4 * 33))()
+        assert shim.secp_encode_batch4(buf(b"".join(e(x) for x in pts)), out4) == 0
+        assert bytes(out4) == b"".join(e(G.exp(x, 3)) for x in pts)
