@@ -128,8 +128,8 @@ def bench_ec(eng, name, args):
         for a in rc:
             acc = (acc * i + a) % order
         pvals.append(acc)
-    cm = eng.ec_batch_exp(gid, cfg["gen"] * t, b"".join(map(sb, coeffs)))
-    pks = eng.ec_batch_exp(gid, cfg["gen"] * n, b"".join(map(sb, privs)))
+    cm = eng.ec_batch_exp_generator(gid, b"".join(map(sb, coeffs)))       # C_j = a_j G (fixed-base comb)
+    pks = eng.ec_batch_exp_generator(gid, b"".join(map(sb, privs)))      # y_i = x_i G
     t_deal = time.perf_counter()
     d = eng.ec_distribute(gid, cm, positions, pks, b"".join(map(sb, pvals)), b"".join(map(sb, wits)))
     deal_s = time.perf_counter() - t_deal
@@ -155,23 +155,49 @@ def bench_ec(eng, name, args):
         assert bool(verdict.value) and bytes(dg) == d["digest"], f"parity gate failed ({name})"
 
     verify(dump=True)                                   # warm-up + the outputs for the CPU comparison
+    # isolated launches: one synchronous box, nothing else on the GPU
+    eng.pipeline_stats(reset=True)
+    verify()
+    lst = eng.pipeline_stats(reset=True)
+    lone = {"x_path": lst["kernel_ms"][0], "dual_win": lst["kernel_ms"][1], "tables": lst["kernel_ms"][2],
+            "encode": lst["kernel_ms"][3], "dual_win_launches": lst["kernel_launches"][1]}
+    dual_ms = lone["dual_win"] / max(lone["dual_win_launches"], 1)
+    # timed: K boxes through the library's pipeline (mpvss_ec_verify_many): EC_DEPTH boxes in flight in ONE context
+    k = args.ec_boxes
+    depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "8")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "3"))
+    box = capi.EcBox(d_cm.data_ptr(), t, d_pos.data_ptr(), d_pk.data_ptr(), d_Y.data_ptr(), d_r.data_ptr(), n,
+                     C.cast(chal, C.c_void_p))
+
+    def run_many(count):
+        arr = (capi.EcBox * count)(*([box] * count))
+        verdicts = (C.c_int * count)()
+        digests = (C.c_uint8 * (32 * count))()
+        eng._check(eng.lib.mpvss_ec_verify_many(eng.ctx, gid, capi.MPVSS_DEVICE, arr, count, depth, threads, verdicts,
+                                                C.cast(digests, C.c_void_p)), "ec_verify_many")
+        raw = bytes(digests)
+        assert all(verdicts[i] == 1 and raw[32 * i:32 * i + 32] == d["digest"] for i in range(count)), f"parity gate failed ({name})"
+
+    run_many(depth)                                     # slot workspaces
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kms = [0.0, 0.0]
-    for _ in range(args.ec_boxes):
-        verify()
-        kms[0] += eng.kernel_ms(0); kms[1] += eng.kernel_ms(1)
-    dt = (time.perf_counter() - t0) / args.ec_boxes
-    x_ms, dual_ms = kms[0] / args.ec_boxes, kms[1] / args.ec_boxes / 2      # two dual-multiplication launches per box
-    out = {"value": n / dt, "unit": "share verifications/s", "ms_per_box": dt * 1e3,
+    run_many(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    pst = eng.pipeline_stats(reset=True)
+    nb = max(pst["blocks"], 1)
+    out = {"value": n / dt, "unit": "share verifications/s", "ms_per_box": dt * 1e3, "boxes": k,
            "config": {"workload": f"{name} verify_distribution_shares n={n} t={t}, honest-dealer box, inputs resident in HBM, "
-                                  f"synchronous calls on one context ({cfg['ref']})"},
+                                  f"{depth} boxes in flight in one context, {threads} hash threads ({cfg['ref']})"},
            "dtype": "u32 limbs (radix 2^26), u64 accumulators",
-           "roofline": {"bound": "hbm", "kernel": ("k_secp_dual_mul" if gid == 1 else "k_rist_dual_mul"),
+           "roofline": {"bound": "hbm", "kernel": ("k_secp_dual_win" if gid == 1 else "k_rist_dual_win"),
                         "achieved": cfg["algo_bytes"] * n / (dual_ms * 1e-3) / 1e9 if dual_ms > 0 else None, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": cfg["algo_bytes"] * n / (dual_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if dual_ms > 0 else None,
                         "traffic": None, "kernel_ms": dual_ms,
-                        "kernel_ms_is": "one of the two double-scalar-multiplication launches of a box, alone on the GPU (synchronous call)",
-                        "x_path_ms": x_ms},
+                        "kernel_ms_is": "one of the two windowed double-scalar-multiplication launches of a box, alone on the GPU "
+                                        "(synchronous call after the timed region)"},
+           "kernel_ms_isolated": lone,
+           "host_per_box_ms": {"enqueue": pst["enqueue_ms"] / nb, "wait_for_gpu": pst["wait_ms"] / nb,
+                               "sha256_transcript": pst["hash_ms"] / nb},
            "distribute_shares_per_s": n / deal_s}
     if args.cpu_sample != 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -213,7 +239,7 @@ def main():
     ap.add_argument("--registered-keys", type=int, default=1,
                     help="also time the opt-in registered-key variant at N=1 (0: skip)")
     ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
-    ap.add_argument("--ec-boxes", type=int, default=4, help="boxes timed per curve group for the `ec` objects (0: skip)")
+    ap.add_argument("--ec-boxes", type=int, default=24, help="boxes timed per curve group for the `ec` objects (0: skip)")
     ap.add_argument("--ec-n", type=int, default=65536)
     ap.add_argument("--ec-t", type=int, default=256)
     ap.add_argument("--lone-boxes", type=int, default=2, help="boxes verified one at a time after the timed region "
@@ -680,33 +706,34 @@ def main():
                                                     m, verd), "verify_shares")
         wb_s = (time.perf_counter() - tw) / reps
         assert bytes(verd) == b"\x01" * m, "verify_share verdicts"
-        # the same batches from three contexts (one workspace, stream and host thread each) side by side
-        import threading
-        engines = [capi.Engine(local_rank) for _ in range(3)]
-        verds = [(C.c_uint8 * m)() for _ in engines]
+        # the block form: several batches in flight in ONE context (compute = enqueue only, absorb = wait + n verdict bytes)
+        inflight, batches = 4, 12
+        d_verd = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(inflight)]
 
-        def wb_job(e, v, count):
-            for _ in range(count):
-                e._check(e.lib.mpvss_modp_verify_shares(e.ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb),
-                                                        vp(d_rb), m, v), "verify_shares")
+        def wb_pipelined(count):
+            issued = done = 0
+            while done < count:
+                while issued < count and issued - done < inflight:
+                    eng._check(lib.mpvss_modp_verify_shares_compute(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb),
+                                                                    vp(d_rb), m, vp(d_verd[issued % inflight])), "verify_shares_compute")
+                    issued += 1
+                eng._check(lib.mpvss_modp_verify_shares_absorb(ctx, verd), "verify_shares_absorb")
+                assert bytes(verd) == b"\x01" * m, "verify_share verdicts (block API)"
+                done += 1
 
-        for e, v in zip(engines, verds):
-            wb_job(e, v, 1)                                   # workspace and comb tables of the context
-        ths = [threading.Thread(target=wb_job, args=(e, v, reps)) for e, v in zip(engines, verds)]
+        wb_pipelined(inflight)                                # slot workspaces
+        torch.cuda.synchronize()
         tw = time.perf_counter()
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        wb3_s = time.perf_counter() - tw
-        assert all(bytes(v) == b"\x01" * m for v in verds), "verify_share verdicts (3 contexts)"
-        for e in engines:
-            e.close()
-        result["verify_share"] = {"value": m / wb_s, "unit": "share-box verifications/s", "batch": m,
-                                  "value_3_contexts": 3 * reps * m / wb3_s,
-                                  "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c, per-share SHA-256 verdict on the host; "
-                                          "inputs resident in HBM; `value`: synchronous calls on one context, "
-                                          "`value_3_contexts`: three contexts and host threads side by side"}
+        wb_pipelined(batches)
+        torch.cuda.synchronize()
+        wbp_s = (time.perf_counter() - tw) / batches
+        assert all(bool((dv == 1).all()) for dv in d_verd), "device verdict tensors"
+        result["verify_share"] = {"value": m / wbp_s, "unit": "share-box verifications/s", "batch": m,
+                                  "batches_in_flight": inflight, "value_synchronous_calls": m / wb_s,
+                                  "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c and the per-share SHA-256 verdict (K7) on the device; "
+                                          "inputs resident in HBM; `value`: mpvss_modp_verify_shares_compute/_absorb with "
+                                          f"{inflight} batches in flight in one context, verdict bytes also left in device tensors; "
+                                          "`value_synchronous_calls`: one mpvss_modp_verify_shares call at a time"}
     if world == 1:
         result["distribute"] = {"value": n / deal_s, "unit": "shares dealt/s",
                                 "note": "dealer side of distribute_secret (participant.rs:160-286): X_i, Y_i = y_i^P(i), "

@@ -233,11 +233,35 @@ int mpvss_ec_commit_eval(mpvss_ctx* ctx, int group, int space, const uint8_t* co
 int mpvss_ec_dleq_commitments(mpvss_ctx* ctx, int group, int space, const uint8_t* g1_host, const uint8_t* h1,
                               const uint8_t* g2, const uint8_t* h2, const uint8_t* r, const uint8_t* c, int c_per_share,
                               size_t n, uint8_t* a1_out, uint8_t* a2_out);
-/* src/participant.rs:1384-1442 (secp256k1), 1827-1885 (ristretto255) */
+/* out[i] = scalars[i] * G for the group's generator: keygen (secp256k1.rs:168-171, ristretto255.rs:239-242), commitments
+ * C_j = a_j G (participant.rs:1145-1152, 1626-1633), a1 = w G (dleq.rs:207-211) -- fixed-base comb, no doublings */
+int mpvss_ec_batch_exp_generator(mpvss_ctx* ctx, int group, int space, const uint8_t* scalars, size_t n, uint8_t* out);
+/* src/participant.rs:1384-1442 (secp256k1), 1827-1885 (ristretto255).  Positions become scalars by
+ * `Scalar::from(position as u64)` (participant.rs:1419, 1862), so a negative position wraps instead of failing. */
 int mpvss_ec_verify_distribution(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
                                  const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                  const uint8_t* responses, size_t n, const uint8_t* challenge_host, int* verdict,
                                  uint8_t* digest32_out, uint8_t* x_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host);
+/* The same split into compute (enqueue only) / absorb (wait, validate, hash) / verdict, sharing the sixteen block slots
+ * and the FIFO order of the MODP block calls, so that several boxes are in flight inside one context; and the
+ * library-pipelined form for many boxes (see mpvss_modp_verify_many).  An invalid encoding or a response that is not
+ * below the group order is reported by `absorb` (MPVSS_E_INVALID). */
+int mpvss_ec_verify_block_compute(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
+                                  const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
+                                  const uint8_t* responses, size_t n, const uint8_t* challenge_host);
+int mpvss_ec_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* a1_out_host,
+                                 uint8_t* a2_out_host);
+int mpvss_ec_transcript_absorb(int group, uint8_t* state, const uint8_t* elements, size_t count);
+int mpvss_ec_transcript_verdict(int group, const uint8_t* state, const uint8_t* challenge_host, int* verdict,
+                                uint8_t* digest32_out);
+typedef struct mpvss_ec_box {
+  const uint8_t* commitments; size_t t;
+  const int64_t* positions;
+  const uint8_t* pubkeys; const uint8_t* shares; const uint8_t* responses; size_t n;
+  const uint8_t* challenge_host;
+} mpvss_ec_box;
+int mpvss_ec_verify_many(mpvss_ctx* ctx, int group, int space, const mpvss_ec_box* boxes, size_t count, int depth,
+                         int hash_threads, int* verdicts, uint8_t* digests32);
 /* src/participant.rs:1346-1371 (secp256k1), 1789-1814 (ristretto255) */
 int mpvss_ec_verify_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
                            const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_host);

@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
     "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_sha256_uses_shani",
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
+    "mpvss_ec_batch_exp_generator", "mpvss_ec_verify_block_compute", "mpvss_ec_verify_block_absorb",
+    "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
 )
 
 GROUP_SECP256K1 = 1
@@ -52,6 +54,12 @@ class ModpBox(C.Structure):
     _fields_ = [("commitments", C.c_void_p), ("t", C.c_size_t), ("positions", C.c_void_p), ("pubkeys", C.c_void_p),
                 ("shares", C.c_void_p), ("responses", C.c_void_p), ("n", C.c_size_t), ("challenge_host", C.c_void_p),
                 ("keyset", C.c_void_p), ("key_offset", C.c_size_t)]
+
+
+class EcBox(C.Structure):
+    """struct mpvss_ec_box"""
+    _fields_ = [("commitments", C.c_void_p), ("t", C.c_size_t), ("positions", C.c_void_p), ("pubkeys", C.c_void_p),
+                ("shares", C.c_void_p), ("responses", C.c_void_p), ("n", C.c_size_t), ("challenge_host", C.c_void_p)]
 
 
 class PipelineStats(C.Structure):
@@ -115,6 +123,12 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_verify_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
+    lib.mpvss_ec_batch_exp_generator.argtypes = [vp, ci, ci, u8p, sz, u8p]
+    lib.mpvss_ec_verify_block_compute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_ec_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_transcript_absorb.argtypes = [ci, u8p, u8p, sz]
+    lib.mpvss_ec_transcript_verdict.argtypes = [ci, u8p, u8p, C.POINTER(ci), u8p]
+    lib.mpvss_ec_verify_many.argtypes = [vp, ci, ci, C.POINTER(EcBox), sz, ci, ci, C.POINTER(ci), u8p]
     lib.mpvss_modp_verify_many.argtypes = [vp, ci, C.POINTER(ModpBox), sz, ci, ci, C.POINTER(ci), u8p]
     lib.mpvss_pipeline_stats_get.argtypes = [vp, C.POINTER(PipelineStats), ci]
     lib.mpvss_sha256_uses_shani.restype = ci
@@ -336,6 +350,46 @@ class Engine:
         self._check(self.lib.mpvss_ec_batch_exp(self.ctx, group, MPVSS_HOST, pa, pb, n, po), "ec_batch_exp")
         return bytes(ko)[: n * EC_ENC[group]]
 
+    def ec_batch_exp_generator(self, group: int, scalars: bytes) -> bytes:
+        n = len(scalars) // 32
+        kb, pb = _buf(scalars); ko, po = _out(n * EC_ENC[group])
+        self._check(self.lib.mpvss_ec_batch_exp_generator(self.ctx, group, MPVSS_HOST, pb, n, po), "ec_batch_exp_generator")
+        return bytes(ko)[: n * EC_ENC[group]]
+
+    def ec_verify_block_compute(self, group: int, commitments: bytes, positions: Sequence[int], pubkeys: bytes,
+                                shares: bytes, responses: bytes, challenge: bytes) -> None:
+        e = EC_ENC[group]
+        t, n = len(commitments) // e, len(positions)
+        kc, pc = _buf(commitments); ky, py = _buf(pubkeys); kY, pY = _buf(shares); kr, pr = _buf(responses)
+        kch, pch = _buf(challenge)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        self._check(self.lib.mpvss_ec_verify_block_compute(self.ctx, group, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p),
+                                                           py, pY, pr, n, pch), "ec_verify_block_compute")
+
+    def ec_verify_block_absorb(self, state: bytes) -> bytes:
+        ks, ps = _buf(state)
+        self._check(self.lib.mpvss_ec_verify_block_absorb(self.ctx, ps, None, None, None), "ec_verify_block_absorb")
+        return bytes(ks)
+
+    def ec_verify_many(self, group: int, boxes: Sequence[dict], depth: int = 6, hash_threads: int = 3):
+        """boxes: dicts with commitments, positions, pubkeys, shares, responses, challenge (host bytes).
+        Returns [(verdict, digest)] in box order."""
+        keep, arr = [], (EcBox * max(len(boxes), 1))()
+        e = EC_ENC[group]
+        for i, b in enumerate(boxes):
+            n = len(b["positions"])
+            pos = (C.c_int64 * max(n, 1))(*b["positions"])
+            bufs = [_buf(b[k]) for k in ("commitments", "pubkeys", "shares", "responses", "challenge")]
+            keep.append((pos, bufs))
+            arr[i] = EcBox(bufs[0][1], len(b["commitments"]) // e, C.cast(pos, C.c_void_p), bufs[1][1], bufs[2][1],
+                           bufs[3][1], n, bufs[4][1])
+        verdicts = (C.c_int * max(len(boxes), 1))()
+        kd, pd = _out(32 * len(boxes))
+        self._check(self.lib.mpvss_ec_verify_many(self.ctx, group, MPVSS_HOST, arr, len(boxes), depth, hash_threads, verdicts,
+                                                  pd), "ec_verify_many")
+        raw = bytes(kd)
+        return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(len(boxes))]
+
     def ec_batch_mul(self, group: int, a: bytes, b: bytes) -> bytes:
         n = len(a) // EC_ENC[group]
         ka, pa = _buf(a); kb, pb = _buf(b); ko, po = _out(n * EC_ENC[group])
@@ -484,3 +538,22 @@ def ec_hash_to_scalar(group: int, data: bytes) -> bytes:
     if rc != 0:
         raise EngineError(f"ec_hash_to_scalar failed: {rc}")
     return bytes(ko)[:32]
+
+
+def ec_transcript_verdict(group: int, state: bytes, challenge: bytes):
+    lib = load_library()
+    ks, ps = _buf(state); kc, pc = _buf(challenge); kd, pd = _out(32)
+    v = C.c_int(0)
+    rc = lib.mpvss_ec_transcript_verdict(group, ps, pc, C.byref(v), pd)
+    if rc != 0:
+        raise EngineError(f"ec_transcript_verdict failed: {rc}")
+    return bool(v.value), bytes(kd)[:32]
+
+
+def ec_transcript_absorb(group: int, state: bytes, elements: bytes) -> bytes:
+    lib = load_library()
+    ks, ps = _buf(state); ke, pe = _buf(elements if elements else b"\0")
+    rc = lib.mpvss_ec_transcript_absorb(group, ps, pe, len(elements) // EC_ENC[group])
+    if rc != 0:
+        raise EngineError(f"ec_transcript_absorb failed: {rc}")
+    return bytes(ks)

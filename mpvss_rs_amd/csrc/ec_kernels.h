@@ -10,15 +10,17 @@ extern "C" {
 #endif
 int ec_point_words(int group);
 int ec_launch_decode(int group, const uint8_t* enc, int count, uint32_t* pts, uint8_t* ok, hipStream_t s);
+/* gate / want: run only if *gate == want (null: always) -- the forward-difference kernels and Horner's rule exclude
+ * each other through a device flag when the positions are device-resident */
 int ec_launch_commit_eval(int group, const uint32_t* cm, int t, const int64_t* positions, int count, uint8_t* x_enc,
-                          hipStream_t s);
+                          const int* gate, int want, hipStream_t s);
 int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uint8_t* k1, const uint8_t* p2,
                        const uint8_t* k2, size_t k2_stride, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
 /* forward differences for consecutive positions: seeds at chain indices w0..w0+t-1, tables, stepping both ways,
  * encoding; pts [count][point words], state_fwd / state_bwd [chains*t][point words] */
 int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
                  int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc, int split_seeds,
-                 hipStream_t s);
+                 const int* gate, hipStream_t s);
 int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
 /* windowed double-scalar multiplication (signed 4-bit windows; see ec_kernels.hip):
  *   comb: 65 x 8 packed affine multiples of the generator (ec_comb_words() words, built once by ec_launch_comb_build)
@@ -28,10 +30,11 @@ int ec_cached_words(int group);
 int ec_comb_words(int group);
 int ec_launch_comb_build(int group, uint32_t* comb, hipStream_t s);
 int ec_launch_build_tables(int group, const uint8_t* enc, size_t enc_stride, const uint32_t* pts, int count, uint32_t* tab,
-                           uint8_t* ok, hipStream_t s);
+                           uint8_t* ok, const int* gate, hipStream_t s);
 int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_t* tab1, const uint8_t* k1, size_t k1_stride,
                        const uint32_t* tab2, const uint8_t* k2, size_t k2_stride, int count, uint32_t* out_pts, hipStream_t s);
 int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s);
+int ec_launch_encode_gated(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,11 @@ __device__ __forceinline__ void decode_body(const uint8_t* __restrict__ enc, int
 // X_i = sum_j (i^j) C_j by Horner's rule:  X = ((C_{t-1} * i + C_{t-2}) * i + ...) * i + C_0.
 // Same group element as the reference's loop (participant.rs:1411-1417 reduces i^j mod the group
 // order, which is the order of every element of these prime-order groups).
+// gate / want: the forward-difference kernels and Horner's rule exclude each other through a device flag when the
+// positions live in device memory (the choice then needs no host synchronisation); gate == null: always run
+#define EC_GATE_CHECK(gate, want) \
+  if ((gate) != nullptr && *(gate) != (want)) return
+
 template <class C>
 __device__ __forceinline__ void commit_eval_body(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions,
                                                  int count, uint8_t* __restrict__ x_enc) {
@@ -287,11 +292,13 @@ __device__ __forceinline__ void load_cached(typename C::Cached& e, const u32* __
 template <class C>
 __device__ __forceinline__ void build_tables_body(const uint8_t* __restrict__ enc, size_t enc_stride,
                                                   const u32* __restrict__ pts, int count, u32* __restrict__ tab,
-                                                  uint8_t* __restrict__ ok) {
+                                                  uint8_t* __restrict__ ok, const int* __restrict__ gate) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= count) return;
   typename C::Point p;
-  if (enc != nullptr) {
+  // both sources given: the internal points are valid when the forward-difference path ran (*gate == 1)
+  const bool from_enc = enc != nullptr && (pts == nullptr || (gate != nullptr && *gate != 1));
+  if (from_enc) {
     const bool good = C::decode(p, enc + (size_t)x * enc_stride);
     if (ok != nullptr) ok[x] = good ? 1 : 0;
   } else {
@@ -404,7 +411,9 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
     decode_body<CURVE>(enc, count, pts, ok);                                                                           \
   }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_commit_eval(const u32* cm, int t, const int64_t* pos,    \
-                                                                          int count, uint8_t* x_enc) {                 \
+                                                                          int count, uint8_t* x_enc, const int* gate,  \
+                                                                          int want) {                                  \
+    EC_GATE_CHECK(gate, want);                                                                                         \
     commit_eval_body<CURVE>(cm, t, pos, count, x_enc);                                                                 \
   }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_dual_mul(                                                \
@@ -417,23 +426,29 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
     add_body<CURVE>(a, b, count, out, ok);                                                                             \
   }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds(const u32* cm, int t, const int64_t* pos,       \
-                                                                       int count, u32* pts) {                          \
+                                                                       int count, u32* pts, const int* gate) {         \
+    EC_GATE_CHECK(gate, 1);                                                                                            \
     seeds_body<CURVE>(cm, t, pos, count, pts);                                                                         \
   }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds_split(const u32* cm, int t, const int64_t* pos, \
-                                                                             int count, u32* pts) {                    \
+                                                                             int count, u32* pts, const int* gate) {   \
+    EC_GATE_CHECK(gate, 1);                                                                                            \
     seeds_split_body<CURVE, ORDER, 8>(cm, t, pos, count, pts);                                                         \
   }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_table(const u32* seeds, int chains, int t, u32* fwd, \
-                                                                        u32* bwd) {                                    \
+                                                                        u32* bwd, const int* gate) {                   \
+    EC_GATE_CHECK(gate, 1);                                                                                            \
     fd_table_body<CURVE>(seeds, chains, t, fwd, bwd);                                                                  \
   }                                                                                                                    \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_step(const u32* fwd, const u32* bwd, int chains,     \
                                                                        int t, int w0, int chain_len, int count,        \
-                                                                       u32* pts) {                                     \
+                                                                       u32* pts, const int* gate) {                    \
+    EC_GATE_CHECK(gate, 1);                                                                                            \
     fd_step_body<CURVE>(fwd, bwd, chains, t, w0, chain_len, count, pts);                                               \
   }                                                                                                                    \
-  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_encode(const u32* pts, int count, uint8_t* enc) {        \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_encode(const u32* pts, int count, uint8_t* enc,          \
+                                                                     const int* gate) {                                \
+    EC_GATE_CHECK(gate, 1);                                                                                            \
     encode_body<CURVE>(pts, count, enc);                                                                               \
   }
 
@@ -441,9 +456,9 @@ EC_KERNELS(secp, Secp, OrderSecp)
 EC_KERNELS(rist, Ristretto, OrderEd)
 
 #define EC_WIN_KERNELS(NAME, CURVE)                                                                                          \
-  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_build_tables(const uint8_t* enc, size_t enc_stride,            \
-                                                                           const u32* pts, int count, u32* tab, uint8_t* ok) { \
-    build_tables_body<CURVE>(enc, enc_stride, pts, count, tab, ok);                                                          \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_build_tables(                                                  \
+      const uint8_t* enc, size_t enc_stride, const u32* pts, int count, u32* tab, uint8_t* ok, const int* gate) {            \
+    build_tables_body<CURVE>(enc, enc_stride, pts, count, tab, ok, gate);                                                    \
   }                                                                                                                          \
   extern "C" __global__ void __launch_bounds__(128) k_##NAME##_comb_build(u32* comb) { comb_build_body<CURVE>(comb); }       \
   extern "C" __global__ void __launch_bounds__(DW_THREADS) k_##NAME##_dual_win(                                              \
@@ -454,7 +469,8 @@ EC_KERNELS(rist, Ristretto, OrderEd)
   }
 EC_WIN_KERNELS(secp, Secp)
 EC_WIN_KERNELS(rist, Ristretto)
-extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc) {
+extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate) {
+  EC_GATE_CHECK(gate, 1);
   secp_encode_batch_body(pts, count, enc);
 }
 
@@ -470,10 +486,12 @@ extern "C" int ec_launch_decode(int group, const uint8_t* enc, int count, uint32
   return (int)hipGetLastError();
 }
 extern "C" int ec_launch_commit_eval(int group, const uint32_t* cm, int t, const int64_t* positions, int count,
-                                     uint8_t* x_enc, hipStream_t s) {
+                                     uint8_t* x_enc, const int* gate, int want, hipStream_t s) {
   if (count <= 0) return 0;
-  if (group == 1) hipLaunchKernelGGL(k_secp_commit_eval, dim3(blocks_for(count)), dim3(64), 0, s, cm, t, positions, count, x_enc);
-  else hipLaunchKernelGGL(k_rist_commit_eval, dim3(blocks_for(count)), dim3(64), 0, s, cm, t, positions, count, x_enc);
+  if (group == 1)
+    hipLaunchKernelGGL(k_secp_commit_eval, dim3(blocks_for(count)), dim3(64), 0, s, cm, t, positions, count, x_enc, gate, want);
+  else
+    hipLaunchKernelGGL(k_rist_commit_eval, dim3(blocks_for(count)), dim3(64), 0, s, cm, t, positions, count, x_enc, gate, want);
   return (int)hipGetLastError();
 }
 extern "C" int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uint8_t* k1, const uint8_t* p2,
@@ -494,11 +512,13 @@ extern "C" int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int 
   return (int)hipGetLastError();
 }
 
+extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, hipStream_t s);
+
 // ---- forward differences: seeds (m0 positions from `positions`), tables, stepping, encoding -------------------------
 // pts: [count][point words] internal points, index 0 = first position of the batch; seeds go to pts + seed0.
 extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
                             int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc,
-                            int split_seeds, hipStream_t s) {
+                            int split_seeds, const int* gate, hipStream_t s) {
   const int m0 = chains * t;
   const size_t seed0 = (size_t)chains * w0;
   const int pw = ec_point_words(group);
@@ -507,26 +527,28 @@ extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t*
   const size_t lds = (size_t)lanes * pw * 4;
   const bool split = split_seeds && t >= 64;                    // 8 lanes per seed
   const size_t lds_seed = (size_t)64 * pw * 4;
-  if (split) {
-    if (group == 1)
-      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
-                         seeds);
-    else
-      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
-                         seeds);
-  }
   if (group == 1) {
-    if (!split) hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
-    hipLaunchKernelGGL(k_secp_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd);
+    if (split)
+      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
+                         seeds, gate);
+    else
+      hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds, gate);
+    hipLaunchKernelGGL(k_secp_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate);
     hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
-                       count, pts);
-    hipLaunchKernelGGL(k_secp_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, x_enc);
+                       count, pts, gate);
   } else {
-    if (!split) hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds);
-    hipLaunchKernelGGL(k_rist_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd);
+    if (split)
+      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
+                         seeds, gate);
+    else
+      hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds, gate);
+    hipLaunchKernelGGL(k_rist_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate);
     hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
-                       count, pts);
-    hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, x_enc);
+                       count, pts, gate);
+  }
+  if (x_enc != nullptr) {
+    const int rc = ec_launch_encode_gated(group, pts, count, x_enc, gate, s);
+    if (rc != 0) return rc;
   }
   return (int)hipGetLastError();
 }
@@ -543,10 +565,12 @@ extern "C" int ec_launch_comb_build(int group, uint32_t* comb, hipStream_t s) {
 // tables of `count` bases: from encodings (enc, stride 0 = one shared base; ok receives the validity flags) or from
 // internal points (pts)
 extern "C" int ec_launch_build_tables(int group, const uint8_t* enc, size_t enc_stride, const uint32_t* pts, int count,
-                                      uint32_t* tab, uint8_t* ok, hipStream_t s) {
+                                      uint32_t* tab, uint8_t* ok, const int* gate, hipStream_t s) {
   if (count <= 0) return 0;
-  if (group == 1) hipLaunchKernelGGL(k_secp_build_tables, dim3(blocks_for(count)), dim3(64), 0, s, enc, enc_stride, pts, count, tab, ok);
-  else hipLaunchKernelGGL(k_rist_build_tables, dim3(blocks_for(count)), dim3(64), 0, s, enc, enc_stride, pts, count, tab, ok);
+  if (group == 1)
+    hipLaunchKernelGGL(k_secp_build_tables, dim3(blocks_for(count)), dim3(64), 0, s, enc, enc_stride, pts, count, tab, ok, gate);
+  else
+    hipLaunchKernelGGL(k_rist_build_tables, dim3(blocks_for(count)), dim3(64), 0, s, enc, enc_stride, pts, count, tab, ok, gate);
   return (int)hipGetLastError();
 }
 // out_pts[x] = k1[x] * (G if comb else P1[x]) + k2[x] * P2[x]; tab2 may be null (single multiplication)
@@ -562,10 +586,13 @@ extern "C" int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_
     hipLaunchKernelGGL(k_rist_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);
   return (int)hipGetLastError();
 }
-// internal points -> canonical encodings (secp256k1: eight points per lane share an inversion)
-extern "C" int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s) {
+// internal points -> canonical encodings (secp256k1: eight points per lane share an inversion); gate: run only if *gate == 1
+extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, hipStream_t s) {
   if (count <= 0) return 0;
-  if (group == 1) hipLaunchKernelGGL(k_secp_encode_batch, dim3(blocks_for((count + 7) / 8)), dim3(64), 0, s, pts, count, enc);
-  else hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, enc);
+  if (group == 1) hipLaunchKernelGGL(k_secp_encode_batch, dim3(blocks_for((count + 7) / 8)), dim3(64), 0, s, pts, count, enc, gate);
+  else hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, enc, gate);
   return (int)hipGetLastError();
+}
+extern "C" int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s) {
+  return ec_launch_encode_gated(group, pts, count, enc, nullptr, s);
 }

@@ -47,9 +47,15 @@ struct DevBuf {
 
 }  // namespace
 
-struct EcWork {   // device workspace of the elliptic-curve entry points
+struct EcWork {   // device workspace of the elliptic-curve entry points (one per context and one per block slot)
   DevBuf a, b, c, d, e, pos, cm, cmenc, x, o1, o2, ok, gen, chal, pts, fdst;
-  std::vector<int64_t> hpos;     // host copy of device-resident positions (forward-difference decision)
+  DevBuf tab1, tab2, tab3;       // window tables of per-share bases: [n][8][cached words]
+  DevBuf p1, p2;                 // results of the double-scalar multiplications in internal coordinates
+  DevBuf flags;                  // ints: [0] forward-difference gate, [1] first bad response, [2] first bad challenge
+  std::vector<DevBuf*> all() {
+    return {&a, &b, &c, &d, &e, &pos, &cm, &cmenc, &x, &o1, &o2, &ok, &gen, &chal, &pts, &fdst, &tab1, &tab2, &tab3, &p1, &p2,
+            &flags};
+  }
 };
 
 // Registered public keys: per-key tables for y^r in HBM plus a device copy of the keys themselves.
@@ -125,7 +131,11 @@ struct mpvss_ctx {
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
-    int kind = 0;                  // 0: block of verify_distribution_shares, 1: batch of verify_share proofs (W_B)
+    int kind = 0;                  // 0: block of verify_distribution_shares, 1: batch of verify_share proofs (W_B),
+                                   // 2: block of a curve group's verify_distribution_shares
+    int group = 0;                 // kind 2: MPVSS_GROUP_*
+    size_t t = 0;                  // kind 2: number of commitments (their decode flags sit in the staging)
+    EcWork ecw;
     double enqueue_ms = 0;         // host time spent enqueueing this block's GPU work
     hipEvent_t done = nullptr;
     SpanSet spans;
@@ -138,6 +148,8 @@ struct mpvss_ctx {
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
+  DevBuf ec_comb[2];             // fixed-base combs of the curve groups' generators (built on first use)
+  bool ec_comb_ready[2] = {false, false};
   // host-side accounting of the block pipeline (mpvss_pipeline_stats_get): sums over absorbed blocks
   struct PipeStats {
     double enqueue_ms = 0, wait_ms = 0, hash_ms = 0;
@@ -489,10 +501,13 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   work_destroy(ctx->work0, ctx->own_stream);
   for (DevBuf* b : {&ctx->comb[0], &ctx->comb[1], &ctx->comb16[0], &ctx->comb16[1]})
     if (b->p) (void)hipFree(b->p);
-  for (DevBuf* b : {&ctx->ecwork.a, &ctx->ecwork.b, &ctx->ecwork.c, &ctx->ecwork.d, &ctx->ecwork.e, &ctx->ecwork.pos,
-                    &ctx->ecwork.cm, &ctx->ecwork.cmenc, &ctx->ecwork.x, &ctx->ecwork.o1, &ctx->ecwork.o2, &ctx->ecwork.ok,
-                    &ctx->ecwork.gen, &ctx->ecwork.chal, &ctx->ecwork.pts, &ctx->ecwork.fdst})
+  for (DevBuf* b : ctx->ecwork.all())
     if (b->p) (void)hipFree(b->p);
+  for (auto& sl : ctx->slot)
+    for (DevBuf* b : sl.ecw.all())
+      if (b->p) (void)hipFree(b->p);
+  for (DevBuf& b : ctx->ec_comb)
+    if (b.p) (void)hipFree(b.p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
@@ -1370,22 +1385,18 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
 // The calling thread enqueues the GPU work of up to `depth` boxes ahead; `hash_threads` library threads wait for the
 // boxes in FIFO order and hash them (every box has its own transcript, so the hashes of consecutive boxes run side
 // by side).  Nothing of this depends on the caller's scheduler.
-extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
-                                      int hash_threads, int* verdicts, uint8_t* digests32) {
-  if (!ctx) return MPVSS_E_INVALID;
-  if (count == 0) return MPVSS_OK;
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!boxes || !verdicts) return fail(ctx, MPVSS_E_INVALID, "verify_many: bad argument");
-    if (ctx->head != ctx->tail)
-      return fail(ctx, MPVSS_E_INVALID, "verify_many: blocks of the block API are in flight, absorb them first");
-  }
+namespace {
+
+int ec_verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
+                                  uint8_t* a1_out, uint8_t* a2_out);     // capi_ec.inc
+
+// issue(b): enqueue box b (called with the context lock held); finish(idx, state): verdict of box idx from its state
+template <class Issue, class Finish>
+int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, Issue issue, Finish finish) {
   if (hash_threads < 1) hash_threads = 1;
   if (hash_threads > 8) hash_threads = 8;
   if (depth < 1) depth = 1;
   if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
-  for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
-
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
@@ -1412,11 +1423,11 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
       {
         std::unique_lock<std::mutex> lk(ctx->mu);
         idx = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
-        rc = verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
+        const int kind = ctx->slot[ctx->tail % mpvss_ctx::NSLOT].kind;
+        rc = kind == 2 ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr)
+                       : verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
       }
-      if (rc == MPVSS_OK && idx < count)
-        rc = mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],
-                                           digests32 ? digests32 + 32 * idx : nullptr);
+      if (rc == MPVSS_OK && idx < count) rc = finish(idx, state);
       {
         std::lock_guard<std::mutex> l(sh.m);
         if (idx < count) sh.finished[idx] = 1;
@@ -1437,12 +1448,10 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
       sh.cv.wait(l, [&] { return sh.issued - sh.low < (size_t)depth || sh.rc != MPVSS_OK; });
       if (sh.rc != MPVSS_OK) break;
     }
-    const mpvss_modp_box& bx = boxes[b];
     int rc;
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
-      rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
-                                       bx.n, bx.challenge_host, bx.keyset, bx.key_offset);
+      rc = issue(b);
     }
     {
       std::lock_guard<std::mutex> l(sh.m);
@@ -1462,6 +1471,32 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   sh.cv.notify_all();
   for (auto& th : pool) th.join();     // the workers drain every issued block, so no slot stays busy
   return sh.rc;
+}
+
+}  // namespace
+
+extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
+                                      int hash_threads, int* verdicts, uint8_t* digests32) {
+  if (!ctx) return MPVSS_E_INVALID;
+  if (count == 0) return MPVSS_OK;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!boxes || !verdicts) return fail(ctx, MPVSS_E_INVALID, "verify_many: bad argument");
+    if (ctx->head != ctx->tail)
+      return fail(ctx, MPVSS_E_INVALID, "verify_many: blocks of the block API are in flight, absorb them first");
+  }
+  for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
+  return run_box_pipeline(
+      ctx, count, depth, hash_threads,
+      [&](size_t b) {
+        const mpvss_modp_box& bx = boxes[b];
+        return verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
+                                           bx.n, bx.challenge_host, bx.keyset, bx.key_offset);
+      },
+      [&](size_t idx, const uint8_t* state) {
+        return mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],
+                                             digests32 ? digests32 + 32 * idx : nullptr);
+      });
 }
 
 extern "C" int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* out, int reset) {
@@ -1783,554 +1818,5 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
   return MPVSS_OK;
 }
 
-// =====================================================================================================
-// Elliptic-curve groups: secp256k1 (src/groups/secp256k1.rs) and ristretto255 (src/groups/ristretto255.rs)
-// =====================================================================================================
-#include "ec_kernels.h"
-#include "sha512.h"
-
-namespace {
-
-struct EcInfo {
-  int group;
-  size_t enc;            // element bytes
-  bool scalar_be;        // scalar byte order
-  uint8_t order_be[32];  // group order, big-endian
-  uint8_t gen[33];       // canonical encoding of the generator
-};
-
-const EcInfo* ec_info(int group) {
-  static const EcInfo secp = {
-      MPVSS_GROUP_SECP256K1, 33, true,
-      {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFE,
-       0xBA, 0xAE, 0xDC, 0xE6, 0xAF, 0x48, 0xA0, 0x3B, 0xBF, 0xD2, 0x5E, 0x8C, 0xD0, 0x36, 0x41, 0x41},   // secp256k1.rs:47-51
-      {0x02, 0x79, 0xBE, 0x66, 0x7E, 0xF9, 0xDC, 0xBB, 0xAC, 0x55, 0xA0, 0x62, 0x95, 0xCE, 0x87, 0x0B, 0x07,
-       0x02, 0x9B, 0xFC, 0xDB, 0x2D, 0xCE, 0x28, 0xD9, 0x59, 0xF2, 0x81, 0x5B, 0x16, 0xF8, 0x17, 0x98}};
-  static const EcInfo rist = {
-      MPVSS_GROUP_RISTRETTO255, 32, false,
-      {0x10, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00,
-       0x14, 0xde, 0xf9, 0xde, 0xa2, 0xf7, 0x9c, 0xd6, 0x58, 0x12, 0x63, 0x1a, 0x5c, 0xf5, 0xd3, 0xed},   // ristretto255.rs:55-59
-      {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f, 0x58,
-       0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76, 0x00}};
-  if (group == MPVSS_GROUP_SECP256K1) return &secp;
-  if (group == MPVSS_GROUP_RISTRETTO255) return &rist;
-  return nullptr;
-}
-
-// scalar (in the group's byte order) < group order ?
-bool scalar_canonical(const EcInfo* gi, const uint8_t* s) {
-  for (int i = 0; i < 32; ++i) {
-    const uint8_t a = gi->scalar_be ? s[i] : s[31 - i];
-    if (a != gi->order_be[i]) return a < gi->order_be[i];
-  }
-  return false;
-}
-
-// hash_to_scalar(digest) in the group's scalar byte order
-void ec_hash_to_scalar(const EcInfo* gi, const uint8_t digest[32], uint8_t out[32]) {
-  if (gi->group == MPVSS_GROUP_SECP256K1) {
-    // SHA-256 -> big-endian integer -> mod n (secp256k1.rs:121-131); 2^256 < 2n so one subtraction suffices
-    uint8_t h[32];
-    mpvss::sha256(digest, 32, h);
-    if (!scalar_canonical(gi, h)) {
-      int borrow = 0;
-      for (int i = 31; i >= 0; --i) {
-        const int d = (int)h[i] - gi->order_be[i] - borrow;
-        h[i] = (uint8_t)(d & 0xff);
-        borrow = d < 0;
-      }
-    }
-    memcpy(out, h, 32);
-    return;
-  }
-  // SHA-512 -> 64-byte little-endian integer -> mod l (ristretto255.rs:196-205): bitwise long division
-  uint8_t wide[64];
-  mpvss::sha512(digest, 32, wide);
-  uint64_t l[4] = {0, 0, 0, 0};
-  for (int i = 0; i < 32; ++i) l[3 - i / 8] |= (uint64_t)gi->order_be[i] << (8 * (7 - i % 8));
-  uint64_t r[5] = {0, 0, 0, 0, 0};
-  for (int bit = 511; bit >= 0; --bit) {
-    for (int k = 4; k > 0; --k) r[k] = (r[k] << 1) | (r[k - 1] >> 63);
-    r[0] = (r[0] << 1) | ((wide[bit >> 3] >> (bit & 7)) & 1);
-    bool ge = r[4] != 0;
-    if (!ge) {
-      ge = true;
-      for (int k = 3; k >= 0; --k)
-        if (r[k] != l[k]) { ge = r[k] > l[k]; break; }
-    }
-    if (ge) {
-      unsigned __int128 borrow = 0;
-      for (int k = 0; k < 4; ++k) {
-        const unsigned __int128 d = (unsigned __int128)r[k] - l[k] - (uint64_t)borrow;
-        r[k] = (uint64_t)d;
-        borrow = (d >> 64) & 1;
-      }
-      r[4] -= (uint64_t)borrow;
-    }
-  }
-  for (int i = 0; i < 32; ++i) out[i] = (uint8_t)(r[i / 8] >> (8 * (i % 8)));
-}
-
-inline void ec_frame_update(mpvss::Sha256& h, const uint8_t* e, size_t len) {
-  uint8_t pre[8] = {0, 0, 0, 0, 0, 0, 0, (uint8_t)len};      // dleq.rs:58-61: u64 big-endian length
-  h.update(pre, 8);
-  h.update(e, len);
-}
-
-EcWork& ecw(mpvss_ctx* ctx) { return ctx->ecwork; }
-
-int ec_check_ok(mpvss_ctx* ctx, const uint8_t* ok_dev, size_t n, const char* what) {
-  std::vector<uint8_t> h(n);
-  HIPCHK(ctx, hipMemcpyAsync(h.data(), ok_dev, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i < n; ++i)
-    if (!h[i]) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "%s: element %zu is not a valid group-element encoding", what, i);
-      return fail(ctx, MPVSS_E_INVALID, buf);
-    }
-  return 0;
-}
-
-int ec_check_scalars(mpvss_ctx* ctx, const EcInfo* gi, int space, const uint8_t* s, size_t n, const char* what) {
-  std::vector<uint8_t> h;
-  RET_IF(small_vec_to_host(ctx, space, s, n * 32, h));
-  for (size_t i = 0; i < n; ++i)
-    if (!scalar_canonical(gi, h.data() + i * 32)) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "%s: scalar %zu is not below the group order (the reference cannot represent it)", what, i);
-      return fail(ctx, MPVSS_E_INVALID, buf);
-    }
-  return 0;
-}
-
-// commitments (encoded, `space`) -> decoded points in w.cm
-int ec_stage_commitments(mpvss_ctx* ctx, const EcInfo* gi, EcWork& w, int space, const uint8_t* commitments, size_t t) {
-  const void* dc;
-  RET_IF(stage_in(ctx, space, commitments, t * gi->enc, w.cmenc, &dc));
-  RET_IF(ensure(ctx, w.cm, t * (size_t)ec_point_words(gi->group) * 4));
-  RET_IF(ensure(ctx, w.ok, t > 4096 ? t : 4096));
-  LAUNCHCHK(ctx, ec_launch_decode(gi->group, (const uint8_t*)dc, (int)t, (uint32_t*)w.cm.p, (uint8_t*)w.ok.p, ctx->stream));
-  return ec_check_ok(ctx, (const uint8_t*)w.ok.p, t, "commitments");
-}
-
-int ec_generator_dev(mpvss_ctx* ctx, const EcInfo* gi, EcWork& w, const uint8_t* gen_host, const uint8_t** dev) {
-  RET_IF(ensure(ctx, w.gen, 64));
-  HIPCHK(ctx, hipMemcpyAsync(w.gen.p, gen_host ? gen_host : gi->gen, gi->enc, hipMemcpyHostToDevice, ctx->stream));
-  *dev = (const uint8_t*)w.gen.p;
-  return 0;
-}
-
-}  // namespace
-
-#define EC_PROLOGUE(what)                                                             \
-  if (!ctx) return MPVSS_E_INVALID;                                                   \
-  std::lock_guard<std::mutex> lk(ctx->mu);                                            \
-  const EcInfo* gi = ec_info(group);                                                  \
-  if (!gi) return fail(ctx, MPVSS_E_UNSUPPORTED, what ": unknown group");             \
-  HIPCHK(ctx, hipSetDevice(ctx->device));                                             \
-  EcWork& w = ecw(ctx);                                                               \
-  spans_reset(ctx)
-
-// ---- Group::exp / Group::mul -----------------------------------------------------------------------
-extern "C" int mpvss_ec_batch_exp(mpvss_ctx* ctx, int group, int space, const uint8_t* bases, const uint8_t* scalars,
-                                  size_t n, uint8_t* out) {
-  EC_PROLOGUE("ec_batch_exp");
-  if (n == 0) return MPVSS_OK;
-  if (!bases || !scalars || !out || n > 0x7fffffff) return fail(ctx, MPVSS_E_INVALID, "ec_batch_exp: bad argument");
-  RET_IF(ec_check_scalars(ctx, gi, space, scalars, n, "ec_batch_exp"));
-  const void *db, *dk;
-  RET_IF(stage_in(ctx, space, bases, n * gi->enc, w.a, &db));
-  RET_IF(stage_in(ctx, space, scalars, n * 32, w.b, &dk));
-  uint8_t* dout = out;
-  if (space == MPVSS_HOST) { RET_IF(ensure(ctx, w.o1, n * gi->enc)); dout = (uint8_t*)w.o1.p; }
-  RET_IF(ensure(ctx, w.ok, n > 4096 ? n : 4096));
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)db, gi->enc, (const uint8_t*)dk, nullptr, nullptr, 0,
-                                          (int)n, dout, (uint8_t*)w.ok.p, ctx->stream));
-  if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out, dout, n * gi->enc));
-  RET_IF(ec_check_ok(ctx, (const uint8_t*)w.ok.p, n, "ec_batch_exp bases"));
-  RET_IF(spans_collect(ctx));
-  return MPVSS_OK;
-}
-
-extern "C" int mpvss_ec_batch_mul(mpvss_ctx* ctx, int group, int space, const uint8_t* a, const uint8_t* b, size_t n,
-                                  uint8_t* out) {
-  EC_PROLOGUE("ec_batch_mul");
-  if (n == 0) return MPVSS_OK;
-  if (!a || !b || !out || n > 0x7fffffff) return fail(ctx, MPVSS_E_INVALID, "ec_batch_mul: bad argument");
-  const void *da, *db;
-  RET_IF(stage_in(ctx, space, a, n * gi->enc, w.a, &da));
-  RET_IF(stage_in(ctx, space, b, n * gi->enc, w.b, &db));
-  uint8_t* dout = out;
-  if (space == MPVSS_HOST) { RET_IF(ensure(ctx, w.o1, n * gi->enc)); dout = (uint8_t*)w.o1.p; }
-  RET_IF(ensure(ctx, w.ok, n > 4096 ? n : 4096));
-  LAUNCHCHK(ctx, ec_launch_add(group, (const uint8_t*)da, (const uint8_t*)db, (int)n, dout, (uint8_t*)w.ok.p, ctx->stream));
-  if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out, dout, n * gi->enc));
-  RET_IF(ec_check_ok(ctx, (const uint8_t*)w.ok.p, n, "ec_batch_mul operands"));
-  return MPVSS_OK;
-}
-
-// X_i for n shares into dX (encoded): forward differences (ec_kernels.hip) when the positions are consecutive and the
-// batch is large enough -- one point addition per share and coefficient -- otherwise Horner's rule.
-// MPVSS_EC_FD=0 disables the path, MPVSS_EC_FD_CHAINS overrides the number of chains.
-int ec_eval_x(mpvss_ctx* ctx, const EcInfo* gi, int group, EcWork& w, int space, size_t t, const int64_t* positions,
-              const int64_t* dpos, size_t n, uint8_t* dX) {
-  static const int fd_on = fd_env("MPVSS_EC_FD", 1), chains_env = fd_env("MPVSS_EC_FD_CHAINS", 0);
-  static const int split_seeds = fd_env("MPVSS_EC_FD_SPLIT", 1);     // every seed evaluated by 8 lanes (shorter latency)
-  bool fd = fd_on && t >= 16 && t <= 256 && n >= 16 * t && n >= 4096;
-  if (fd) {
-    const int64_t* hp = positions;
-    if (space == MPVSS_DEVICE) {
-      w.hpos.resize(n);
-      HIPCHK(ctx, hipMemcpyAsync(w.hpos.data(), positions, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      hp = w.hpos.data();
-    }
-    fd = hp[0] >= 0 && hp[0] < ((int64_t)1 << 61);
-    for (size_t i = 1; i < n && fd; ++i) fd = hp[i] == hp[0] + (int64_t)i;
-  }
-  if (!fd) {
-    TIMED_LAUNCH(ctx, 0, ec_launch_commit_eval(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, dX, ctx->stream));
-    return 0;
-  }
-  int S = chains_env > 0 ? chains_env : std::max((int)(4096 / t), 4);
-  const int s_max = (int)(n / (4 * t));
-  if (S > s_max) S = s_max;
-  if (S < 1) S = 1;
-  const int chain_len = (int)((n + S - 1) / S);
-  const int w0 = (chain_len - (int)t) / 2;
-  const size_t pw = (size_t)ec_point_words(group);
-  RET_IF(ensure(ctx, w.pts, n * pw * 4));
-  RET_IF(ensure(ctx, w.fdst, (size_t)2 * S * t * pw * 4));
-  uint32_t* st = (uint32_t*)w.fdst.p;
-  (void)gi;
-  TIMED_LAUNCH(ctx, 0, ec_launch_fd(group, (const uint32_t*)w.cm.p, (int)t, dpos, (int)n, S, w0, chain_len, (uint32_t*)w.pts.p,
-                                    st, st + (size_t)S * t * pw, dX, split_seeds, ctx->stream));
-  return 0;
-}
-
-// ---- X_i = sum_j i^j C_j ------------------------------------------------------------------------------
-extern "C" int mpvss_ec_commit_eval(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
-                                    const int64_t* positions, size_t n, uint8_t* x_out) {
-  EC_PROLOGUE("ec_commit_eval");
-  if (n == 0) return MPVSS_OK;
-  if (!commitments || !positions || !x_out || t == 0 || t > 0x7fffffff || n > 0x7fffffff)
-    return fail(ctx, MPVSS_E_INVALID, "ec_commit_eval: bad argument (t must be >= 1)");
-  RET_IF(ec_stage_commitments(ctx, gi, w, space, commitments, t));
-  const int64_t* dpos;
-  RET_IF(stage_positions(ctx, space, positions, n, &dpos));
-  uint8_t* dout = x_out;
-  if (space == MPVSS_HOST) { RET_IF(ensure(ctx, w.x, n * gi->enc)); dout = (uint8_t*)w.x.p; }
-  RET_IF(ec_eval_x(ctx, gi, group, w, space, t, positions, dpos, n, dout));
-  if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, x_out, dout, n * gi->enc));
-  RET_IF(spans_collect(ctx));
-  return MPVSS_OK;
-}
-
-// ---- DLEQ verifier commitments --------------------------------------------------------------------------
-extern "C" int mpvss_ec_dleq_commitments(mpvss_ctx* ctx, int group, int space, const uint8_t* g1_host, const uint8_t* h1,
-                                         const uint8_t* g2, const uint8_t* h2, const uint8_t* r, const uint8_t* c,
-                                         int c_per_share, size_t n, uint8_t* a1_out, uint8_t* a2_out) {
-  EC_PROLOGUE("ec_dleq_commitments");
-  if (n == 0) return MPVSS_OK;
-  if (!g1_host || !h1 || !g2 || !h2 || !r || !c || !a1_out || !a2_out || n > 0x7fffffff)
-    return fail(ctx, MPVSS_E_INVALID, "ec_dleq_commitments: bad argument");
-  RET_IF(ec_check_scalars(ctx, gi, space, r, n, "responses"));
-  RET_IF(ec_check_scalars(ctx, gi, c_per_share ? space : MPVSS_HOST, c, c_per_share ? n : 1, "challenge"));
-  const uint8_t* dg;
-  RET_IF(ec_generator_dev(ctx, gi, w, g1_host, &dg));
-  const void *dh1, *dg2, *dh2, *dr, *dc;
-  RET_IF(stage_in(ctx, space, h1, n * gi->enc, w.a, &dh1));
-  RET_IF(stage_in(ctx, space, g2, n * gi->enc, w.b, &dg2));
-  RET_IF(stage_in(ctx, space, h2, n * gi->enc, w.c, &dh2));
-  RET_IF(stage_in(ctx, space, r, n * 32, w.d, &dr));
-  if (c_per_share) RET_IF(stage_in(ctx, space, c, n * 32, w.e, &dc)); else RET_IF(stage_in(ctx, MPVSS_HOST, c, 32, w.chal, &dc));
-  uint8_t *d1 = a1_out, *d2 = a2_out;
-  if (space == MPVSS_HOST) {
-    RET_IF(ensure(ctx, w.o1, n * gi->enc)); RET_IF(ensure(ctx, w.o2, n * gi->enc));
-    d1 = (uint8_t*)w.o1.p; d2 = (uint8_t*)w.o2.p;
-  }
-  RET_IF(ensure(ctx, w.ok, 2 * (n > 4096 ? n : 4096)));
-  const size_t cs = c_per_share ? 32 : 0;
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dr, (const uint8_t*)dh1, (const uint8_t*)dc, cs, (int)n,
-                                          d1, (uint8_t*)w.ok.p, ctx->stream));
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dg2, gi->enc, (const uint8_t*)dr, (const uint8_t*)dh2,
-                                          (const uint8_t*)dc, cs, (int)n, d2, (uint8_t*)w.ok.p + n, ctx->stream));
-  if (space == MPVSS_HOST) {
-    RET_IF(copy_out(ctx, space, a1_out, d1, n * gi->enc));
-    RET_IF(copy_out(ctx, space, a2_out, d2, n * gi->enc));
-  }
-  RET_IF(ec_check_ok(ctx, (const uint8_t*)w.ok.p, 2 * n, "ec_dleq_commitments elements"));
-  RET_IF(spans_collect(ctx));
-  return MPVSS_OK;
-}
-
-// ---- verify_distribution_shares (participant.rs:1384-1442 secp256k1, 1827-1885 ristretto255) --------------
-extern "C" int mpvss_ec_verify_distribution(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
-                                            const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
-                                            const uint8_t* responses, size_t n, const uint8_t* challenge_host,
-                                            int* verdict, uint8_t* digest32_out, uint8_t* x_out_host,
-                                            uint8_t* a1_out_host, uint8_t* a2_out_host) {
-  EC_PROLOGUE("ec_verify_distribution");
-  if (!verdict || !challenge_host) return fail(ctx, MPVSS_E_INVALID, "ec_verify_distribution: bad argument");
-  *verdict = 0;
-  mpvss::Sha256 transcript;
-  if (n > 0) {
-    if (!commitments || !positions || !pubkeys || !shares || !responses || t == 0 || t > 0x7fffffff || n > 0x7fffffff)
-      return fail(ctx, MPVSS_E_INVALID, "ec_verify_distribution: bad argument (t must be >= 1)");
-    RET_IF(ec_check_scalars(ctx, gi, space, responses, n, "responses"));
-    RET_IF(ec_check_scalars(ctx, gi, MPVSS_HOST, challenge_host, 1, "challenge"));
-    RET_IF(ec_stage_commitments(ctx, gi, w, space, commitments, t));
-    const int64_t* dpos;
-    RET_IF(stage_positions(ctx, space, positions, n, &dpos));
-    const uint8_t* dg;
-    RET_IF(ec_generator_dev(ctx, gi, w, nullptr, &dg));
-    const void *dy, *dY, *dr, *dc;
-    RET_IF(stage_in(ctx, space, pubkeys, n * gi->enc, w.a, &dy));
-    RET_IF(stage_in(ctx, space, shares, n * gi->enc, w.b, &dY));
-    RET_IF(stage_in(ctx, space, responses, n * 32, w.d, &dr));
-    RET_IF(stage_in(ctx, MPVSS_HOST, challenge_host, 32, w.chal, &dc));
-    RET_IF(ensure(ctx, w.x, n * gi->enc));
-    RET_IF(ensure(ctx, w.o1, n * gi->enc));
-    RET_IF(ensure(ctx, w.o2, n * gi->enc));
-    RET_IF(ensure(ctx, w.ok, 2 * (n > 4096 ? n : 4096)));
-    uint8_t *dX = (uint8_t*)w.x.p, *d1 = (uint8_t*)w.o1.p, *d2 = (uint8_t*)w.o2.p;
-    RET_IF(ec_eval_x(ctx, gi, group, w, space, t, positions, dpos, n, dX));
-    // a1 = r*G + c*X, a2 = r*y + c*Y   (dleq.rs:66-84)
-    TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dr, dX, (const uint8_t*)dc, 0, (int)n, d1,
-                                            (uint8_t*)w.ok.p, ctx->stream));
-    TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dy, gi->enc, (const uint8_t*)dr, (const uint8_t*)dY,
-                                            (const uint8_t*)dc, 0, (int)n, d2, (uint8_t*)w.ok.p + n, ctx->stream));
-    RET_IF(ensure_pinned(ctx, n * gi->enc * 4));
-    uint8_t* hX = (uint8_t*)ctx->pin;
-    uint8_t* hY = hX + n * gi->enc;
-    uint8_t* h1 = hY + n * gi->enc;
-    uint8_t* h2 = h1 + n * gi->enc;
-    HIPCHK(ctx, hipMemcpyAsync(hX, dX, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hY, dY, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h1, d1, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h2, d2, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    RET_IF(ec_check_ok(ctx, (const uint8_t*)w.ok.p, 2 * n, "public keys / encrypted shares"));
-    for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99
-      ec_frame_update(transcript, hX + i * gi->enc, gi->enc);
-      ec_frame_update(transcript, hY + i * gi->enc, gi->enc);
-      ec_frame_update(transcript, h1 + i * gi->enc, gi->enc);
-      ec_frame_update(transcript, h2 + i * gi->enc, gi->enc);
-    }
-    if (x_out_host) memcpy(x_out_host, hX, n * gi->enc);
-    if (a1_out_host) memcpy(a1_out_host, h1, n * gi->enc);
-    if (a2_out_host) memcpy(a2_out_host, h2, n * gi->enc);
-    RET_IF(spans_collect(ctx));
-  }
-  uint8_t digest[32], hs[32];
-  transcript.final(digest);
-  if (digest32_out) memcpy(digest32_out, digest, 32);
-  ec_hash_to_scalar(gi, digest, hs);
-  *verdict = memcmp(hs, challenge_host, 32) == 0 ? 1 : 0;
-  return MPVSS_OK;
-}
-
-// ---- verify_share, batched (participant.rs:1346-1371, 1789-1814) ---------------------------------------------
-extern "C" int mpvss_ec_verify_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* s,
-                                      const uint8_t* y, const uint8_t* c, const uint8_t* r, size_t n,
-                                      uint8_t* verdicts_host) {
-  EC_PROLOGUE("ec_verify_shares");
-  if (n == 0) return MPVSS_OK;
-  if (!pk || !s || !y || !c || !r || !verdicts_host || n > 0x7fffffff)
-    return fail(ctx, MPVSS_E_INVALID, "ec_verify_shares: bad argument");
-  const uint8_t* dg;
-  RET_IF(ec_generator_dev(ctx, gi, w, nullptr, &dg));
-  const void *dpk, *ds, *dy, *dc, *dr;
-  RET_IF(stage_in(ctx, space, pk, n * gi->enc, w.a, &dpk));
-  RET_IF(stage_in(ctx, space, s, n * gi->enc, w.b, &ds));
-  RET_IF(stage_in(ctx, space, y, n * gi->enc, w.c, &dy));
-  RET_IF(stage_in(ctx, space, r, n * 32, w.d, &dr));
-  RET_IF(stage_in(ctx, space, c, n * 32, w.e, &dc));
-  RET_IF(ensure(ctx, w.o1, n * gi->enc));
-  RET_IF(ensure(ctx, w.o2, n * gi->enc));
-  const size_t okn = n > 4096 ? n : 4096;
-  RET_IF(ensure(ctx, w.ok, 4 * okn));          // decode flags of a1's and a2's inputs, scalar flags, verdicts
-  uint8_t *d1 = (uint8_t*)w.o1.p, *d2 = (uint8_t*)w.o2.p;
-  uint8_t *ok = (uint8_t*)w.ok.p, *dv = ok + 3 * okn;
-  // a1 = r*G + c*pk ; a2 = r*S + c*Y
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dr, (const uint8_t*)dpk, (const uint8_t*)dc, 32, (int)n,
-                                          d1, ok, ctx->stream));
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)ds, gi->enc, (const uint8_t*)dr, (const uint8_t*)dy,
-                                          (const uint8_t*)dc, 32, (int)n, d2, ok + n, ctx->stream));
-  // K7: per-share SHA-256 of the framed elements, hash_to_scalar, comparison with c_i -- on the device
-  TIMED_LAUNCH(ctx, 0, verdict_launch_ec(group, (const uint8_t*)dpk, (const uint8_t*)dy, d1, d2, (const uint8_t*)dc,
-                                         (const uint8_t*)dr, (int)n, dv, ok + 2 * n, ctx->stream));
-  RET_IF(ensure_pinned(ctx, 4 * n));
-  uint8_t* hok = (uint8_t*)ctx->pin;
-  HIPCHK(ctx, hipMemcpyAsync(hok, ok, 3 * n, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(hok + 3 * n, dv, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i < n; ++i)
-    if (!hok[2 * n + i]) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "ec_verify_shares: response or challenge %zu is not below the group order (the reference cannot represent it)", i);
-      return fail(ctx, MPVSS_E_INVALID, buf);
-    }
-  for (size_t i = 0; i < 2 * n; ++i)
-    if (!hok[i]) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "share boxes: element %zu is not a valid group-element encoding", i % n);
-      return fail(ctx, MPVSS_E_INVALID, buf);
-    }
-  memcpy(verdicts_host, hok + 3 * n, n);
-  RET_IF(spans_collect(ctx));
-  return MPVSS_OK;
-}
-
-// ---- distribute_secret, group part (participant.rs:1094-1274, 1573-1717) ------------------------------------
-extern "C" int mpvss_ec_distribute(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
-                                   const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
-                                   const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out, uint8_t* a1_out,
-                                   uint8_t* a2_out, uint8_t* digest32_out) {
-  EC_PROLOGUE("ec_distribute");
-  if (n > 0 && (!commitments || !positions || !pubkeys || !p_values || !witnesses || !x_out || !y_out || !a1_out ||
-                !a2_out || t == 0 || t > 0x7fffffff || n > 0x7fffffff))
-    return fail(ctx, MPVSS_E_INVALID, "ec_distribute: bad argument");
-  if (t > n) return fail(ctx, MPVSS_E_INVALID, "ec_distribute: threshold > number of public keys (participant.rs:1100)");
-  mpvss::Sha256 transcript;
-  if (n > 0) {
-    RET_IF(ec_check_scalars(ctx, gi, space, p_values, n, "polynomial values"));
-    RET_IF(ec_check_scalars(ctx, gi, space, witnesses, n, "witnesses"));
-    RET_IF(ec_stage_commitments(ctx, gi, w, space, commitments, t));
-    const int64_t* dpos;
-    RET_IF(stage_positions(ctx, space, positions, n, &dpos));
-    const uint8_t* dg;
-    RET_IF(ec_generator_dev(ctx, gi, w, nullptr, &dg));
-    const void *dy, *dp, *dw;
-    RET_IF(stage_in(ctx, space, pubkeys, n * gi->enc, w.a, &dy));
-    RET_IF(stage_in(ctx, space, p_values, n * 32, w.d, &dp));
-    RET_IF(stage_in(ctx, space, witnesses, n * 32, w.e, &dw));
-    uint8_t *dX = x_out, *dY = y_out, *d1 = a1_out, *d2 = a2_out;
-    if (space == MPVSS_HOST) {
-      RET_IF(ensure(ctx, w.x, n * gi->enc)); RET_IF(ensure(ctx, w.b, n * gi->enc));
-      RET_IF(ensure(ctx, w.o1, n * gi->enc)); RET_IF(ensure(ctx, w.o2, n * gi->enc));
-      dX = (uint8_t*)w.x.p; dY = (uint8_t*)w.b.p; d1 = (uint8_t*)w.o1.p; d2 = (uint8_t*)w.o2.p;
-    }
-    RET_IF(ensure(ctx, w.ok, 3 * (n > 4096 ? n : 4096)));
-    uint8_t* ok = (uint8_t*)w.ok.p;
-    RET_IF(ec_eval_x(ctx, gi, group, w, space, t, positions, dpos, n, dX));
-    TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dy, gi->enc, (const uint8_t*)dp, nullptr, nullptr, 0, (int)n,
-                                            dY, ok, ctx->stream));                      // Y = p * y
-    TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n, d1, ok + n,
-                                            ctx->stream));                              // a1 = w * G
-    TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dy, gi->enc, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n,
-                                            d2, ok + 2 * n, ctx->stream));              // a2 = w * y
-    RET_IF(ensure_pinned(ctx, n * gi->enc * 4));
-    uint8_t* hX = (uint8_t*)ctx->pin;
-    uint8_t* hY = hX + n * gi->enc;
-    uint8_t* h1 = hY + n * gi->enc;
-    uint8_t* h2 = h1 + n * gi->enc;
-    HIPCHK(ctx, hipMemcpyAsync(hX, dX, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hY, dY, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h1, d1, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h2, d2, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-    RET_IF(ec_check_ok(ctx, ok, 3 * n, "public keys"));
-    for (size_t i = 0; i < n; ++i) {
-      ec_frame_update(transcript, hX + i * gi->enc, gi->enc);
-      ec_frame_update(transcript, hY + i * gi->enc, gi->enc);
-      ec_frame_update(transcript, h1 + i * gi->enc, gi->enc);
-      ec_frame_update(transcript, h2 + i * gi->enc, gi->enc);
-    }
-    if (space == MPVSS_HOST) {
-      memcpy(x_out, hX, n * gi->enc); memcpy(y_out, hY, n * gi->enc);
-      memcpy(a1_out, h1, n * gi->enc); memcpy(a2_out, h2, n * gi->enc);
-    }
-    RET_IF(spans_collect(ctx));
-  }
-  if (digest32_out) transcript.final(digest32_out);
-  return MPVSS_OK;
-}
-
-extern "C" int mpvss_ec_hash_to_scalar(int group, const uint8_t* data, size_t len, uint8_t out32[32]) {
-  const EcInfo* gi = ec_info(group);
-  if (!gi || (!data && len) || !out32) return MPVSS_E_INVALID;
-  // Group::hash_to_scalar hashes `data` itself (secp256k1.rs:121-131 SHA-256, ristretto255.rs:196-205 SHA-512)
-  if (gi->group == MPVSS_GROUP_SECP256K1) {
-    uint8_t h[32];
-    mpvss::sha256(data, len, h);
-    if (!scalar_canonical(gi, h)) {
-      int borrow = 0;
-      for (int i = 31; i >= 0; --i) { const int d = (int)h[i] - gi->order_be[i] - borrow; h[i] = (uint8_t)(d & 0xff); borrow = d < 0; }
-    }
-    memcpy(out32, h, 32);
-    return MPVSS_OK;
-  }
-  // reuse the wide reduction: ec_hash_to_scalar hashes a 32-byte digest, so inline the general form here
-  uint8_t wide[64];
-  mpvss::sha512(data, len, wide);
-  uint64_t l[4] = {0, 0, 0, 0};
-  for (int i = 0; i < 32; ++i) l[3 - i / 8] |= (uint64_t)gi->order_be[i] << (8 * (7 - i % 8));
-  uint64_t r[5] = {0, 0, 0, 0, 0};
-  for (int bit = 511; bit >= 0; --bit) {
-    for (int k = 4; k > 0; --k) r[k] = (r[k] << 1) | (r[k - 1] >> 63);
-    r[0] = (r[0] << 1) | ((wide[bit >> 3] >> (bit & 7)) & 1);
-    bool ge = r[4] != 0;
-    if (!ge) { ge = true; for (int k = 3; k >= 0; --k) if (r[k] != l[k]) { ge = r[k] > l[k]; break; } }
-    if (ge) {
-      unsigned __int128 borrow = 0;
-      for (int k = 0; k < 4; ++k) { const unsigned __int128 d = (unsigned __int128)r[k] - l[k] - (uint64_t)borrow; r[k] = (uint64_t)d; borrow = (d >> 64) & 1; }
-      r[4] -= (uint64_t)borrow;
-    }
-  }
-  for (int i = 0; i < 32; ++i) out32[i] = (uint8_t)(r[i / 8] >> (8 * (i % 8)));
-  return MPVSS_OK;
-}
-
-// ---- extract_secret_share, batched, EC groups (participant.rs:1282-1338, 1725-1781) ---------------------------
-extern "C" int mpvss_ec_extract_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* y,
-                                       const uint8_t* xinv, const uint8_t* wit, size_t n, uint8_t* s_out,
-                                       uint8_t* c_out_host) {
-  EC_PROLOGUE("ec_extract_shares");
-  if (n == 0) return MPVSS_OK;
-  if (!pk || !y || !xinv || !wit || !s_out || !c_out_host || n > 0x7fffffff)
-    return fail(ctx, MPVSS_E_INVALID, "ec_extract_shares: bad argument");
-  RET_IF(ec_check_scalars(ctx, gi, space, xinv, n, "inverse private keys"));
-  RET_IF(ec_check_scalars(ctx, gi, space, wit, n, "witnesses"));
-  const uint8_t* dg;
-  RET_IF(ec_generator_dev(ctx, gi, w, nullptr, &dg));
-  const void *dy, *dxi, *dw;
-  RET_IF(stage_in(ctx, space, y, n * gi->enc, w.a, &dy));
-  RET_IF(stage_in(ctx, space, xinv, n * 32, w.d, &dxi));
-  RET_IF(stage_in(ctx, space, wit, n * 32, w.e, &dw));
-  uint8_t* dS = s_out;
-  if (space == MPVSS_HOST) { RET_IF(ensure(ctx, w.x, n * gi->enc)); dS = (uint8_t*)w.x.p; }
-  RET_IF(ensure(ctx, w.o1, n * gi->enc));
-  RET_IF(ensure(ctx, w.o2, n * gi->enc));
-  RET_IF(ensure(ctx, w.ok, 3 * (n > 4096 ? n : 4096)));
-  uint8_t *d1 = (uint8_t*)w.o1.p, *d2 = (uint8_t*)w.o2.p, *ok = (uint8_t*)w.ok.p;
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, (const uint8_t*)dy, gi->enc, (const uint8_t*)dxi, nullptr, nullptr, 0, (int)n,
-                                          dS, ok, ctx->stream));                       // S = (1/x) * Y
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dg, 0, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n, d1, ok + n,
-                                          ctx->stream));                               // a1 = w * G
-  TIMED_LAUNCH(ctx, 1, ec_launch_dual_mul(group, dS, gi->enc, (const uint8_t*)dw, nullptr, nullptr, 0, (int)n, d2, ok + 2 * n,
-                                          ctx->stream));                               // a2 = w * S
-  RET_IF(ensure_pinned(ctx, n * gi->enc * 3));
-  uint8_t* hS = (uint8_t*)ctx->pin;
-  uint8_t* h1 = hS + n * gi->enc;
-  uint8_t* h2 = h1 + n * gi->enc;
-  HIPCHK(ctx, hipMemcpyAsync(hS, dS, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h1, d1, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h2, d2, n * gi->enc, hipMemcpyDeviceToHost, ctx->stream));
-  RET_IF(ec_check_ok(ctx, ok, 3 * n, "encrypted shares"));
-  std::vector<uint8_t> hpk, hy;
-  RET_IF(small_vec_to_host(ctx, space, pk, n * gi->enc, hpk));
-  RET_IF(small_vec_to_host(ctx, space, y, n * gi->enc, hy));
-  for (size_t i = 0; i < n; ++i) {
-    mpvss::Sha256 h;
-    ec_frame_update(h, hpk.data() + i * gi->enc, gi->enc);
-    ec_frame_update(h, hy.data() + i * gi->enc, gi->enc);
-    ec_frame_update(h, h1 + i * gi->enc, gi->enc);
-    ec_frame_update(h, h2 + i * gi->enc, gi->enc);
-    uint8_t digest[32];
-    h.final(digest);
-    ec_hash_to_scalar(gi, digest, c_out_host + i * 32);
-  }
-  if (space == MPVSS_HOST) memcpy(s_out, hS, n * gi->enc);
-  RET_IF(spans_collect(ctx));
-  return MPVSS_OK;
-}
+// Elliptic-curve groups (secp256k1, ristretto255): same translation unit, separate file
+#include "capi_ec.inc"

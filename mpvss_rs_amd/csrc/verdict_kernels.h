@@ -13,6 +13,8 @@ int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1,
  * ok[i] = 0 when c_i or r_i is not below the group order */
 int verdict_launch_ec(int group, const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,
                       const uint8_t* c, const uint8_t* r, int count, uint8_t* verdict, uint8_t* ok, hipStream_t s);
+/* *first_bad = min(*first_bad, index of the first scalar >= the group order); scalars [count][32] */
+int verdict_launch_check_scalars(int group, const uint8_t* scalars, int count, int* first_bad, hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

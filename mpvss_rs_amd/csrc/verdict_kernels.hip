@@ -363,6 +363,19 @@ k_rist_share_verdict(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, co
   ec_share_verdict_body<2>(h1, h2, a1, a2, c, r, count, verdict, ok, lds);
 }
 
+// first_bad = min index of a scalar that is not below the group order (INT_MAX when all are canonical); stride 32
+template <int GROUP>
+__device__ __forceinline__ void check_scalars_body(const uint8_t* __restrict__ s, int count, int* __restrict__ first_bad) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= count) return;
+  u32 w[8];
+  scalar_words<GROUP == 1>(w, s + (size_t)x * 32);
+  const bool ok = GROUP == 1 ? below_order<ec::OrderSecp>(w) : below_order<ec::OrderEd>(w);
+  if (!ok) atomicMin(first_bad, x);
+}
+extern "C" __global__ void k_secp_check_scalars(const uint8_t* s, int count, int* first_bad) { check_scalars_body<1>(s, count, first_bad); }
+extern "C" __global__ void k_rist_check_scalars(const uint8_t* s, int count, int* first_bad) { check_scalars_body<2>(s, count, first_bad); }
+
 // ---- launchers ------------------------------------------------------------------------------------------------
 extern "C" int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,
                                    const uint8_t* c, int count, uint8_t* verdict, hipStream_t s) {
@@ -378,5 +391,11 @@ extern "C" int verdict_launch_ec(int group, const uint8_t* h1, const uint8_t* h2
     hipLaunchKernelGGL(k_secp_share_verdict, dim3((count + 63) / 64), dim3(64), 0, s, h1, h2, a1, a2, c, r, count, verdict, ok);
   else
     hipLaunchKernelGGL(k_rist_share_verdict, dim3((count + 63) / 64), dim3(64), 0, s, h1, h2, a1, a2, c, r, count, verdict, ok);
+  return (int)hipGetLastError();
+}
+extern "C" int verdict_launch_check_scalars(int group, const uint8_t* scalars, int count, int* first_bad, hipStream_t s) {
+  if (count <= 0) return 0;
+  if (group == 1) hipLaunchKernelGGL(k_secp_check_scalars, dim3((count + 255) / 256), dim3(256), 0, s, scalars, count, first_bad);
+  else hipLaunchKernelGGL(k_rist_check_scalars, dim3((count + 255) / 256), dim3(256), 0, s, scalars, count, first_bad);
   return (int)hipGetLastError();
 }

@@ -125,3 +125,109 @@ def test_ec_rejects_invalid_encodings_and_scalars(engine, name):
     with pytest.raises(capi.EngineError):
         engine.ec_batch_exp(gid, good, G.scalar_to_bytes(G.group_order_int()) if name == "secp256k1"
                             else G.group_order_int().to_bytes(32, "little"))
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_fixed_base_comb_and_window_digits(engine, name):
+    """k * G through the fixed-base comb (mpvss_ec_batch_exp_generator) and k * P through the signed-window tables,
+    with scalars whose digits hit the window boundaries (-8, +8, carries into the 65th window)."""
+    G, gid = mk(name)
+    rng = random.Random(43)
+    order = G.group_order_int()
+    special = [0, 1, 2, 7, 8, 9, 15, 16, 0x88888888, 0x77777777, (0x8 << 252) % order, order - 1, order - 2,
+               int("8" * 62, 16), int("7" * 63, 16) % order, int("f" * 63, 16) % order]
+    ks = special + [rng.randrange(order) for _ in range(70)]
+    out = engine.ec_batch_exp_generator(gid, sc(G, ks))
+    assert split(out, G.elem_len) == [G.element_to_bytes(G.exp(G.generator(), k)) for k in ks]
+    P = G.exp(G.generator(), rng.randrange(1, order))
+    out = engine.ec_batch_exp(gid, enc(G, [P] * len(ks)), sc(G, ks))
+    assert split(out, G.elem_len) == [G.element_to_bytes(G.exp(P, k)) for k in ks]
+    # generic (non-generator) shared base g1 in dleq_commitments
+    n = 20
+    h1 = [G.exp(G.generator(), rng.randrange(order)) for _ in range(n)]
+    g2 = [G.exp(G.generator(), rng.randrange(order)) for _ in range(n)]
+    h2 = [G.exp(G.generator(), rng.randrange(order)) for _ in range(n)]
+    h2[3] = G.identity()
+    g2[4] = G.identity()
+    r = [rng.randrange(order) for _ in range(n)]
+    cs = [rng.randrange(order) for _ in range(n)]
+    for g1 in (P, G.generator()):
+        a1, a2 = engine.ec_dleq_commitments(gid, G.element_to_bytes(g1), enc(G, h1), enc(G, g2), enc(G, h2), sc(G, r), sc(G, cs), True)
+        exp = [O.dleq_verifier_commitments(G, g1, h1[i], g2[i], h2[i], r[i], cs[i]) for i in range(n)]
+        assert split(a1, G.elem_len) == [G.element_to_bytes(e[0]) for e in exp]
+        assert split(a2, G.elem_len) == [G.element_to_bytes(e[1]) for e in exp]
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_block_api_and_verify_many(engine, name):
+    """Several curve boxes in flight inside one context: compute, compute, absorb, absorb; the library-pipelined
+    mpvss_ec_verify_many; an invalid encoding is reported by the absorbing call; negative positions wrap (u64) as
+    in the reference instead of failing."""
+    fx = json.load(open(os.path.join(HERE, "golden", f"{name}_n8_t4.json")))
+    gid = GID[name]
+    b = fx["box"]
+    cat = lambda hs: bytes.fromhex("".join(hs))
+    good = {"commitments": cat(b["commitments"]), "positions": b["positions"], "pubkeys": cat(b["publickeys"]),
+            "shares": cat(b["shares"]), "responses": cat(b["responses"]), "challenge": bytes.fromhex(b["challenge"])}
+    tam = fx["tampered"][0]
+    bad = dict(good, commitments=cat(tam["commitments"]), shares=cat(tam["shares"]), responses=cat(tam["responses"]),
+               challenge=bytes.fromhex(tam["challenge"]))
+    want_good = (True, bytes.fromhex(fx["expected"]["transcript_digest"]))
+    want_bad = (False, bytes.fromhex(tam["transcript_digest"]))
+    order_args = lambda x: (x["commitments"], x["positions"], x["pubkeys"], x["shares"], x["responses"], x["challenge"])
+    for x in (good, bad, good):
+        engine.ec_verify_block_compute(gid, *order_args(x))
+    got = []
+    for x in (good, bad, good):
+        st = engine.ec_verify_block_absorb(capi.transcript_init())
+        got.append(capi.ec_transcript_verdict(gid, st, x["challenge"]))
+    assert got == [want_good, want_bad, want_good]
+    boxes = [good, bad] * 9 + [good]
+    for depth, threads in ((1, 1), (4, 2), (16, 4)):
+        assert engine.ec_verify_many(gid, boxes, depth=depth, hash_threads=threads) == [want_good, want_bad] * 9 + [want_good]
+    G = O.GROUPS[name]()
+    L = G.elem_len
+    broken = bytearray(good["pubkeys"])
+    broken[2 * L:3 * L] = (b"\x05" + bytes(32)) if name == "secp256k1" else bytes.fromhex("01" + "00" * 31)
+    with pytest.raises(capi.EngineError, match="public keys: element 2"):
+        engine.ec_verify_many(gid, [good, dict(good, pubkeys=bytes(broken)), good], depth=3, hash_threads=2)
+    big = G.group_order_int().to_bytes(32, "big" if name == "secp256k1" else "little")
+    with pytest.raises(capi.EngineError, match="responses: scalar 1"):
+        engine.ec_verify_many(gid, [dict(good, responses=good["responses"][:32] + big + good["responses"][64:])])
+    assert engine.ec_verify_many(gid, [good]) == [want_good]
+    # Scalar::from(position as u64): position -3 is the scalar 2^64 - 3 (participant.rs:1419, 1862)
+    cm = [G.element_from_fixed(good["commitments"][i * L:(i + 1) * L]) for i in range(fx["t"])]
+    xs = engine.ec_commit_eval(gid, good["commitments"], [-3, 5])
+    assert xs[:L] == G.element_to_bytes(O.commitment_eval(G, cm, (1 << 64) - 3))
+    assert xs[L:] == G.element_to_bytes(O.commitment_eval(G, cm, 5))
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_device_resident_positions_pick_the_path_on_the_device(engine, name):
+    """Inputs in HBM: whether the forward-difference path applies is decided by a kernel (consecutive positions) and a
+    device flag gates the two X paths; both answers must equal the host-buffer call."""
+    import ctypes as C
+
+    import torch
+    G, gid = mk(name)
+    rng = random.Random(44)
+    order = G.group_order_int()
+    L = G.elem_len
+    t, n = 16, 4200
+    gen = G.element_to_bytes(G.generator())
+    cm = engine.ec_batch_exp_generator(gid, sc(G, [rng.randrange(order) for _ in range(t)]))
+    dev = torch.device("cuda", 0)
+    d_cm = torch.frombuffer(bytearray(cm), dtype=torch.uint8).to(dev)
+    for positions in (list(range(7, 7 + n)), list(range(7, 7 + n - 1)) + [99999]):
+        want = engine.ec_commit_eval(gid, cm, positions)
+        d_pos = torch.tensor(positions, dtype=torch.int64, device=dev)
+        d_out = torch.zeros(n * L, dtype=torch.uint8, device=dev)
+        rc = engine.lib.mpvss_ec_commit_eval(engine.ctx, gid, capi.MPVSS_DEVICE, C.c_void_p(d_cm.data_ptr()), t,
+                                             C.c_void_p(d_pos.data_ptr()), n, C.c_void_p(d_out.data_ptr()))
+        engine._check(rc, "ec_commit_eval(device)")
+        engine.lib.mpvss_ctx_synchronize(engine.ctx)
+        assert bytes(d_out.cpu().numpy().tobytes()) == want
+    i = n - 1
+    cmp = [G.element_from_fixed(cm[k * L:(k + 1) * L]) for k in range(t)]
+    assert want[i * L:(i + 1) * L] == G.element_to_bytes(O.commitment_eval(G, cmp, 99999))
+    assert len(gen) == L
