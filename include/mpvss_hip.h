@@ -284,6 +284,40 @@ int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, cons
 int mpvss_ec_extract_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* y,
                             const uint8_t* xinv, const uint8_t* w, size_t n, uint8_t* s_out, uint8_t* c_out_host);
 
+/* ---- scalar-field side (host only, no context needed) ------------------------------------------------------------
+ * The reference's scalar rings: Z/(q-1) for MODP-2048 (256-byte big-endian scalars), Z/n for secp256k1 (32-byte
+ * big-endian), Z/l for ristretto255 (32-byte little-endian).  O(n) / O(n t) word operations per box against O(3000 n)
+ * 2048-bit products on the group side: threaded over the shares on the host (threads <= 0: up to 16). */
+/* Group::scalar_mul: (a * b) % order        src/group.rs:108, modp.rs:180-182, secp256k1.rs:173-176, ristretto255.rs:244-247 */
+int mpvss_modp_scalar_mul(const uint8_t* a256, const uint8_t* b256, uint8_t* out256);
+int mpvss_ec_scalar_mul(int group, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
+/* Group::scalar_sub: a - b normalised into [0, order)   src/group.rs:113, modp.rs:184-192, secp256k1.rs:178-181 */
+int mpvss_modp_scalar_sub(const uint8_t* a256, const uint8_t* b256, uint8_t* out256);
+int mpvss_ec_scalar_sub(int group, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
+/* r[i] = w[i] - alpha[i] * c_i (mod order): Prover::response / DLEQ::get_r (src/dleq.rs:42-50,221-228) for n proofs --
+ * the dealer's responses (participant.rs:255-264: alpha = P(i), one shared c) and the participants'
+ * (participant.rs:345-350: alpha = private key, c per share).  c: one scalar (c_per_share == 0) or n. */
+int mpvss_modp_dleq_responses(const uint8_t* w, const uint8_t* alpha, const uint8_t* c, int c_per_share, size_t n,
+                              uint8_t* r_out, int threads);
+int mpvss_ec_dleq_responses(int group, const uint8_t* w, const uint8_t* alpha, const uint8_t* c, int c_per_share, size_t n,
+                            uint8_t* r_out, int threads);
+/* out[i] = P(positions[i]) mod order for P = sum_j coeffs[j] x^j: Polynomial::get_value (src/polynomial.rs:50-58) followed
+ * by the caller's `% order` (participant.rs:202, 1155-1157, 1619-1621).  MODP positions must be >= 0. */
+int mpvss_modp_poly_eval(const uint8_t* coeffs, size_t t, const int64_t* positions, size_t n, uint8_t* out, int threads);
+int mpvss_ec_poly_eval(int group, const uint8_t* coeffs, size_t t, const int64_t* positions, size_t n, uint8_t* out, int threads);
+
+/* ---- reconstruct ---------------------------------------------------------------------------------------------------
+ * G^s = prod_i S_i^lambda_i from m >= t decrypted shares S_i at pairwise different positions (host int64):
+ * src/participant.rs:462-561 (MODP; positions >= 1 as util.rs:47-64 assumes), 1452-1557 (secp256k1), 1895-2002
+ * (ristretto255).  Lagrange coefficients in the scalar field on the host, the m exponentiations and their product on
+ * the GPU.  gs_out: G^s (256 / 33 / 32 bytes); mask_out32 (optional): the 32-byte big-endian mask the reference XORs
+ * onto U -- int_BE(SHA256(bytes(G^s))) mod q / mod n / mod l (participant.rs:512-517, 1495-1511, 1939-1949):
+ * secret = mask XOR U.  shares in `space`. */
+int mpvss_modp_reconstruct(mpvss_ctx* ctx, int space, const int64_t* positions_host, const uint8_t* shares, size_t m,
+                           uint8_t* gs_out256, uint8_t* mask_out32);
+int mpvss_ec_reconstruct(mpvss_ctx* ctx, int group, int space, const int64_t* positions_host, const uint8_t* shares, size_t m,
+                         uint8_t* gs_out, uint8_t* mask_out32);
+
 /* ---- hashing helpers (host only; Group::hash_to_scalar, src/groups/modp.rs:142-148) ------ */
 
 /* out32 = SHA-256(data) */

@@ -36,6 +36,9 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
     "mpvss_ec_batch_exp_generator", "mpvss_ec_verify_block_compute", "mpvss_ec_verify_block_absorb",
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
+    "mpvss_modp_scalar_mul", "mpvss_modp_scalar_sub", "mpvss_ec_scalar_mul", "mpvss_ec_scalar_sub",
+    "mpvss_modp_dleq_responses", "mpvss_ec_dleq_responses", "mpvss_modp_poly_eval", "mpvss_ec_poly_eval",
+    "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
 )
 
 GROUP_SECP256K1 = 1
@@ -124,6 +127,16 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
     lib.mpvss_ec_batch_exp_generator.argtypes = [vp, ci, ci, u8p, sz, u8p]
+    lib.mpvss_modp_scalar_mul.argtypes = [u8p, u8p, u8p]
+    lib.mpvss_modp_scalar_sub.argtypes = [u8p, u8p, u8p]
+    lib.mpvss_ec_scalar_mul.argtypes = [ci, u8p, u8p, u8p]
+    lib.mpvss_ec_scalar_sub.argtypes = [ci, u8p, u8p, u8p]
+    lib.mpvss_modp_dleq_responses.argtypes = [u8p, u8p, u8p, ci, sz, u8p, ci]
+    lib.mpvss_ec_dleq_responses.argtypes = [ci, u8p, u8p, u8p, ci, sz, u8p, ci]
+    lib.mpvss_modp_poly_eval.argtypes = [u8p, sz, i64p, sz, u8p, ci]
+    lib.mpvss_ec_poly_eval.argtypes = [ci, u8p, sz, i64p, sz, u8p, ci]
+    lib.mpvss_modp_reconstruct.argtypes = [vp, ci, i64p, u8p, sz, u8p, u8p]
+    lib.mpvss_ec_reconstruct.argtypes = [vp, ci, ci, i64p, u8p, sz, u8p, u8p]
     lib.mpvss_ec_verify_block_compute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_ec_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_transcript_absorb.argtypes = [ci, u8p, u8p, sz]
@@ -350,6 +363,22 @@ class Engine:
         self._check(self.lib.mpvss_ec_batch_exp(self.ctx, group, MPVSS_HOST, pa, pb, n, po), "ec_batch_exp")
         return bytes(ko)[: n * EC_ENC[group]]
 
+    def reconstruct(self, positions: Sequence[int], shares: bytes):
+        """(G^s, mask) from m decrypted shares: secret = int(mask) ^ U (participant.rs:462-519)"""
+        m = len(positions)
+        pos = (C.c_int64 * max(m, 1))(*positions)
+        ks, ps = _buf(shares); kg, pg = _out(EB); km, pm = _out(32)
+        self._check(self.lib.mpvss_modp_reconstruct(self.ctx, MPVSS_HOST, C.cast(pos, C.c_void_p), ps, m, pg, pm), "reconstruct")
+        return bytes(kg)[:EB], bytes(km)[:32]
+
+    def ec_reconstruct(self, group: int, positions: Sequence[int], shares: bytes):
+        m = len(positions)
+        pos = (C.c_int64 * max(m, 1))(*positions)
+        ks, ps = _buf(shares); kg, pg = _out(EC_ENC[group]); km, pm = _out(32)
+        self._check(self.lib.mpvss_ec_reconstruct(self.ctx, group, MPVSS_HOST, C.cast(pos, C.c_void_p), ps, m, pg, pm),
+                    "ec_reconstruct")
+        return bytes(kg)[:EC_ENC[group]], bytes(km)[:32]
+
     def ec_batch_exp_generator(self, group: int, scalars: bytes) -> bytes:
         n = len(scalars) // 32
         kb, pb = _buf(scalars); ko, po = _out(n * EC_ENC[group])
@@ -557,3 +586,55 @@ def ec_transcript_absorb(group: int, state: bytes, elements: bytes) -> bytes:
     if rc != 0:
         raise EngineError(f"ec_transcript_absorb failed: {rc}")
     return bytes(ks)
+
+
+# ---- scalar-field side (host only) -------------------------------------------------------------------------------
+def _scalar_width(group: int) -> int:
+    return EB if group == 0 else 32
+
+
+def scalar_mul(group: int, a: bytes, b: bytes) -> bytes:
+    """Group::scalar_mul; group 0 = MODP-2048 (256-byte big-endian), else GROUP_*"""
+    lib = load_library()
+    ka, pa = _buf(a); kb, pb = _buf(b); ko, po = _out(_scalar_width(group))
+    rc = lib.mpvss_modp_scalar_mul(pa, pb, po) if group == 0 else lib.mpvss_ec_scalar_mul(group, pa, pb, po)
+    if rc != 0:
+        raise EngineError(f"scalar_mul failed: {rc}")
+    return bytes(ko)[:_scalar_width(group)]
+
+
+def scalar_sub(group: int, a: bytes, b: bytes) -> bytes:
+    lib = load_library()
+    ka, pa = _buf(a); kb, pb = _buf(b); ko, po = _out(_scalar_width(group))
+    rc = lib.mpvss_modp_scalar_sub(pa, pb, po) if group == 0 else lib.mpvss_ec_scalar_sub(group, pa, pb, po)
+    if rc != 0:
+        raise EngineError(f"scalar_sub failed: {rc}")
+    return bytes(ko)[:_scalar_width(group)]
+
+
+def dleq_responses(group: int, w: bytes, alpha: bytes, c: bytes, threads: int = 0) -> bytes:
+    """r_i = w_i - alpha_i * c_i mod order; c is one scalar or one per proof"""
+    lib = load_library()
+    sw = _scalar_width(group)
+    n = len(w) // sw
+    kw, pw = _buf(w); ka, pa = _buf(alpha); kc, pc = _buf(c); ko, po = _out(n * sw)
+    per = int(len(c) != sw)
+    rc = (lib.mpvss_modp_dleq_responses(pw, pa, pc, per, n, po, threads) if group == 0
+          else lib.mpvss_ec_dleq_responses(group, pw, pa, pc, per, n, po, threads))
+    if rc != 0:
+        raise EngineError(f"dleq_responses failed: {rc}")
+    return bytes(ko)[: n * sw]
+
+
+def poly_eval(group: int, coeffs: bytes, positions: Sequence[int], threads: int = 0) -> bytes:
+    """P(i) mod order for every position (polynomial.rs:50-58 + the caller's % order)"""
+    lib = load_library()
+    sw = _scalar_width(group)
+    t, n = len(coeffs) // sw, len(positions)
+    kc, pc = _buf(coeffs); ko, po = _out(n * sw)
+    pos = (C.c_int64 * max(n, 1))(*positions)
+    rc = (lib.mpvss_modp_poly_eval(pc, t, C.cast(pos, C.c_void_p), n, po, threads) if group == 0
+          else lib.mpvss_ec_poly_eval(group, pc, t, C.cast(pos, C.c_void_p), n, po, threads))
+    if rc != 0:
+        raise EngineError(f"poly_eval failed: {rc}")
+    return bytes(ko)[: n * sw]

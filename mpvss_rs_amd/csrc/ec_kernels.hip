@@ -389,6 +389,29 @@ __device__ __forceinline__ void dual_win_body(const u32* __restrict__ comb, cons
   if (live) store_point_aos<C>(out_pts + (size_t)x * C::POINT_WORDS, acc);
 }
 
+// out = sum of m points (internal coordinates): the fold of reconstruct's Lagrange factors (participant.rs:1489-1492).
+// One workgroup: every lane adds up a strided subset, then a tree through LDS.
+template <class C>
+__device__ __forceinline__ void sum_points_body(const u32* __restrict__ pts, int m, u32* __restrict__ out, u32* lds) {
+  const int k = threadIdx.x;
+  typename C::Point acc, p;
+  C::identity(acc);
+  for (int i = k; i < m; i += blockDim.x) {
+    load_point_aos<C>(p, pts + (size_t)i * C::POINT_WORDS);
+    C::add(acc, acc, p);
+  }
+  for (int d = blockDim.x / 2; d >= 1; d >>= 1) {
+    lds_put_raw<C>(lds, k, acc);
+    __syncthreads();
+    if (k < d) {
+      lds_get_raw<C>(p, lds, k + d);
+      C::add(acc, acc, p);
+    }
+    __syncthreads();
+  }
+  if (k == 0) store_point_aos<C>(out, acc);
+}
+
 // secp256k1: eight points per lane share one field inversion (Montgomery's trick)
 __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ pts, int count, uint8_t* __restrict__ enc) {
   constexpr int B = 8;
@@ -469,6 +492,14 @@ EC_KERNELS(rist, Ristretto, OrderEd)
   }
 EC_WIN_KERNELS(secp, Secp)
 EC_WIN_KERNELS(rist, Ristretto)
+extern "C" __global__ void __launch_bounds__(256) k_secp_sum_points(const u32* pts, int m, u32* out) {
+  extern __shared__ u32 lds[];
+  sum_points_body<Secp>(pts, m, out, lds);
+}
+extern "C" __global__ void __launch_bounds__(256) k_rist_sum_points(const u32* pts, int m, u32* out) {
+  extern __shared__ u32 lds[];
+  sum_points_body<Ristretto>(pts, m, out, lds);
+}
 extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate) {
   EC_GATE_CHECK(gate, 1);
   secp_encode_batch_body(pts, count, enc);
@@ -595,4 +626,12 @@ extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count,
 }
 extern "C" int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s) {
   return ec_launch_encode_gated(group, pts, count, enc, nullptr, s);
+}
+// out (one point, may alias pts) = sum of the m points at pts
+extern "C" int ec_launch_sum(int group, const uint32_t* pts, int m, uint32_t* out, hipStream_t s) {
+  if (m <= 0) return 0;
+  const size_t lds = (size_t)256 * ec_point_words(group) * 4;
+  if (group == 1) hipLaunchKernelGGL(k_secp_sum_points, dim3(1), dim3(256), lds, s, pts, m, out);
+  else hipLaunchKernelGGL(k_rist_sum_points, dim3(1), dim3(256), lds, s, pts, m, out);
+  return (int)hipGetLastError();
 }

@@ -305,6 +305,13 @@ inline void frame_update(mpvss::Sha256& h, const uint8_t* e256) {
   h.update(e256 + skip, (size_t)len);
 }
 
+// the minimal-length bytes alone (no length prefix): SHA256(element_to_bytes(e)) of reconstruct, participant.rs:512
+inline void frame_min_bytes_update(mpvss::Sha256& h, const uint8_t* e256) {
+  size_t skip = 0;
+  while (skip < EB - 1 && e256[skip] == 0) ++skip;
+  h.update(e256 + skip, EB - skip);
+}
+
 // hash_to_scalar(digest) == c  (modp.rs:142-148; the 256-bit hash is already < (q-1)/2)
 inline bool challenge_matches(const uint8_t digest[32], const uint8_t c256[256]) {
   uint8_t hh[32];
@@ -1820,3 +1827,5 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
 
 // Elliptic-curve groups (secp256k1, ristretto255): same translation unit, separate file
 #include "capi_ec.inc"
+// scalar-field entry points and reconstruct
+#include "capi_scalar.inc"
