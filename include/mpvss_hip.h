@@ -318,6 +318,31 @@ int mpvss_modp_reconstruct(mpvss_ctx* ctx, int space, const int64_t* positions_h
 int mpvss_ec_reconstruct(mpvss_ctx* ctx, int group, int space, const int64_t* positions_host, const uint8_t* shares, size_t m,
                          uint8_t* gs_out, uint8_t* mask_out32);
 
+/* ---- flat wire format of a DistributionSharesBox ("MPVSSBX1") ---------------------------------------------------------
+ * The reference keeps a box as three HashMap<Vec<u8>, _> (src/sharebox.rs:74-86) and defines no serialisation.  This
+ * format is the boundary's own layout -- rows in `publickeys` order (the order src/participant.rs:408-448 iterates in),
+ * fixed-width encodings -- so that a box can be handed to the engine, or cut into byte ranges for the ranks of a sharded
+ * verification, without rebuilding maps.  Integers little-endian; every section starts at a multiple of 8 bytes
+ * (zero padding); E = element bytes (256 / 33 / 32), S = scalar bytes (256 / 32 / 32):
+ *   0  "MPVSSBX1"   8  u32 group (0 MODP-2048, 1 secp256k1, 2 ristretto255)   12  u32 E   16  u64 n   24  u64 t
+ *   32 u64 u_len    40 commitments [t][E] | positions i64 [n] | publickeys [n][E] | shares [n][E] | responses [n][S] |
+ *   challenge [S] | U (big-endian magnitude, u_len bytes).                          (full specification: INTEGRATION.md) */
+typedef struct mpvss_box_view {
+  int group;
+  size_t element_bytes, scalar_bytes, n, t, u_len;
+  const uint8_t* commitments;
+  const int64_t* positions;
+  const uint8_t *pubkeys, *shares, *responses, *challenge, *u_be;
+} mpvss_box_view;
+size_t mpvss_box_wire_size(int group, size_t n, size_t t, size_t u_len);     /* 0: unknown group or absurd sizes */
+int mpvss_box_serialize(int group, const uint8_t* commitments, size_t t, const int64_t* positions, const uint8_t* pubkeys,
+                        const uint8_t* shares, const uint8_t* responses, size_t n, const uint8_t* challenge,
+                        const uint8_t* u_be, size_t u_len, uint8_t* out, size_t out_cap, size_t* out_len);
+/* Zero-copy view into `buf` (which must be 8-byte aligned and stay alive); rejects anything that is not exactly one box. */
+int mpvss_box_parse(const uint8_t* buf, size_t len, mpvss_box_view* view);
+/* verify_distribution_shares of a serialized box in host memory (any of the three groups) */
+int mpvss_box_verify_wire(mpvss_ctx* ctx, const uint8_t* buf, size_t len, int* verdict, uint8_t* digest32_out);
+
 /* ---- hashing helpers (host only; Group::hash_to_scalar, src/groups/modp.rs:142-148) ------ */
 
 /* out32 = SHA-256(data) */

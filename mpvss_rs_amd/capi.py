@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_scalar_mul", "mpvss_modp_scalar_sub", "mpvss_ec_scalar_mul", "mpvss_ec_scalar_sub",
     "mpvss_modp_dleq_responses", "mpvss_ec_dleq_responses", "mpvss_modp_poly_eval", "mpvss_ec_poly_eval",
     "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
+    "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
 )
 
 GROUP_SECP256K1 = 1
@@ -63,6 +64,14 @@ class EcBox(C.Structure):
     """struct mpvss_ec_box"""
     _fields_ = [("commitments", C.c_void_p), ("t", C.c_size_t), ("positions", C.c_void_p), ("pubkeys", C.c_void_p),
                 ("shares", C.c_void_p), ("responses", C.c_void_p), ("n", C.c_size_t), ("challenge_host", C.c_void_p)]
+
+
+class BoxView(C.Structure):
+    """struct mpvss_box_view"""
+    _fields_ = [("group", C.c_int), ("element_bytes", C.c_size_t), ("scalar_bytes", C.c_size_t), ("n", C.c_size_t),
+                ("t", C.c_size_t), ("u_len", C.c_size_t), ("commitments", C.c_void_p), ("positions", C.c_void_p),
+                ("pubkeys", C.c_void_p), ("shares", C.c_void_p), ("responses", C.c_void_p), ("challenge", C.c_void_p),
+                ("u_be", C.c_void_p)]
 
 
 class PipelineStats(C.Structure):
@@ -127,6 +136,11 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
     lib.mpvss_ec_batch_exp_generator.argtypes = [vp, ci, ci, u8p, sz, u8p]
+    lib.mpvss_box_wire_size.argtypes = [ci, sz, sz, sz]
+    lib.mpvss_box_wire_size.restype = sz
+    lib.mpvss_box_serialize.argtypes = [ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, sz, u8p, sz, C.POINTER(sz)]
+    lib.mpvss_box_parse.argtypes = [u8p, sz, C.POINTER(BoxView)]
+    lib.mpvss_box_verify_wire.argtypes = [vp, u8p, sz, C.POINTER(ci), u8p]
     lib.mpvss_modp_scalar_mul.argtypes = [u8p, u8p, u8p]
     lib.mpvss_modp_scalar_sub.argtypes = [u8p, u8p, u8p]
     lib.mpvss_ec_scalar_mul.argtypes = [ci, u8p, u8p, u8p]
@@ -362,6 +376,15 @@ class Engine:
         ka, pa = _buf(bases); kb, pb = _buf(scalars); ko, po = _out(n * EC_ENC[group])
         self._check(self.lib.mpvss_ec_batch_exp(self.ctx, group, MPVSS_HOST, pa, pb, n, po), "ec_batch_exp")
         return bytes(ko)[: n * EC_ENC[group]]
+
+    def verify_wire(self, wire: bytes):
+        """verify_distribution_shares of a serialized box (any group): (verdict, digest)"""
+        buf = (C.c_uint64 * ((len(wire) + 7) // 8))()          # 8-byte aligned copy
+        C.memmove(buf, wire, len(wire))
+        v = C.c_int(0)
+        kd, pd = _out(32)
+        self._check(self.lib.mpvss_box_verify_wire(self.ctx, C.cast(buf, C.c_void_p), len(wire), C.byref(v), pd), "box_verify_wire")
+        return bool(v.value), bytes(kd)[:32]
 
     def reconstruct(self, positions: Sequence[int], shares: bytes):
         """(G^s, mask) from m decrypted shares: secret = int(mask) ^ U (participant.rs:462-519)"""
@@ -638,3 +661,39 @@ def poly_eval(group: int, coeffs: bytes, positions: Sequence[int], threads: int 
     if rc != 0:
         raise EngineError(f"poly_eval failed: {rc}")
     return bytes(ko)[: n * sw]
+
+
+# ---- flat wire format ("MPVSSBX1") ---------------------------------------------------------------------------------
+def box_serialize(group: int, commitments: bytes, positions: Sequence[int], pubkeys: bytes, shares: bytes, responses: bytes,
+                  challenge: bytes, u_be: bytes = b"") -> bytes:
+    lib = load_library()
+    e = EB if group == 0 else EC_ENC[group]
+    t, n = len(commitments) // e, len(positions)
+    size = lib.mpvss_box_wire_size(group, n, t, len(u_be))
+    if size == 0:
+        raise EngineError("box_serialize: bad dimensions")
+    k = [_buf(x if x else b"\0") for x in (commitments, pubkeys, shares, responses, challenge, u_be)]
+    pos = (C.c_int64 * max(n, 1))(*positions)
+    ko, po = _out(size)
+    out_len = C.c_size_t(0)
+    rc = lib.mpvss_box_serialize(group, k[0][1], t, C.cast(pos, C.c_void_p), k[1][1], k[2][1], k[3][1], n, k[4][1], k[5][1],
+                                 len(u_be), po, size, C.byref(out_len))
+    if rc != 0:
+        raise EngineError(f"box_serialize failed: {rc}")
+    return bytes(ko)[: out_len.value]
+
+
+def box_parse(wire: bytes) -> dict:
+    lib = load_library()
+    buf = (C.c_uint64 * ((len(wire) + 7) // 8))()
+    C.memmove(buf, wire, len(wire))
+    view = BoxView()
+    rc = lib.mpvss_box_parse(C.cast(buf, C.c_void_p), len(wire), C.byref(view))
+    if rc != 0:
+        raise EngineError(f"box_parse failed: {rc}")
+    e, s_, n, t = view.element_bytes, view.scalar_bytes, view.n, view.t
+    at = lambda p, ln: C.string_at(p, ln) if ln else b""
+    return {"group": view.group, "n": n, "t": t, "commitments": at(view.commitments, t * e),
+            "positions": list((C.c_int64 * n).from_address(view.positions)) if n else [],
+            "pubkeys": at(view.pubkeys, n * e), "shares": at(view.shares, n * e), "responses": at(view.responses, n * s_),
+            "challenge": at(view.challenge, s_), "U": at(view.u_be, view.u_len)}

@@ -1829,3 +1829,5 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
 #include "capi_ec.inc"
 // scalar-field entry points and reconstruct
 #include "capi_scalar.inc"
+// flat wire format of a box
+#include "capi_wire.inc"

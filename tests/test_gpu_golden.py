@@ -48,3 +48,30 @@ def test_modp_fixture_on_gpu(engine, path):
     assert d["X"].hex() == "".join(fx["expected"]["X"]) and d["Y"].hex() == "".join(b["shares"])
     assert d["a1"].hex() == "".join(fx["expected"]["a1"]) and d["a2"].hex() == "".join(fx["expected"]["a2"])
     assert d["digest"].hex() == fx["expected"]["transcript_digest"]
+
+
+def test_serialized_boxes_verify_from_the_wire_format(engine):
+    """mpvss_box_verify_wire: a box serialized to "MPVSSBX1" (any of the three groups) verifies from its bytes with the
+    fixture's transcript digest; the tampered variants are rejected with theirs."""
+    import glob
+
+    from mpvss_rs_amd import capi
+    gid_of = {"modp2048": 0, "secp256k1": capi.GROUP_SECP256K1, "ristretto255": capi.GROUP_RISTRETTO255}
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.json")))
+    assert len(paths) >= 6
+    for path in paths:
+        fx = json.load(open(path))
+        b = fx["box"]
+        cat = lambda hs: bytes.fromhex("".join(hs))
+        gid = gid_of[fx["group"]]
+        wire = capi.box_serialize(gid, cat(b["commitments"]), b["positions"], cat(b["publickeys"]), cat(b["shares"]),
+                                  cat(b["responses"]), bytes.fromhex(b["challenge"]), b"\x01\x02")
+        verdict, digest = engine.verify_wire(wire)
+        assert verdict is True and digest.hex() == fx["expected"]["transcript_digest"], path
+        for tam in fx["tampered"]:
+            wire = capi.box_serialize(gid, cat(tam["commitments"]), b["positions"], cat(b["publickeys"]), cat(tam["shares"]),
+                                      cat(tam["responses"]), bytes.fromhex(tam["challenge"]))
+            verdict, digest = engine.verify_wire(wire)
+            assert verdict is False and digest.hex() == tam["transcript_digest"], path
+    with pytest.raises(capi.EngineError):
+        engine.verify_wire(wire[:-3])
