@@ -27,3 +27,15 @@ def test_reference_modp_tests_on_the_host_mirror():
                          timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all passed" in out.stdout
+
+
+@pytest.mark.parametrize("binary,message", [("mpvss_all_secp256k1", "Hello MPVSS Example (secp256k1)."),
+                                            ("mpvss_all_ristretto255", "Hello MPVSS Example (Ristretto255).")])
+def test_curve_group_examples_print_recovered_secret(binary, message):
+    """C++ counterparts of examples/mpvss_all_secp256k1.rs and examples/mpvss_all_ristretto255.rs (the reference's only
+    end-to-end coverage of the ristretto255 Participant): distribute, verify, extract, verify_share, reconstruct."""
+    _build()
+    for seed in ("7", "1234567"):
+        out = subprocess.run([os.path.join(ROOT, "examples", binary), seed], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.splitlines() == [f"secret message: {message}"] + [f"r{k} str: {message}" for k in (1, 2, 3)]
