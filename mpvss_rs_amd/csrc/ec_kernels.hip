@@ -356,22 +356,27 @@ __device__ __forceinline__ void dual_win_body(const u32* __restrict__ comb, cons
   typename C::Point acc;
   C::identity(acc);
   if (t1 != nullptr || t2 != nullptr) {
-    u32 w1 = 0, w2 = 0;
+    // the table(s) and the LDS rows of their recoded scalars; with a comb for the first scalar the (single) table
+    // belongs to the SECOND scalar
+    const u32* tabs[2] = {t1 != nullptr ? t1 : t2, t2};
+    const int rows[2] = {(t1 != nullptr) ? 0 : 9, 9};
+    const int ntab = (t1 != nullptr && t2 != nullptr) ? 2 : 1;
+    u32 words[2] = {0, 0};
     for (int w = 64; w >= 0; --w) {
       if ((w & 7) == 7 || w == 64) {
-        w1 = lds_k[(w >> 3) * DW_THREADS + threadIdx.x];
-        if (t2 != nullptr) w2 = lds_k[(9 + (w >> 3)) * DW_THREADS + threadIdx.x];
+        words[0] = lds_k[(rows[0] + (w >> 3)) * DW_THREADS + threadIdx.x];
+        words[1] = lds_k[(rows[1] + (w >> 3)) * DW_THREADS + threadIdx.x];
       }
       if (w != 64) {
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) C::dbl(acc, acc);
       }
-      if (t1 != nullptr)
-        add_signed_digit<C>(acc, signed_digit4(w1, w), [&](typename C::Cached& e, int i) { load_cached<C>(e, t1 + i * C::CACHED_WORDS); });
-      if (t2 != nullptr) {
-        // with a comb for the first scalar the table belongs to the SECOND scalar; without, to the second as well
-        const u32 word = (t1 != nullptr || comb != nullptr) ? w2 : w1;
-        add_signed_digit<C>(acc, signed_digit4(word, w), [&](typename C::Cached& e, int i) { load_cached<C>(e, t2 + i * C::CACHED_WORDS); });
+      // ONE addition site for both tables: the loop body (a doubling and an addition, about 50 KB of code for
+      // secp256k1) has to stay inside the 64 KB instruction cache
+#pragma unroll 1
+      for (int b = 0; b < ntab; ++b) {
+        const u32* tb = tabs[b];
+        add_signed_digit<C>(acc, signed_digit4(words[b], w), [&](typename C::Cached& e, int i) { load_cached<C>(e, tb + i * C::CACHED_WORDS); });
       }
     }
   }

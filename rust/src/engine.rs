@@ -1,0 +1,75 @@
+//! Owner of one `mpvss_ctx` (one engine bound to one GPU).  `Send + Sync`: the C library serialises calls on a
+//! context internally, which is what `Group: Send + Sync` (src/group.rs:24) and rayon's use of `exp` in
+//! `reconstruct` (src/participant.rs:490-500) need.
+use std::ffi::CStr;
+use std::fmt;
+use std::ptr;
+use std::sync::Arc;
+
+use crate::ffi;
+
+#[derive(Debug, Clone)]
+pub struct EngineError {
+    pub code: i32,
+    pub message: String,
+}
+
+impl fmt::Display for EngineError {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        write!(f, "mpvss_hip error {}: {}", self.code, self.message)
+    }
+}
+impl std::error::Error for EngineError {}
+
+#[derive(Debug)]
+struct Ctx(*mut ffi::mpvss_ctx);
+unsafe impl Send for Ctx {}
+unsafe impl Sync for Ctx {}
+impl Drop for Ctx {
+    fn drop(&mut self) {
+        unsafe { ffi::mpvss_ctx_destroy(self.0) }
+    }
+}
+
+/// Shared handle; cloning is cheap (the groups keep one in their `Arc`).
+#[derive(Debug, Clone)]
+pub struct Engine {
+    ctx: Arc<Ctx>,
+}
+
+impl Engine {
+    /// Fails when no HIP device is visible: there is no CPU fallback.
+    pub fn new(device_id: i32) -> Result<Engine, EngineError> {
+        let mut raw: *mut ffi::mpvss_ctx = ptr::null_mut();
+        let rc = unsafe { ffi::mpvss_ctx_create(device_id, &mut raw) };
+        if rc != ffi::MPVSS_OK || raw.is_null() {
+            return Err(EngineError { code: rc, message: "mpvss_ctx_create failed (no MI355X / HIP device?)".into() });
+        }
+        Ok(Engine { ctx: Arc::new(Ctx(raw)) })
+    }
+
+    pub fn device_count() -> i32 {
+        unsafe { ffi::mpvss_device_count() }
+    }
+
+    pub(crate) fn raw(&self) -> *mut ffi::mpvss_ctx {
+        self.ctx.0
+    }
+
+    /// Maps a return code to `Result`, attaching `mpvss_last_error`.
+    pub(crate) fn check(&self, rc: i32) -> Result<(), EngineError> {
+        if rc == ffi::MPVSS_OK {
+            return Ok(());
+        }
+        let msg = unsafe { CStr::from_ptr(ffi::mpvss_last_error(self.ctx.0)) }.to_string_lossy().into_owned();
+        Err(EngineError { code: rc, message: msg })
+    }
+
+    /// For trait methods that cannot return an error (`Group::exp`): a failing engine is a programmer / hardware
+    /// error there, as a panic in the reference's arithmetic crates would be.
+    pub(crate) fn expect(&self, rc: i32, what: &str) {
+        if let Err(e) = self.check(rc) {
+            panic!("{what}: {e}");
+        }
+    }
+}

@@ -1,0 +1,22 @@
+//! HIP-backed `Group` implementations and batched Participant paths for the `mpvss-rs` crate (MI355X, gfx950).
+//!
+//! The reference keeps its public surface -- `trait Group` (src/group.rs:24-124), `Participant<G>`, `DLEQ<G>`,
+//! `PVSS<G>` -- and this crate plugs in underneath it:
+//!
+//! * [`groups::HipModpGroup`], [`groups::HipSecp256k1Group`], [`groups::HipRistretto255Group`] implement `Group`
+//!   with the same `Scalar` / `Element` types as the reference's groups, so they are drop-in type parameters;
+//!   every `exp` / `mul` is one call into `libmpvss_hip.so` (a batch of one).
+//! * [`batch`] holds what makes the GPU worthwhile: the three loops of the hot path
+//!   (`distribute_secret`, `verify_distribution_shares`, `verify_share`) as single batched calls, plus batched
+//!   `extract_secret_share`, `reconstruct` and key generation.
+//!
+//! STATUS: this crate has never been compiled -- the repository's build image has no cargo / rustc.  The C ABI
+//! it binds (include/mpvss_hip.h) is what the repository tests; the C++ mirror under mpvss_rs_amd/host/ is the
+//! host side that actually runs there.  `ffi.rs` is checked symbol by symbol against the header.
+pub mod batch;
+pub mod engine;
+pub mod ffi;
+pub mod groups;
+
+pub use engine::{Engine, EngineError};
+pub use groups::{HipModpGroup, HipRistretto255Group, HipSecp256k1Group};

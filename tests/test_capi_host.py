@@ -60,3 +60,14 @@ def test_ec_hash_to_scalar_host():
         G = O.GROUPS[name]()
         for data in (b"", b"test data", bytes(range(32)), b"\xff" * 100):
             assert capi.ec_hash_to_scalar(gid, data) == G.scalar_to_bytes(G.hash_to_scalar(data))
+
+
+def test_rust_ffi_declares_the_exported_symbols():
+    """rust/src/ffi.rs (never compiled here: no Rust toolchain) must declare exactly the functions include/mpvss_hip.h
+    exports, so that the shipped binding cannot drift from the library."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ffi = open(os.path.join(root, "rust", "src", "ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (mpvss_\w+)\(", ffi))
+    from mpvss_rs_amd import EXPORTED_SYMBOLS
+    assert declared == set(EXPORTED_SYMBOLS), (sorted(declared - set(EXPORTED_SYMBOLS)), sorted(set(EXPORTED_SYMBOLS) - declared))
