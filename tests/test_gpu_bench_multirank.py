@@ -1,0 +1,36 @@
+"""The multi-rank flow of bench.py with the REAL engine: two fresh processes under torch.distributed.run, both on the
+one GPU of the test box (MPVSS_BENCH_SMOKE_ONE_GPU=1: gloo instead of RCCL for the rendezvous, everything else as in
+the N > 1 runs the driver launches).  Each rank holds a contiguous block of the box, the SHA-256 running state travels
+rank 0 -> rank 1 per box, the verdicts are broadcast; bench.py aborts unless every box verifies with the dealer's
+transcript digest, so a clean exit with a JSON line IS the parity check."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_ranks_share_one_box_through_bench_py():
+    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH="3", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--participants", "16384", "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0", "--registered-keys", "0",
+           "--ec-boxes", "0", "--lone-boxes", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")]
+    assert len(lines) == 1, out.stdout[-2000:]           # rank 0 prints ONE line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
+    assert res["config"]["n_per_gpu"] == 16384 and "32768 participants in the box" in res["config"]["workload"]
+    assert res["value"] > 0 and res["compute"]["fd_fallbacks"] == 0
+    assert res["host"]["pipeline"].startswith("verify_block_compute/absorb")
