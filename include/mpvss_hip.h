@@ -206,6 +206,20 @@ int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* commitments,
                           const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out,
                           uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out);
 
+/* The same in the compute / absorb form of the verifier's blocks (shared slots and FIFO order): `compute` enqueues the
+ * GPU work of one block of shares and returns, `absorb` waits for it and extends the dealer's transcript `state` with
+ * framed(X_i) framed(Y_i) framed(a1_i) framed(a2_i) in share order (participant.rs:238-245); the digest of the finished
+ * transcript is mpvss_modp_transcript_verdict's digest32_out.  With space == MPVSS_DEVICE the four *_dev_out arrays (optional)
+ * receive the results in HBM; absorb's host pointers are optional copies.
+ * commitments == NULL: X_i is computed as g^p_i through the fixed-base comb -- the same element as the loop of
+ * participant.rs:207-215 whenever the box's commitments are C_j = g^a_j of the polynomial behind p_i = P(i), which is what
+ * the dealer of participant.rs:160-286 builds (t and positions are then unused). */
+int mpvss_modp_distribute_compute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t, const int64_t* positions,
+                                  const uint8_t* pubkeys, const uint8_t* p_values, const uint8_t* witnesses, size_t n,
+                                  uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out);
+int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,
+                                 uint8_t* a1_out_host, uint8_t* a2_out_host);
+
 /* ---- elliptic-curve groups --------------------------------------------------------------------
  * The same entry points for the reference's two curve groups, selected by `group`:
  *   MPVSS_GROUP_SECP256K1    src/groups/secp256k1.rs:38-189     elements 33-byte SEC1 compressed

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_dleq_responses", "mpvss_ec_dleq_responses", "mpvss_modp_poly_eval", "mpvss_ec_poly_eval",
     "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
     "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
+    "mpvss_modp_distribute_compute", "mpvss_modp_distribute_absorb",
 )
 
 GROUP_SECP256K1 = 1
@@ -113,6 +114,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_verify_shares_compute.argtypes = [vp, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_modp_verify_shares_absorb.argtypes = [vp, u8p]
     lib.mpvss_modp_distribute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
+    lib.mpvss_modp_distribute_compute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p]
+    lib.mpvss_modp_distribute_absorb.argtypes = [vp, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_sha256.argtypes = [u8p, sz, u8p]
     lib.mpvss_sha256.restype = None
     lib.mpvss_modp_hash_to_scalar.argtypes = [u8p, sz, u8p]
@@ -517,6 +520,26 @@ class Engine:
         self._check(self.lib.mpvss_modp_verify_shares(self.ctx, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
                                                       k[4][1], n, pv), "verify_shares")
         return bytes(kv)[:n]
+
+    def distribute_compute(self, commitments: Optional[bytes], positions: Optional[Sequence[int]], pubkeys: bytes,
+                           p_values: bytes, witnesses: bytes) -> int:
+        """Enqueue one dealer block (returns its size).  commitments None: X_i = g^p_i (the dealer knows the polynomial)."""
+        n = len(pubkeys) // EB
+        t = len(commitments) // EB if commitments else 0
+        kc, pc = _buf(commitments) if commitments else (None, None)
+        ky, py = _buf(pubkeys); kp, pp = _buf(p_values); kw, pw = _buf(witnesses)
+        pos = (C.c_int64 * max(n, 1))(*(positions or [0] * n))
+        self._check(self.lib.mpvss_modp_distribute_compute(self.ctx, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pp, pw, n,
+                                                           None, None, None, None), "distribute_compute")
+        return n
+
+    def distribute_absorb(self, state: bytes, n: int):
+        """(state, X, Y, a1, a2) of the oldest dealer block"""
+        ks, ps = _buf(state)
+        outs = [_out(n * EB) for _ in range(4)]
+        self._check(self.lib.mpvss_modp_distribute_absorb(self.ctx, ps, outs[0][1], outs[1][1], outs[2][1], outs[3][1]),
+                    "distribute_absorb")
+        return (bytes(ks),) + tuple(bytes(o[0])[: n * EB] for o in outs)
 
     def verify_shares_compute(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes, verdicts_dev_ptr: int = 0) -> int:
         """Enqueue one batch of share-box proofs (returns its size); verdicts_dev_ptr: optional device address that

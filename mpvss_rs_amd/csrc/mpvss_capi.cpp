@@ -1198,7 +1198,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
 // and hashes it, so that other host threads can enqueue blocks or absorb the next ones meanwhile (every box has its
 // own transcript; a 65536-share box is 40 ms of SHA-256).  Blocks are handed out in FIFO order at entry.
 int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
-                               uint8_t* a1_out, uint8_t* a2_out) {
+                               uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
   mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
   if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
@@ -1236,6 +1236,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
       }
       memcpy(state, &tr, sizeof(tr));
       if (x_out) memcpy(x_out, hX, n * EB);
+      if (y_out) memcpy(y_out, hY, n * EB);
       if (a1_out) memcpy(a1_out, h1, n * EB);
       if (a2_out) memcpy(a2_out, h2, n * EB);
     }
@@ -1677,88 +1678,209 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
 }
 
 // ---- distribute_secret, group part ---------------------------------------------------------------------
+// Dealer side of src/participant.rs:160-286 in the same compute / absorb form as the verifier's blocks (same slots,
+// same pinned staging layout X | Y | a1 | a2, same ordered hash in absorb):
+//   stream B (low priority):  64-entry tables of y_i, Y_i = y_i^p_i (:219), a2_i = y_i^w_i (dleq.rs:213-216)
+//   stream A (high priority): X_i -- from the commitments exactly as the verifier does (:207-215), or, when the caller
+//                             passes NO commitments, as g^p_i through the fixed-base comb (the same element whenever
+//                             the commitments are g^a_j of the polynomial behind p_i: 127 products instead of a
+//                             forward-difference chain);  a1_i = g^w_i (dleq.rs:207-211) through the comb.
+namespace {
+
+int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t, const int64_t* positions,
+                                    const uint8_t* pubkeys, const uint8_t* p_values, const uint8_t* witnesses, size_t n,
+                                    uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out) {
+  if (n > 0 && (!pubkeys || !p_values || !witnesses || (commitments && (!positions || t == 0 || t > 0x7fffffff))))
+    return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
+  if (commitments && t > n) return fail(ctx, MPVSS_E_INVALID, "distribute: threshold > number of public keys (participant.rs:166)");
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "distribute: sixteen blocks already in flight, absorb one first");
+  const auto t_enq0 = std::chrono::steady_clock::now();
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!sl.done) {
+    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+  }
+  sl.n = n;
+  sl.kind = 0;                 // absorbed like a verifier's block: same staging layout, same hash
+  sl.check_positions = false;
+  sl.fd_used = false;
+  sl.fd_chunks = 0;
+  sl.enqueue_ms = 0;
+  if (n == 0) {
+    sl.busy = true;
+    ++ctx->head;
+    return MPVSS_OK;
+  }
+  if (commitments && space == MPVSS_HOST) RET_IF(check_positions_host(ctx, positions, n));
+  RET_IF(work_init(ctx, sl.work, nullptr));
+  struct Restore {
+    mpvss_ctx* c;
+    hipStream_t a, b;
+    ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
+  } restore{ctx, ctx->stream, ctx->stream_b};
+  ctx->w = &sl.work;
+  sl.work.fd_used = false;
+  ctx->stream = sl.work.sa;
+  ctx->stream_b = sl.work.sb;
+  ctx->sp = &sl.spans;
+  spans_reset(ctx);
+  constexpr size_t FLAGS = 64;
+  const size_t out_bytes = n * EB * 4 + n * 8 + FLAGS * 4;
+  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + (commitments ? t * EB : 0) : 0);
+  if (need > sl.cap) {
+    if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
+    sl.pin = nullptr;
+    sl.cap = 0;
+    hipError_t e = hipHostMalloc(&sl.pin, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(block staging)", e);
+    sl.cap = need;
+  }
+  uint8_t* hX = (uint8_t*)sl.pin;
+  uint8_t* hY = hX + n * EB;
+  uint8_t* h1 = hY + n * EB;
+  uint8_t* h2 = h1 + n * EB;
+  int64_t* hpos = (int64_t*)(h2 + n * EB);
+  int* hflags = (int*)((uint8_t*)sl.pin + n * EB * 4 + n * 8);
+  if (space == MPVSS_HOST) {
+    uint8_t* in = (uint8_t*)sl.pin + out_bytes;
+    memcpy(in, pubkeys, n * EB); pubkeys = in;
+    memcpy(in + n * EB, p_values, n * EB); p_values = in + n * EB;
+    memcpy(in + 2 * n * EB, witnesses, n * EB); witnesses = in + 2 * n * EB;
+    if (commitments) { memcpy(in + 3 * n * EB, commitments, t * EB); commitments = in + 3 * n * EB; memcpy(hpos, positions, n * 8); }
+  }
+  if (commitments) RET_IF(stage_commitments(ctx, space, commitments, t));
+  const uint32_t* cg;
+  RET_IF(comb_table(ctx, 0, &cg, n));
+  for (size_t off = 0; off < n; off += MAX_CHUNK) {
+    const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
+    const void *dy, *dp, *dw;
+    RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
+    RET_IF(stage_in(ctx, space, p_values + off * EB, cnt * EB, ctx->w->in_b, &dp));
+    RET_IF(stage_in(ctx, space, witnesses + off * EB, cnt * EB, ctx->w->in_c, &dw));
+    RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->in_d, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
+    RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
+    uint8_t *dX = (uint8_t*)ctx->w->xbe.p, *dY = (uint8_t*)ctx->w->in_d.p, *da1 = (uint8_t*)ctx->w->out1.p, *da2 = (uint8_t*)ctx->w->out2.p;
+    struct Swap {
+      mpvss_ctx* c; hipStream_t a;
+      Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
+      ~Swap() { c->stream = a; }
+    };
+    HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
+    {
+      Swap sw(ctx, ctx->w->sb);
+      // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:213-216)
+      uint32_t* ty = (uint32_t*)ctx->w->tab1.p;
+      if (cnt >= 1024) {          // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
+        TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dp, nullptr, 0, (int)cnt, dY, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dw, nullptr, 0, (int)cnt, da2, ctx->consts, ctx->stream));
+      } else {
+        TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dY,
+                                                  ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt, da2,
+                                                  ctx->consts, ctx->stream));
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
+    }
+    if (commitments) {
+      const int64_t* dpos;
+      const void* d;
+      if (space == MPVSS_HOST) {
+        RET_IF(stage_in(ctx, space, hpos + off, cnt * 8, ctx->w->pos, &d));
+        dpos = (const int64_t*)d;
+      } else {
+        dpos = positions + off;
+        HIPCHK(ctx, hipMemcpyAsync(hpos + off, dpos, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        sl.check_positions = true;
+      }
+      sl.work.fd_used = false;
+      RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? hpos + off : nullptr, cnt, dX));          // :207-215
+      if (sl.work.fd_used) {
+        sl.fd_used = true;
+        if (sl.fd_chunks < FLAGS)
+          HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ++sl.fd_chunks;
+      }
+    } else {
+      // X_i = g^P(i): the dealer knows the polynomial
+      TIMED_LAUNCH(ctx, 0, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dX,
+                                                     comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+    }
+    // a1 = g^w (dleq.rs:207-211)
+    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt, da1,
+                                                   comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
+    HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    if (space == MPVSS_DEVICE) {      // results stay in HBM for the caller as well
+      if (x_dev_out) HIPCHK(ctx, hipMemcpyAsync(x_dev_out + off * EB, dX, cnt * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      if (y_dev_out) HIPCHK(ctx, hipMemcpyAsync(y_dev_out + off * EB, dY, cnt * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      if (a1_dev_out) HIPCHK(ctx, hipMemcpyAsync(a1_dev_out + off * EB, da1, cnt * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      if (a2_dev_out) HIPCHK(ctx, hipMemcpyAsync(a2_dev_out + off * EB, da2, cnt * EB, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (off + MAX_CHUNK < n) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
+      HIPCHK(ctx, hipStreamSynchronize(ctx->w->sb));
+    }
+  }
+  HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+  sl.busy = true;
+  sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
+  ++ctx->head;
+  return MPVSS_OK;
+}
+
+}  // namespace
+
+extern "C" int mpvss_modp_distribute_compute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                             const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
+                                             const uint8_t* witnesses, size_t n, uint8_t* x_dev_out, uint8_t* y_dev_out,
+                                             uint8_t* a1_dev_out, uint8_t* a2_dev_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return distribute_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, p_values, witnesses, n, x_dev_out,
+                                         y_dev_out, a1_dev_out, a2_dev_out);
+}
+
+extern "C" int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,
+                                            uint8_t* a1_out_host, uint8_t* a2_out_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  return verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host, y_out_host);
+}
+
 extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                      const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
                                      const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out,
                                      uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out) {
   if (!ctx) return MPVSS_E_INVALID;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::unique_lock<std::mutex> lk(ctx->mu);
   if (n > 0 && (!commitments || !positions || !pubkeys || !p_values || !witnesses || !x_out || !y_out || !a1_out ||
                 !a2_out || t == 0 || t > 0x7fffffff))
     return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
   if (t > n) return fail(ctx, MPVSS_E_INVALID, "distribute: threshold > number of public keys (participant.rs:166)");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  spans_reset(ctx);
-  mpvss::Sha256 transcript;
-  if (n > 0) {
-    RET_IF(stage_commitments(ctx, space, commitments, t));
-    const uint32_t* cg;
-    RET_IF(comb_table(ctx, 0, &cg, n));
-    for (size_t off = 0; off < n; off += MAX_CHUNK) {
-      const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
-      const int64_t* dpos;
-      RET_IF(stage_positions(ctx, space, positions + off, cnt, &dpos));
-      const void *dy, *dp, *dw;
-      RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
-      RET_IF(stage_in(ctx, space, p_values + off * EB, cnt * EB, ctx->w->in_b, &dp));
-      RET_IF(stage_in(ctx, space, witnesses + off * EB, cnt * EB, ctx->w->in_c, &dw));
-      uint8_t *dX = x_out + off * EB, *dY = y_out + off * EB, *da1 = a1_out + off * EB, *da2 = a2_out + off * EB;
-      if (space == MPVSS_HOST) {
-        RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
-        RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
-        RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
-        RET_IF(ensure(ctx, ctx->w->in_d, cnt * EB));
-        dX = (uint8_t*)ctx->w->xbe.p;
-        dY = (uint8_t*)ctx->w->in_d.p;
-        da1 = (uint8_t*)ctx->w->out1.p;
-        da2 = (uint8_t*)ctx->w->out2.p;
-      }
-      RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions + off : nullptr, cnt, dX));
-      // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:214-216)
-      static const int w6 = fd_env("MPVSS_A2_W6", 1);
-      if (w6 && cnt >= 1024) {          // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
-        RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
-        uint32_t* ty = (uint32_t*)ctx->w->tab1.p;
-        TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dp, nullptr, 0, (int)cnt, dY, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dw, nullptr, 0, (int)cnt, da2, ctx->consts, ctx->stream));
-      } else {
-        const uint32_t* ty;
-        RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->w->tab1, &ty));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0,
-                                                  (int)cnt, dY, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0,
-                                                  (int)cnt, da2, ctx->consts, ctx->stream));
-      }
-      // a1 = g^w (dleq.rs:207-211)
-      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
-                                                     da1, comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
-      RET_IF(ensure_pinned(ctx, cnt * EB * 4));
-      uint8_t* hX = (uint8_t*)ctx->pin;
-      uint8_t* hY = hX + cnt * EB;
-      uint8_t* h1 = hY + cnt * EB;
-      uint8_t* h2 = h1 + cnt * EB;
-      HIPCHK(ctx, hipMemcpyAsync(hX, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(hY, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(h1, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(h2, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      for (size_t i = 0; i < cnt; ++i) {                     // participant.rs:238-245
-        frame_update(transcript, hX + i * EB);
-        frame_update(transcript, hY + i * EB);
-        frame_update(transcript, h1 + i * EB);
-        frame_update(transcript, h2 + i * EB);
-      }
-      if (space == MPVSS_HOST) {
-        memcpy(x_out + off * EB, hX, cnt * EB);
-        memcpy(y_out + off * EB, hY, cnt * EB);
-        memcpy(a1_out + off * EB, h1, cnt * EB);
-        memcpy(a2_out + off * EB, h2, cnt * EB);
-      }
-    }
-    RET_IF(spans_collect(ctx));
+  if (ctx->head != ctx->tail)
+    return fail(ctx, MPVSS_E_INVALID, "distribute: blocks of the block API are in flight, absorb them first");
+  uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
+  mpvss_transcript_init(state);
+  const bool dev = space == MPVSS_DEVICE;
+  RET_IF(distribute_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, p_values, witnesses, n, dev ? x_out : nullptr,
+                                         dev ? y_out : nullptr, dev ? a1_out : nullptr, dev ? a2_out : nullptr));
+  RET_IF(verify_block_absorb_locked(ctx, lk, state, dev ? nullptr : x_out, dev ? nullptr : a1_out, dev ? nullptr : a2_out,
+                                    dev ? nullptr : y_out));
+  if (digest32_out) {
+    mpvss::Sha256 tr;
+    memcpy(&tr, state, sizeof(tr));
+    tr.final(digest32_out);                       // participant.rs:251: the dealer's transcript digest
   }
-  if (digest32_out) transcript.final(digest32_out);
   return MPVSS_OK;
 }
 

@@ -120,6 +120,11 @@ unsafe extern "C" {
     pub fn mpvss_modp_distribute(ctx: *mut mpvss_ctx, space: c_int, commitments: *const u8, t: usize, positions: *const i64, pubkeys: *const u8,
                                  p_values: *const u8, witnesses: *const u8, n: usize, x_out: *mut u8, y_out: *mut u8, a1_out: *mut u8,
                                  a2_out: *mut u8, digest32_out: *mut u8) -> c_int;
+    pub fn mpvss_modp_distribute_compute(ctx: *mut mpvss_ctx, space: c_int, commitments: *const u8, t: usize, positions: *const i64,
+                                         pubkeys: *const u8, p_values: *const u8, witnesses: *const u8, n: usize, x_dev_out: *mut u8,
+                                         y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
+    pub fn mpvss_modp_distribute_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, y_out_host: *mut u8, a1_out_host: *mut u8,
+                                        a2_out_host: *mut u8) -> c_int;
     // ---- curve groups
     pub fn mpvss_ec_batch_exp(ctx: *mut mpvss_ctx, group: c_int, space: c_int, bases: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn mpvss_ec_batch_mul(ctx: *mut mpvss_ctx, group: c_int, space: c_int, a: *const u8, b: *const u8, n: usize, out: *mut u8) -> c_int;

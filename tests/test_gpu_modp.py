@@ -267,6 +267,40 @@ def test_distribute_group_part(engine):
     assert res["digest"] == box["_digest"]
 
 
+def test_distribute_block_api_and_dealer_shortcut(engine):
+    """The dealer's blocks in compute / absorb form: several in flight, X_i either from the commitments (the reference's
+    loop, participant.rs:207-215) or as g^P(i) through the comb (commitments = None) -- identical outputs and transcript;
+    a box cut into two blocks carries the running hash state from one to the next."""
+    g, privs, pks, coeffs, ws, box = make_modp_instance(11, 4, 31)
+    order = g.group_order_int()
+    positions = list(range(1, 12))
+    p_vals = [O.poly_get_value(coeffs, i) % order for i in positions]
+    keys = [g.element_to_bytes(p) for p in pks]
+    cm = cat(g, box["commitments"])
+    args = (cat(g, pks), cat(g, p_vals), cat(g, ws))
+    engine.distribute_compute(cm, positions, *args)
+    engine.distribute_compute(None, None, *args)
+    for _ in range(2):
+        st, X, Y, a1, a2 = engine.distribute_absorb(capi.transcript_init(), 11)
+        assert split(X) == box["_X"] and split(Y) == [box["shares"][k] for k in keys]
+        assert split(a1) == box["_a1"] and split(a2) == box["_a2"]
+        assert capi.transcript_verdict(st, bytes(256))[1] == box["_digest"]
+    # two blocks of one box (5 + 6 shares), state carried across
+    cut = 5 * 256
+    engine.distribute_compute(cm, positions[:5], args[0][:cut], args[1][:cut], args[2][:cut])
+    engine.distribute_compute(None, None, args[0][cut:], args[1][cut:], args[2][cut:])
+    st = capi.transcript_init()
+    st, X1, _, _, _ = engine.distribute_absorb(st, 5)
+    st, X2, _, _, _ = engine.distribute_absorb(st, 6)
+    assert split(X1 + X2) == box["_X"]
+    assert capi.transcript_verdict(st, bytes(256))[1] == box["_digest"]
+    # scalar side behind the C ABI closes the box: P(i), challenge, responses (participant.rs:200-202, 251-264)
+    pv = capi.poly_eval(0, cat(g, coeffs), positions)
+    assert split(pv) == p_vals
+    r = capi.dleq_responses(0, cat(g, ws), pv, fx(box["challenge"]))
+    assert split(r) == [box["responses"][k] for k in keys]
+
+
 def test_rejects_bad_arguments(engine):
     from mpvss_rs_amd import EngineError
     with pytest.raises(EngineError):
