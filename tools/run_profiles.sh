@@ -1,19 +1,26 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for bench.py's kernels (run on the GPU box through gpurun).
-#   1. --kernel-trace --stats summary of the default bench configuration
-#   2. PMC passes (separate runs, no tracing): FETCH_SIZE / WRITE_SIZE, SQ busy/wait counters
+# Collect the rocprofv3 evidence for bench.py's kernels (run on the GPU box through gpurun), round 2.
+#   1. --kernel-trace --stats of the default bench configuration (boxes overlapping, as timed)
+#   2. --kernel-trace of boxes verified ONE AT A TIME (MPVSS_BENCH_DEPTH=1): isolated kernel durations
+#   3. PMC passes (separate runs, no tracing): FETCH_SIZE / WRITE_SIZE, SQ busy / wait counters
+# The program goes directly after `--` (no env/bash wrappers: the profiler initialises the GPU before the program).
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
-ARGS="bench.py --cpu-sample 0 --wb-shares 0 --registered-keys 0"
-PMCARGS="bench.py --steps 2 --warmup 1 --cpu-sample 0 --wb-shares 0 --registered-keys 0"
+ARGS="bench.py --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0"
+LONE="bench.py --steps 3 --warmup 1 --lone-boxes 0 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0"
+PMCARGS="bench.py --steps 2 --warmup 1 --lone-boxes 0 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 grep "^{\"metric\"" $OUT/trace.log > $OUT/bench_under_rocprof.json
+export MPVSS_BENCH_DEPTH=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lone -- python3 $LONE > $OUT/trace_lone.log 2>&1
+export MPVSS_BENCH_DEPTH=2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $PMCARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $PMCARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $PMCARGS > $OUT/pmc_sq.log 2>&1
+unset MPVSS_BENCH_DEPTH
 tail -1 $OUT/trace.log | cut -c1-300
 find $OUT -name "*.csv" | xargs ls -la
