@@ -56,7 +56,7 @@ int modp_launch_fd_apply_ok(const int* ok, int* flag, hipStream_t s);
 size_t modp_fd_table_hand_words(int chains, int t);
 size_t modp_fd_step_hand_words(int chains, int t, int chain_len);
 int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state,
-                         uint32_t* state_back, uint32_t* hand, int* gate, const void* cs, hipStream_t s);
+                         uint32_t* state_back, uint32_t* hand, int* gate, int inject_fault, const void* cs, hipStream_t s);
 int modp_launch_fd_step(const uint32_t* state, const uint32_t* state_back, int chains, int t, int w0, int chain_len,
                         int count, uint32_t* x_m, uint32_t* hand, int* gate, int inject_fault, const void* cs,
                         hipStream_t s);

@@ -467,10 +467,12 @@ __device__ __forceinline__ bool hand_receive(const u32* __restrict__ src, u32* d
   return __builtin_amdgcn_ballot_w64(!ok) == 0;
 }
 
-extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
+// (two products per level keep E, F, T1 and the modulus live: 2 waves per SIMD's worth of registers instead of 3 --
+// the launch is a few dozen latency-bound waves, occupancy is not its problem, spilling would be)
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int chains, int t, int tpad,
                 u32* __restrict__ state, u32* __restrict__ state_back, u32* __restrict__ hand, int* __restrict__ gate,
-                const ModpConsts* __restrict__ cs) {
+                int inject_fault, const ModpConsts* __restrict__ cs) {
   // state[c][l]      = E_l[0]                       = D_l at the first seed: the chain that steps forward
   // state_back[c][l] = (l even ? E_l : F_l)[t-1-l]  = g^((-1)^l nabla^l P) at the last seed: with H_l(i-1) = H_l(i) H_{l+1}(i)
   //                    the same recurrence steps BACKWARD from the last seed, H_0 being X (one seed window serves
@@ -520,6 +522,11 @@ k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int ch
     slot_store(eslot, E, ln);
     slot_store(fslot, F, ln);
     const bool need_up = has_up && (kbase + NUMS_PER_WAVE - 1 <= t - 1 - lvl);
+    if (inject_fault == 4 && sidx == 0 && chain == 0 && lvl == 3) {      // test hook: the top stage gives up
+      if (threadIdx.x == 0) *gate = 0;
+      if (has_down && quad == 0) hand_publish(mine + (size_t)lvl * 2 * L, E, ln, HAND_POISON);
+      return;
+    }
     if (need_up && lvl > 1) {
       const u32* src = up + (size_t)(lvl - 1) * 2 * L;
       const bool ok = hand_receive(src, in_e, reader, ln) && hand_receive(src + L, in_f, reader, ln);
@@ -591,8 +598,11 @@ k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back
   const bool writer = kbase == 0 && quad == 0;
   for (int step = 1; step <= steps; ++step) {
     slot_store(slot, D, ln);
-    if (inject_fault && !has_up && dir == 0 && chain == 0 && step == 5) {
-      // test hook (MPVSS_FD_TEST_FAULT=1): behave like a stage whose wait timed out
+    // test hooks (MPVSS_FD_TEST_FAULT): behave like a stage whose wait timed out -- 1: the top stage of the first forward
+    // chain early on; 2: a middle stage of the last backward chain, later
+    const bool faulty = (inject_fault == 1 && !has_up && dir == 0 && chain == 0 && step == 5) ||
+                        (inject_fault == 2 && dir == 1 && chain == chains - 1 && sidx == (stages > 1 ? 1 : 0) && step == 40);
+    if (faulty) {
       if (threadIdx.x == 0) *gate = 0;
       if (has_down && quad == 0) hand_publish(mine + (size_t)step * L, D, ln, HAND_POISON);
       return;
@@ -1221,10 +1231,11 @@ extern "C" size_t modp_fd_step_hand_words(int chains, int t, int chain_len) {
   return (size_t)2 * chains * (modp_fd_tpad(t) / NUMS_PER_WAVE) * (size_t)(chain_len + t) * L;
 }
 extern "C" int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, int chains, int t, uint32_t* state,
-                                    uint32_t* state_back, uint32_t* hand, int* gate, const void* cs, hipStream_t s) {
+                                    uint32_t* state_back, uint32_t* hand, int* gate, int inject_fault, const void* cs,
+                                    hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
   hipLaunchKernelGGL(k_modp_fd_table, dim3(chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, x, x_inv, chains, t, tpad,
-                     state, state_back, hand, gate, (const ModpConsts*)cs);
+                     state, state_back, hand, gate, inject_fault, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 // x_m: base of the chains (position index 0); w0: index of the first seed inside every chain

@@ -767,6 +767,9 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // for the first t of the S*t seed positions; a stride-1 forward-difference chain built from those t values steps
   // through the remaining (S-1)*t seed positions at t products each.  Same values (uniqueness of the group element);
   // 180 products per share fewer at (65536, 256), for about 15 ms more latency of the box's chain.
+  // tests only: one pipeline stage gives up and the flag falls -- 1 / 2: a stage of the stepping pipelines, 3: of the
+  // stride-1 seeding chain, 4: of the table pipeline
+  static const int inject_fault = fd_env("MPVSS_FD_TEST_FAULT", 0);
   static const int two_level_env = fd_env("MPVSS_FD_L1", 1);
   const bool two_level = two_level_env && S > 1;
   // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
@@ -847,9 +850,10 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
     RET_IF(invert_batch(xseed, (int)t, (uint32_t*)w.fd_xinv.p, &w.root[1]));
     // one chain of stride 1 over the seed window: tables from its first t values, then m0 - 1 steps forward
     LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, 1, (int)t, state_fwd, state_bwd,
-                                        (uint32_t*)((uint8_t*)w.fd_hand_t.p + hand_t), flag, ctx->consts, ctx->stream));
+                                        (uint32_t*)((uint8_t*)w.fd_hand_t.p + hand_t), flag, 0, ctx->consts, ctx->stream));
     LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, 1, (int)t, 0, m0, m0, xseed,
-                                       (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), flag, 0, ctx->consts, ctx->stream));
+                                       (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), flag, inject_fault == 3 ? 1 : 0, ctx->consts,
+                                       ctx->stream));
   } else {
     LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
                                                  dpos + seed0, m0, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
@@ -858,8 +862,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // difference tables, stepping, conversion -- all gated on flag == 1.  Both kernels are pipelines of single-wave
   // stages that hand numbers down through zeroed buffers (see modp_kernels.hip).
   LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, S, (int)t, state_fwd, state_bwd,
-                                      (uint32_t*)w.fd_hand_t.p, flag, ctx->consts, ctx->stream));
-  static const int inject_fault = fd_env("MPVSS_FD_TEST_FAULT", 0);   // tests only: one stage gives up, the flag falls
+                                      (uint32_t*)w.fd_hand_t.p, flag, inject_fault, ctx->consts, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, S, (int)t, w0, chain_len, (int)cnt, xm,
                                      (uint32_t*)w.fd_hand_s.p, flag, inject_fault, ctx->consts, ctx->stream));
   LAUNCHCHK(ctx, modp_launch_from_mont(xm, (int)cnt, dX, flag, ctx->consts, ctx->stream));

@@ -53,15 +53,18 @@ def test_fd_equals_horner():
         assert ha == hb, case
 
 
-def test_a_stage_that_gives_up_falls_back_to_horner():
-    """MPVSS_FD_TEST_FAULT=1 makes one pipeline stage behave as if its wait had timed out: it clears the device flag
-    and poisons its output; the stages below must give up at once and the gated Horner launch must produce every X."""
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
+def test_a_stage_that_gives_up_falls_back_to_horner(mode):
+    """MPVSS_FD_TEST_FAULT makes one pipeline stage behave as if its wait had timed out (1: top stage of the first
+    forward stepping chain, 2: a middle stage of the last backward chain, 3: a stage of the stride-1 seeding chain,
+    4: the top stage of the table pipeline): it clears the device flag and poisons its output; the stages below must
+    give up at once and the gated Horner launch must produce every X."""
     case = [(64, 8192, 1, "")]
     t0 = time.time()
     b = run(case, {"MPVSS_FD": "0"})
     ref = time.time() - t0
     t0 = time.time()
-    a = run(case, {"MPVSS_FD": "1", "MPVSS_FD_TEST_FAULT": "1"})
+    a = run(case, {"MPVSS_FD": "1", "MPVSS_FD_TEST_FAULT": mode})
     took = time.time() - t0
     assert a == b and len(a[0]) == 64
     # poisoned stages must give up at once, not wait for their 2 s timeouts one after the other (16 stages per chain)
