@@ -148,6 +148,12 @@ struct mpvss_ctx {
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
+  // Wide-launch ordering between boxes in flight: the a2 launches of box k wait for those of box k - A2_CONC, so that the
+  // boxes finish staggered (oldest first) instead of all at once -- see verify_block_compute_locked
+  static constexpr unsigned A2_RING = 8;
+  hipEvent_t a2_done[A2_RING] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long a2_seq = 0;
+  std::atomic<unsigned long long> gpu_done{0};   // blocks whose GPU work has completed (seen by an absorbing thread)
   DevBuf ec_comb[2];             // fixed-base combs of the curve groups' generators (built on first use)
   bool ec_comb_ready[2] = {false, false};
   // host-side accounting of the block pipeline (mpvss_pipeline_stats_get): sums over absorbed blocks
@@ -515,6 +521,8 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
       if (b->p) (void)hipFree(b->p);
   for (DevBuf& b : ctx->ec_comb)
     if (b.p) (void)hipFree(b.p);
+  for (hipEvent_t e : ctx->a2_done)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
@@ -1131,6 +1139,18 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       };
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
+      // Boxes in flight share the chip.  Left alone they share it EQUALLY: eight boxes enqueued together finish
+      // together, the host then hashes and re-enqueues all of them at once, and while it does the GPU has nothing wide
+      // left to run (measured: 50-110 ms without any a2 launch per ~450 ms convoy).  So the wide launches of box k
+      // (tables, a2, g^r) wait for those of box k - MPVSS_A2_CONCURRENCY: at most that many boxes' a2 run side by side
+      // (one box's a2 is 4096 waves, more than the chip holds), boxes finish oldest first, one per ~70 ms, and the
+      // host's hashing and enqueueing of one box hides behind the GPU work of the others.
+      static const unsigned a2_conc = (unsigned)fd_env("MPVSS_A2_CONCURRENCY", 2);
+      const unsigned long long seq = ctx->a2_seq++;
+      if (a2_conc > 0 && a2_conc < mpvss_ctx::A2_RING && seq >= a2_conc) {
+        hipEvent_t prev = ctx->a2_done[(seq - a2_conc) % mpvss_ctx::A2_RING];
+        if (prev) HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, prev, 0));
+      }
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
         uint32_t* t2p = (uint32_t*)ctx->w->tab2.p;
@@ -1153,6 +1173,11 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                     (int)cnt, da2, ctx->consts, ctx->stream));
         }
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
+        {
+          hipEvent_t& mine = ctx->a2_done[seq % mpvss_ctx::A2_RING];
+          if (!mine) HIPCHK(ctx, hipEventCreateWithFlags(&mine, hipEventDisableTiming));
+          HIPCHK(ctx, hipEventRecord(mine, ctx->stream));
+        }
         // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase
         TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
                                                              (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
@@ -1210,6 +1235,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   ++ctx->tail;
   if (n == 0) {
     sl.busy = false;
+    ctx->gpu_done.fetch_add(1);
     return MPVSS_OK;
   }
   sl.absorbing = true;
@@ -1218,6 +1244,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   const auto t_w0 = std::chrono::steady_clock::now();
   const hipError_t e = hipEventSynchronize(sl.done);
   const auto t_w1 = std::chrono::steady_clock::now();
+  ctx->gpu_done.fetch_add(1);
   const uint8_t* hX = (const uint8_t*)sl.pin;
   const uint8_t* hY = hX + n * EB;
   const uint8_t* h1 = hY + n * EB;
@@ -1418,6 +1445,10 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   } sh;
   sh.finished.assign(count, 0);
   const unsigned base_tail = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->tail; }();
+  // `depth` bounds the boxes whose GPU work is pending; a box whose GPU work is done but whose transcript is still being
+  // hashed keeps its slot (the ring has NSLOT of them) without holding back the enqueueing of the next one
+  static const int issue_on_gpu_done = fd_env("MPVSS_ISSUE_ON_GPU_DONE", 1);
+  const unsigned long long gpu_done0 = ctx->gpu_done.load();
 
   auto worker = [&]() {
     for (;;) {
@@ -1455,8 +1486,14 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   for (size_t b = 0; b < count; ++b) {
     {
       std::unique_lock<std::mutex> l(sh.m);
-      // slots are a ring: box b may be enqueued once box b - depth has been absorbed (the threads finish in any order)
-      sh.cv.wait(l, [&] { return sh.issued - sh.low < (size_t)depth || sh.rc != MPVSS_OK; });
+      // slots are a ring: box b may be enqueued once box b - NSLOT has been absorbed (the threads finish in any order)
+      auto may_issue = [&] {
+        if (sh.rc != MPVSS_OK) return true;
+        if (!issue_on_gpu_done) return sh.issued - sh.low < (size_t)depth;
+        const size_t pending_gpu = sh.issued - (size_t)(ctx->gpu_done.load() - gpu_done0);
+        return pending_gpu < (size_t)depth && sh.issued - sh.low < (size_t)mpvss_ctx::NSLOT - 1;
+      };
+      while (!may_issue()) sh.cv.wait_for(l, std::chrono::microseconds(200));
       if (sh.rc != MPVSS_OK) break;
     }
     int rc;
@@ -1627,6 +1664,7 @@ int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk
   ++ctx->tail;
   if (n == 0) {
     sl.busy = false;
+    ctx->gpu_done.fetch_add(1);
     return MPVSS_OK;
   }
   sl.absorbing = true;
@@ -1635,6 +1673,7 @@ int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk
   const auto t_w0 = std::chrono::steady_clock::now();
   const hipError_t e = hipEventSynchronize(sl.done);
   const auto t_w1 = std::chrono::steady_clock::now();
+  ctx->gpu_done.fetch_add(1);
   if (e == hipSuccess && verdicts_host) memcpy(verdicts_host, sl.pin, n);
   lk.lock();
   sl.busy = false;
