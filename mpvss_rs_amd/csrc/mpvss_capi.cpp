@@ -1139,13 +1139,15 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       };
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
-      // Boxes in flight share the chip.  Left alone they share it EQUALLY: eight boxes enqueued together finish
-      // together, the host then hashes and re-enqueues all of them at once, and while it does the GPU has nothing wide
-      // left to run (measured: 50-110 ms without any a2 launch per ~450 ms convoy).  So the wide launches of box k
-      // (tables, a2, g^r) wait for those of box k - MPVSS_A2_CONCURRENCY: at most that many boxes' a2 run side by side
-      // (one box's a2 is 4096 waves, more than the chip holds), boxes finish oldest first, one per ~70 ms, and the
-      // host's hashing and enqueueing of one box hides behind the GPU work of the others.
-      static const unsigned a2_conc = (unsigned)fd_env("MPVSS_A2_CONCURRENCY", 2);
+      // Boxes in flight share the chip equally: eight boxes enqueued together finish together (a convoy).  What that
+      // costs is the host's turn-around at the end of a convoy, and the cure that works is to enqueue the next box as
+      // soon as a box's GPU work is done instead of after its transcript is hashed (run_box_pipeline,
+      // MPVSS_ISSUE_ON_GPU_DONE: 0.90-0.93 -> 0.97 M share verifications/s at K = 20).  Ordering the wide launches
+      // between boxes -- box k's tables, a2 and g^r wait for those of box k - MPVSS_A2_CONCURRENCY, so that boxes
+      // finish oldest first -- was measured as well and LOSES (1: 0.75 M, 2: 0.86 M, 3: 0.89 M against 0.97 M
+      // unordered; profiles/r02_pipeline_scheduling_ab.txt): one box's a2 is 4096 waves for 3072 wave slots, and with
+      // few of them in flight the tail of each launch leaves slots empty.  Default 0 = unordered.
+      static const unsigned a2_conc = (unsigned)fd_env("MPVSS_A2_CONCURRENCY", 0);
       const unsigned long long seq = ctx->a2_seq++;
       if (a2_conc > 0 && a2_conc < mpvss_ctx::A2_RING && seq >= a2_conc) {
         hipEvent_t prev = ctx->a2_done[(seq - a2_conc) % mpvss_ctx::A2_RING];
