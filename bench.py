@@ -70,7 +70,7 @@ def keygen(rng: random.Random) -> int:
             return k
 
 
-PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "8"))   # boxes in flight (the engine has 16 block slots)
+PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "12"))  # boxes with GPU work pending (the engine has 16 block slots)
 HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "6"))   # host threads absorbing (hashing) boxes at N=1
 USE_VERIFY_MANY = os.environ.get("MPVSS_BENCH_VERIFY_MANY", "1") != "0"   # N=1: the library's own pipeline (0: Python threads)
 
@@ -404,8 +404,8 @@ def main():
         whole pipeline runs inside the library (run_steps_many); with several ranks the running hash state travels
         rank to rank per box, in order, on one thread."""
         if world == 1 and USE_VERIFY_MANY and k > 0:
-            return run_steps_many(k, min(depth or PIPE_DEPTH, 16 - max(HASH_THREADS, 1)))
-        depth = depth or (PIPE_DEPTH if world == 1 else PIPE_DEPTH + world)
+            return run_steps_many(k, min(depth or PIPE_DEPTH, 16))
+        depth = depth or (min(PIPE_DEPTH, 8) if world == 1 else min(PIPE_DEPTH, 8) + world)
         # the engine has 16 block slots; absorbing threads take the oldest blocks in any order, so leave them slack
         depth = min(depth, 16 - (HASH_THREADS if world == 1 else 0))
         results = []
@@ -449,7 +449,7 @@ def main():
     # Allocation pass: every block slot the pipeline will use gets its workspace (about 1.6 GB of HBM), stream pair and
     # pinned staging now, one box per slot -- first-use allocation (hipMalloc, page pinning) is set-up, not verification,
     # and must not fall into the timed region when W is smaller than the number of boxes in flight.
-    slot_init = PIPE_DEPTH if world == 1 else PIPE_DEPTH + world
+    slot_init = 16 if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8) + world
     for verdict, digest in run_steps(slot_init):
         assert verdict is True and digest == dealer_digest, "parity gate failed (slot initialisation)"
     for verdict, digest in run_steps(args.warmup) if args.warmup > 0 else []:
@@ -579,7 +579,7 @@ def main():
                  "per_box_ms": {"enqueue": pst["enqueue_ms"] / nb, "wait_for_gpu": pst["wait_ms"] / nb,
                                 "sha256_transcript": pst["hash_ms"] / nb},
                  "hash_threads": HASH_THREADS if world == 1 else 1,
-                 "boxes_in_flight": PIPE_DEPTH if world == 1 else PIPE_DEPTH + world,
+                 "boxes_in_flight": PIPE_DEPTH if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8) + (world if world > 1 else 0),
                  "pipeline": ("mpvss_modp_verify_many (library threads)" if (world == 1 and USE_VERIFY_MANY)
                               else "verify_block_compute/absorb driven from Python"),
                  "slot_init_boxes": slot_init,
