@@ -30,6 +30,7 @@ import math
 import os
 import random
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -240,6 +241,8 @@ def main():
                     help="also time the opt-in registered-key variant at N=1 (0: skip)")
     ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
     ap.add_argument("--ec-boxes", type=int, default=24, help="boxes timed per curve group for the `ec` objects (0: skip)")
+    ap.add_argument("--host-boxes", type=int, default=8, help="boxes verified from HOST buffers (PCIe included) for the "
+                    "`host_buffers` figure (0: skip)")
     ap.add_argument("--ec-n", type=int, default=65536)
     ap.add_argument("--ec-t", type=int, default=256)
     ap.add_argument("--lone-boxes", type=int, default=2, help="boxes verified one at a time after the timed region "
@@ -358,30 +361,30 @@ def main():
         eng._check(rcode, "verify_block_compute")
 
     hash_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(HASH_THREADS, 1))
-    pending_send = [None, None]     # outstanding isend of the hash state to the next rank
+    claim_lock = threading.Lock()
+    box_seq = [0]                   # boxes claimed so far on this rank (every rank counts the same boxes in the same order)
 
     def finish_block():
-        """absorb the oldest in-flight block into the (chained) transcript; returns (verdict, digest)"""
+        """Absorb the oldest in-flight block into its transcript; returns (box number, (verdict, digest)) -- None instead
+        of the pair on the ranks that only pass the state on.  Runs on the hash threads, several boxes at a time: the boxes are independent
+        transcripts, only the ranks of ONE box form a chain.  claim -> (state of this box from the previous rank) ->
+        wait for the GPU and hash -> (state to the next rank); the message tag is the box's sequence number."""
+        with claim_lock:
+            ticket = eng.block_claim()
+            seq = box_seq[0]
+            box_seq[0] += 1
         if world == 1 or rank == 0:
             state = capi.transcript_init()
         else:
             buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
-            dist.recv(buf, src=rank - 1, group=chain)
+            dist.recv(buf, src=rank - 1, group=chain, tag=seq)
             state = bytes(buf.cpu().numpy().tobytes())
-        state = eng.verify_block_absorb(state)          # waits for this block's GPU work, then hashes it
-        if world == 1:
-            return capi.transcript_verdict(state, challenge)
-        # Several ranks: hand the state on and return at once -- the ranks form a pipeline over the boxes (rank r hashes
-        # box b while rank r+1 hashes box b-1).  Only the last rank knows the verdicts; they are broadcast once, at the
-        # end of run_steps(), not per box (a per-box broadcast would hold every rank until the last one is done).
-        if rank + 1 < world:
-            if pending_send[0] is not None:
-                pending_send[0].wait()
-            msg = torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev)
-            pending_send[0] = dist.isend(msg, dst=rank + 1, group=chain)
-            pending_send[1] = msg                               # keep the buffer alive until the send completes
-            return None
-        return capi.transcript_verdict(state, challenge)
+        state = eng.verify_block_absorb_claimed(ticket, state)   # waits for this block's GPU work, then hashes it
+        if world > 1 and rank + 1 < world:
+            # hand the state on; only the last rank knows the verdicts, they are broadcast once at the end of run_steps()
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain, tag=seq)
+            return seq, None
+        return seq, capi.transcript_verdict(state, challenge)
 
     def run_steps_many(k, depth):
         """N = 1: k complete verifications of the box in ONE library call (mpvss_modp_verify_many): the calling thread
@@ -400,38 +403,18 @@ def main():
 
     def run_steps(k, depth=None):
         """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
-        enqueued while the host hashes the oldest ones.  On one GPU the boxes are independent transcripts and the
-        whole pipeline runs inside the library (run_steps_many); with several ranks the running hash state travels
-        rank to rank per box, in order, on one thread."""
+        enqueued while host threads hash the oldest ones.  On one GPU the whole pipeline runs inside the library
+        (run_steps_many); with several ranks the running hash state of every box travels rank to rank, so the blocks
+        are driven from here (compute / claim / absorb_claimed) with HASH_THREADS boxes being absorbed at a time."""
         if world == 1 and USE_VERIFY_MANY and k > 0:
             return run_steps_many(k, min(depth or PIPE_DEPTH, 16))
-        depth = depth or (min(PIPE_DEPTH, 8) if world == 1 else min(PIPE_DEPTH, 8) + world)
-        # the engine has 16 block slots; absorbing threads take the oldest blocks in any order, so leave them slack
-        depth = min(depth, 16 - (HASH_THREADS if world == 1 else 0))
+        # the engine has 16 block slots; absorbing threads hold the oldest blocks, so leave them slack
+        depth = min(depth or min(PIPE_DEPTH, 8), 16 - max(HASH_THREADS, 1))
         results = []
         issued = 0
         while issued < min(depth, k):
             compute_block()
             issued += 1
-        if world > 1 or HASH_THREADS <= 1:
-            for _ in range(k):
-                results.append(finish_block())
-                if issued < k:
-                    compute_block()
-                    issued += 1
-            if world > 1:                      # one broadcast of all k verdicts and digests from the last rank
-                if pending_send[0] is not None:
-                    pending_send[0].wait()
-                    pending_send[0] = None
-                if rank == world - 1:
-                    flat = b"".join(bytes([int(v)]) + d for v, d in results)
-                    out = torch.frombuffer(bytearray(flat), dtype=torch.uint8).to(commdev)
-                else:
-                    out = torch.zeros(33 * k, dtype=torch.uint8, device=commdev)
-                dist.broadcast(out, src=world - 1, group=chain)
-                raw = bytes(out.cpu().numpy().tobytes())
-                results = [(bool(raw[33 * i]), raw[33 * i + 1:33 * i + 33]) for i in range(k)]
-            return results
         pending = collections.deque(hash_pool.submit(finish_block) for _ in range(issued))
         while pending:
             results.append(pending.popleft().result())
@@ -439,6 +422,16 @@ def main():
                 compute_block()
                 issued += 1
                 pending.append(hash_pool.submit(finish_block))
+        results = [r for _, r in sorted(results, key=lambda sr: sr[0])]      # threads claim boxes in order, finish in any
+        if world > 1:                      # one broadcast of all k verdicts and digests from the last rank
+            if rank == world - 1:
+                flat = b"".join(bytes([int(v)]) + d for v, d in results)
+                out = torch.frombuffer(bytearray(flat), dtype=torch.uint8).to(commdev)
+            else:
+                out = torch.zeros(33 * k, dtype=torch.uint8, device=commdev)
+            dist.broadcast(out, src=world - 1, group=chain)
+            raw = bytes(out.cpu().numpy().tobytes())
+            results = [(bool(raw[33 * i]), raw[33 * i + 1:33 * i + 33]) for i in range(k)]
         return results
 
     def barrier():
@@ -449,7 +442,7 @@ def main():
     # Allocation pass: every block slot the pipeline will use gets its workspace (about 1.6 GB of HBM), stream pair and
     # pinned staging now, one box per slot -- first-use allocation (hipMalloc, page pinning) is set-up, not verification,
     # and must not fall into the timed region when W is smaller than the number of boxes in flight.
-    slot_init = 16 if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8) + world
+    slot_init = 16
     for verdict, digest in run_steps(slot_init):
         assert verdict is True and digest == dealer_digest, "parity gate failed (slot initialisation)"
     for verdict, digest in run_steps(args.warmup) if args.warmup > 0 else []:
@@ -492,7 +485,7 @@ def main():
     a2_launch_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else a2_launch_ms_overlapped
 
     # work accounting: Montgomery products the kernels execute per step on this rank
-    fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "8192"))
+    fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "4096"))
     if fd:
         chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(min(2048 // t, n // 8192), n // 16384, 4),
                             n // (4 * t)))                                   # as eval_x() in mpvss_capi.cpp
@@ -578,10 +571,13 @@ def main():
         "host": {"sha_ni": bool(lib.mpvss_sha256_uses_shani()),
                  "per_box_ms": {"enqueue": pst["enqueue_ms"] / nb, "wait_for_gpu": pst["wait_ms"] / nb,
                                 "sha256_transcript": pst["hash_ms"] / nb},
-                 "hash_threads": HASH_THREADS if world == 1 else 1,
-                 "boxes_in_flight": PIPE_DEPTH if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8) + (world if world > 1 else 0),
-                 "pipeline": ("mpvss_modp_verify_many (library threads)" if (world == 1 and USE_VERIFY_MANY)
-                              else "verify_block_compute/absorb driven from Python"),
+                 "hash_threads": max(HASH_THREADS, 1),
+                 "boxes_in_flight": (min(PIPE_DEPTH, 16) if (world == 1 and USE_VERIFY_MANY)
+                                     else min(PIPE_DEPTH, 8, 16 - max(HASH_THREADS, 1))),
+                 "pipeline": ("mpvss_modp_verify_many (library threads; boxes_in_flight = boxes with GPU work pending)"
+                              if (world == 1 and USE_VERIFY_MANY)
+                              else "verify_block_compute / block_claim / absorb_claimed from a Python thread pool"
+                                   + ("; the hash state of every box travels rank to rank (gloo, tag = box)" if world > 1 else "")),
                  "slot_init_boxes": slot_init,
                  "setup_s": setup_s},
     }
@@ -638,6 +634,31 @@ def main():
                       f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
                       f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
         }
+    # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
+    if world == 1 and args.host_boxes > 0:
+        pos_arr = (C.c_int64 * n)(*positions)
+        hb = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in (commitments, pubkeys, shares, responses)]
+        hbox = capi.ModpBox(C.addressof(hb[0]), t, C.addressof(pos_arr), C.addressof(hb[1]), C.addressof(hb[2]),
+                            C.addressof(hb[3]), n, C.cast(ch_buf, C.c_void_p), None, 0)
+
+        def host_many(count):
+            arr = (capi.ModpBox * count)(*([hbox] * count))
+            vd = (C.c_int * count)()
+            dg = (C.c_uint8 * (32 * count))()
+            eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_HOST, arr, count, min(PIPE_DEPTH, 16), max(HASH_THREADS, 1), vd,
+                                                  C.cast(dg, C.c_void_p)), "verify_many(host)")
+            return all(vd[i] == 1 for i in range(count)) and all(bytes(dg)[32 * i:32 * i + 32] == dealer_digest for i in range(count))
+
+        assert host_many(16), "host-buffer boxes: verdict or digest wrong"      # every slot grows its pinned staging here
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        ok_h = host_many(args.host_boxes)
+        host_s = (time.perf_counter() - t_h) / args.host_boxes
+        assert ok_h, "host-buffer boxes: verdict or digest wrong"
+        result["host_buffers"] = {"value": n / host_s, "unit": "share verifications/s", "ms_per_box": host_s * 1e3,
+                                  "boxes": args.host_boxes,
+                                  "note": "same boxes, every input in pageable host memory: the library copies them into pinned "
+                                          "staging and over PCIe (3 x n x 256 B per box) inside the timed calls; not `value`"}
     # ---------------- opt-in variant: registered public keys (include/mpvss_hip.h) ----------------
     # NOT the headline: `value` above recomputes y_i^r_i from the bare keys in every step.  Here the per-key tables
     # are built once (timed separately) and the same K steps are repeated against them -- the situation of a verifier
@@ -739,7 +760,7 @@ def main():
         # host hashing of the oldest box beside the GPU work of the next ones; plus the scalar side of one box
         # (P(i), responses) behind the C ABI, timed separately
         d_pv, d_wt = dev_u8(pv_bytes), dev_u8(wit_bytes)
-        deal_depth, deal_boxes = 4, 8
+        deal_depth, deal_boxes = 8, 12
 
         def deal_pipelined(count):
             issued = done = 0

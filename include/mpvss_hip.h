@@ -132,6 +132,14 @@ int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const uint8_t* co
                                     const uint8_t* responses, size_t n, const uint8_t* challenge_host);
 int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* a1_out_host,
                                    uint8_t* a2_out_host);
+/* The same in two steps, for callers whose transcript state arrives from elsewhere (one rank of a sharded verification:
+ * the state of box b comes from the previous rank): mpvss_block_claim takes the oldest block in flight (MODP
+ * distribution blocks only) and returns its ticket -- tickets count the blocks of this context in enqueue order --,
+ * mpvss_modp_verify_block_absorb_claimed waits for and hashes exactly that block.  Several threads may hold claimed
+ * blocks at once; every claimed block must be absorbed. */
+int mpvss_block_claim(mpvss_ctx* ctx, unsigned long long* ticket_out);
+int mpvss_modp_verify_block_absorb_claimed(mpvss_ctx* ctx, unsigned long long ticket, uint8_t* state,
+                                           uint8_t* x_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host);
 /* Host-only: extend the transcript with `count` 256-byte elements, each framed as
  * u64-BE(minimal length) || minimal-length big-endian bytes (src/dleq.rs:58-61, modp.rs:150-152). */
 int mpvss_modp_transcript_absorb(uint8_t* state, const uint8_t* elements, size_t count);
@@ -389,6 +397,9 @@ typedef struct mpvss_pipeline_stats {
   unsigned long long blocks;
 } mpvss_pipeline_stats;
 int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* out, int reset);
+/* Blocks of the block API currently in flight in this context (enqueued, not yet fully absorbed) and how many of them
+ * still have GPU work pending: for monitoring and for callers that schedule compute / absorb themselves. */
+int mpvss_blocks_in_flight(mpvss_ctx* ctx, int* in_flight_out, int* gpu_pending_out);
 /* 1 when the transcript hash uses the CPU's SHA extensions (about 1.7 GB/s per thread), 0 for the portable code */
 int mpvss_sha256_uses_shani(void);
 

@@ -26,13 +26,14 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_verify_shares", "mpvss_modp_distribute", "mpvss_sha256", "mpvss_modp_hash_to_scalar",
     "mpvss_last_kernel_ms",
     "mpvss_transcript_init", "mpvss_modp_verify_block_compute", "mpvss_modp_verify_block_absorb",
+    "mpvss_block_claim", "mpvss_modp_verify_block_absorb_claimed",
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
-    "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_sha256_uses_shani",
+    "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani",
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
     "mpvss_ec_batch_exp_generator", "mpvss_ec_verify_block_compute", "mpvss_ec_verify_block_absorb",
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
@@ -127,6 +128,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_transcript_init.restype = None
     lib.mpvss_modp_verify_block_compute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_modp_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
+    lib.mpvss_block_claim.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    lib.mpvss_modp_verify_block_absorb_claimed.argtypes = [vp, C.c_ulonglong, u8p, u8p, u8p, u8p]
     lib.mpvss_modp_transcript_verdict.argtypes = [u8p, u8p, C.POINTER(ci), u8p]
     lib.mpvss_modp_transcript_absorb.argtypes = [u8p, u8p, sz]
     lib.mpvss_ec_batch_exp.argtypes = [vp, ci, ci, u8p, u8p, sz, u8p]
@@ -161,6 +164,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_verify_many.argtypes = [vp, ci, ci, C.POINTER(EcBox), sz, ci, ci, C.POINTER(ci), u8p]
     lib.mpvss_modp_verify_many.argtypes = [vp, ci, C.POINTER(ModpBox), sz, ci, ci, C.POINTER(ci), u8p]
     lib.mpvss_pipeline_stats_get.argtypes = [vp, C.POINTER(PipelineStats), ci]
+    lib.mpvss_blocks_in_flight.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.mpvss_sha256_uses_shani.restype = ci
     lib.mpvss_modp_extract_shares.argtypes = [vp, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
     lib.mpvss_ec_extract_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
@@ -345,6 +349,12 @@ class Engine:
         return {"enqueue_ms": st.enqueue_ms, "wait_ms": st.wait_ms, "hash_ms": st.hash_ms,
                 "kernel_ms": list(st.kernel_ms), "kernel_launches": list(st.kernel_launches), "blocks": int(st.blocks)}
 
+    def blocks_in_flight(self) -> Tuple[int, int]:
+        """(blocks enqueued and not yet fully absorbed, of those: GPU work still pending)"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._check(self.lib.mpvss_blocks_in_flight(self.ctx, C.byref(a), C.byref(b)), "blocks_in_flight")
+        return int(a.value), int(b.value)
+
     def fd_stats(self) -> Tuple[int, int]:
         """(blocks absorbed through the forward-difference path, of those: fell back to Horner on the device)"""
         b, f = C.c_ulonglong(0), C.c_ulonglong(0)
@@ -354,6 +364,18 @@ class Engine:
     def verify_block_absorb(self, state: bytes) -> bytes:
         ks, ps = _buf(state)
         self._check(self.lib.mpvss_modp_verify_block_absorb(self.ctx, ps, None, None, None), "verify_block_absorb")
+        return bytes(ks)
+
+    def block_claim(self) -> int:
+        """take the oldest MODP distribution block in flight; returns its ticket (blocks count in enqueue order)"""
+        tk = C.c_ulonglong(0)
+        self._check(self.lib.mpvss_block_claim(self.ctx, C.byref(tk)), "block_claim")
+        return int(tk.value)
+
+    def verify_block_absorb_claimed(self, ticket: int, state: bytes) -> bytes:
+        ks, ps = _buf(state)
+        self._check(self.lib.mpvss_modp_verify_block_absorb_claimed(self.ctx, ticket, ps, None, None, None),
+                    "verify_block_absorb_claimed")
         return bytes(ks)
 
     def extract_shares(self, pk: bytes, y: bytes, xinv: bytes, w: bytes) -> Tuple[bytes, bytes]:

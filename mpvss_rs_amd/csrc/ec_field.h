@@ -4,8 +4,8 @@
 // (tests/ec_host_shim.cpp) and for gfx950 by hipcc.
 //
 // Representation: value = sum v[i] * 2^(26 i); capacity 260 bits, values are only weakly reduced
-// (any representative below ~2^260).  After mul / sqr / carry: v[0] < 2^26 + 2^21, v[1] < 2^27,
-// v[2..9] < 2^26.  mul accepts limbs up to 2^30 (10 products of 2^60 fit a 64-bit column).
+// (any representative below ~2^261).  After carry: v[0] < 2^26 + 2^21, v[1] < 2^27, v[2..9] < 2^26; after mul / sqr:
+// every limb < 2^27 + 2^12 (reduce_columns).  mul accepts limbs up to 2^30 (10 products of 2^60 fit a 64-bit column).
 //
 // Folding: 2^260 = R1 * 2^26 + R0 (mod p):  secp256k1 p = 2^256 - 2^32 - 977 -> 2^260 = 16 (2^32 + 977)
 // = 2^10 * 2^26 + 15632;   curve25519 p = 2^255 - 19 -> 2^260 = 32 * 19 = 608.
@@ -106,45 +106,52 @@ struct F {
     r.v[1] += t * P::R1;
   }
 
+  // the three 26-bit-aligned pieces of a 64-bit column: bits 0..25, 26..51, 52..63 (an and, a funnel shift + and, a shift)
+  static EC_HD void pieces(u32& p0, u32& p1, u32& p2, u64 c) {
+    const u32 lo = (u32)c, hi = (u32)(c >> 32);
+    p0 = lo & M26;
+    p1 = ((lo >> 26) | (hi << 6)) & M26;
+    p2 = hi >> 20;
+  }
+  // 19 product columns (each < 2^64) -> 10 limbs.  No carry chain over 64-bit columns: a high column is cut into its
+  // three pieces, which are folded (2^260 = R1 2^26 + R0) straight into the low columns with multiply-adds -- top
+  // column first, so that what lands in columns 10 and 11 is folded again when their turn comes; the low columns are
+  // then cut the same way and limb k = piece0[k] + piece1[k-1] + piece2[k-2].
+  // Out: v[0] < 2^26, v[1] < 2^27, v[2..9] < 2^27 + 2^12.
   static EC_HD void reduce_columns(Fe& r, u64 (&c)[20]) {
-    // carry the 19 product columns so that every column is < 2^26 (c[19] takes the overflow, < 2^38)
 #pragma unroll
-    for (int k = 0; k < 19; ++k) {
-      c[k + 1] += c[k] >> 26;
-      c[k] &= M26;
-    }
-    // fold columns 10..19
-    u64 extra = 0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const u64 h = c[10 + i];
-      c[i] += h * P::R0;
+    for (int i = 8; i >= 0; --i) {
+      u32 p0, p1, p2;
+      pieces(p0, p1, p2, c[10 + i]);
+      c[i] += (u64)p0 * P::R0;
+      c[i + 1] += (u64)p1 * P::R0;
+      c[i + 2] += (u64)p2 * P::R0;
       if (P::R1 != 0) {
-        if (i < 9) c[i + 1] += h * P::R1; else extra = h * P::R1;
+        c[i + 1] += (u64)p0 * P::R1;
+        c[i + 2] += (u64)p1 * P::R1;
+        c[i + 3] += (u64)p2 * P::R1;
       }
     }
-    if (P::R1 != 0) {                 // extra sits at 2^260 again (< 2^48)
-      c[0] += extra * P::R0;
-      c[1] += extra * P::R1;
-    }
-    // two carry passes: the first leaves up to ~2^41 in c[0] when the inputs were at the 2^30 limb
-    // bound, the second brings every limb back to the documented range
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        c[k + 1] += c[k] >> 26;
-        c[k] &= M26;
+    // columns 8 and 9 first: their upper pieces wrap around into columns 0..2
+    u32 q0[10], q1[10], q2[10];
+    pieces(q0[9], q1[9], q2[9], c[9]);
+    pieces(q0[8], q1[8], q2[8], c[8]);
+    {
+      const u32 w10 = q1[9] + q2[8];        // weight 2^260, < 2^26 + 2^12
+      const u32 w11 = q2[9];                // weight 2^286, < 2^12
+      c[0] += (u64)w10 * P::R0;
+      c[1] += (u64)w11 * P::R0;
+      if (P::R1 != 0) {
+        c[1] += (u64)w10 * P::R1;
+        c[2] += (u64)w11 * P::R1;
       }
-      const u64 t = c[9] >> 26;
-      c[9] &= M26;
-      c[0] += t * P::R0;
-      c[1] += t * P::R1;
     }
-    c[1] += c[0] >> 26;
-    c[0] &= M26;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) r.v[i] = (u32)c[i];
+    for (int k = 0; k < 8; ++k) pieces(q0[k], q1[k], q2[k], c[k]);
+    r.v[0] = q0[0];
+    r.v[1] = q0[1] + q1[0];
+#pragma unroll
+    for (int k = 2; k < 10; ++k) r.v[k] = q0[k] + q1[k - 1] + q2[k - 2];
   }
 
   static EC_HD void mul(Fe& r, const Fe& a, const Fe& b) {

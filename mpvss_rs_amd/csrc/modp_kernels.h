@@ -34,6 +34,11 @@ int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, 
 int modp_launch_build_table64(const uint8_t* base_be, int count, uint32_t* tab, const void* cs, hipStream_t s);
 int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
                             size_t c_stride, int count, uint8_t* out, const void* cs, hipStream_t s);
+/* one base, two exponents, two results (dealer: Y = y^p, a2 = y^w): right-to-left 5-bit buckets in HBM, shared squarings.
+   buckets: count * modp_twin_exp_bucket_words() u32 of scratch, occupancy: count * 2 u32 of scratch */
+size_t modp_twin_exp_bucket_words(void);
+int modp_launch_twin_exp(const uint8_t* base_be, const uint8_t* e1, const uint8_t* e2, int count, uint32_t* buckets,
+                         uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, hipStream_t s);
 /* registered public keys: per-key tables for y^r (see modp_kernels.hip) */
 size_t modp_keyset_words_per_key(void);
 int modp_launch_keyset_build(const uint8_t* pk_be, int count, uint32_t* ks, const void* cs, hipStream_t s);

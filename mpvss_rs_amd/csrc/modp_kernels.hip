@@ -1011,6 +1011,137 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
 }
 
 // ---------------------------------------------------------------------------------------
+// One base, two exponents, two results (the dealer: Y_i = y_i^P(i), participant.rs:219, and a2_i = y_i^w_i,
+// dleq.rs:213-216).  Left-to-right windows cannot share the squarings of two exponentiations; right-to-left can:
+//   cur_k = y^(2^(5k)) is computed once (2 045 squarings), and for each exponent e = sum_k d_k 2^(5k)
+//   y^e = prod_{d=1..31} B[d]^d  with the buckets  B[d] = prod_{k : d_k = d} cur_k        (Yao 1976 / BGMW)
+// 410 bucket products per exponent, then at most 60 products for prod B[d]^d (running products, k_modp_bucket_combine).
+// The 2 x 31 buckets of a share live in HBM (17.9 KB per share; a quad reads and writes ITS 288 bytes, every bucket
+// is private to its quad), a 32-bit occupancy mask per exponent stays in a register: a bucket's first factor is stored,
+// not multiplied.  ~2 500 product equivalents for both results instead of ~3 870 for two 6-bit-window ladders.
+// ---------------------------------------------------------------------------------------
+constexpr int BK_W = 5;                       // window bits
+constexpr int BK_ENT = (1 << BK_W) - 1;       // buckets per exponent (digit 0 has none)
+constexpr int BK_WINDOWS = (2048 + BK_W - 1) / BK_W;
+
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_twin_exp_buckets(const uint8_t* __restrict__ base_be, const uint8_t* __restrict__ e1_be,
+                        const uint8_t* __restrict__ e2_be, int count, u32* __restrict__ buckets,
+                        u32* __restrict__ occupancy, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], cur[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(cur, base_be + (size_t)x * 256, ln);
+  u32* mine = buckets + (size_t)x * 2 * BK_ENT * L;
+  const uint8_t* ex0 = e1_be + (size_t)x * 256;
+  const uint8_t* ex1 = e2_be + (size_t)x * 256;
+  u32 occ0 = 0, occ1 = 0;
+  // op 0: base to Montgomery form.  Then per window k: ops 1, 2 = the two bucket updates, ops 3..7 = five squarings.
+  int k = 0, op = 0;
+  while (true) {
+    if (op == 0) {
+      slot_fill_from_global(slot, cs->r2, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(cur, cur, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    } else if (op <= 2) {
+      const uint8_t* ex = (op == 1) ? ex0 : ex1;
+      const int o = BK_W * k, b = o >> 3;
+      const u32 lo = ex[255 - b];
+      const u32 hi = (b + 1 < 256) ? ex[254 - b] : 0u;
+      const u32 d = ((lo | (hi << 8)) >> (o & 7)) & (u32)BK_ENT;
+      const u32 occ = (op == 1) ? occ0 : occ1;
+      const bool has = (occ >> d) & 1u;            // bit 0 is never set: digit 0 touches nothing
+      u32* bk = mine + ((size_t)(op - 1) * BK_ENT + (d ? d - 1 : 0)) * L;
+      // the bucket is the LDS operand, cur stays in registers: no second register operand is live across the product
+      if (d != 0 && has) slot_fill_from_global(slot, bk, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(acc, cur, slot, n, ln);        // quads with nothing to multiply compute and drop a product
+      __builtin_amdgcn_wave_barrier();
+      if (d != 0 && live) {
+        if (has) store_lane_limbs(bk, acc, ln); else store_lane_limbs(bk, cur, ln);
+      }
+      const u32 bit = d ? (1u << d) : 0u;
+      if (op == 1) occ0 |= bit; else occ1 |= bit;
+    } else {
+      slot_store(slot, cur, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_sqr<MODP_N0INV_C>(cur, cur, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (op == 0) { op = 1; continue; }
+    if (op == 2 && k == BK_WINDOWS - 1) break;
+    if (op == 2 + BK_W) { op = 1; ++k; } else ++op;
+  }
+  if (live && ln.q == 0) {
+    occupancy[(size_t)x * 2] = occ0;
+    occupancy[(size_t)x * 2 + 1] = occ1;
+  }
+}
+
+// y^e = prod_d B[d]^d: run = B[31]; res = run; then for d = 30..1: run *= B[d]; res *= run.  One quad per (share, exponent);
+// empty buckets and a not-yet-started run / res skip their product (the result for e = 0 is 1).
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modp_bucket_combine(const u32* __restrict__ buckets, const u32* __restrict__ occupancy, int count,
+                      uint8_t* __restrict__ out1_be, uint8_t* __restrict__ out2_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < 2 * count;
+  const int x = live ? xi : 2 * count - 1;      // (share, exponent) pair: share x >> 1, exponent x & 1
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], run[LPL], res[LPL], tmp[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_lane_limbs(run, cs->one_m, ln);
+  load_lane_limbs(res, cs->one_m, ln);
+  const u32 occ = occupancy[x];
+  const u32* mine = buckets + (size_t)x * BK_ENT * L;
+  bool run_set = false, res_set = false;
+  // two ops per digit: op 0 folds B[d] into run, op 1 folds run into res
+  for (int step = 0; step < 2 * BK_ENT; ++step) {
+    const int d = BK_ENT - (step >> 1);
+    const bool has = (occ >> d) & 1u;
+    if ((step & 1) == 0) {
+      if (has) slot_fill_from_global(slot, mine + (size_t)(d - 1) * L, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(tmp, run, slot, n, ln);
+      if (has) {
+        if (run_set) {
+#pragma unroll
+          for (int j = 0; j < LPL; ++j) run[j] = tmp[j];
+        } else {
+          slot_load(run, slot, ln);
+        }
+        run_set = true;
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      slot_store(slot, run, ln);
+      __builtin_amdgcn_wave_barrier();
+      mont_mul<MODP_N0INV_C>(tmp, res, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+      if (run_set) {
+        if (res_set) {
+#pragma unroll
+          for (int j = 0; j < LPL; ++j) res[j] = tmp[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < LPL; ++j) res[j] = run[j];
+        }
+        res_set = true;
+      }
+    }
+  }
+  uint8_t* out = ((x & 1) ? out2_be : out1_be) + (size_t)(x >> 1) * 256;
+  store_canonical_be256(out, res, true, slot, cs, n, ln, live);
+}
+
+// ---------------------------------------------------------------------------------------
 // Registered public keys (opt-in): per-key tables for y^r, built once per key set and reused by every box that is
 // verified against it.  ks[key][j][d] = y^(d * 2^(256 j)), j < 8, d < 256 (Montgomery form; 8 x 256 x 304 B =
 // 622 KB per key, 41 GB for 65536 keys -- sized for 288 GB of HBM).  With r = sum_j r_j 2^(256 j):
@@ -1289,6 +1420,17 @@ extern "C" int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_dual_exp_w6, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab2, e1, c, c_stride, count,
                      out, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+extern "C" size_t modp_twin_exp_bucket_words() { return (size_t)2 * BK_ENT * L; }
+// Y = base^e1, A = base^e2 (same base): buckets [count][2][31][72] u32 and occupancy [count][2] u32 are scratch
+extern "C" int modp_launch_twin_exp(const uint8_t* base_be, const uint8_t* e1, const uint8_t* e2, int count, uint32_t* buckets,
+                                    uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_twin_exp_buckets, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, base_be, e1, e2, count,
+                     buckets, occupancy, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_bucket_combine, dim3(grid_for(2 * count)), dim3(BLOCK_THREADS), 0, s, buckets, occupancy, count,
+                     out1, out2, (const ModpConsts*)cs);
   return (int)hipGetLastError();
 }
 extern "C" size_t modp_keyset_words_per_key() { return (size_t)KS_SUB * KS_ENT * L; }

@@ -128,6 +128,8 @@ struct mpvss_ctx {
     size_t n = 0;
     bool busy = false;
     bool absorbing = false;        // a host thread is waiting for / hashing this block (context lock released)
+    bool claimed = false;          // taken by mpvss_block_claim, its absorb call has not started yet
+    unsigned ticket = 0;           // value of `tail` when the block was claimed
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
@@ -738,7 +740,7 @@ void invert_root_on_host(void* p) {
 // does the forward-difference path apply to this run of shares?  (host-side part of the decision)
 bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
   static const int fd_on = fd_env("MPVSS_FD", 1);
-  static const size_t max_t = (size_t)fd_env("MPVSS_FD_MAX_T", 1024), min_shares = (size_t)fd_env("MPVSS_FD_MIN_SHARES", 8192);
+  static const size_t max_t = (size_t)fd_env("MPVSS_FD_MAX_T", 1024), min_shares = (size_t)fd_env("MPVSS_FD_MIN_SHARES", 4096);
   bool fd = fd_on && t >= 16 && t <= max_t && cnt >= 16 * t && cnt >= min_shares;
   if (fd && hpos) {                       // host positions: decide here; device positions are checked by a kernel
     for (size_t i = 0; i < cnt && fd; ++i) fd = hpos[i] == hpos[0] + (int64_t)i;
@@ -1228,15 +1230,24 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
 // and hashes it, so that other host threads can enqueue blocks or absorb the next ones meanwhile (every box has its
 // own transcript; a 65536-share box is 40 ms of SHA-256).  Blocks are handed out in FIFO order at entry.
 int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
-                               uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr) {
+                               uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr,
+                               const unsigned long long* ticket = nullptr) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
-  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
-  if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the oldest block in flight is a verify_share batch");
+  mpvss_ctx::BlockSlot& sl = ctx->slot[(ticket ? (unsigned)*ticket : ctx->tail) % mpvss_ctx::NSLOT];
+  if (ticket) {
+    if (!sl.busy || !sl.claimed || sl.ticket != (unsigned)*ticket)
+      return fail(ctx, MPVSS_E_INVALID, "absorb: no block was claimed with this ticket");
+    if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the claimed block is not a MODP distribution block");
+    sl.claimed = false;
+  } else {
+    if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
+    if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the oldest block in flight is a verify_share batch");
+    ++ctx->tail;
+  }
   const size_t n = sl.n;
-  ++ctx->tail;
   if (n == 0) {
     sl.busy = false;
+    sl.absorbing = false;
     ctx->gpu_done.fetch_add(1);
     return MPVSS_OK;
   }
@@ -1402,6 +1413,31 @@ extern "C" int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, ui
   return verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host);
 }
 
+// Claim / absorb in two steps: several host threads can then absorb blocks concurrently AND know which block each of
+// them holds -- needed when the transcript state of a block comes from somewhere else (the previous rank of a sharded
+// verification) and has to be fetched between the two steps.
+extern "C" int mpvss_block_claim(mpvss_ctx* ctx, unsigned long long* ticket_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ticket_out) return fail(ctx, MPVSS_E_INVALID, "claim: null ticket");
+  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
+  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "claim: no block in flight");
+  if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "claim: the oldest block in flight is not a MODP distribution block");
+  sl.absorbing = true;
+  sl.claimed = true;
+  sl.ticket = ctx->tail;
+  *ticket_out = ctx->tail;
+  ++ctx->tail;
+  return MPVSS_OK;
+}
+
+extern "C" int mpvss_modp_verify_block_absorb_claimed(mpvss_ctx* ctx, unsigned long long ticket, uint8_t* state,
+                                                      uint8_t* x_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  return verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host, nullptr, &ticket);
+}
+
 extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                               const int64_t* positions, const uint8_t* pubkeys,
                                               const uint8_t* shares, const uint8_t* responses, size_t n,
@@ -1547,6 +1583,22 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
         return mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],
                                              digests32 ? digests32 + 32 * idx : nullptr);
       });
+}
+
+extern "C" int mpvss_blocks_in_flight(mpvss_ctx* ctx, int* in_flight_out, int* gpu_pending_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int busy = 0, pending = 0;
+  for (int i = 0; i < mpvss_ctx::NSLOT; ++i) {
+    const mpvss_ctx::BlockSlot& sl = ctx->slot[i];
+    if (!sl.busy) continue;
+    ++busy;
+    if (sl.n != 0 && sl.done && hipEventQuery(sl.done) == hipErrorNotReady) ++pending;
+  }
+  if (in_flight_out) *in_flight_out = busy;
+  if (gpu_pending_out) *gpu_pending_out = pending;
+  return MPVSS_OK;
 }
 
 extern "C" int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* out, int reset) {
@@ -1819,7 +1871,15 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
       Swap sw(ctx, ctx->w->sb);
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:213-216)
       uint32_t* ty = (uint32_t*)ctx->w->tab1.p;
-      if (cnt >= 1024) {          // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
+      static const int twin = fd_env("MPVSS_DEALER_BUCKETS", 1);
+      if (cnt >= 1024 && twin) {
+        // same base, two exponents: right-to-left buckets share the 2 045 squarings (tab1 holds buckets + occupancy)
+        const size_t bw = modp_twin_exp_bucket_words();
+        RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + 2) * 4));
+        uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
+        TIMED_LAUNCH(ctx, 3, modp_launch_twin_exp((const uint8_t*)dy, (const uint8_t*)dp, (const uint8_t*)dw, (int)cnt, bk,
+                                                  bk + cnt * bw, dY, da2, ctx->consts, ctx->stream));
+      } else if (cnt >= 1024) {   // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
         TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
         TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dp, nullptr, 0, (int)cnt, dY, ctx->consts, ctx->stream));
         TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dw, nullptr, 0, (int)cnt, da2, ctx->consts, ctx->stream));

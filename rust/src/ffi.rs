@@ -99,6 +99,9 @@ unsafe extern "C" {
     pub fn mpvss_modp_verify_block_compute(ctx: *mut mpvss_ctx, space: c_int, commitments: *const u8, t: usize, positions: *const i64,
                                            pubkeys: *const u8, shares: *const u8, responses: *const u8, n: usize, challenge_host: *const u8) -> c_int;
     pub fn mpvss_modp_verify_block_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
+    pub fn mpvss_block_claim(ctx: *mut mpvss_ctx, ticket_out: *mut c_ulonglong) -> c_int;
+    pub fn mpvss_modp_verify_block_absorb_claimed(ctx: *mut mpvss_ctx, ticket: c_ulonglong, state: *mut u8,
+        x_out_host: *mut u8, a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
     pub fn mpvss_modp_transcript_absorb(state: *mut u8, elements: *const u8, count: usize) -> c_int;
     pub fn mpvss_modp_transcript_verdict(state: *const u8, challenge_host: *const u8, verdict: *mut c_int, digest32_out: *mut u8) -> c_int;
     pub fn mpvss_modp_verify_many(ctx: *mut mpvss_ctx, space: c_int, boxes: *const mpvss_modp_box, count: usize, depth: c_int, hash_threads: c_int,
@@ -185,5 +188,6 @@ unsafe extern "C" {
     pub fn mpvss_last_kernel_launches(ctx: *const mpvss_ctx, kernel_id: c_int) -> c_int;
     pub fn mpvss_modp_fd_stats(ctx: *mut mpvss_ctx, blocks: *mut c_ulonglong, fallbacks: *mut c_ulonglong) -> c_int;
     pub fn mpvss_pipeline_stats_get(ctx: *mut mpvss_ctx, out: *mut mpvss_pipeline_stats, reset: c_int) -> c_int;
+    pub fn mpvss_blocks_in_flight(ctx: *mut mpvss_ctx, in_flight_out: *mut c_int, gpu_pending_out: *mut c_int) -> c_int;
     pub fn mpvss_sha256_uses_shani() -> c_int;
 }

@@ -126,6 +126,26 @@ int ec_decode_ok(int curve, const uint8_t* p) {
   Ristretto::Point a; return Ristretto::decode(a, p);
 }
 // field self-test hooks: r = a*b, a^2, a-b (canonical 32-byte LE)
+// mul (op 0) / sqr (op 1) on RAW limbs (10 x u32, any value up to the documented 2^30 input bound); writes the
+// canonical result and returns the largest output limb before canonicalisation (the documented output bound is checked
+// by the caller)
+uint32_t fe_limb_op(int curve, int op, const uint32_t* a10, const uint32_t* b10, uint8_t* out) {
+  Fe a, b, r;
+  for (int i = 0; i < 10; ++i) { a.v[i] = a10[i]; b.v[i] = b10[i]; }
+  uint32_t top = 0;
+  if (curve == 0) {
+    typedef F<PrimeSecp> Fp;
+    if (op == 0) Fp::mul(r, a, b); else Fp::sqr(r, a);
+    for (int i = 0; i < 10; ++i) top = r.v[i] > top ? r.v[i] : top;
+    Fp::canon(r); Fp::to_le32(out, r);
+  } else {
+    typedef F<PrimeEd> Fp;
+    if (op == 0) Fp::mul(r, a, b); else Fp::sqr(r, a);
+    for (int i = 0; i < 10; ++i) top = r.v[i] > top ? r.v[i] : top;
+    Fp::canon(r); Fp::to_le32(out, r);
+  }
+  return top;
+}
 int fe_op(int curve, int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out) {
   Fe a, b, r;
   if (curve == 0) {

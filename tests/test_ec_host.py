@@ -50,6 +50,26 @@ def test_field_ops(shim, curve, p):
     assert int.from_bytes(bytes(out), "little") == want
 
 
+@pytest.mark.parametrize("curve,p", [(0, O.SECP_P), (1, O.ED_P)])
+def test_field_product_at_the_limb_bounds(shim, curve, p):
+    """mul / sqr take lazily added operands: every limb up to 2^30 - 1 (ec_field.h).  Worst-case and random limb
+    patterns at that bound: the value is right and every output limb is below 2^27 + 2^12 (reduce_columns)."""
+    rng = random.Random(77 + curve)
+    top = (1 << 30) - 1
+    shim.fe_limb_op.restype = C.c_uint32
+    pats = [[top] * 10, [top] * 9 + [0], [0] * 9 + [top], [top if i % 2 else 0 for i in range(10)], [1 << 26] * 10]
+    pats += [[rng.randrange(top + 1) for _ in range(10)] for _ in range(300)]
+    pats += [[rng.choice((0, top, top - 1, 1 << 29)) for _ in range(10)] for _ in range(200)]
+    val = lambda limbs: sum(v << (26 * i) for i, v in enumerate(limbs))
+    for it, a in enumerate(pats):
+        b = pats[(it * 7 + 3) % len(pats)]
+        for op, want in ((0, val(a) * val(b) % p), (1, val(a) * val(a) % p)):
+            out = (C.c_uint8 * 32)()
+            biggest = shim.fe_limb_op(curve, op, (C.c_uint32 * 10)(*a), (C.c_uint32 * 10)(*b), out)
+            assert int.from_bytes(bytes(out), "little") == want
+            assert biggest < (1 << 27) + (1 << 12)
+
+
 @pytest.mark.parametrize("curve,name", [(0, "secp256k1"), (1, "ristretto255")])
 def test_group_law_and_encodings(shim, curve, name):
     G = O.GROUPS[name]()

@@ -267,6 +267,33 @@ def test_distribute_group_part(engine):
     assert res["digest"] == box["_digest"]
 
 
+def test_dealer_shared_squarings_bucket_path(engine):
+    """From 1024 shares per block the dealer computes Y_i = y_i^P(i) (participant.rs:219) and a2_i = y_i^w_i
+    (dleq.rs:213-216) with ONE chain of squarings per share and right-to-left 5-bit buckets (k_modp_twin_exp_buckets,
+    k_modp_bucket_combine).  Every output against Python's pow, including the exponents that leave buckets empty, fill
+    only one, put every window in the same bucket, or are 0 / not reduced; the 4-bit-window path on the same inputs."""
+    rng = random.Random(0xB0C4E7)
+    n = 1024 + 40
+    same = sum(d << (5 * k) for k in range(410) for d in [9]) % (1 << 2048)          # every window the same digit
+    top = 7 << 2045                                                                  # only the (3-bit) top window
+    edge_e = [0, 1, 31, 32, Q - 2, Q - 1, Q, (1 << 2048) - 1, 1 << 2047, same, top, (1 << 2045) - 1, 1 << 5, 17 << 2040]
+    ys = [rng.randrange(2, Q) for _ in range(n - len(EDGE))] + EDGE
+    ps = [rng.randrange(1 << 2048) for _ in range(n - 2 * len(edge_e))] + edge_e + edge_e[::-1]
+    ws = [rng.randrange(Q - 1) for _ in range(n - 2 * len(edge_e))] + edge_e[::-1] + edge_e
+    rng.shuffle(ys)
+    args = (b"".join(map(fx, ys)), b"".join(map(fx, ps)), b"".join(map(fx, ws)))
+    engine.distribute_compute(None, None, *args)
+    st, X, Y, a1, a2 = engine.distribute_absorb(capi.transcript_init(), n)
+    assert split(Y) == [pow(y, e, Q) for y, e in zip(ys, ps)]
+    assert split(a2) == [pow(y, e, Q) for y, e in zip(ys, ws)]
+    assert split(X) == [pow(4, e, Q) for e in ps] and split(a1) == [pow(4, e, Q) for e in ws]     # g = 4, modp.rs:65-66
+    # below 1024 shares: left-to-right windows, same results
+    m = 200
+    engine.distribute_compute(None, None, *(a[-m * EB:] for a in args))
+    st2, X2, Y2, a12, a22 = engine.distribute_absorb(capi.transcript_init(), m)
+    assert Y2 == Y[-m * EB:] and a22 == a2[-m * EB:] and X2 == X[-m * EB:]
+
+
 def test_distribute_block_api_and_dealer_shortcut(engine):
     """The dealer's blocks in compute / absorb form: several in flight, X_i either from the commitments (the reference's
     loop, participant.rs:207-215) or as g^P(i) through the comb (commitments = None) -- identical outputs and transcript;

@@ -163,6 +163,50 @@ def test_blocks_absorbed_by_several_host_threads(engine):
         engine.verify_block_absorb(capi.transcript_init())
 
 
+def test_claimed_blocks_are_absorbed_by_ticket(engine):
+    """mpvss_block_claim / mpvss_modp_verify_block_absorb_claimed: a thread learns WHICH block it holds before it has to
+    provide the transcript state (a rank of a sharded verification fetches that state from the previous rank in
+    between).  Tickets count the blocks in enqueue order; claimed blocks may be absorbed in any order and from several
+    threads; a block cut in two carries its state from the first ticket to the second."""
+    import concurrent.futures
+    g, privs, pks, coeffs, ws, box = make_modp_instance(12, 4, 22)
+    flat = O.box_to_flat(g, box)
+    tampered = bytearray(flat["shares"]); tampered[300] ^= 1
+    kinds = [flat["shares"], bytes(tampered), flat["shares"], flat["shares"], bytes(tampered)]
+    for sh in kinds:
+        engine.verify_block_compute(flat["commitments"], flat["positions"], flat["publickeys"], sh, flat["responses"],
+                                    flat["challenge"])
+    tickets = [engine.block_claim() for _ in kinds]
+    assert tickets == list(range(tickets[0], tickets[0] + len(kinds)))
+    with pytest.raises(capi.EngineError):
+        engine.block_claim()                                             # nothing unclaimed is left
+    with pytest.raises(capi.EngineError):
+        engine.verify_block_absorb(capi.transcript_init())               # ... for the one-step call either
+    with pytest.raises(capi.EngineError):
+        engine.verify_block_absorb_claimed(tickets[-1] + 1, capi.transcript_init())
+
+    def absorb(i):
+        st = engine.verify_block_absorb_claimed(tickets[i], capi.transcript_init())
+        return capi.transcript_verdict(st, flat["challenge"])
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=3) as pool:
+        out = list(pool.map(absorb, reversed(range(len(kinds)))))[::-1]
+    assert [v for v, _ in out] == [True, False, True, True, False]       # by ticket, not by arrival
+    assert all((d == box["_digest"]) == v for v, d in out)
+    with pytest.raises(capi.EngineError):
+        engine.verify_block_absorb_claimed(tickets[0], capi.transcript_init())      # a ticket is good once
+    # one box as two blocks (5 + 7 shares), claimed together, state carried from the first to the second
+    a = slice(0, 5 * EB); b = slice(5 * EB, 12 * EB)
+    for sl, pos in ((a, flat["positions"][:5]), (b, flat["positions"][5:])):
+        engine.verify_block_compute(flat["commitments"], pos, flat["publickeys"][sl], flat["shares"][sl],
+                                    flat["responses"][sl], flat["challenge"])
+    t1, t2 = engine.block_claim(), engine.block_claim()
+    st = engine.verify_block_absorb_claimed(t1, capi.transcript_init())
+    st = engine.verify_block_absorb_claimed(t2, st)
+    assert capi.transcript_verdict(st, flat["challenge"]) == (True, box["_digest"])
+    assert engine.blocks_in_flight() == (0, 0)
+
+
 def test_verify_many_pipelines_boxes_inside_the_library(engine):
     """mpvss_modp_verify_many == one verify_distribution per box, in box order: honest, tampered, empty and
     different-sized boxes mixed; more boxes than block slots; an invalid box aborts the call with its error."""
