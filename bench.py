@@ -762,21 +762,25 @@ def main():
         d_pv, d_wt = dev_u8(pv_bytes), dev_u8(wit_bytes)
         deal_depth, deal_boxes = 8, 12
 
+        def deal_absorb():
+            st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+            eng._check(lib.mpvss_modp_distribute_absorb(ctx, st, None, None, None, None), "distribute_absorb")
+            return capi.transcript_verdict(bytes(st), bytes(EB))[1]
+
         def deal_pipelined(count):
-            issued = done = 0
-            digests = []
-            while done < count:
-                while issued < count and issued - done < deal_depth:
+            issued = 0
+            pend, digests = collections.deque(), []
+            while issued < count or pend:
+                if issued < count and len(pend) < deal_depth:
                     eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pv), vp(d_wt), n,
                                                                  None, None, None, None), "distribute_compute")
                     issued += 1
-                st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
-                eng._check(lib.mpvss_modp_distribute_absorb(ctx, st, None, None, None, None), "distribute_absorb")
-                digests.append(capi.transcript_verdict(bytes(st), bytes(EB))[1])
-                done += 1
+                    pend.append(hash_pool.submit(deal_absorb))        # absorbs take the blocks in FIFO order
+                else:
+                    digests.append(pend.popleft().result())
             return digests
 
-        deal_pipelined(deal_depth)
+        deal_pipelined(16)                 # every slot's workspace grows to the dealer's size here
         torch.cuda.synchronize()
         t_d = time.perf_counter()
         dg = deal_pipelined(deal_boxes)

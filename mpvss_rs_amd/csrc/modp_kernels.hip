@@ -1024,58 +1024,100 @@ constexpr int BK_W = 5;                       // window bits
 constexpr int BK_ENT = (1 << BK_W) - 1;       // buckets per exponent (digit 0 has none)
 constexpr int BK_WINDOWS = (2048 + BK_W - 1) / BK_W;
 
+// The bucket a product needs is fetched while the wave is still squaring: an LDS-DMA (global_load_lds_dwordx4, no
+// registers) of the 16 numbers' buckets into a second operand slot, issued before the five squarings for the first
+// exponent's bucket and before the first bucket product for the second one (whose slot the squarings were using).
+// One DMA instruction moves 64 x 16 bytes to consecutive LDS addresses; a number's 288-byte slot is 18 such pieces, so
+// lane l of instruction i fetches piece (l + 64 i) % 18 of number (l + 64 i) / 18 -- whose digit it gets by a shuffle.
+__device__ __forceinline__ void bucket_prefetch(u32* wave_slots, const u32* __restrict__ buckets, int first_x, int count,
+                                                int e, u32 d_eff) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int c = lane + 64 * i;
+    const int jn = (c < NUMS_PER_WAVE * 18) ? c / 18 : NUMS_PER_WAVE - 1;
+    const int part = c - 18 * jn;
+    const u32 dj = (u32)__shfl((int)d_eff, jn * 4);
+    const int xj = (first_x + jn < count) ? first_x + jn : count - 1;
+    const u32* src = buckets + (((size_t)xj * 2 + (size_t)e) * BK_ENT + (dj - 1)) * L + part * 4;
+    if (c < NUMS_PER_WAVE * 18)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)src,
+                                       (__attribute__((address_space(3))) void*)(uintptr_t)(wave_slots + i * 256), 16, 0, 0);
+  }
+}
+
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_twin_exp_buckets(const uint8_t* __restrict__ base_be, const uint8_t* __restrict__ e1_be,
                         const uint8_t* __restrict__ e2_be, int count, u32* __restrict__ buckets,
                         u32* __restrict__ occupancy, const ModpConsts* __restrict__ cs) {
-  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds[2 * NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
-  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const int wave = threadIdx.x >> 6;
+  const int first_x = blockIdx.x * NUMS_PER_BLOCK + wave * NUMS_PER_WAVE;
+  const int xi = first_x + ((threadIdx.x & 63) >> 2);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
-  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32* wslot1 = lds + wave * 2 * NUMS_PER_WAVE * SLOT_WORDS;     // squarings (a copy of cur), then the second exponent's bucket
+  u32* wslot2 = wslot1 + NUMS_PER_WAVE * SLOT_WORDS;             // the first exponent's bucket
+  u32* slot1 = wslot1 + ((threadIdx.x & 63) >> 2) * SLOT_WORDS;
+  u32* slot2 = wslot2 + ((threadIdx.x & 63) >> 2) * SLOT_WORDS;
   u32 n[LPL], cur[LPL], acc[LPL];
   load_lane_limbs(n, cs->n, ln);
   load_be256(cur, base_be + (size_t)x * 256, ln);
   u32* mine = buckets + (size_t)x * 2 * BK_ENT * L;
   const uint8_t* ex0 = e1_be + (size_t)x * 256;
   const uint8_t* ex1 = e2_be + (size_t)x * 256;
+  auto digit = [&](const uint8_t* ex, int k) -> u32 {
+    const int o = BK_W * k, b = o >> 3;
+    const u32 lo = ex[255 - b];
+    const u32 hi = (b + 1 < 256) ? ex[254 - b] : 0u;
+    return ((lo | (hi << 8)) >> (o & 7)) & (u32)BK_ENT;
+  };
   u32 occ0 = 0, occ1 = 0;
-  // op 0: base to Montgomery form.  Then per window k: ops 1, 2 = the two bucket updates, ops 3..7 = five squarings.
-  int k = 0, op = 0;
+  // base to Montgomery form
+  slot_fill_from_global(slot1, cs->r2, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(cur, cur, slot1, n, ln);
+  __builtin_amdgcn_wave_barrier();
+  u32 d0 = digit(ex0, 0), d1 = digit(ex1, 0);
+  // per window k: op 1 = bucket of the first exponent, op 2 = of the second, ops 3..7 = five squarings.
+  // bit 0 of an occupancy mask is never set: digit 0 touches nothing.
+  int k = 0, op = 1;
   while (true) {
-    if (op == 0) {
-      slot_fill_from_global(slot, cs->r2, ln);
-      __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(cur, cur, slot, n, ln);
-      __builtin_amdgcn_wave_barrier();
-    } else if (op <= 2) {
-      const uint8_t* ex = (op == 1) ? ex0 : ex1;
-      const int o = BK_W * k, b = o >> 3;
-      const u32 lo = ex[255 - b];
-      const u32 hi = (b + 1 < 256) ? ex[254 - b] : 0u;
-      const u32 d = ((lo | (hi << 8)) >> (o & 7)) & (u32)BK_ENT;
+    if (op <= 2) {
+      const u32 d = (op == 1) ? d0 : d1;
       const u32 occ = (op == 1) ? occ0 : occ1;
-      const bool has = (occ >> d) & 1u;            // bit 0 is never set: digit 0 touches nothing
+      const bool has = (occ >> d) & 1u;
       u32* bk = mine + ((size_t)(op - 1) * BK_ENT + (d ? d - 1 : 0)) * L;
-      // the bucket is the LDS operand, cur stays in registers: no second register operand is live across the product
-      if (d != 0 && has) slot_fill_from_global(slot, bk, ln);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this op's bucket has landed (and earlier stores are done)
+      if (op == 1) {
+        // the squarings are over: their slot takes the second exponent's bucket while the first product runs
+        const bool has1 = (occ1 >> d1) & 1u;
+        bucket_prefetch(wslot1, buckets, first_x, count, 1, (d1 != 0 && has1) ? d1 : 1u);
+      }
       __builtin_amdgcn_wave_barrier();
-      mont_mul<MODP_N0INV_C>(acc, cur, slot, n, ln);        // quads with nothing to multiply compute and drop a product
+      // the bucket is the LDS operand, cur stays in registers; quads with nothing to multiply compute and drop a product
+      mont_mul<MODP_N0INV_C>(acc, cur, (op == 1) ? slot2 : slot1, n, ln);
       __builtin_amdgcn_wave_barrier();
       if (d != 0 && live) {
         if (has) store_lane_limbs(bk, acc, ln); else store_lane_limbs(bk, cur, ln);
       }
       const u32 bit = d ? (1u << d) : 0u;
       if (op == 1) occ0 |= bit; else occ1 |= bit;
+      if (op == 2) {
+        if (k == BK_WINDOWS - 1) break;
+        d0 = digit(ex0, k + 1);
+        d1 = digit(ex1, k + 1);
+        const bool has0 = (occ0 >> d0) & 1u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the bucket stores above are done before the next fetch
+        bucket_prefetch(wslot2, buckets, first_x, count, 0, (d0 != 0 && has0) ? d0 : 1u);
+      }
     } else {
-      slot_store(slot, cur, ln);
+      slot_store(slot1, cur, ln);
       __builtin_amdgcn_wave_barrier();
-      mont_sqr<MODP_N0INV_C>(cur, cur, slot, n, ln);
+      mont_sqr<MODP_N0INV_C>(cur, cur, slot1, n, ln);
       __builtin_amdgcn_wave_barrier();
     }
-    if (op == 0) { op = 1; continue; }
-    if (op == 2 && k == BK_WINDOWS - 1) break;
     if (op == 2 + BK_W) { op = 1; ++k; } else ++op;
   }
   if (live && ln.q == 0) {

@@ -33,4 +33,4 @@ def test_two_ranks_share_one_box_through_bench_py():
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
     assert res["config"]["n_per_gpu"] == 16384 and "32768 participants in the box" in res["config"]["workload"]
     assert res["value"] > 0 and res["compute"]["fd_fallbacks"] == 0
-    assert res["host"]["pipeline"].startswith("verify_block_compute/absorb")
+    assert res["host"]["pipeline"].startswith("verify_block_compute / block_claim / absorb_claimed")
