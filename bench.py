@@ -71,7 +71,7 @@ def keygen(rng: random.Random) -> int:
             return k
 
 
-PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "12"))  # boxes with GPU work pending (the engine has 16 block slots)
+PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "12"))  # boxes with GPU work pending (the engine has capi.BLOCK_SLOTS block slots)
 HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "6"))   # host threads absorbing (hashing) boxes at N=1
 USE_VERIFY_MANY = os.environ.get("MPVSS_BENCH_VERIFY_MANY", "1") != "0"   # N=1: the library's own pipeline (0: Python threads)
 
@@ -169,7 +169,7 @@ def bench_ec(eng, name, args):
     box = capi.EcBox(d_cm.data_ptr(), t, d_pos.data_ptr(), d_pk.data_ptr(), d_Y.data_ptr(), d_r.data_ptr(), n,
                      C.cast(chal, C.c_void_p))
 
-    def run_many(count):
+    def run_many(count, depth=depth):
         arr = (capi.EcBox * count)(*([box] * count))
         verdicts = (C.c_int * count)()
         digests = (C.c_uint8 * (32 * count))()
@@ -178,7 +178,8 @@ def bench_ec(eng, name, args):
         raw = bytes(digests)
         assert all(verdicts[i] == 1 and raw[32 * i:32 * i + 32] == d["digest"] for i in range(count)), f"parity gate failed ({name})"
 
-    run_many(depth)                                     # slot workspaces
+    init = min(depth + threads + 4, capi.BLOCK_SLOTS - 1)
+    run_many(init, init)                                # slot workspaces: as many boxes at once as can ever be in flight
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_many(k)
@@ -407,9 +408,9 @@ def main():
         (run_steps_many); with several ranks the running hash state of every box travels rank to rank, so the blocks
         are driven from here (compute / claim / absorb_claimed) with HASH_THREADS boxes being absorbed at a time."""
         if world == 1 and USE_VERIFY_MANY and k > 0:
-            return run_steps_many(k, min(depth or PIPE_DEPTH, 16))
-        # the engine has 16 block slots; absorbing threads hold the oldest blocks, so leave them slack
-        depth = min(depth or min(PIPE_DEPTH, 8), 16 - max(HASH_THREADS, 1))
+            return run_steps_many(k, min(depth or PIPE_DEPTH, capi.BLOCK_SLOTS))
+        # absorbing threads hold the oldest blocks, so leave them slack in the ring of block slots
+        depth = min(depth or min(PIPE_DEPTH, 8), capi.BLOCK_SLOTS - max(HASH_THREADS, 1))
         results = []
         issued = 0
         while issued < min(depth, k):
@@ -442,8 +443,11 @@ def main():
     # Allocation pass: every block slot the pipeline will use gets its workspace (about 1.6 GB of HBM), stream pair and
     # pinned staging now, one box per slot -- first-use allocation (hipMalloc, page pinning) is set-up, not verification,
     # and must not fall into the timed region when W is smaller than the number of boxes in flight.
-    slot_init = 16
-    for verdict, digest in run_steps(slot_init):
+    # (slots are reused most-recently-released first, so the pass enqueues as many boxes AT ONCE as the pipeline can
+    # ever have in flight: boxes with GPU work pending + boxes being hashed + slack)
+    slot_init = min((PIPE_DEPTH if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8)) + max(HASH_THREADS, 1) + 4,
+                    capi.BLOCK_SLOTS - 1)
+    for verdict, digest in run_steps(slot_init, depth=slot_init):
         assert verdict is True and digest == dealer_digest, "parity gate failed (slot initialisation)"
     for verdict, digest in run_steps(args.warmup) if args.warmup > 0 else []:
         assert verdict is True and digest == dealer_digest, "parity gate failed in warm-up"
@@ -572,8 +576,8 @@ def main():
                  "per_box_ms": {"enqueue": pst["enqueue_ms"] / nb, "wait_for_gpu": pst["wait_ms"] / nb,
                                 "sha256_transcript": pst["hash_ms"] / nb},
                  "hash_threads": max(HASH_THREADS, 1),
-                 "boxes_in_flight": (min(PIPE_DEPTH, 16) if (world == 1 and USE_VERIFY_MANY)
-                                     else min(PIPE_DEPTH, 8, 16 - max(HASH_THREADS, 1))),
+                 "boxes_in_flight": (min(PIPE_DEPTH, capi.BLOCK_SLOTS) if (world == 1 and USE_VERIFY_MANY)
+                                     else min(PIPE_DEPTH, 8, capi.BLOCK_SLOTS - max(HASH_THREADS, 1))),
                  "pipeline": ("mpvss_modp_verify_many (library threads; boxes_in_flight = boxes with GPU work pending)"
                               if (world == 1 and USE_VERIFY_MANY)
                               else "verify_block_compute / block_claim / absorb_claimed from a Python thread pool"
@@ -645,7 +649,7 @@ def main():
             arr = (capi.ModpBox * count)(*([hbox] * count))
             vd = (C.c_int * count)()
             dg = (C.c_uint8 * (32 * count))()
-            eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_HOST, arr, count, min(PIPE_DEPTH, 16), max(HASH_THREADS, 1), vd,
+            eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_HOST, arr, count, min(PIPE_DEPTH, capi.BLOCK_SLOTS), max(HASH_THREADS, 1), vd,
                                                   C.cast(dg, C.c_void_p)), "verify_many(host)")
             return all(vd[i] == 1 for i in range(count)) and all(bytes(dg)[32 * i:32 * i + 32] == dealer_digest for i in range(count))
 

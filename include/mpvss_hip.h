@@ -122,10 +122,12 @@ int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* com
  *   mpvss_modp_transcript_verdict(state, challenge, &verdict, digest);
  * `compute` only enqueues GPU work (kernels + device-to-host copies) and returns; `absorb` waits
  * for it, so the wait for the previous block's state overlaps this block's GPU work.
- * Up to sixteen blocks may be in flight per engine (compute, compute, ..., absorb, absorb in FIFO order): the
+ * Up to MPVSS_BLOCK_SLOTS blocks may be in flight per engine (compute, compute, ..., absorb, absorb in FIFO order): the
  * host hash of box k then overlaps the GPU work of boxes k+1.. (bench.py).
  * mpvss_modp_verify_distribution == init + compute + absorb + verdict on one engine. */
 #define MPVSS_TRANSCRIPT_STATE_BYTES 128
+/* blocks of the block API that may be in flight in one context (any mix of the compute calls below) */
+#define MPVSS_BLOCK_SLOTS 32
 void mpvss_transcript_init(uint8_t* state);
 int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                     const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
@@ -190,7 +192,7 @@ int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space, const uint
  * come back.  pk, s (decrypted shares S_i), y (encrypted shares Y_i), c, r: n x 256 in `space`; verdicts: n bytes, host. */
 int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
                              const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_host);
-/* The same in two steps, so that several batches are in flight (they share the sixteen block slots and the FIFO order
+/* The same in two steps, so that several batches are in flight (they share the MPVSS_BLOCK_SLOTS block slots and the FIFO order
  * of mpvss_modp_verify_block_compute / _absorb): `compute` only enqueues GPU work and returns; `absorb` waits for the
  * oldest batch and hands out its verdict bytes.  verdicts_dev_out (optional, device memory, n bytes) receives the
  * verdicts in stream order as well -- the tensor a multi-GPU caller all-gathers over RCCL without a host round trip
@@ -264,7 +266,7 @@ int mpvss_ec_verify_distribution(mpvss_ctx* ctx, int group, int space, const uin
                                  const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                  const uint8_t* responses, size_t n, const uint8_t* challenge_host, int* verdict,
                                  uint8_t* digest32_out, uint8_t* x_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host);
-/* The same split into compute (enqueue only) / absorb (wait, validate, hash) / verdict, sharing the sixteen block slots
+/* The same split into compute (enqueue only) / absorb (wait, validate, hash) / verdict, sharing the MPVSS_BLOCK_SLOTS block slots
  * and the FIFO order of the MODP block calls, so that several boxes are in flight inside one context; and the
  * library-pipelined form for many boxes (see mpvss_modp_verify_many).  An invalid encoding or a response that is not
  * below the group order is reported by `absorb` (MPVSS_E_INVALID). */

@@ -130,6 +130,7 @@ struct mpvss_ctx {
     bool absorbing = false;        // a host thread is waiting for / hashing this block (context lock released)
     bool claimed = false;          // taken by mpvss_block_claim, its absorb call has not started yet
     unsigned ticket = 0;           // value of `tail` when the block was claimed
+    unsigned ring_pos = 0;         // ring position the block occupies
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
@@ -144,9 +145,40 @@ struct mpvss_ctx {
     double kernel_ms[4] = {0, 0, 0, 0};
     Work work;
   };
-  static constexpr unsigned NSLOT = 16;
+  // Blocks in flight form a ring of NSLOT positions in enqueue order (head: next to fill, tail: next to hand to an
+  // absorbing thread).  A position borrows a slot from a free stack -- the most recently released one first, so a caller
+  // that keeps k blocks in flight touches k slots' workspaces, not NSLOT of them.
+  static constexpr unsigned NSLOT = MPVSS_BLOCK_SLOTS;
   BlockSlot slot[NSLOT];
-  unsigned head = 0, tail = 0;   // next slot to fill / to absorb
+  BlockSlot none_slot, full_slot;          // what ring_slot() / head_slot() answer when there is no block / no room
+  int ring[NSLOT];
+  int free_stack[NSLOT];
+  unsigned free_top = NSLOT;
+  unsigned head = 0, tail = 0;
+  mpvss_ctx() {
+    for (unsigned i = 0; i < NSLOT; ++i) { ring[i] = -1; free_stack[i] = (int)(NSLOT - 1 - i); }
+    full_slot.busy = true;
+  }
+  BlockSlot& head_slot() {
+    if (ring[head % NSLOT] >= 0 || free_top == 0) return full_slot;
+    return slot[free_stack[free_top - 1]];
+  }
+  void commit_head(BlockSlot& sl) {          // the block in `sl` (from head_slot()) is fully enqueued
+    sl.ring_pos = head % NSLOT;
+    ring[sl.ring_pos] = (int)(&sl - slot);
+    --free_top;
+    sl.busy = true;
+    ++head;
+  }
+  BlockSlot& ring_slot(unsigned position) {
+    const int i = ring[position % NSLOT];
+    return i < 0 ? none_slot : slot[i];
+  }
+  void release(BlockSlot& sl) {
+    sl.busy = false;
+    ring[sl.ring_pos] = -1;
+    free_stack[free_top++] = (int)(&sl - slot);
+  }
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
@@ -1024,8 +1056,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     pubkeys = (const uint8_t*)ks->keys.p + key_offset * EB;
     key_space = MPVSS_DEVICE;
   }
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
-  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: sixteen blocks already in flight, absorb one first");
+  mpvss_ctx::BlockSlot& sl = ctx->head_slot();
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!sl.done) {
@@ -1041,7 +1073,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   sl.enqueue_ms = 0;
   if (n == 0) {
     sl.busy = true;
-    ++ctx->head;
+    ctx->commit_head(sl);
     return MPVSS_OK;
   }
   if (space == MPVSS_HOST) RET_IF(check_positions_host(ctx, positions, n));
@@ -1222,7 +1254,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
   sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
-  ++ctx->head;
+  ctx->commit_head(sl);
   return MPVSS_OK;
 }
 
@@ -1233,7 +1265,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
                                uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr,
                                const unsigned long long* ticket = nullptr) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[(ticket ? (unsigned)*ticket : ctx->tail) % mpvss_ctx::NSLOT];
+  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ticket ? (unsigned)*ticket : ctx->tail);
   if (ticket) {
     if (!sl.busy || !sl.claimed || sl.ticket != (unsigned)*ticket)
       return fail(ctx, MPVSS_E_INVALID, "absorb: no block was claimed with this ticket");
@@ -1246,7 +1278,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   }
   const size_t n = sl.n;
   if (n == 0) {
-    sl.busy = false;
+    ctx->release(sl);
     sl.absorbing = false;
     ctx->gpu_done.fetch_add(1);
     return MPVSS_OK;
@@ -1286,7 +1318,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   }
   const auto t_h1 = std::chrono::steady_clock::now();
   lk.lock();
-  sl.busy = false;
+  ctx->release(sl);
   sl.absorbing = false;
   if (e == hipSuccess && sl.fd_used) {
     const int* hflags = (const int*)(h2 + n * EB + n * 8);
@@ -1420,7 +1452,7 @@ extern "C" int mpvss_block_claim(mpvss_ctx* ctx, unsigned long long* ticket_out)
   if (!ctx) return MPVSS_E_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!ticket_out) return fail(ctx, MPVSS_E_INVALID, "claim: null ticket");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
+  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
   if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "claim: no block in flight");
   if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "claim: the oldest block in flight is not a MODP distribution block");
   sl.absorbing = true;
@@ -1503,7 +1535,7 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
       {
         std::unique_lock<std::mutex> lk(ctx->mu);
         idx = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
-        const int kind = ctx->slot[ctx->tail % mpvss_ctx::NSLOT].kind;
+        const int kind = ctx->ring_slot(ctx->tail).kind;
         rc = kind == 2 ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr)
                        : verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
       }
@@ -1628,8 +1660,8 @@ namespace {
 int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
                                  const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_dev_out) {
   if (n > 0 && (!pk || !s || !y || !c || !r)) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
-  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify_shares: sixteen blocks already in flight, absorb one first");
+  mpvss_ctx::BlockSlot& sl = ctx->head_slot();
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify_shares: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!sl.done) {
@@ -1644,7 +1676,7 @@ int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, c
   sl.enqueue_ms = 0;
   if (n == 0) {
     sl.busy = true;
-    ++ctx->head;
+    ctx->commit_head(sl);
     return MPVSS_OK;
   }
   RET_IF(work_init(ctx, sl.work, nullptr));
@@ -1706,18 +1738,18 @@ int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, c
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   sl.busy = true;
   sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
-  ++ctx->head;
+  ctx->commit_head(sl);
   return MPVSS_OK;
 }
 
 int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* verdicts_host) {
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->tail % mpvss_ctx::NSLOT];
+  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
   if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "verify_shares_absorb: no batch in flight");
   if (sl.kind != 1) return fail(ctx, MPVSS_E_INVALID, "verify_shares_absorb: the oldest block in flight is a verify_distribution block");
   const size_t n = sl.n;
   ++ctx->tail;
   if (n == 0) {
-    sl.busy = false;
+    ctx->release(sl);
     ctx->gpu_done.fetch_add(1);
     return MPVSS_OK;
   }
@@ -1730,7 +1762,7 @@ int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk
   ctx->gpu_done.fetch_add(1);
   if (e == hipSuccess && verdicts_host) memcpy(verdicts_host, sl.pin, n);
   lk.lock();
-  sl.busy = false;
+  ctx->release(sl);
   sl.absorbing = false;
   if (e != hipSuccess) return fail(ctx, MPVSS_E_DEVICE, "verify_shares_absorb: hipEventSynchronize", e);
   RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
@@ -1789,8 +1821,8 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   if (n > 0 && (!pubkeys || !p_values || !witnesses || (commitments && (!positions || t == 0 || t > 0x7fffffff))))
     return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
   if (commitments && t > n) return fail(ctx, MPVSS_E_INVALID, "distribute: threshold > number of public keys (participant.rs:166)");
-  mpvss_ctx::BlockSlot& sl = ctx->slot[ctx->head % mpvss_ctx::NSLOT];
-  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "distribute: sixteen blocks already in flight, absorb one first");
+  mpvss_ctx::BlockSlot& sl = ctx->head_slot();
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "distribute: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!sl.done) {
@@ -1805,7 +1837,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   sl.enqueue_ms = 0;
   if (n == 0) {
     sl.busy = true;
-    ++ctx->head;
+    ctx->commit_head(sl);
     return MPVSS_OK;
   }
   if (commitments && space == MPVSS_HOST) RET_IF(check_positions_host(ctx, positions, n));
@@ -1938,7 +1970,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   sl.busy = true;
   sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
-  ++ctx->head;
+  ctx->commit_head(sl);
   return MPVSS_OK;
 }
 

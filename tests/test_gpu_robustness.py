@@ -58,15 +58,15 @@ def test_two_blocks_in_flight_then_absorbed_in_order(engine):
                                 flat["responses"][a], flat["challenge"])
     engine.verify_block_compute(flat["commitments"], flat["positions"][4:], flat["publickeys"][b], flat["shares"][b],
                                 flat["responses"][b], flat["challenge"])
-    for _ in range(14):                        # sixteen blocks may be in flight ...
+    for _ in range(capi.BLOCK_SLOTS - 2):      # MPVSS_BLOCK_SLOTS blocks may be in flight ...
         engine.verify_block_compute(flat["commitments"], flat["positions"][:4], flat["publickeys"][a], flat["shares"][a],
                                     flat["responses"][a], flat["challenge"])
-    with pytest.raises(capi.EngineError):      # ... a seventeenth is refused until one is absorbed
+    with pytest.raises(capi.EngineError):      # ... one more is refused until one is absorbed
         engine.verify_block_compute(flat["commitments"], flat["positions"][:4], flat["publickeys"][a], flat["shares"][a],
                                     flat["responses"][a], flat["challenge"])
     st = engine.verify_block_absorb(capi.transcript_init())
     st = engine.verify_block_absorb(st)
-    for _ in range(14):
+    for _ in range(capi.BLOCK_SLOTS - 2):
         engine.verify_block_absorb(capi.transcript_init())
     verdict, digest = capi.transcript_verdict(st, flat["challenge"])
     assert verdict is True and digest == box["_digest"]
