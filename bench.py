@@ -180,6 +180,7 @@ def bench_ec(eng, name, args):
 
     init = min(depth + threads + 4, capi.BLOCK_SLOTS - 1)
     run_many(init, init)                                # slot workspaces: as many boxes at once as can ever be in flight
+    eng.pipeline_stats(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_many(k)

@@ -19,8 +19,8 @@ int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uin
 /* forward differences for consecutive positions: seeds at chain indices w0..w0+t-1, tables, stepping both ways,
  * encoding; pts [count][point words], state_fwd / state_bwd [chains*t][point words] */
 int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
-                 int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc, int split_seeds,
-                 const int* gate, hipStream_t s);
+                 int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1, uint8_t* x_enc,
+                 int split_seeds, const int* gate, hipStream_t s);   /* state_l1: 2 * t points of scratch (two-level seeding) or null */
 int ec_launch_add(int group, const uint8_t* a, const uint8_t* b, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
 /* windowed double-scalar multiplication (signed 4-bit windows; see ec_kernels.hip):
  *   comb: 65 x 8 packed affine multiples of the generator (ec_comb_words() words, built once by ec_launch_comb_build)

@@ -552,9 +552,13 @@ extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count,
 
 // ---- forward differences: seeds (m0 positions from `positions`), tables, stepping, encoding -------------------------
 // pts: [count][point words] internal points, index 0 = first position of the batch; seeds go to pts + seed0.
+// Two-level seeding (state_l1 != null, chains > 1): Horner's rule -- (t-1) small scalar multiplications per seed, most of
+// a box's instructions when all chains*t seeds are computed that way -- only for the t positions in the MIDDLE of the seed
+// window; one stride-1 forward-difference chain built from those t values steps both ways through the rest of the
+// window at t additions per seed.  Then the strided chains as before.
 extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
-                            int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint8_t* x_enc,
-                            int split_seeds, const int* gate, hipStream_t s) {
+                            int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                            uint8_t* x_enc, int split_seeds, const int* gate, hipStream_t s) {
   const int m0 = chains * t;
   const size_t seed0 = (size_t)chains * w0;
   const int pw = ec_point_words(group);
@@ -563,21 +567,34 @@ extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t*
   const size_t lds = (size_t)lanes * pw * 4;
   const bool split = split_seeds && t >= 64;                    // 8 lanes per seed
   const size_t lds_seed = (size_t)64 * pw * 4;
+  const bool two_level = state_l1 != nullptr && chains > 1;
+  const int w1 = two_level ? (m0 - t) / 2 : 0;                  // first Horner seed inside the window
+  const int horner = two_level ? t : m0;
+  const int64_t* hpos = positions + seed0 + w1;
+  uint32_t* hseeds = seeds + (size_t)w1 * pw;
+  uint32_t* l1_fwd = state_l1;
+  uint32_t* l1_bwd = two_level ? state_l1 + (size_t)t * pw : nullptr;
   if (group == 1) {
     if (split)
-      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
-                         seeds, gate);
+      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * horner)), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate);
     else
-      hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds, gate);
+      hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(horner)), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate);
+    if (two_level) {
+      hipLaunchKernelGGL(k_secp_fd_table, dim3(1), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate);
+      hipLaunchKernelGGL(k_secp_fd_step, dim3(2), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate);
+    }
     hipLaunchKernelGGL(k_secp_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate);
     hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
                        count, pts, gate);
   } else {
     if (split)
-      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * m0)), dim3(64), lds_seed, s, cm, t, positions + seed0, m0,
-                         seeds, gate);
+      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * horner)), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate);
     else
-      hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(m0)), dim3(64), 0, s, cm, t, positions + seed0, m0, seeds, gate);
+      hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(horner)), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate);
+    if (two_level) {
+      hipLaunchKernelGGL(k_rist_fd_table, dim3(1), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate);
+      hipLaunchKernelGGL(k_rist_fd_step, dim3(2), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate);
+    }
     hipLaunchKernelGGL(k_rist_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate);
     hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
                        count, pts, gate);
