@@ -433,83 +433,75 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
 
 }  // namespace
 
-#define EC_KERNELS(NAME, CURVE, ORDER)                                                                                        \
+// The file is compiled twice (Makefile): EC_PART 1 = the secp256k1 kernels and every launcher, EC_PART 2 = the
+// ristretto255 kernels.  The launchers only need the other part's kernels declared (BODY = EC_DECL).
+#ifndef EC_PART
+#define EC_PART 0
+#endif
+#define EC_DEF(...) { __VA_ARGS__ }
+#define EC_DECL(...) ;
+#define EC_KERNELS(NAME, CURVE, ORDER, BODY)                                                                           \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_decode(const uint8_t* enc, int count, u32* pts,          \
-                                                                     uint8_t* ok) {                                    \
-    decode_body<CURVE>(enc, count, pts, ok);                                                                           \
-  }                                                                                                                    \
+                                                                     uint8_t* ok)                                      \
+      BODY(decode_body<CURVE>(enc, count, pts, ok);)                                                                   \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_commit_eval(const u32* cm, int t, const int64_t* pos,    \
                                                                           int count, uint8_t* x_enc, const int* gate,  \
-                                                                          int want) {                                  \
-    EC_GATE_CHECK(gate, want);                                                                                         \
-    commit_eval_body<CURVE>(cm, t, pos, count, x_enc);                                                                 \
-  }                                                                                                                    \
+                                                                          int want)                                    \
+      BODY(EC_GATE_CHECK(gate, want); commit_eval_body<CURVE>(cm, t, pos, count, x_enc);)                              \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_dual_mul(                                                \
       const uint8_t* p1, size_t p1_stride, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, size_t k2_stride,  \
-      int count, uint8_t* out, uint8_t* ok) {                                                                          \
-    dual_mul_body<CURVE>(p1, p1_stride, k1, p2, k2, k2_stride, count, out, ok);                                        \
-  }                                                                                                                    \
+      int count, uint8_t* out, uint8_t* ok)                                                                            \
+      BODY(dual_mul_body<CURVE>(p1, p1_stride, k1, p2, k2, k2_stride, count, out, ok);)                                \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_add(const uint8_t* a, const uint8_t* b, int count,       \
-                                                                  uint8_t* out, uint8_t* ok) {                         \
-    add_body<CURVE>(a, b, count, out, ok);                                                                             \
-  }                                                                                                                    \
+                                                                  uint8_t* out, uint8_t* ok)                           \
+      BODY(add_body<CURVE>(a, b, count, out, ok);)                                                                     \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds(const u32* cm, int t, const int64_t* pos,       \
-                                                                       int count, u32* pts, const int* gate) {         \
-    EC_GATE_CHECK(gate, 1);                                                                                            \
-    seeds_body<CURVE>(cm, t, pos, count, pts);                                                                         \
-  }                                                                                                                    \
+                                                                       int count, u32* pts, const int* gate)           \
+      BODY(EC_GATE_CHECK(gate, 1); seeds_body<CURVE>(cm, t, pos, count, pts);)                                         \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds_split(const u32* cm, int t, const int64_t* pos, \
-                                                                             int count, u32* pts, const int* gate) {   \
-    EC_GATE_CHECK(gate, 1);                                                                                            \
-    seeds_split_body<CURVE, ORDER, 8>(cm, t, pos, count, pts);                                                         \
-  }                                                                                                                    \
+                                                                             int count, u32* pts, const int* gate)     \
+      BODY(EC_GATE_CHECK(gate, 1); seeds_split_body<CURVE, ORDER, 8>(cm, t, pos, count, pts);)                         \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_table(const u32* seeds, int chains, int t, u32* fwd, \
-                                                                        u32* bwd, const int* gate) {                   \
-    EC_GATE_CHECK(gate, 1);                                                                                            \
-    fd_table_body<CURVE>(seeds, chains, t, fwd, bwd);                                                                  \
-  }                                                                                                                    \
+                                                                        u32* bwd, const int* gate)                     \
+      BODY(EC_GATE_CHECK(gate, 1); fd_table_body<CURVE>(seeds, chains, t, fwd, bwd);)                                  \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_step(const u32* fwd, const u32* bwd, int chains,     \
                                                                        int t, int w0, int chain_len, int count,        \
-                                                                       u32* pts, const int* gate) {                    \
-    EC_GATE_CHECK(gate, 1);                                                                                            \
-    fd_step_body<CURVE>(fwd, bwd, chains, t, w0, chain_len, count, pts);                                               \
-  }                                                                                                                    \
+                                                                       u32* pts, const int* gate)                      \
+      BODY(EC_GATE_CHECK(gate, 1); fd_step_body<CURVE>(fwd, bwd, chains, t, w0, chain_len, count, pts);)               \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_encode(const u32* pts, int count, uint8_t* enc,          \
-                                                                     const int* gate) {                                \
-    EC_GATE_CHECK(gate, 1);                                                                                            \
-    encode_body<CURVE>(pts, count, enc);                                                                               \
-  }
+                                                                     const int* gate)                                  \
+      BODY(EC_GATE_CHECK(gate, 1); encode_body<CURVE>(pts, count, enc);)
 
-EC_KERNELS(secp, Secp, OrderSecp)
-EC_KERNELS(rist, Ristretto, OrderEd)
-
-#define EC_WIN_KERNELS(NAME, CURVE)                                                                                          \
+#define EC_WIN_KERNELS(NAME, CURVE, BODY)                                                                                    \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_build_tables(                                                  \
-      const uint8_t* enc, size_t enc_stride, const u32* pts, int count, u32* tab, uint8_t* ok, const int* gate) {            \
-    build_tables_body<CURVE>(enc, enc_stride, pts, count, tab, ok, gate);                                                    \
-  }                                                                                                                          \
-  extern "C" __global__ void __launch_bounds__(128) k_##NAME##_comb_build(u32* comb) { comb_build_body<CURVE>(comb); }       \
+      const uint8_t* enc, size_t enc_stride, const u32* pts, int count, u32* tab, uint8_t* ok, const int* gate)              \
+      BODY(build_tables_body<CURVE>(enc, enc_stride, pts, count, tab, ok, gate);)                                            \
+  extern "C" __global__ void __launch_bounds__(128) k_##NAME##_comb_build(u32* comb) BODY(comb_build_body<CURVE>(comb);)     \
   extern "C" __global__ void __launch_bounds__(DW_THREADS) k_##NAME##_dual_win(                                              \
       const u32* comb, const u32* tab1, const uint8_t* k1, size_t k1_stride, const u32* tab2, const uint8_t* k2,             \
-      size_t k2_stride, int count, u32* out_pts) {                                                                           \
-    extern __shared__ u32 lds[];                                                                                             \
-    dual_win_body<CURVE>(comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts, lds);                               \
-  }
-EC_WIN_KERNELS(secp, Secp)
-EC_WIN_KERNELS(rist, Ristretto)
-extern "C" __global__ void __launch_bounds__(256) k_secp_sum_points(const u32* pts, int m, u32* out) {
-  extern __shared__ u32 lds[];
-  sum_points_body<Secp>(pts, m, out, lds);
-}
-extern "C" __global__ void __launch_bounds__(256) k_rist_sum_points(const u32* pts, int m, u32* out) {
-  extern __shared__ u32 lds[];
-  sum_points_body<Ristretto>(pts, m, out, lds);
-}
+      size_t k2_stride, int count, u32* out_pts)                                                                             \
+      BODY(extern __shared__ u32 lds[];                                                                                      \
+           dual_win_body<CURVE>(comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts, lds);)                       \
+  extern "C" __global__ void __launch_bounds__(256) k_##NAME##_sum_points(const u32* pts, int m, u32* out)                   \
+      BODY(extern __shared__ u32 lds[]; sum_points_body<CURVE>(pts, m, out, lds);)
+
+#if EC_PART != 2
+EC_KERNELS(secp, Secp, OrderSecp, EC_DEF)
+EC_WIN_KERNELS(secp, Secp, EC_DEF)
 extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate) {
   EC_GATE_CHECK(gate, 1);
   secp_encode_batch_body(pts, count, enc);
 }
+#endif
+#if EC_PART == 1
+EC_KERNELS(rist, Ristretto, OrderEd, EC_DECL)
+EC_WIN_KERNELS(rist, Ristretto, EC_DECL)
+#else
+EC_KERNELS(rist, Ristretto, OrderEd, EC_DEF)
+EC_WIN_KERNELS(rist, Ristretto, EC_DEF)
+#endif
 
+#if EC_PART != 2
 // ---- launchers ---------------------------------------------------------------------------------------
 static inline int blocks_for(int count) { return (count + 63) / 64; }
 
@@ -657,3 +649,4 @@ extern "C" int ec_launch_sum(int group, const uint32_t* pts, int m, uint32_t* ou
   else hipLaunchKernelGGL(k_rist_sum_points, dim3(1), dim3(256), lds, s, pts, m, out);
   return (int)hipGetLastError();
 }
+#endif  // EC_PART != 2
