@@ -165,7 +165,7 @@ def bench_ec(eng, name, args):
     dual_ms = lone["dual_win"] / max(lone["dual_win_launches"], 1)
     # timed: K boxes through the library's pipeline (mpvss_ec_verify_many): EC_DEPTH boxes in flight in ONE context
     k = args.ec_boxes
-    depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "16")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "3"))
+    depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "46")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "6"))
     box = capi.EcBox(d_cm.data_ptr(), t, d_pos.data_ptr(), d_pk.data_ptr(), d_Y.data_ptr(), d_r.data_ptr(), n,
                      C.cast(chal, C.c_void_p))
 
@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--registered-keys", type=int, default=1,
                     help="also time the opt-in registered-key variant at N=1 (0: skip)")
     ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
-    ap.add_argument("--ec-boxes", type=int, default=24, help="boxes timed per curve group for the `ec` objects (0: skip)")
+    ap.add_argument("--ec-boxes", type=int, default=64, help="boxes timed per curve group for the `ec` objects (0: skip)")
     ap.add_argument("--host-boxes", type=int, default=8, help="boxes verified from HOST buffers (PCIe included) for the "
                     "`host_buffers` figure (0: skip)")
     ap.add_argument("--ec-n", type=int, default=65536)

@@ -127,7 +127,7 @@ int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const uint8_t* com
  * mpvss_modp_verify_distribution == init + compute + absorb + verdict on one engine. */
 #define MPVSS_TRANSCRIPT_STATE_BYTES 128
 /* blocks of the block API that may be in flight in one context (any mix of the compute calls below) */
-#define MPVSS_BLOCK_SLOTS 32
+#define MPVSS_BLOCK_SLOTS 64
 void mpvss_transcript_init(uint8_t* state);
 int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                     const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,

@@ -49,7 +49,7 @@ GROUP_RISTRETTO255 = 2
 EC_ENC = {GROUP_SECP256K1: 33, GROUP_RISTRETTO255: 32}
 
 TRANSCRIPT_STATE_BYTES = 128
-BLOCK_SLOTS = 32                 # MPVSS_BLOCK_SLOTS: blocks of the block API in flight per context
+BLOCK_SLOTS = 64                 # MPVSS_BLOCK_SLOTS: blocks of the block API in flight per context
 
 
 class EngineError(RuntimeError):

@@ -18,6 +18,17 @@ int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uin
                        const uint8_t* k2, size_t k2_stride, int count, uint8_t* out, uint8_t* ok, hipStream_t s);
 /* forward differences for consecutive positions: seeds at chain indices w0..w0+t-1, tables, stepping both ways,
  * encoding; pts [count][point words], state_fwd / state_bwd [chains*t][point words] */
+/* the same launches for `boxes` boxes of one shape laid out one after the other (strides per box: words of commitments,
+   positions, words of points, words of difference tables, bytes of encodings; gate[b] per box) */
+int ec_launch_fd_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                       int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                       uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride, size_t pos_stride,
+                       size_t pts_stride, size_t state_stride, size_t enc_stride, hipStream_t s);
+int ec_launch_commit_eval_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count, uint8_t* x_enc,
+                                const int* gate, int want, int boxes, size_t cm_stride, size_t pos_stride, size_t enc_stride,
+                                hipStream_t s);
+int ec_launch_encode_boxes(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, int boxes,
+                           size_t pts_stride, size_t enc_stride, hipStream_t s);
 int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
                  int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1, uint8_t* x_enc,
                  int split_seeds, const int* gate, hipStream_t s);   /* state_l1: 2 * t points of scratch (two-level seeding) or null */

@@ -46,6 +46,18 @@ __device__ __forceinline__ void decode_body(const uint8_t* __restrict__ enc, int
 // positions live in device memory (the choice then needs no host synchronisation); gate == null: always run
 #define EC_GATE_CHECK(gate, want) \
   if ((gate) != nullptr && *(gate) != (want)) return
+// Several boxes in one launch (blockIdx.y = box): the X path of a box is a chain of narrow launches, and the device runs
+// only as many launches side by side as it has hardware queues -- batching the boxes of one mpvss_ec_verify_many call
+// makes each launch B times wider instead.  Per-box strides of the operands (0 for a single box):
+struct BoxStride {
+  size_t cm;      // decoded commitments, u32 words
+  size_t pos;     // positions, elements
+  size_t pts;     // internal points, u32 words
+  size_t state;   // difference tables, u32 words
+  size_t enc;     // encodings, bytes
+};
+#define EC_BOX_GATE_CHECK(gate, want) \
+  if ((gate) != nullptr && (gate)[blockIdx.y] != (want)) return
 
 template <class C>
 __device__ __forceinline__ void commit_eval_body(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions,
@@ -446,8 +458,10 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
       BODY(decode_body<CURVE>(enc, count, pts, ok);)                                                                   \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_commit_eval(const u32* cm, int t, const int64_t* pos,    \
                                                                           int count, uint8_t* x_enc, const int* gate,  \
-                                                                          int want)                                    \
-      BODY(EC_GATE_CHECK(gate, want); commit_eval_body<CURVE>(cm, t, pos, count, x_enc);)                              \
+                                                                          int want, BoxStride bs)                      \
+      BODY(EC_BOX_GATE_CHECK(gate, want);                                                                              \
+           commit_eval_body<CURVE>(cm + blockIdx.y * bs.cm, t, pos + blockIdx.y * bs.pos, count,                       \
+                                   x_enc + blockIdx.y * bs.enc);)                                                      \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_dual_mul(                                                \
       const uint8_t* p1, size_t p1_stride, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, size_t k2_stride,  \
       int count, uint8_t* out, uint8_t* ok)                                                                            \
@@ -456,21 +470,31 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
                                                                   uint8_t* out, uint8_t* ok)                           \
       BODY(add_body<CURVE>(a, b, count, out, ok);)                                                                     \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds(const u32* cm, int t, const int64_t* pos,       \
-                                                                       int count, u32* pts, const int* gate)           \
-      BODY(EC_GATE_CHECK(gate, 1); seeds_body<CURVE>(cm, t, pos, count, pts);)                                         \
+                                                                       int count, u32* pts, const int* gate,           \
+                                                                       BoxStride bs)                                   \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           seeds_body<CURVE>(cm + blockIdx.y * bs.cm, t, pos + blockIdx.y * bs.pos, count, pts + blockIdx.y * bs.pts);) \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds_split(const u32* cm, int t, const int64_t* pos, \
-                                                                             int count, u32* pts, const int* gate)     \
-      BODY(EC_GATE_CHECK(gate, 1); seeds_split_body<CURVE, ORDER, 8>(cm, t, pos, count, pts);)                         \
+                                                                             int count, u32* pts, const int* gate,     \
+                                                                             BoxStride bs)                             \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           seeds_split_body<CURVE, ORDER, 8>(cm + blockIdx.y * bs.cm, t, pos + blockIdx.y * bs.pos, count,             \
+                                             pts + blockIdx.y * bs.pts);)                                              \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_table(const u32* seeds, int chains, int t, u32* fwd, \
-                                                                        u32* bwd, const int* gate)                     \
-      BODY(EC_GATE_CHECK(gate, 1); fd_table_body<CURVE>(seeds, chains, t, fwd, bwd);)                                  \
+                                                                        u32* bwd, const int* gate, BoxStride bs)       \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           fd_table_body<CURVE>(seeds + blockIdx.y * bs.pts, chains, t, fwd + blockIdx.y * bs.state,                   \
+                                bwd + blockIdx.y * bs.state);)                                                         \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_step(const u32* fwd, const u32* bwd, int chains,     \
                                                                        int t, int w0, int chain_len, int count,        \
-                                                                       u32* pts, const int* gate)                      \
-      BODY(EC_GATE_CHECK(gate, 1); fd_step_body<CURVE>(fwd, bwd, chains, t, w0, chain_len, count, pts);)               \
+                                                                       u32* pts, const int* gate, BoxStride bs)        \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           fd_step_body<CURVE>(fwd + blockIdx.y * bs.state, bwd + blockIdx.y * bs.state, chains, t, w0, chain_len,     \
+                               count, pts + blockIdx.y * bs.pts);)                                                     \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_encode(const u32* pts, int count, uint8_t* enc,          \
-                                                                     const int* gate)                                  \
-      BODY(EC_GATE_CHECK(gate, 1); encode_body<CURVE>(pts, count, enc);)
+                                                                     const int* gate, BoxStride bs)                    \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           encode_body<CURVE>(pts + blockIdx.y * bs.pts, count, enc + blockIdx.y * bs.enc);)
 
 #define EC_WIN_KERNELS(NAME, CURVE, BODY)                                                                                    \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_build_tables(                                                  \
@@ -488,9 +512,10 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
 #if EC_PART != 2
 EC_KERNELS(secp, Secp, OrderSecp, EC_DEF)
 EC_WIN_KERNELS(secp, Secp, EC_DEF)
-extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate) {
-  EC_GATE_CHECK(gate, 1);
-  secp_encode_batch_body(pts, count, enc);
+extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate,
+                                                                     BoxStride bs) {
+  EC_BOX_GATE_CHECK(gate, 1);
+  secp_encode_batch_body(pts + blockIdx.y * bs.pts, count, enc + blockIdx.y * bs.enc);
 }
 #endif
 #if EC_PART == 1
@@ -513,14 +538,21 @@ extern "C" int ec_launch_decode(int group, const uint8_t* enc, int count, uint32
   else hipLaunchKernelGGL(k_rist_decode, dim3(blocks_for(count)), dim3(64), 0, s, enc, count, pts, ok);
   return (int)hipGetLastError();
 }
+// boxes > 1: the same launch for `boxes` boxes laid out one after the other (strides in the units of BoxStride; gate[b])
+extern "C" int ec_launch_commit_eval_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count,
+                                           uint8_t* x_enc, const int* gate, int want, int boxes, size_t cm_stride,
+                                           size_t pos_stride, size_t enc_stride, hipStream_t s) {
+  if (count <= 0 || boxes <= 0) return 0;
+  const BoxStride bs{cm_stride, pos_stride, 0, 0, enc_stride};
+  if (group == 1)
+    hipLaunchKernelGGL(k_secp_commit_eval, dim3(blocks_for(count), boxes), dim3(64), 0, s, cm, t, positions, count, x_enc, gate, want, bs);
+  else
+    hipLaunchKernelGGL(k_rist_commit_eval, dim3(blocks_for(count), boxes), dim3(64), 0, s, cm, t, positions, count, x_enc, gate, want, bs);
+  return (int)hipGetLastError();
+}
 extern "C" int ec_launch_commit_eval(int group, const uint32_t* cm, int t, const int64_t* positions, int count,
                                      uint8_t* x_enc, const int* gate, int want, hipStream_t s) {
-  if (count <= 0) return 0;
-  if (group == 1)
-    hipLaunchKernelGGL(k_secp_commit_eval, dim3(blocks_for(count)), dim3(64), 0, s, cm, t, positions, count, x_enc, gate, want);
-  else
-    hipLaunchKernelGGL(k_rist_commit_eval, dim3(blocks_for(count)), dim3(64), 0, s, cm, t, positions, count, x_enc, gate, want);
-  return (int)hipGetLastError();
+  return ec_launch_commit_eval_boxes(group, cm, t, positions, count, x_enc, gate, want, 1, 0, 0, 0, s);
 }
 extern "C" int ec_launch_dual_mul(int group, const uint8_t* p1, size_t p1_stride, const uint8_t* k1, const uint8_t* p2,
                                   const uint8_t* k2, size_t k2_stride, int count, uint8_t* out, uint8_t* ok,
@@ -548,9 +580,15 @@ extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count,
 // a box's instructions when all chains*t seeds are computed that way -- only for the t positions in the MIDDLE of the seed
 // window; one stride-1 forward-difference chain built from those t values steps both ways through the rest of the
 // window at t additions per seed.  Then the strided chains as before.
-extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
-                            int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
-                            uint8_t* x_enc, int split_seeds, const int* gate, hipStream_t s) {
+extern "C" int ec_launch_encode_boxes(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, int boxes,
+                                      size_t pts_stride, size_t enc_stride, hipStream_t s);
+// boxes > 1: `boxes` boxes of the same shape in every launch.  Per box: cm_stride words of commitments, pos_stride
+// positions, pts_stride words of points, enc_stride bytes of encodings, state_stride words of difference tables
+// (state_fwd, state_bwd and state_l1 all advance by it), gate[b].
+extern "C" int ec_launch_fd_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                                  int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                                  uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride,
+                                  size_t pos_stride, size_t pts_stride, size_t state_stride, size_t enc_stride, hipStream_t s) {
   const int m0 = chains * t;
   const size_t seed0 = (size_t)chains * w0;
   const int pw = ec_point_words(group);
@@ -566,36 +604,44 @@ extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t*
   uint32_t* hseeds = seeds + (size_t)w1 * pw;
   uint32_t* l1_fwd = state_l1;
   uint32_t* l1_bwd = two_level ? state_l1 + (size_t)t * pw : nullptr;
+  const BoxStride bs{cm_stride, pos_stride, pts_stride, state_stride, enc_stride};
+  const unsigned B = (unsigned)boxes;
   if (group == 1) {
     if (split)
-      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * horner)), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate);
+      hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * horner), B), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate, bs);
     else
-      hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(horner)), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate);
+      hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(horner), B), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate, bs);
     if (two_level) {
-      hipLaunchKernelGGL(k_secp_fd_table, dim3(1), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate);
-      hipLaunchKernelGGL(k_secp_fd_step, dim3(2), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate);
+      hipLaunchKernelGGL(k_secp_fd_table, dim3(1, B), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate, bs);
+      hipLaunchKernelGGL(k_secp_fd_step, dim3(2, B), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate, bs);
     }
-    hipLaunchKernelGGL(k_secp_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate);
-    hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
-                       count, pts, gate);
+    hipLaunchKernelGGL(k_secp_fd_table, dim3(chains, B), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate, bs);
+    hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains, B), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
+                       count, pts, gate, bs);
   } else {
     if (split)
-      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * horner)), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate);
+      hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * horner), B), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate, bs);
     else
-      hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(horner)), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate);
+      hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(horner), B), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate, bs);
     if (two_level) {
-      hipLaunchKernelGGL(k_rist_fd_table, dim3(1), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate);
-      hipLaunchKernelGGL(k_rist_fd_step, dim3(2), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate);
+      hipLaunchKernelGGL(k_rist_fd_table, dim3(1, B), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate, bs);
+      hipLaunchKernelGGL(k_rist_fd_step, dim3(2, B), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate, bs);
     }
-    hipLaunchKernelGGL(k_rist_fd_table, dim3(chains), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate);
-    hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
-                       count, pts, gate);
+    hipLaunchKernelGGL(k_rist_fd_table, dim3(chains, B), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate, bs);
+    hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains, B), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
+                       count, pts, gate, bs);
   }
   if (x_enc != nullptr) {
-    const int rc = ec_launch_encode_gated(group, pts, count, x_enc, gate, s);
+    const int rc = ec_launch_encode_boxes(group, pts, count, x_enc, gate, boxes, pts_stride, enc_stride, s);
     if (rc != 0) return rc;
   }
   return (int)hipGetLastError();
+}
+extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                            int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                            uint8_t* x_enc, int split_seeds, const int* gate, hipStream_t s) {
+  return ec_launch_fd_boxes(group, cm, t, positions, count, chains, w0, chain_len, pts, state_fwd, state_bwd, state_l1, x_enc,
+                            split_seeds, gate, 1, 0, 0, 0, 0, 0, s);
 }
 
 // ---- windowed path ---------------------------------------------------------------------------------------------------
@@ -631,12 +677,19 @@ extern "C" int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_
     hipLaunchKernelGGL(k_rist_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);
   return (int)hipGetLastError();
 }
-// internal points -> canonical encodings (secp256k1: eight points per lane share an inversion); gate: run only if *gate == 1
-extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, hipStream_t s) {
-  if (count <= 0) return 0;
-  if (group == 1) hipLaunchKernelGGL(k_secp_encode_batch, dim3(blocks_for((count + 7) / 8)), dim3(64), 0, s, pts, count, enc, gate);
-  else hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count)), dim3(64), 0, s, pts, count, enc, gate);
+// internal points -> canonical encodings (secp256k1: eight points per lane share an inversion); gate: run only if gate[b] == 1
+extern "C" int ec_launch_encode_boxes(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, int boxes,
+                                      size_t pts_stride, size_t enc_stride, hipStream_t s) {
+  if (count <= 0 || boxes <= 0) return 0;
+  const BoxStride bs{0, 0, pts_stride, 0, enc_stride};
+  if (group == 1)
+    hipLaunchKernelGGL(k_secp_encode_batch, dim3(blocks_for((count + 7) / 8), boxes), dim3(64), 0, s, pts, count, enc, gate, bs);
+  else
+    hipLaunchKernelGGL(k_rist_encode, dim3(blocks_for(count), boxes), dim3(64), 0, s, pts, count, enc, gate, bs);
   return (int)hipGetLastError();
+}
+extern "C" int ec_launch_encode_gated(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, hipStream_t s) {
+  return ec_launch_encode_boxes(group, pts, count, enc, gate, 1, 0, 0, s);
 }
 extern "C" int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s) {
   return ec_launch_encode_gated(group, pts, count, enc, nullptr, s);

@@ -179,6 +179,16 @@ struct mpvss_ctx {
     ring[sl.ring_pos] = -1;
     free_stack[free_top++] = (int)(&sl - slot);
   }
+  // Curve groups: X paths of several boxes of one mpvss_ec_verify_many call computed by the same launches (capi_ec.inc)
+  struct XBatch {
+    DevBuf cmenc, cm, okcm, pos, pts, xenc, state, flags;
+    hipStream_t s = nullptr;
+    hipEvent_t done = nullptr;
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    std::vector<DevBuf*> all() { return {&cmenc, &cm, &okcm, &pos, &pts, &xenc, &state, &flags}; }
+  };
+  std::vector<XBatch*> ec_xb;
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
@@ -555,6 +565,14 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
       if (b->p) (void)hipFree(b->p);
   for (DevBuf& b : ctx->ec_comb)
     if (b.p) (void)hipFree(b.p);
+  for (mpvss_ctx::XBatch* xb : ctx->ec_xb) {
+    if (xb->s) { (void)hipStreamSynchronize(xb->s); (void)hipStreamDestroy(xb->s); }
+    if (xb->done) (void)hipEventDestroy(xb->done);
+    if (xb->pin) (void)hipHostFree(xb->pin);
+    for (DevBuf* b : xb->all())
+      if (b->p) (void)hipFree(b->p);
+    delete xb;
+  }
   for (hipEvent_t e : ctx->a2_done)
     if (e) (void)hipEventDestroy(e);
   if (ctx->pin) (void)hipHostFree(ctx->pin);

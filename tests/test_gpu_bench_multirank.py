@@ -19,13 +19,17 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _run(ranks, steps, n, depth, timeout=900):
+    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH=str(depth), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps",
+           str(steps), "--warmup", "1", "--participants", str(n), "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0",
+           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0"]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
 def test_two_ranks_share_one_box_through_bench_py():
-    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH="3", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--participants", "16384", "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0", "--registered-keys", "0",
-           "--ec-boxes", "0", "--lone-boxes", "0"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    out = _run(2, 3, 16384, 3)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")]
     assert len(lines) == 1, out.stdout[-2000:]           # rank 0 prints ONE line
@@ -34,3 +38,14 @@ def test_two_ranks_share_one_box_through_bench_py():
     assert res["config"]["n_per_gpu"] == 16384 and "32768 participants in the box" in res["config"]["workload"]
     assert res["value"] > 0 and res["compute"]["fd_fallbacks"] == 0
     assert res["host"]["pipeline"].startswith("verify_block_compute / block_claim / absorb_claimed")
+
+
+def test_four_ranks_many_boxes_every_rank_absorbing_several_at_once():
+    """The driver's N > 1 shape in small: 4 ranks (one GPU), 14 timed boxes of 4 x 4096 shares, 6 boxes in flight per rank
+    and as many hash threads claiming blocks, receiving by box tag and sending on -- a lost or crossed state would fail
+    bench.py's digest check, a missing recv would hang into the timeout."""
+    out = _run(4, 14, 4096, 6, timeout=420)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+    assert res["n_gpus"] == 4 and res["steps"] == 14 and "16384 participants in the box" in res["config"]["workload"]
+    assert res["host"]["hash_threads"] >= 2 and res["compute"]["fd_fallbacks"] == 0

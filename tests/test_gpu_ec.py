@@ -231,3 +231,76 @@ def test_ec_device_resident_positions_pick_the_path_on_the_device(engine, name):
     cmp = [G.element_from_fixed(cm[k * L:(k + 1) * L]) for k in range(t)]
     assert want[i * L:(i + 1) * L] == G.element_to_bytes(O.commitment_eval(G, cmp, 99999))
     assert len(gen) == L
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_verify_many_batches_the_x_paths_of_several_boxes(engine, name):
+    """mpvss_ec_verify_many computes the X paths of runs of consecutive boxes of one shape (up to MPVSS_EC_X_BATCH) by the
+    same launches (box = second grid dimension).  Ten boxes from different dealers, one with a tampered share, one whose
+    positions are not consecutive (host buffers: it ends the run and takes the per-box path; device buffers: it stays in
+    the batch and falls back to Horner's rule through its own gate), one of another size near the end: every verdict
+    and transcript digest must equal the one-box-at-a-time call's, which the other tests pin."""
+    import ctypes as C
+
+    import torch
+    G, gid = mk(name)
+    order = G.group_order_int()
+    L = G.elem_len
+    sb = G.scalar_to_fixed
+    gen = G.element_to_bytes(G.generator())
+    n, t = 4096 + 64, 16
+    rng = random.Random(0xBA7C + gid)
+    privs = [rng.randrange(1, order) for _ in range(n)]
+    pks = engine.ec_batch_exp(gid, gen * n, b"".join(map(sb, privs)))
+
+    def deal(positions, m=n):
+        coeffs = [rng.randrange(order) for _ in range(t)]
+        wits = [rng.randrange(1, order) for _ in range(m)]
+        pvals = [sum(c * pow(p % order, j, order) for j, c in enumerate(coeffs)) % order for p in positions]
+        cm = engine.ec_batch_exp(gid, gen * t, b"".join(map(sb, coeffs)))
+        d = engine.ec_distribute(gid, cm, positions, pks[:m * L], b"".join(map(sb, pvals)), b"".join(map(sb, wits)))
+        c = G.hash_to_scalar(d["digest"])
+        resp = b"".join(sb((w - p * c) % order) for w, p in zip(wits, pvals))
+        return {"commitments": cm, "positions": positions, "pubkeys": pks[:m * L], "shares": d["Y"], "responses": resp,
+                "challenge": sb(c)}, d["digest"]
+
+    consecutive = list(range(1, n + 1))
+    boxes, digests = zip(*[deal(consecutive) for _ in range(5)])
+    boxes, digests = list(boxes), list(digests)
+    tampered = dict(boxes[1])
+    y = bytearray(tampered["shares"]); y[7 * L:8 * L] = pks[9 * L:10 * L]; tampered["shares"] = bytes(y)
+    scattered, dg_scattered = deal(list(range(1, n)) + [3 * n])                 # last position out of line
+    small, dg_small = deal(list(range(5, 5 + 4096)), 4096)                      # another shape inside a batch
+    # host: a batch of 5, the out-of-line box alone, a batch of 2, two single boxes; device: a batch of 8, two single boxes
+    seq = [boxes[0], tampered, boxes[2], boxes[3], boxes[4], scattered, boxes[0], boxes[2], small, boxes[3]]
+    one_by_one = []
+    for b in seq:
+        r = engine.ec_verify_distribution(gid, b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"],
+                                          b["challenge"])
+        one_by_one.append((r["verdict"], r["digest"]))
+    assert [v for v, _ in one_by_one] == [True, False] + [True] * 8
+    assert one_by_one[0][1] == digests[0] and one_by_one[5][1] == dg_scattered and one_by_one[8][1] == dg_small
+    for depth, threads in ((2, 1), (8, 3)):
+        assert engine.ec_verify_many(gid, seq, depth=depth, hash_threads=threads) == one_by_one
+    # the same boxes resident in HBM: positions are judged on the device, box by box
+    dev = torch.device("cuda", 0)
+    keep = []
+
+    def dptr(b):
+        tns = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        keep.append(tns)
+        return tns.data_ptr()
+
+    arr = (capi.EcBox * len(seq))()
+    for i, b in enumerate(seq):
+        pos = torch.tensor(b["positions"], dtype=torch.int64, device=dev)
+        ch = (C.c_uint8 * 32).from_buffer_copy(b["challenge"])
+        keep += [pos, ch]
+        arr[i] = capi.EcBox(dptr(b["commitments"]), t, pos.data_ptr(), dptr(b["pubkeys"]), dptr(b["shares"]),
+                            dptr(b["responses"]), len(b["positions"]), C.cast(ch, C.c_void_p))
+    verdicts = (C.c_int * len(seq))()
+    out = (C.c_uint8 * (32 * len(seq)))()
+    engine._check(engine.lib.mpvss_ec_verify_many(engine.ctx, gid, capi.MPVSS_DEVICE, arr, len(seq), 6, 2, verdicts,
+                                                  C.cast(out, C.c_void_p)), "ec_verify_many(device)")
+    raw = bytes(out)
+    assert [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(len(seq))] == one_by_one
