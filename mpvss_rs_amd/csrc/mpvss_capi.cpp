@@ -40,6 +40,12 @@ static size_t max_chunk_init() {
 }
 static const size_t MAX_CHUNK = max_chunk_init();
 
+// ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); launches of streams that share a queue run
+// one after the other.  The block pipeline wants 8 (measured: 16 or 32 make every kernel 2-3x slower,
+// profiles/r02_ec_streams_ab.txt).  The runtime reads the variable when it initialises, so this only helps when the
+// library is loaded before the process's first HIP call; a value the user has set is left alone.
+__attribute__((constructor)) static void mpvss_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;

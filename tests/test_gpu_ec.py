@@ -282,6 +282,12 @@ def test_ec_verify_many_batches_the_x_paths_of_several_boxes(engine, name):
     assert one_by_one[0][1] == digests[0] and one_by_one[5][1] == dg_scattered and one_by_one[8][1] == dg_small
     for depth, threads in ((2, 1), (8, 3)):
         assert engine.ec_verify_many(gid, seq, depth=depth, hash_threads=threads) == one_by_one
+    # a commitment that is no group element, inside a batch: reported by the box it belongs to, as on the per-box path
+    bad_cm = bytearray(boxes[2]["commitments"])
+    bad_cm[3 * L:4 * L] = (b"\x05" + bytes(32)) if name == "secp256k1" else bytes.fromhex("01" + "00" * 31)
+    with pytest.raises(capi.EngineError, match="commitments: element 3"):
+        engine.ec_verify_many(gid, [boxes[0], dict(boxes[2], commitments=bytes(bad_cm)), boxes[3]], depth=3, hash_threads=2)
+    assert engine.ec_verify_many(gid, seq[:3], depth=3, hash_threads=2) == one_by_one[:3]      # the context is usable again
     # the same boxes resident in HBM: positions are judged on the device, box by box
     dev = torch.device("cuda", 0)
     keep = []
