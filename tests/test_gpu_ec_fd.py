@@ -44,8 +44,9 @@ def run(env_extra):
 
 
 def test_ec_fd_equals_horner():
-    a = run({"MPVSS_EC_FD": "1", "CHECK_ORACLE": "1"})
+    a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "0", "CHECK_ORACLE": "1"})     # Horner for every seed
     b = run({"MPVSS_EC_FD": "0"})
+    c = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "2", "CHECK_ORACLE": "1"})     # two-level seeding (what pipelined boxes use)
     assert len(a) == len(CASES) and all(len(h) == 64 for h in a)
-    for case, ha, hb in zip(CASES, a, b):
-        assert ha == hb, case
+    for case, ha, hb, hc in zip(CASES, a, b, c):
+        assert ha == hb == hc, case
