@@ -776,17 +776,22 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
 // bound the thresholds and batch sizes it is used for.
 
 // stream callback: out = in^-1 mod q (canonical big-endian), ok = 0 when in is 0 mod q.  No HIP calls in here.
+// q as 256 big-endian bytes, assembled from its limbs
+void modq_modulus_bytes(uint8_t* qbe) {
+  for (size_t byte = 0; byte < EB; ++byte) {
+    unsigned v = 0;
+    for (int bit = 0; bit < 8; ++bit) {
+      const size_t b = byte * 8 + bit;
+      v |= ((MODP_N_LIMBS[b / MODP_W] >> (b % MODP_W)) & 1u) << bit;
+    }
+    qbe[EB - 1 - byte] = (uint8_t)v;
+  }
+}
+
 void invert_root_on_host(void* p) {
   static const hostq::Field* field = [] {
     uint8_t qbe[EB];
-    for (size_t byte = 0; byte < EB; ++byte) {     // assemble q from its limbs
-      unsigned v = 0;
-      for (int bit = 0; bit < 8; ++bit) {
-        const size_t b = byte * 8 + bit;
-        v |= ((MODP_N_LIMBS[b / MODP_W] >> (b % MODP_W)) & 1u) << bit;
-      }
-      qbe[EB - 1 - byte] = (uint8_t)v;
-    }
+    modq_modulus_bytes(qbe);
     return new hostq::Field(qbe);
   }();
   auto* job = (mpvss_ctx::Work::RootJob*)p;
@@ -2077,10 +2082,46 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
     RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
     uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
-    RET_IF(exp_dev(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, cnt, dS));                       // S = Y^(1/x)
-    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
-                                                   da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));                // a1 = G^w
-    RET_IF(exp_dev(ctx, dS, (const uint8_t*)dw, cnt, da2));                                        // a2 = S^w
+    // a2 = S^w = Y^(w/x): the same base as S = Y^(1/x), so both come out of ONE chain of squarings (the bucket kernels of
+    // the dealer) once the host has the second exponent  e2 = w * (1/x) mod (q-1)  -- exact for every Y that is a unit
+    // mod q; a Y that is 0 mod q (not a group element) would make S = 0 and the reduced exponent matter, so such a
+    // batch takes the two dependent exponentiations.  Host buffers and at least 1024 shares (as for the dealer).
+    static const int twin = fd_env("MPVSS_EXTRACT_SHARED_SQUARINGS", 1);
+    bool shared = twin && space == MPVSS_HOST && cnt >= 1024;
+    if (shared) {
+      uint8_t qb[EB];
+      modq_modulus_bytes(qb);
+      static const uint8_t zero[EB] = {0};
+      const uint8_t* hy = y + off * EB;
+      for (size_t i = 0; i < cnt && shared; ++i)
+        shared = memcmp(hy + i * EB, zero, EB) != 0 && memcmp(hy + i * EB, qb, EB) != 0;
+    }
+    if (shared) {
+      std::vector<uint8_t> e2(cnt * EB);
+      const uint8_t *hx = xinv + off * EB, *hw = w + off * EB;
+      const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      std::vector<std::thread> pool;
+      for (unsigned k = 0; k < nt; ++k)
+        pool.emplace_back([&, k] {
+          for (size_t i = k; i < cnt; i += nt) mpvss_modp_scalar_mul(hw + i * EB, hx + i * EB, e2.data() + i * EB);
+        });
+      for (auto& th : pool) th.join();
+      const void* de2;
+      RET_IF(stage_in(ctx, space, e2.data(), cnt * EB, ctx->w->in_d, &de2));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // e2 is a local buffer: its copy must have left before it dies
+      const size_t bw = modp_twin_exp_bucket_words();
+      RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + 2) * 4));
+      uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
+      TIMED_LAUNCH(ctx, 3, modp_launch_twin_exp((const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, (int)cnt, bk,
+                                                bk + cnt * bw, dS, da2, ctx->consts, ctx->stream));
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
+                                                     da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));              // a1 = G^w
+    } else {
+      RET_IF(exp_dev(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, cnt, dS));                       // S = Y^(1/x)
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
+                                                     da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));              // a1 = G^w
+      RET_IF(exp_dev(ctx, dS, (const uint8_t*)dw, cnt, da2));                                        // a2 = S^w
+    }
     RET_IF(ensure_pinned(ctx, cnt * EB * 3));
     uint8_t* hS = (uint8_t*)ctx->pin;
     uint8_t* h1 = hS + cnt * EB;

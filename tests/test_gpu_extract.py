@@ -76,3 +76,37 @@ def test_modp_verify_shares_large_batch_uses_wide_windows(engine):
         rb[i * 256 + 200] ^= 1
     verdicts = list(engine.verify_shares(cat(g, pks), S, cat(g, Y), c, bytes(rb)))
     assert verdicts == [0 if i in (5, 600, 1099) else 1 for i in range(n)]
+
+
+def test_modp_extract_shares_large_batch_shares_the_squarings(engine):
+    """From 1024 shares (host buffers) S = Y^(1/x) and a2 = S^w = Y^(w/x) come out of one chain of squarings, with
+    e2 = w * (1/x) mod (q-1) formed on the host.  The challenges hash a1 and a2, so they pin a2: compared with the
+    two-exponentiation path on a slice (< 1024 shares) of the same inputs and with Python's pow; exponents whose
+    product is a multiple of q-1, w = 0 and an unreduced 1/x are among them.  A batch that contains a Y that is
+    0 mod q must take the two-step path (0^e is not periodic in e): S = 0 there, and the results still agree."""
+    g = O.ModpGroup()
+    q, order = g.q, g.group_order_int()
+    rng = random.Random(0xE77)
+    n = 1024 + 36
+    ys = [rng.randrange(2, q) for _ in range(n)]
+    xinv = [rng.randrange(1, order) for _ in range(n)]
+    wit = [rng.randrange(1, order) for _ in range(n)]
+    xinv[1], wit[1] = order // 2, 2                  # product = q - 1: reduced exponent 0
+    wit[2] = 0
+    xinv[3] = (1 << 2048) - 1                        # not reduced
+    xinv[4], wit[4] = order, 5                       # 1/x = q - 1 itself
+    pks = [pow(2, rng.randrange(order), q) for _ in range(8)]
+    pk = [pks[i % 8] for i in range(n)]
+    S, c = engine.extract_shares(cat(g, pk), cat(g, ys), cat(g, xinv), cat(g, wit))
+    assert split(S) == [pow(y, e, q) for y, e in zip(ys, xinv)]
+    m = 300                                          # the slice goes through two dependent exponentiations
+    S2, c2 = engine.extract_shares(cat(g, pk[:m]), cat(g, ys[:m]), cat(g, xinv[:m]), cat(g, wit[:m]))
+    assert S2 == S[:m * 256] and c2 == c[:m * 256]
+    for i in (0, 1, 2, 3, 4, n - 1):                 # participant.rs:329-343 with a1 = G^w, a2 = S^w
+        a1, a2 = pow(2, wit[i], q), pow(pow(ys[i], xinv[i], q), wit[i], q)
+        digest = O.sha256(O.append_transcript(g, pk[i], ys[i], a1, a2))
+        assert split(c)[i] == g.hash_to_scalar(digest), i
+    ys0 = list(ys); ys0[7] = 0; ys0[9] = q
+    S0, c0 = engine.extract_shares(cat(g, pk), cat(g, ys0), cat(g, xinv), cat(g, wit))
+    assert split(S0)[7] == 0 and split(S0)[9] == 0 and split(S0)[8] == split(S)[8]
+    assert c0[:7 * 256] == c[:7 * 256] and c0[10 * 256:] == c[10 * 256:]
