@@ -522,9 +522,26 @@ def main():
     gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
     w6 = os.environ.get("MPVSS_A2_W6", "1") != "0"            # 6-bit windows for y^r (64-entry table) or 4-bit
     # full-product equivalents: squarings weigh SQ_COST
-    a2_products = (2046 * SQ_COST + 341 + 64 + 1) if w6 else (2044 * SQ_COST + 511 + 64 + 1)
-    mm_dual = n * (a2_products + (252 * SQ_COST + 64 + gr + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
-    mm_table = n * (2 * 15 + (63 if w6 else 15))              # window tables of X, Y (16 entries) and y (+1 conversion each)
+    # X^c and Y^c: 64 fixed 4-bit windows, or -- one c for the whole box, forward-difference path -- the sliding-window
+    # schedule the library makes from it (width 4, odd digits; the tables of X and Y then hold the odd powers only)
+    sliding = fd and w6 and os.environ.get("MPVSS_C_SLIDING", "1") != "0" and c > 0
+    c_win, c_top, i = 0, 0, 255
+    while sliding and i >= 0:
+        if not (c >> i) & 1:
+            i -= 1
+            continue
+        low = max(i - 3, 0)
+        while not (c >> low) & 1:
+            low += 1
+        c_top = low if c_win == 0 else c_top
+        c_win += 1
+        i = low - 1
+    yc = c_win if sliding else 64                              # products with the table of Y (a2) / X (a1; its first is a load)
+    xc_sq, xc = (c_top, c_win - 1) if sliding else (252, 63)
+    a2_products = (2046 * SQ_COST + 341 + yc + 1) if w6 else (2044 * SQ_COST + 511 + 64 + 1)
+    mm_dual = n * (a2_products + (xc_sq * SQ_COST + xc + 1 + gr + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
+    tab_xy = (8 + SQ_COST) if sliding else 15                # conversion + b^2 + seven odd powers, or conversion + 14 powers
+    mm_table = n * (2 * tab_xy + (63 if w6 else 15))          # window tables of X, Y and y (+1 conversion each)
     mm_total = mm_x + mm_dual + mm_table
     achieved_modmul = mm_total / (ms_per_step * 1e-3)         # against the step's wall time (kernels overlap)
     peak_modmul = PEAK_MODMUL_PER_S

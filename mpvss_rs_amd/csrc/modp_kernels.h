@@ -34,6 +34,14 @@ int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint32_t* tab2, 
 int modp_launch_build_table64(const uint8_t* base_be, int count, uint32_t* tab, const void* cs, hipStream_t s);
 int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
                             size_t c_stride, int count, uint8_t* out, const void* cs, hipStream_t s);
+/* One challenge c for all shares of a box, as a sliding-window schedule (device memory, uint16: [0] = windows, then
+   (lowest bit position of the window, odd digit) by descending position); tables of the second base need their odd
+   entries only (modp_launch_build_table_odd).  About 51 products instead of 64 per base, 8 instead of 14 per table. */
+int modp_launch_build_table_odd(const uint8_t* base_be, int count, uint32_t* tab, const void* cs, hipStream_t s);
+int modp_launch_dual_exp_w6_sched(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint16_t* c_sched,
+                                  int count, uint8_t* out, const void* cs, hipStream_t s);
+int modp_launch_comb_dual_exp_sched(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride, const uint16_t* c_sched,
+                                    int count, uint8_t* out, uint32_t* p_m, int comb_bits, const void* cs, hipStream_t s);
 /* one base, two exponents, two results (dealer: Y = y^p, a2 = y^w): right-to-left 5-bit buckets in HBM, shared squarings.
    buckets: count * modp_twin_exp_bucket_words() u32 of scratch, occupancy: count * 2 u32 of scratch */
 size_t modp_twin_exp_bucket_words(void);

@@ -647,7 +647,7 @@ k_modp_from_mont(const u32* __restrict__ x_m, int count, uint8_t* __restrict__ o
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_build_table(const uint8_t* __restrict__ base_be, int count, u32* __restrict__ tab,
-                   const ModpConsts* __restrict__ cs) {
+                   const ModpConsts* __restrict__ cs, int odd_only) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
   const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -666,6 +666,20 @@ k_modp_build_table(const uint8_t* __restrict__ base_be, int count, u32* __restri
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int k = 0; k < LPL; ++k) acc[k] = b[k];
+  if (odd_only) {
+    // a sliding window over an exponent that every share has in common only ever asks for the odd powers:
+    // b^2 once, then b^3, b^5, .. b^15 -- 1 squaring + 7 products instead of 14 products (even entries stay unwritten)
+    u32 b2[LPL];
+    mont_sqr<MODP_N0INV_C>(b2, b, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    slot_store(slot, b2, ln);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = 3; e < 16; e += 2) {
+      mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      if (live) store_lane_limbs(my + (size_t)e * L, acc, ln);
+    }
+    return;
+  }
   for (int e = 2; e < 16; ++e) {
     mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
     if (live) store_lane_limbs(my + (size_t)e * L, acc, ln);
@@ -826,7 +840,8 @@ extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2, size_t tab2_stride,
                      const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride,
                      int e2_windows, int count, uint8_t* __restrict__ out_be, int mode, u32* __restrict__ p_m,
-                     int comb_bits, const ModpConsts* __restrict__ cs) {
+                     int comb_bits, const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched) {
+  // c_sched: sliding-window schedule of a shared e2 (see k_modp_dual_exp_w6); tab2 then needs its odd entries only
   // comb_bits: 4 = comb[k][d] = g^(d 16^k), 512 rows of 16; 16 = comb[k][d] = g^(d 65536^k), 128 rows of 65536
   // (2.5 GB in HBM, a quarter of the products).
   // mode 0: the whole product.  mode 1: only g^e1 (needs nothing but the exponent, so it can run before B2 is
@@ -851,11 +866,18 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
   enum { PH_A, PH_B, PH_P, PH_F };
   int phase = (e2_windows > 0 && mode != 1) ? PH_A : PH_B;
   int w = first_e2, s = 4, k = 0;
+  int cur = 0, si = 1, a_stage = 0;                      // schedule mode: weight of the accumulator's unit, next window
+  const int sn = c_sched ? (int)c_sched[0] : 0;
   if (phase == PH_A) {
-    const u32 byte = e2[w >> 1];
-    const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
-    load_lane_limbs(acc, t2 + (size_t)d * L, ln);       // first window: load instead of multiply
-    s = 5;
+    if (c_sched != nullptr) {
+      load_lane_limbs(acc, t2 + (size_t)c_sched[2] * L, ln);       // top window: load instead of multiply
+      cur = (int)c_sched[1];
+    } else {
+      const u32 byte = e2[w >> 1];
+      const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+      load_lane_limbs(acc, t2 + (size_t)d * L, ln);       // first window: load instead of multiply
+      s = 5;
+    }
   }
   while (true) {
     const u32* bptr = slot;
@@ -863,8 +885,33 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
     u32* fill_to = slot;
     bool skip = false, sq = false;
     if (phase == PH_A) {
-      if (s == 5) { ++w; s = 0; }
-      if (w == 512) {
+      bool a_done = false;
+      if (c_sched != nullptr) {
+        if (a_stage == 0) {                              // square down one bit, or finish at weight 0
+          if (cur == 0) a_done = true;
+          else { slot_store(slot, acc, ln); sq = true; --cur; a_stage = 1; }
+        } else {                                         // a window that ends at this bit?
+          a_stage = 0;
+          if (si < sn && cur == (int)c_sched[1 + 2 * si]) { fill = t2 + (size_t)c_sched[2 + 2 * si] * L; ++si; }
+          else skip = true;
+        }
+      } else {
+        if (s == 5) { ++w; s = 0; }
+        if (w == 512) {
+          a_done = true;
+        } else {
+          if (s < 4) {
+            slot_store(slot, acc, ln);
+            sq = true;
+          } else {
+            const u32 byte = e2[w >> 1];
+            const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+            fill = t2 + (size_t)d * L;
+          }
+          ++s;
+        }
+      }
+      if (a_done) {
         if (mode == 2) {                                 // multiply by the stored g^e1
           fill = p_m + (size_t)x * L;
           fill_to = pslot;
@@ -875,16 +922,6 @@ k_modp_comb_dual_exp(const u32* __restrict__ comb, const u32* __restrict__ tab2,
           phase = PH_B; k = 0;
           continue;
         }
-      } else {
-        if (s < 4) {
-          slot_store(slot, acc, ln);
-          sq = true;
-        } else {
-          const u32 byte = e2[w >> 1];
-          const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
-          fill = t2 + (size_t)d * L;
-        }
-        ++s;
       }
     } else if (phase == PH_B) {
       size_t ent;
@@ -956,7 +993,10 @@ k_modp_build_table64(const uint8_t* __restrict__ base_be, int count, u32* __rest
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
                    const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
-                   const ModpConsts* __restrict__ cs) {
+                   const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched) {
+  // c_sched (one challenge for all shares): a sliding-window schedule made by the host -- [0] = number of windows, then
+  // (bit position of the window's lowest bit, odd digit) in descending position -- instead of 64 fixed 4-bit windows:
+  // about 51 products for Y^c and a table of the odd powers only (dleq.rs:79-81 has the same c for every share of a box)
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
   const Lane ln = make_lane();
   const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
@@ -980,6 +1020,8 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
   load_lane_limbs(acc, t1 + (size_t)digit6(341) * L, ln);
   int cur = 2046;
   int s = 0;                       // 0: square (cur decreases), 1: product with tab1, 2: product with tab2, 3: final
+  int si = 0;
+  const int sn = c_sched ? (int)c_sched[0] : 0;
   while (true) {
     const u32* fill = nullptr;
     bool skip = false;
@@ -989,7 +1031,14 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
     } else if (s == 1) {
       if (cur % 6 == 0) fill = t1 + (size_t)digit6(cur / 6) * L; else skip = true;
     } else if (s == 2) {
-      if ((cur & 3) == 0 && cur < 256 && c_all != nullptr) {
+      if (c_sched != nullptr) {
+        if (si < sn && cur == (int)c_sched[1 + 2 * si]) {
+          fill = t2 + (size_t)c_sched[2 + 2 * si] * L;
+          ++si;
+        } else {
+          skip = true;
+        }
+      } else if ((cur & 3) == 0 && cur < 256 && c_all != nullptr) {
         const u32 byte = c_be[255 - (cur >> 3)];
         fill = t2 + (size_t)((cur & 4) ? (byte >> 4) : (byte & 15)) * L;
       } else {
@@ -1432,7 +1481,14 @@ extern "C" int modp_launch_build_table(const uint8_t* base_be, int count, uint32
                                        hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_build_table, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, base_be, count, tab,
-                     (const ModpConsts*)cs);
+                     (const ModpConsts*)cs, 0);
+  return (int)hipGetLastError();
+}
+// entries 0, 1, 3, 5, .. 15 only (what a sliding-window schedule asks for)
+extern "C" int modp_launch_build_table_odd(const uint8_t* base_be, int count, uint32_t* tab, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_build_table, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, base_be, count, tab,
+                     (const ModpConsts*)cs, 1);
   return (int)hipGetLastError();
 }
 
@@ -1461,7 +1517,15 @@ extern "C" int modp_launch_dual_exp_w6(const uint32_t* tab1, const uint32_t* tab
                                        size_t c_stride, int count, uint8_t* out, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_dual_exp_w6, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab2, e1, c, c_stride, count,
-                     out, (const ModpConsts*)cs);
+                     out, (const ModpConsts*)cs, (const uint16_t*)nullptr);
+  return (int)hipGetLastError();
+}
+// one c for all shares, given as a sliding-window schedule (device memory; tab2: odd entries)
+extern "C" int modp_launch_dual_exp_w6_sched(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1,
+                                             const uint16_t* c_sched, int count, uint8_t* out, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_dual_exp_w6, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, tab1, tab2, e1,
+                     (const uint8_t*)nullptr, (size_t)0, count, out, (const ModpConsts*)cs, c_sched);
   return (int)hipGetLastError();
 }
 extern "C" size_t modp_twin_exp_bucket_words() { return (size_t)2 * BK_ENT * L; }
@@ -1507,7 +1571,8 @@ extern "C" int modp_launch_comb_dual_exp(const uint32_t* comb, const uint32_t* t
                                          int count, uint8_t* out, int comb_bits, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
-                     e1, e2, e2_stride, e2_windows, count, out, 0, (uint32_t*)nullptr, comb_bits, (const ModpConsts*)cs);
+                     e1, e2, e2_stride, e2_windows, count, out, 0, (uint32_t*)nullptr, comb_bits, (const ModpConsts*)cs,
+                     (const uint16_t*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1518,6 +1583,17 @@ extern "C" int modp_launch_comb_dual_exp_split(const uint32_t* comb, const uint3
                                                const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
-                     e1, e2, e2_stride, e2_windows, count, out, mode, p_m, comb_bits, (const ModpConsts*)cs);
+                     e1, e2, e2_stride, e2_windows, count, out, mode, p_m, comb_bits, (const ModpConsts*)cs,
+                     (const uint16_t*)nullptr);
+  return (int)hipGetLastError();
+}
+// mode 2 with the shared second exponent given as a sliding-window schedule (tab2: odd entries)
+extern "C" int modp_launch_comb_dual_exp_sched(const uint32_t* comb, const uint32_t* tab2, size_t tab2_stride,
+                                               const uint16_t* c_sched, int count, uint8_t* out, uint32_t* p_m, int comb_bits,
+                                               const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_comb_dual_exp, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, comb, tab2, tab2_stride,
+                     (const uint8_t*)nullptr, (const uint8_t*)nullptr, (size_t)0, 64, count, out, 2, p_m, comb_bits,
+                     (const ModpConsts*)cs, c_sched);
   return (int)hipGetLastError();
 }

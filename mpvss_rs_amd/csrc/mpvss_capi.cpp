@@ -86,12 +86,14 @@ struct mpvss_ctx {
     DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root, fd_hand_t, fd_hand_s;   // forward differences
     DevBuf tab3, gr_m;   // X tables of a1; gr_m: g^r_i in Montgomery form
     DevBuf verd;         // per-share verdict bytes of verify_share batches (K7)
+    DevBuf csched;       // sliding-window schedule of the box's challenge
     const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
     struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
       uint8_t in_be[256], out_be[256];
       int ok;
       int one;                               // pinned constant 1 (initial value of the forward-difference flag)
       uint8_t challenge[256];                // pinned copy of the call's challenge (the caller's buffer is not kept)
+      uint16_t csched[160];                  // pinned: sliding-window schedule of that challenge (sliding_schedule)
     };
     RootJob* root = nullptr;
     bool fd_used = false;                    // eval_x took the forward-difference path in the call being enqueued
@@ -101,7 +103,8 @@ struct mpvss_ctx {
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
-              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &tab3, &gr_m, &verd};
+              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &tab3, &gr_m, &verd,
+              &csched};
     }
   };
   Work work0;
@@ -453,6 +456,28 @@ int comb_bits_of(const mpvss_ctx* ctx, const uint32_t* comb) {
 }
 
 // per-number tables of `count` bases (device bytes) into buf
+// Sliding-window (width 4, odd digits) schedule of a 256-bit exponent given as 256 big-endian bytes: out[0] = number of
+// windows, then (bit position of the window's lowest bit, digit) from the top window down.  At most 64 windows.
+// The challenge of a box is ONE exponent for all its shares (dleq.rs:75-81), so the kernels can follow a schedule made
+// here instead of 64 fixed windows per share: about 51 products per base, and tables of the odd powers only.
+void sliding_schedule(const uint8_t* c_be256, uint16_t* out) {
+  auto bit = [&](int i) { return (c_be256[255 - (i >> 3)] >> (i & 7)) & 1; };
+  uint16_t n = 0;
+  int i = 255;
+  while (i >= 0) {
+    if (!bit(i)) { --i; continue; }
+    int l = i - 3 < 0 ? 0 : i - 3;
+    while (!bit(l)) ++l;
+    unsigned d = 0;
+    for (int j = i; j >= l; --j) d = (d << 1) | (unsigned)bit(j);
+    out[1 + 2 * n] = (uint16_t)l;
+    out[2 + 2 * n] = (uint16_t)d;
+    ++n;
+    i = l - 1;
+  }
+  out[0] = n;
+}
+
 int number_tables(mpvss_ctx* ctx, const uint8_t* bases_dev, size_t count, DevBuf& buf, const uint32_t** tab) {
   RET_IF(ensure(ctx, buf, count * TABW * 4));
   TIMED_LAUNCH(ctx, 2, modp_launch_build_table(bases_dev, (int)count, (uint32_t*)buf.p, ctx->consts, ctx->stream));
@@ -1216,10 +1241,24 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         hipEvent_t prev = ctx->a2_done[(seq - a2_conc) % mpvss_ctx::A2_RING];
         if (prev) HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, prev, 0));
       }
+      // one challenge for every share of the box: a sliding-window schedule made on the host replaces the 64 fixed windows
+      // of X^c and Y^c (about 51 products each) and their tables hold the odd powers only (8 instead of 14 products)
+      static const int sliding = fd_env("MPVSS_C_SLIDING", 1);
+      const uint16_t* dsched = nullptr;
+      if (sliding && a2_w6 && c_windows == 64 && !use_keys) {
+        uint16_t* hs = sl.work.root[0].csched;
+        sliding_schedule(sl.work.root[0].challenge, hs);
+        if (hs[0] > 0) {
+          RET_IF(ensure(ctx, ctx->w->csched, sizeof(sl.work.root[0].csched)));
+          HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, hs, (1 + 2 * (size_t)hs[0]) * 2, hipMemcpyHostToDevice, ctx->stream));
+          dsched = (const uint16_t*)ctx->w->csched.p;
+        }
+      }
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
         uint32_t* t2p = (uint32_t*)ctx->w->tab2.p;
-        TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
+        if (dsched) TIMED_LAUNCH(ctx, 2, modp_launch_build_table_odd((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
+        else TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
         if (use_keys) {
           // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
           const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
@@ -1229,8 +1268,10 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
-          TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, (int)cnt, da2,
-                                                       ctx->consts, ctx->stream));
+          if (dsched) TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6_sched(t1p, t2p, (const uint8_t*)dr, dsched, (int)cnt, da2,
+                                                                         ctx->consts, ctx->stream));
+          else TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, (int)cnt, da2,
+                                                            ctx->consts, ctx->stream));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
@@ -1253,11 +1294,21 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
         const uint32_t* tx;
-        RET_IF(number_tables(ctx, dX, cnt, ctx->w->tab3, &tx));
+        if (dsched) {
+          RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
+          TIMED_LAUNCH(ctx, 2, modp_launch_build_table_odd(dX, (int)cnt, (uint32_t*)ctx->w->tab3.p, ctx->consts, ctx->stream));
+          tx = (const uint32_t*)ctx->w->tab3.p;
+        } else {
+          RET_IF(number_tables(ctx, dX, cnt, ctx->w->tab3, &tx));
+        }
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_gr, 0));
-        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0,
-                                                             c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
-                                                             comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+        if (dsched)
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_sched(cg, tx, TABW, dsched, (int)cnt, da1, (uint32_t*)ctx->w->gr_m.p,
+                                                               comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+        else
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, (const uint8_t*)dr, (const uint8_t*)dchal, 0,
+                                                               c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
+                                                               comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
     } else {
