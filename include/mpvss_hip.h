@@ -289,6 +289,13 @@ int mpvss_ec_verify_many(mpvss_ctx* ctx, int group, int space, const mpvss_ec_bo
 /* src/participant.rs:1346-1371 (secp256k1), 1789-1814 (ristretto255) */
 int mpvss_ec_verify_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
                            const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_host);
+/* The same in two steps (several batches in flight; they share the block slots and the FIFO order with the other block
+ * calls): compute enqueues, absorb waits, validates (an invalid encoding or scalar is reported here) and hands out the
+ * verdict bytes.  verdicts_dev_out: optional device buffer that receives the n verdict bytes in stream order. */
+int mpvss_ec_verify_shares_compute(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* s,
+                                   const uint8_t* y, const uint8_t* c, const uint8_t* r, size_t n,
+                                   uint8_t* verdicts_dev_out);
+int mpvss_ec_verify_shares_absorb(mpvss_ctx* ctx, uint8_t* verdicts_host);
 /* group part of src/participant.rs:1094-1274 (secp256k1), 1573-1717 (ristretto255); randomness is input */
 int mpvss_ec_distribute(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
                         const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,

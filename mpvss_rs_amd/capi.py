@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_block_claim", "mpvss_modp_verify_block_absorb_claimed",
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
-    "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
+    "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
@@ -140,6 +140,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_verify_distribution.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p,
                                                  C.POINTER(ci), u8p, u8p, u8p, u8p]
     lib.mpvss_ec_verify_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_ec_verify_shares_compute.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
+    lib.mpvss_ec_verify_shares_absorb.argtypes = [vp, u8p]
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
     lib.mpvss_ec_batch_exp_generator.argtypes = [vp, ci, ci, u8p, sz, u8p]
@@ -521,6 +523,21 @@ class Engine:
         kv, pv = _out(n)
         self._check(self.lib.mpvss_ec_verify_shares(self.ctx, group, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
                                                     k[4][1], n, pv), "ec_verify_shares")
+        return bytes(kv)[:n]
+
+    def ec_verify_shares_compute(self, group: int, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes,
+                                 verdicts_dev_ptr: int = 0) -> int:
+        """Enqueue one batch of share-box proofs of a curve group (returns its size)"""
+        n = len(r) // 32
+        k = [_buf(x) for x in (pk, s, y, c, r)]
+        self._check(self.lib.mpvss_ec_verify_shares_compute(self.ctx, group, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                            k[4][1], n, C.c_void_p(verdicts_dev_ptr or None)),
+                    "ec_verify_shares_compute")
+        return n
+
+    def ec_verify_shares_absorb(self, n: int) -> bytes:
+        kv, pv = _out(n)
+        self._check(self.lib.mpvss_ec_verify_shares_absorb(self.ctx, pv), "ec_verify_shares_absorb")
         return bytes(kv)[:n]
 
     def ec_distribute(self, group: int, commitments: bytes, positions: Sequence[int], pubkeys: bytes, p_values: bytes,

@@ -144,7 +144,7 @@ struct mpvss_ctx {
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
     int kind = 0;                  // 0: block of verify_distribution_shares, 1: batch of verify_share proofs (W_B),
-                                   // 2: block of a curve group's verify_distribution_shares
+                                   // 2: block of a curve group's verify_distribution_shares, 3: a curve group's verify_share batch
     int group = 0;                 // kind 2: MPVSS_GROUP_*
     size_t t = 0;                  // kind 2: number of commitments (their decode flags sit in the staging)
     EcWork ecw;

@@ -149,6 +149,9 @@ unsafe extern "C" {
                                 hash_threads: c_int, verdicts: *mut c_int, digests32: *mut u8) -> c_int;
     pub fn mpvss_ec_verify_shares(ctx: *mut mpvss_ctx, group: c_int, space: c_int, pk: *const u8, s: *const u8, y: *const u8, c: *const u8,
                                   r: *const u8, n: usize, verdicts_host: *mut u8) -> c_int;
+    pub fn mpvss_ec_verify_shares_compute(ctx: *mut mpvss_ctx, group: c_int, space: c_int, pk: *const u8, s: *const u8,
+        y: *const u8, c: *const u8, r: *const u8, n: usize, verdicts_dev_out: *mut u8) -> c_int;
+    pub fn mpvss_ec_verify_shares_absorb(ctx: *mut mpvss_ctx, verdicts_host: *mut u8) -> c_int;
     pub fn mpvss_ec_distribute(ctx: *mut mpvss_ctx, group: c_int, space: c_int, commitments: *const u8, t: usize, positions: *const i64,
                                pubkeys: *const u8, p_values: *const u8, witnesses: *const u8, n: usize, x_out: *mut u8, y_out: *mut u8,
                                a1_out: *mut u8, a2_out: *mut u8, digest32_out: *mut u8) -> c_int;

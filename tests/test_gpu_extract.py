@@ -49,6 +49,23 @@ def test_ec_extract_shares(engine, name):
     assert c == sc([e["challenge"] for e in exp])
     r = [O.dleq_response(G, w, x, e["challenge"]) for w, x, e in zip(wit, privs, exp)]
     assert list(engine.ec_verify_shares(gid, enc(pks), S, enc(Y), c, sc(r))) == [1] * n
+    # compute / absorb form: three batches in flight (honest, a tampered response, a tampered share), absorbed in order;
+    # then a batch with an element that is no encoding -- reported by the absorbing call, the context stays usable
+    rb = bytearray(sc(r)); rb[2 * 32 + (31 if name == "secp256k1" else 0)] ^= 1
+    Sb = bytearray(S); L = len(S) // n; Sb[4 * L:5 * L] = S[3 * L:4 * L]
+    for args in ((enc(pks), S, enc(Y), c, sc(r)), (enc(pks), S, enc(Y), c, bytes(rb)), (enc(pks), bytes(Sb), enc(Y), c, sc(r))):
+        assert engine.ec_verify_shares_compute(gid, *args) == n
+    assert list(engine.ec_verify_shares_absorb(n)) == [1] * n
+    assert list(engine.ec_verify_shares_absorb(n)) == [1, 1, 0, 1, 1, 1]
+    assert list(engine.ec_verify_shares_absorb(n)) == [1, 1, 1, 1, 0, 1]
+    with pytest.raises(capi.EngineError):
+        engine.ec_verify_shares_absorb(n)                    # nothing left in flight
+    broken = bytearray(enc(pks)); broken[1 * L:2 * L] = (b"\x05" + bytes(32)) if name == "secp256k1" else bytes.fromhex("01" + "00" * 31)
+    engine.ec_verify_shares_compute(gid, bytes(broken), S, enc(Y), c, sc(r))
+    engine.ec_verify_shares_compute(gid, enc(pks), S, enc(Y), c, sc(r))
+    with pytest.raises(capi.EngineError, match="share boxes: element 1"):
+        engine.ec_verify_shares_absorb(n)
+    assert list(engine.ec_verify_shares_absorb(n)) == [1] * n
 
 
 def test_modp_verify_shares_large_batch_uses_wide_windows(engine):
