@@ -114,21 +114,26 @@ class ShardedVerifier:
         return bool(raw[0]), raw[2:34], counts
 
     # -- verify_share, batched ------------------------------------------------------------------
-    def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes, block: int) -> bytes:
+    def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes, block: int,
+                      ec_group: Optional[int] = None) -> bytes:
         """Arguments are this rank's block of share boxes; `block` is the (equal) padded block
         length.  Returns the verdict bytes of ALL ranks, in rank order, padding removed.
+        ec_group: capi.GROUP_SECP256K1 / GROUP_RISTRETTO255 for the curve groups (None: MODP-2048).
 
         With RCCL ("nccl" group) the engine writes its verdict bytes straight into the device tensor that is
         all-gathered: the per-share verdicts never visit the host before the collective."""
-        n = len(pk) // EB
+        n = len(r) // 32 if ec_group else len(pk) // EB
         t = torch.zeros(block, dtype=torch.uint8, device=self.dev)
         error: Optional[Exception] = None
+        pre = (ec_group,) if ec_group else ()
+        names = ("ec_verify_shares_compute", "ec_verify_shares_absorb", "ec_verify_shares") if ec_group else \
+                ("verify_shares_compute", "verify_shares_absorb", "verify_shares")
         try:
-            if n and self.dev.type == "cuda" and hasattr(self.engine, "verify_shares_compute"):
-                self.engine.verify_shares_compute(pk, s, y, c, r, verdicts_dev_ptr=t.data_ptr())
-                self.engine.verify_shares_absorb(n)             # waits for the batch: t[:n] is final
+            if n and self.dev.type == "cuda" and hasattr(self.engine, names[0]):
+                getattr(self.engine, names[0])(*pre, pk, s, y, c, r, verdicts_dev_ptr=t.data_ptr())
+                getattr(self.engine, names[1])(n)               # waits for the batch: t[:n] is final
             elif n:
-                mine = self.engine.verify_shares(pk, s, y, c, r)
+                mine = getattr(self.engine, names[2])(*pre, pk, s, y, c, r)
                 t[:n] = torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(self.dev)
         except Exception as exc:
             error = exc

@@ -46,6 +46,14 @@ class OracleBlockEngine:
         sp = lambda b: [int.from_bytes(b[i:i + 256], "big") for i in range(0, len(b), 256)]
         return bytes(int(O.dleq_verify(G, G.generator(), *a)) for a in zip(sp(pk), sp(s), sp(y), sp(c), sp(r)))
 
+    def ec_verify_shares(self, group, pk, s, y, c, r):
+        O = self.O
+        E = O.GROUPS["secp256k1" if group == 1 else "ristretto255"]()
+        L = E.elem_len
+        el = lambda b: [E.element_from_fixed(b[i:i + L]) for i in range(0, len(b), L)]
+        sc = lambda b: [E.scalar_from_fixed(b[i:i + 32]) for i in range(0, len(b), 32)]
+        return bytes(int(O.dleq_verify(E, E.generator(), *a)) for a in zip(el(pk), el(s), el(y), sc(c), sc(r)))
+
 
 def _worker(rank, world, port, tamper, q):
     sys.path.insert(0, ROOT)
@@ -83,7 +91,25 @@ def _worker(rank, world, port, tamper, q):
         block = max(block_range(n, world, k)[1] - block_range(n, world, k)[0] for k in range(world))
         allv = sv.verify_shares(cat(g, pks[lo:hi]), cat(g, S[lo:hi]), cat(g, Y[lo:hi]), cat(g, c[lo:hi]),
                                 cat(g, r[lo:hi]), block)
-        q.put((rank, verdict, digest, counts, list(allv)))
+        # the same collective for a curve group (ec_group): 5 share boxes of secp256k1 split 2 + 3, one proof spoiled
+        E = O.GROUPS["secp256k1"]()
+        erng = random.Random(9)
+        eorder = E.group_order_int()
+        eprivs = [erng.randrange(1, eorder) for _ in range(5)]
+        epks = [E.generate_public_key(k) for k in eprivs]
+        ebox = O.distribute_secret(E, 0x77, epks, 2, [erng.randrange(eorder) for _ in range(2)],
+                                   [erng.randrange(1, eorder) for _ in range(5)])
+        esb = [O.extract_secret_share(E, ebox, k, erng.randrange(1, eorder)) for k in eprivs]
+        er = [x["response"] for x in esb]
+        er[3] = (er[3] + 1) % eorder
+        enc = lambda pts: b"".join(E.element_to_bytes(p) for p in pts)
+        scb = lambda ks: b"".join(E.scalar_to_fixed(k) for k in ks)
+        elo, ehi = block_range(5, world, rank)
+        eY = [ebox["shares"][E.element_to_bytes(p)] for p in epks]
+        eblock = max(block_range(5, world, k)[1] - block_range(5, world, k)[0] for k in range(world))
+        ev = sv.verify_shares(enc(epks[elo:ehi]), enc([x["share"] for x in esb[elo:ehi]]), enc(eY[elo:ehi]),
+                              scb([x["challenge"] for x in esb[elo:ehi]]), scb(er[elo:ehi]), eblock, ec_group=1)
+        q.put((rank, verdict, digest, counts, list(allv), list(ev)))
     finally:
         dist.destroy_process_group()
 
@@ -170,10 +196,11 @@ def test_two_rank_sharded_verification(tamper):
     tr = {}
     expect = O.verify_distribution_shares(g, box, tr)
     assert expect is (not tamper)
-    for rank, verdict, digest, counts, allv in results:
+    for rank, verdict, digest, counts, allv, ev in results:
         assert verdict is expect and digest == tr["digest"]
         assert counts == [3, 4]
         assert allv == [1, 0, 1, 1, 1, 1, 0]
+        assert ev == [1, 1, 1, 0, 1]
 
 
 def test_block_range_partitions_everything():
