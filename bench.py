@@ -486,8 +486,25 @@ def main():
         lone = {"x_path": lst["kernel_ms"][0] / lb, "a1_comb_dual_exp": lst["kernel_ms"][1] / lb,
                 "tables": lst["kernel_ms"][2] / lb, "a2_dual_exp": lst["kernel_ms"][3] / lb,
                 "a2_launches": max(lst["kernel_launches"][3] / lb, 1.0), "boxes": lb}
+    # ... and the dominant kernel entirely alone on the chip: the verifier's commitments of the same shares through the
+    # synchronous entry point (mpvss_modp_dleq_commitments: a1, then the tables of y and Y, then a2 = y^r Y^c -- the same
+    # k_modp_dual_exp_w6 launch on the same operands, with nothing beside it; even a lone box runs its X path beside a2)
+    alone_ms = None
+    if world == 1 and args.lone_boxes > 0 and keyset[0] is None:
+        d_X = dev_u8(dres["X"])
+        o1 = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+        o2 = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+        g_host = (C.c_uint8 * EB).from_buffer_copy(fx(4))
+        for _ in range(2):
+            eng._check(lib.mpvss_modp_dleq_commitments(ctx, capi.MPVSS_DEVICE, C.cast(g_host, C.c_void_p), vp(d_X), vp(d_pk), vp(d_sh),
+                                                       vp(d_rs), C.cast(ch_buf, C.c_void_p), 0, n, vp(o1), vp(o2)), "dleq_commitments")
+        alone_ms = eng.kernel_ms(3) / max(eng.kernel_launches(3), 1)
+        assert bytes(o2.cpu().numpy().tobytes()) == dres["a2"] and bytes(o1.cpu().numpy().tobytes()) == dres["a1"], \
+            "verifier commitments differ from the dealer's"
+        del d_X, o1, o2
     a2_launch_ms_overlapped = a2_ms / a2_n
-    a2_launch_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else a2_launch_ms_overlapped
+    a2_one_box_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else None
+    a2_launch_ms = alone_ms if alone_ms else (a2_one_box_ms if a2_one_box_ms else a2_launch_ms_overlapped)
 
     # work accounting: Montgomery products the kernels execute per step on this rank
     fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "4096"))
@@ -571,8 +588,11 @@ def main():
             "frac": (ALGO_BYTES_PER_SHARE * shares_per_a2_launch / (a2_launch_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if a2_launch_ms > 0 else None,
             "traffic": None,
             "kernel_ms": a2_launch_ms,
-            "kernel_ms_is": ("isolated launch (one box in flight, measured live after the timed region)" if lone
+            "kernel_ms_is": ("the launch alone on the chip (same operands through mpvss_modp_dleq_commitments, live after the "
+                             "timed region)" if alone_ms else
+                             "launch of a box that is alone in flight (its own X path runs beside it)" if lone
                              else "overlapped launch (timed region)"),
+            "kernel_ms_one_box_in_flight": a2_one_box_ms,
             "kernel_ms_overlapped": a2_launch_ms_overlapped,
             "launches_per_step": a2_n,
             "shares_per_launch": shares_per_a2_launch,

@@ -866,8 +866,11 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // tests only: one pipeline stage gives up and the flag falls -- 1 / 2: a stage of the stepping pipelines, 3: of the
   // stride-1 seeding chain, 4: of the table pipeline
   static const int inject_fault = fd_env("MPVSS_FD_TEST_FAULT", 0);
+  // MPVSS_FD_L1: 0 never, 1 (default) when other blocks are in flight, 2 always.  The second level saves 180 products per
+  // share and costs a serial chain (about 15 ms of a lone box's latency): a call that has the GPU to itself keeps the
+  // wide Horner launch for all S*t seeds.
   static const int two_level_env = fd_env("MPVSS_FD_L1", 1);
-  const bool two_level = two_level_env && S > 1;
+  const bool two_level = S > 1 && (two_level_env >= 2 || (two_level_env == 1 && mpvss_ctx::NSLOT - ctx->free_top >= 2));
   // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
   constexpr int G = 16;
   auto tree_sizes = [&](int m) {

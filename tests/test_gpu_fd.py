@@ -46,11 +46,13 @@ def run(cases, env_extra):
 
 
 def test_fd_equals_horner():
-    a = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_MIN_SHARES": "2048", "CHECK_ORACLE": "1"})
+    # MPVSS_FD_L1=2: two-level seeding (what pipelined boxes use); 0: Horner's rule for every seed (what a lone call uses)
+    a = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_MIN_SHARES": "2048", "CHECK_ORACLE": "1"})
     b = run(CASES, {"MPVSS_FD": "0"})
+    c = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_L1": "0", "MPVSS_FD_MIN_SHARES": "2048"})
     assert len(a) == len(CASES) and all(len(h) == 64 for h in a)
-    for case, ha, hb in zip(CASES, a, b):
-        assert ha == hb, case
+    for case, ha, hb, hc in zip(CASES, a, b, c):
+        assert ha == hb == hc, case
 
 
 @pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
@@ -64,7 +66,7 @@ def test_a_stage_that_gives_up_falls_back_to_horner(mode):
     b = run(case, {"MPVSS_FD": "0"})
     ref = time.time() - t0
     t0 = time.time()
-    a = run(case, {"MPVSS_FD": "1", "MPVSS_FD_TEST_FAULT": mode})
+    a = run(case, {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_TEST_FAULT": mode})
     took = time.time() - t0
     assert a == b and len(a[0]) == 64
     # poisoned stages must give up at once, not wait for their 2 s timeouts one after the other (16 stages per chain)
