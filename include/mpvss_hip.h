@@ -354,7 +354,8 @@ int mpvss_ec_reconstruct(mpvss_ctx* ctx, int group, int space, const int64_t* po
  * format is the boundary's own layout -- rows in `publickeys` order (the order src/participant.rs:408-448 iterates in),
  * fixed-width encodings -- so that a box can be handed to the engine, or cut into byte ranges for the ranks of a sharded
  * verification, without rebuilding maps.  Integers little-endian; every section starts at a multiple of 8 bytes
- * (zero padding); E = element bytes (256 / 33 / 32), S = scalar bytes (256 / 32 / 32):
+ * (zero padding, checked by the parser: an accepted buffer is its own serialisation); E = element bytes (256 / 33 / 32),
+ * S = scalar bytes (256 / 32 / 32):
  *   0  "MPVSSBX1"   8  u32 group (0 MODP-2048, 1 secp256k1, 2 ristretto255)   12  u32 E   16  u64 n   24  u64 t
  *   32 u64 u_len    40 commitments [t][E] | positions i64 [n] | publickeys [n][E] | shares [n][E] | responses [n][S] |
  *   challenge [S] | U (big-endian magnitude, u_len bytes).                          (full specification: INTEGRATION.md) */

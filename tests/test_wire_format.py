@@ -63,3 +63,45 @@ def test_empty_box_and_size_limits():
     lib = capi.load_library()
     assert lib.mpvss_box_wire_size(7, 1, 1, 0) == 0
     assert lib.mpvss_box_wire_size(0, 1 << 41, 1, 0) == 0
+
+
+def test_parser_never_trusts_the_header():
+    """The parser reads untrusted bytes: every accepted blob must be exactly one canonical box (sections inside the
+    buffer, re-serialising gives the same bytes), everything else must be refused -- no crash, no out-of-bounds view.
+    Random header mutations, truncations and extensions of valid blobs of the three groups, and random noise."""
+    import random
+    rng = random.Random(0xB0C5)
+    blobs = []
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.json"))):
+        fx, gid, box = fixture_box(path)
+        blobs.append(capi.box_serialize(gid, **box))
+    accepted = 0
+    for it in range(4000):
+        base = bytearray(rng.choice(blobs))
+        kind = it % 5
+        if kind == 0:                                   # a header field replaced by an arbitrary value
+            off = rng.choice((8, 12, 16, 24, 32))
+            width = 4 if off in (8, 12) else 8
+            val = rng.choice((0, 1, rng.randrange(1 << 16), rng.randrange(1 << (8 * width)), (1 << (8 * width)) - 1))
+            base[off:off + width] = val.to_bytes(width, "little")
+        elif kind == 1:                                 # truncated or extended
+            cut = rng.randrange(len(base) + 1)
+            base = base[:cut] + bytearray(rng.randbytes(rng.choice((0, 0, 1, 7, 64))))
+        elif kind == 2:                                 # a flipped bit anywhere
+            i = rng.randrange(len(base))
+            base[i] ^= 1 << rng.randrange(8)
+        elif kind == 3:                                 # noise behind a plausible magic
+            base = bytearray(b"MPVSSBX1" + rng.randbytes(rng.randrange(0, 200)))
+        else:                                           # padding bytes must be zero: spoil one byte of a header-implied gap
+            i = rng.randrange(40, len(base))
+            base[i] = (base[i] + rng.randrange(1, 256)) & 0xFF
+        wire = bytes(base)
+        try:
+            back = capi.box_parse(wire)
+        except capi.EngineError:
+            continue
+        accepted += 1
+        again = capi.box_serialize(back["group"], back["commitments"], back["positions"], back["pubkeys"], back["shares"],
+                                   back["responses"], back["challenge"], back["U"])
+        assert again == wire, (it, kind)                # canonical: an accepted blob is its own serialisation
+    assert accepted > 100                               # payload-only changes are still boxes
