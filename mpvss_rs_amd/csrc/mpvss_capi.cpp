@@ -852,6 +852,10 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // seeds are dear (t = 512: 4), never longer than 16384 members (n=131072, t=1024: 8)
   int S = fd_chains_env > 0 ? fd_chains_env
                             : (int)std::max<size_t>(std::max<size_t>(std::min<size_t>(2048 / t, cnt / 8192), cnt / 16384), 4);
+  // a call that has the GPU to itself: more, shorter chains -- the extra seeds are one wide launch on an idle chip, the
+  // stepping (the serial part) shrinks in proportion (MPVSS_FD_LONE_CHAINS, 0 = as in the pipelined case)
+  static const int lone_chains = fd_env("MPVSS_FD_LONE_CHAINS", 16);     // measured: 8 -> 109 ms per box, 16 -> 96.5, 32 -> 104, 64 -> 115
+  if (fd_chains_env <= 0 && lone_chains > S && mpvss_ctx::NSLOT - ctx->free_top < 2 && t <= 256) S = lone_chains;
   const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
   if (S > s_max) S = s_max;
   if (S < 1) S = 1;
