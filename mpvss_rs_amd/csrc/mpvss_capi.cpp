@@ -854,6 +854,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
                             : (int)std::max<size_t>(std::max<size_t>(std::min<size_t>(2048 / t, cnt / 8192), cnt / 16384), 4);
   // a call that has the GPU to itself: more, shorter chains -- the extra seeds are one wide launch on an idle chip, the
   // stepping (the serial part) shrinks in proportion (MPVSS_FD_LONE_CHAINS, 0 = as in the pipelined case)
+  const int S_pipelined = S;
   static const int lone_chains = fd_env("MPVSS_FD_LONE_CHAINS", 16);     // measured: 8 -> 109 ms per box, 16 -> 96.5, 32 -> 104, 64 -> 115
   if (fd_chains_env <= 0 && lone_chains > S && mpvss_ctx::NSLOT - ctx->free_top < 2 && t <= 256) S = lone_chains;
   const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
@@ -882,21 +883,41 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
     while (ms.back() > 1) ms.push_back((ms.back() + G - 1) / G);
     return ms;
   };
-  const std::vector<int> ms_all = tree_sizes(m0);
-  size_t pre_total = 0, tot_total = 0;
-  for (size_t l = 0; l + 1 < ms_all.size(); ++l) pre_total += (size_t)ms_all[l];
-  for (size_t l = 1; l < ms_all.size(); ++l) tot_total += (size_t)ms_all[l];
 
   mpvss_ctx::Work& w = *ctx->w;
   w.fd_used = true;
   RET_IF(ensure(ctx, w.fd_flag, 64));
   RET_IF(ensure(ctx, w.fd_root, 4 * EB));
   RET_IF(ensure(ctx, w.fd_xm, cnt * MODP_L * 4));
-  RET_IF(ensure(ctx, w.fd_xinv, (size_t)m0 * MODP_L * 4));
-  RET_IF(ensure(ctx, w.fd_pre, pre_total * MODP_L * 4));
-  RET_IF(ensure(ctx, w.fd_tot, tot_total * MODP_L * 4));
-  RET_IF(ensure(ctx, w.fd_totinv, tot_total * MODP_L * 4));
-  RET_IF(ensure(ctx, w.fd_state, (size_t)2 * m0 * MODP_L * 4));
+  // The configuration (chains, seeding levels) depends on whether other blocks are in flight, and a slot sees both
+  // over its life: the buffers are sized for the largest of them at once -- growing one later means hipFree, which
+  // waits for the device (58-87 ms inside the enqueue of a timed box, measured with MPVSS_TRACE_ENQUEUE).
+  struct FdBytes { size_t xinv = 0, pre = 0, tot = 0, state = 0, hand_t = 0, hand_s = 0; } need_b;
+  {
+    const int s_cap = (int)(cnt / (4 * t)) < 1 ? 1 : (int)(cnt / (4 * t));
+    int cands[3] = {S, std::min(S_pipelined, s_cap), (t <= 256 && lone_chains > 0) ? std::min(lone_chains, s_cap) : S};
+    for (int c = 0; c < 3; ++c) {
+      const int Sc = cands[c] < 1 ? 1 : cands[c];
+      const int m0c = (int)(Sc * t), clc = (int)((cnt + Sc - 1) / Sc);
+      const std::vector<int> msc = tree_sizes(m0c);
+      size_t prec = 0, totc = 0;
+      for (size_t l = 0; l + 1 < msc.size(); ++l) prec += (size_t)msc[l];
+      for (size_t l = 1; l < msc.size(); ++l) totc += (size_t)msc[l];
+      const size_t l1t = Sc > 1 ? modp_fd_table_hand_words(1, (int)t) * 4 : 0;
+      const size_t l1s = Sc > 1 ? modp_fd_step_hand_words(1, (int)t, m0c) * 4 : 0;
+      need_b.xinv = std::max(need_b.xinv, (size_t)m0c * MODP_L * 4);
+      need_b.pre = std::max(need_b.pre, prec * MODP_L * 4);
+      need_b.tot = std::max(need_b.tot, totc * MODP_L * 4);
+      need_b.state = std::max(need_b.state, (size_t)2 * m0c * MODP_L * 4);
+      need_b.hand_t = std::max(need_b.hand_t, modp_fd_table_hand_words(Sc, (int)t) * 4 + l1t);
+      need_b.hand_s = std::max(need_b.hand_s, modp_fd_step_hand_words(Sc, (int)t, clc) * 4 + l1s);
+    }
+  }
+  RET_IF(ensure(ctx, w.fd_xinv, need_b.xinv));
+  RET_IF(ensure(ctx, w.fd_pre, need_b.pre));
+  RET_IF(ensure(ctx, w.fd_tot, need_b.tot));
+  RET_IF(ensure(ctx, w.fd_totinv, need_b.tot));
+  RET_IF(ensure(ctx, w.fd_state, need_b.state));
   if (!w.root) return fail(ctx, MPVSS_E_DEVICE, "eval_x: workspace not initialised");
   int* flag = (int*)w.fd_flag.p;
   int* dok = flag + 1;
@@ -938,8 +959,8 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   const size_t hand_t = modp_fd_table_hand_words(S, (int)t) * 4, hand_s = modp_fd_step_hand_words(S, (int)t, chain_len) * 4;
   const size_t hand_t1 = two_level ? modp_fd_table_hand_words(1, (int)t) * 4 : 0;
   const size_t hand_s1 = two_level ? modp_fd_step_hand_words(1, (int)t, m0) * 4 : 0;
-  RET_IF(ensure(ctx, w.fd_hand_t, hand_t + hand_t1));
-  RET_IF(ensure(ctx, w.fd_hand_s, hand_s + hand_s1));
+  RET_IF(ensure(ctx, w.fd_hand_t, std::max(need_b.hand_t, hand_t + hand_t1)));
+  RET_IF(ensure(ctx, w.fd_hand_s, std::max(need_b.hand_s, hand_s + hand_s1)));
   w.root[0].one = 1;     // pinned: the copy below is asynchronous and reads it in stream order
   HIPCHK(ctx, hipMemcpyAsync(flag, &w.root[0].one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
@@ -1184,7 +1205,15 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     commitments = in + 3 * n * EB;
   }
   memcpy(sl.work.root->challenge, challenge_host, EB);
+  // MPVSS_TRACE_ENQUEUE=1: a block whose enqueueing took more than 3 ms reports where the time went (stderr)
+  static const int trace_enq = fd_env("MPVSS_TRACE_ENQUEUE", 0);
+  double marks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto mark = [&](int i) {
+    if (trace_enq) marks[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
+  };
+  mark(0);
   RET_IF(stage_commitments(ctx, space, commitments, t));
+  mark(1);
   const uint32_t* cg;
   RET_IF(comb_table(ctx, 0, &cg, n));
   RET_IF(ensure(ctx, ctx->w->in_e, EB));
@@ -1257,12 +1286,15 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         sliding_schedule(sl.work.root[0].challenge, hs);
         if (hs[0] > 0) {
           RET_IF(ensure(ctx, ctx->w->csched, sizeof(sl.work.root[0].csched)));
-          HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, hs, (1 + 2 * (size_t)hs[0]) * 2, hipMemcpyHostToDevice, ctx->stream));
           dsched = (const uint16_t*)ctx->w->csched.p;
         }
       }
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
+        // the schedule travels on THIS stream, ahead of a2; the a1 launch on the other stream waits for ev_gr, recorded below
+        if (dsched)
+          HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, sl.work.root[0].csched, (1 + 2 * (size_t)sl.work.root[0].csched[0]) * 2,
+                                     hipMemcpyHostToDevice, ctx->stream));
         uint32_t* t2p = (uint32_t*)ctx->w->tab2.p;
         if (dsched) TIMED_LAUNCH(ctx, 2, modp_launch_build_table_odd((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
         else TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
@@ -1297,7 +1329,9 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                              ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
+      mark(2);
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
+      mark(3);
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
         const uint32_t* tx;
@@ -1338,9 +1372,14 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     }
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
+  mark(4);
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
   sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
   sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
+  if (trace_enq && sl.enqueue_ms > 3.0)
+    fprintf(stderr, "[mpvss] slow enqueue %.1f ms: staging %.1f | commitments %.1f | tables+a2+g^r %.1f | X path %.1f | a1+copies %.1f | "
+            "event %.1f\n", sl.enqueue_ms, marks[0], marks[1] - marks[0], marks[2] - marks[1], marks[3] - marks[2],
+            marks[4] - marks[3], sl.enqueue_ms - marks[4]);
   ctx->commit_head(sl);
   return MPVSS_OK;
 }
