@@ -279,6 +279,8 @@ def main():
     commdev = torch.device("cpu")
     chain = dist.new_group(backend="gloo") if (world > 1 and not smoke_one_gpu) else None
 
+    if world > 1:
+        os.environ.setdefault("MPVSS_PIPELINED", "1")    # blocks driven from here are never alone on the GPU for long
     eng = capi.Engine(local_rank)     # raises if the HIP library or the GPU is missing
     lib, ctx = eng.lib, eng.ctx
     n, t = args.n, args.t

@@ -168,6 +168,11 @@ struct mpvss_ctx {
     for (unsigned i = 0; i < NSLOT; ++i) { ring[i] = -1; free_stack[i] = (int)(NSLOT - 1 - i); }
     full_slot.busy = true;
   }
+  // a run of many boxes is under way (mpvss_*_verify_many with more than two boxes, or the caller said so through
+  // MPVSS_PIPELINED=1): a block then never takes the configuration meant for a call that has the GPU to itself, not even
+  // the first ones of the run
+  bool pipelined_hint = false;
+  bool busy_with_others() const { return pipelined_hint || NSLOT - free_top >= 2; }
   BlockSlot& head_slot() {
     if (ring[head % NSLOT] >= 0 || free_top == 0) return full_slot;
     return slot[free_stack[free_top - 1]];
@@ -578,6 +583,7 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
     return MPVSS_E_DEVICE;
   }
   ctx->stream_b = ctx->work0.sb;
+  ctx->pipelined_hint = fd_env("MPVSS_PIPELINED", 0) != 0;
   *out = ctx;
   return MPVSS_OK;
 }
@@ -856,7 +862,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // stepping (the serial part) shrinks in proportion (MPVSS_FD_LONE_CHAINS, 0 = as in the pipelined case)
   const int S_pipelined = S;
   static const int lone_chains = fd_env("MPVSS_FD_LONE_CHAINS", 16);     // measured: 8 -> 109 ms per box, 16 -> 96.5, 32 -> 104, 64 -> 115
-  if (fd_chains_env <= 0 && lone_chains > S && mpvss_ctx::NSLOT - ctx->free_top < 2 && t <= 256) S = lone_chains;
+  if (fd_chains_env <= 0 && lone_chains > S && !ctx->busy_with_others() && t <= 256) S = lone_chains;
   const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
   if (S > s_max) S = s_max;
   if (S < 1) S = 1;
@@ -875,7 +881,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // share and costs a serial chain (about 15 ms of a lone box's latency): a call that has the GPU to itself keeps the
   // wide Horner launch for all S*t seeds.
   static const int two_level_env = fd_env("MPVSS_FD_L1", 1);
-  const bool two_level = S > 1 && (two_level_env >= 2 || (two_level_env == 1 && mpvss_ctx::NSLOT - ctx->free_top >= 2));
+  const bool two_level = S > 1 && (two_level_env >= 2 || (two_level_env == 1 && ctx->busy_with_others()));
   // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
   constexpr int G = 16;
   auto tree_sizes = [&](int m) {
@@ -1631,6 +1637,11 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   if (hash_threads > 8) hash_threads = 8;
   if (depth < 1) depth = 1;
   if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
+  struct Hint {
+    mpvss_ctx* c; bool was;
+    Hint(mpvss_ctx* c_, bool on) : c(c_) { std::lock_guard<std::mutex> lk(c->mu); was = c->pipelined_hint; if (on) c->pipelined_hint = true; }
+    ~Hint() { std::lock_guard<std::mutex> lk(c->mu); c->pipelined_hint = was; }
+  } hint(ctx, count > 2 && depth > 1);
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
