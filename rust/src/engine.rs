@@ -65,6 +65,30 @@ impl Engine {
         Err(EngineError { code: rc, message: msg })
     }
 
+    /// Blocks of the block API in flight in this context, and how many of them still have GPU work pending.
+    pub fn blocks_in_flight(&self) -> Result<(i32, i32), EngineError> {
+        let (mut a, mut b) = (0i32, 0i32);
+        self.check(unsafe { ffi::mpvss_blocks_in_flight(self.ctx.0, &mut a, &mut b) })?;
+        Ok((a, b))
+    }
+
+    /// Takes the oldest MODP distribution block in flight; the ticket counts the blocks of this context in enqueue
+    /// order.  For callers whose transcript state arrives from elsewhere (the previous rank of a sharded
+    /// verification): claim, fetch the state of box `ticket`, then `absorb_claimed`.
+    pub fn block_claim(&self) -> Result<u64, EngineError> {
+        let mut t: u64 = 0;
+        self.check(unsafe { ffi::mpvss_block_claim(self.ctx.0, &mut t) })?;
+        Ok(t)
+    }
+
+    /// Waits for the claimed block's GPU work and extends `state` (MPVSS_TRANSCRIPT_STATE_BYTES) with its shares.
+    pub fn absorb_claimed(&self, ticket: u64, state: &mut [u8]) -> Result<(), EngineError> {
+        assert!(state.len() >= ffi::MPVSS_TRANSCRIPT_STATE_BYTES);
+        self.check(unsafe {
+            ffi::mpvss_modp_verify_block_absorb_claimed(self.ctx.0, ticket, state.as_mut_ptr(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut())
+        })
+    }
+
     /// For trait methods that cannot return an error (`Group::exp`): a failing engine is a programmer / hardware
     /// error there, as a panic in the reference's arithmetic crates would be.
     pub(crate) fn expect(&self, rc: i32, what: &str) {

@@ -13,6 +13,7 @@ pub const MPVSS_HOST: c_int = 0;
 pub const MPVSS_DEVICE: c_int = 1;
 pub const MPVSS_MODP_BYTES: usize = 256;
 pub const MPVSS_TRANSCRIPT_STATE_BYTES: usize = 128;
+pub const MPVSS_BLOCK_SLOTS: usize = 64;
 pub const MPVSS_GROUP_SECP256K1: c_int = 1;
 pub const MPVSS_GROUP_RISTRETTO255: c_int = 2;
 
