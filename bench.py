@@ -632,229 +632,239 @@ def main():
         except Exception:
             pass
 
-    # ---------------- CPU baseline (rank 0, N == 1 only): the C port of the reference sequence ----------------
-    if rank == 0 and world == 1 and args.cpu_sample != 0:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        from concurrent.futures import ThreadPoolExecutor
+    # Everything below is secondary to the headline (`value`, `roofline`, `compute` are complete at this point): a failure
+    # there -- an allocation that does not fit, a parity gate of a secondary figure -- must not cost the line; it is
+    # reported in `secondary_error` and the process exits non-zero after printing.
+    secondary_error = None
+    try:
+        # ---------------- CPU baseline (rank 0, N == 1 only): the C port of the reference sequence ----------------
+        if rank == 0 and world == 1 and args.cpu_sample != 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from concurrent.futures import ThreadPoolExecutor
 
-        from modp_ref import ModpRef
-        ref = ModpRef()
-        # Threads that really run in parallel here (cpu_count() ignores cgroup quotas): calibrate with
-        # short full-width modpows, 1 thread vs many.
-        nthreads = min(os.cpu_count() or 1, 64)
-        bb, ee = int.from_bytes(commitments[:EB], "big"), ORDER - 12345
-        t1 = time.perf_counter(); ref.modpow(bb, ee); single = time.perf_counter() - t1
-        with ThreadPoolExecutor(max_workers=nthreads) as ex:
-            t1 = time.perf_counter()
-            list(ex.map(lambda _: ref.modpow(bb, ee), range(2 * nthreads)))
-            par = time.perf_counter() - t1
-        cores = max(1, min(nthreads, int(round(2 * nthreads * single / par))))
-        # one share costs ~(sum of exponent bits) * 1.5 Montgomery products; aim for ~15 s of wall time
-        est_share_s = single * (sum(min(17 * j, 2048) for j in range(t)) + 2 * 2048 + 2 * 256) / 2048.0
-        k = args.cpu_sample if args.cpu_sample > 0 else max(cores, min(8 * cores, int(15.0 * cores / max(est_share_s, 1e-3))))
-        k = min(k, n)
-        idx = sorted({int((j + 0.5) * n / k) for j in range(k)})
-        # GPU outputs for the sampled shares (one more, untimed, dumped verification)
-        X = (C.c_uint8 * (n * EB))(); A1 = (C.c_uint8 * (n * EB))(); A2 = (C.c_uint8 * (n * EB))()
-        v = C.c_int(0); dg = (C.c_uint8 * 32)()
-        eng._check(lib.mpvss_modp_verify_distribution(ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), vp(d_pk),
-                                                      vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p), C.byref(v),
-                                                      dg, X, A1, A2), "verify_distribution(dump)")
-        Xb, A1b, A2b = bytes(X), bytes(A1), bytes(A2)
+            from modp_ref import ModpRef
+            ref = ModpRef()
+            # Threads that really run in parallel here (cpu_count() ignores cgroup quotas): calibrate with
+            # short full-width modpows, 1 thread vs many.
+            nthreads = min(os.cpu_count() or 1, 64)
+            bb, ee = int.from_bytes(commitments[:EB], "big"), ORDER - 12345
+            t1 = time.perf_counter(); ref.modpow(bb, ee); single = time.perf_counter() - t1
+            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+                t1 = time.perf_counter()
+                list(ex.map(lambda _: ref.modpow(bb, ee), range(2 * nthreads)))
+                par = time.perf_counter() - t1
+            cores = max(1, min(nthreads, int(round(2 * nthreads * single / par))))
+            # one share costs ~(sum of exponent bits) * 1.5 Montgomery products; aim for ~15 s of wall time
+            est_share_s = single * (sum(min(17 * j, 2048) for j in range(t)) + 2 * 2048 + 2 * 256) / 2048.0
+            k = args.cpu_sample if args.cpu_sample > 0 else max(cores, min(8 * cores, int(15.0 * cores / max(est_share_s, 1e-3))))
+            k = min(k, n)
+            idx = sorted({int((j + 0.5) * n / k) for j in range(k)})
+            # GPU outputs for the sampled shares (one more, untimed, dumped verification)
+            X = (C.c_uint8 * (n * EB))(); A1 = (C.c_uint8 * (n * EB))(); A2 = (C.c_uint8 * (n * EB))()
+            v = C.c_int(0); dg = (C.c_uint8 * 32)()
+            eng._check(lib.mpvss_modp_verify_distribution(ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), vp(d_pk),
+                                                          vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p), C.byref(v),
+                                                          dg, X, A1, A2), "verify_distribution(dump)")
+            Xb, A1b, A2b = bytes(X), bytes(A1), bytes(A2)
 
-        def work(i):
-            s = slice(i * EB, (i + 1) * EB)
-            return ref.share_work(commitments, positions[i], pubkeys[s], shares[s], responses[s], challenge)
-        tc = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            outs = list(ex.map(work, idx))
-        cpu_s = time.perf_counter() - tc
-        for i, (x, a1, a2) in zip(idx, outs):
-            s = slice(i * EB, (i + 1) * EB)
-            assert (x, a1, a2) == (Xb[s], A1b[s], A2b[s]), f"GPU/CPU mismatch at share {i}"
-        result["cpu_baseline"] = {
-            "value": len(idx) / cpu_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
-            "sample": f"{len(idx)} of {n} shares (positions spread over [1,{n}], all t={t} commitments), "
-                      f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
-                      f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
-        }
-    # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
-    if world == 1 and args.host_boxes > 0:
-        pos_arr = (C.c_int64 * n)(*positions)
-        hb = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in (commitments, pubkeys, shares, responses)]
-        hbox = capi.ModpBox(C.addressof(hb[0]), t, C.addressof(pos_arr), C.addressof(hb[1]), C.addressof(hb[2]),
-                            C.addressof(hb[3]), n, C.cast(ch_buf, C.c_void_p), None, 0)
+            def work(i):
+                s = slice(i * EB, (i + 1) * EB)
+                return ref.share_work(commitments, positions[i], pubkeys[s], shares[s], responses[s], challenge)
+            tc = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                outs = list(ex.map(work, idx))
+            cpu_s = time.perf_counter() - tc
+            for i, (x, a1, a2) in zip(idx, outs):
+                s = slice(i * EB, (i + 1) * EB)
+                assert (x, a1, a2) == (Xb[s], A1b[s], A2b[s]), f"GPU/CPU mismatch at share {i}"
+            result["cpu_baseline"] = {
+                "value": len(idx) / cpu_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
+                "sample": f"{len(idx)} of {n} shares (positions spread over [1,{n}], all t={t} commitments), "
+                          f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
+                          f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
+            }
+        # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
+        if world == 1 and args.host_boxes > 0:
+            pos_arr = (C.c_int64 * n)(*positions)
+            hb = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in (commitments, pubkeys, shares, responses)]
+            hbox = capi.ModpBox(C.addressof(hb[0]), t, C.addressof(pos_arr), C.addressof(hb[1]), C.addressof(hb[2]),
+                                C.addressof(hb[3]), n, C.cast(ch_buf, C.c_void_p), None, 0)
 
-        def host_many(count):
-            arr = (capi.ModpBox * count)(*([hbox] * count))
-            vd = (C.c_int * count)()
-            dg = (C.c_uint8 * (32 * count))()
-            eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_HOST, arr, count, min(PIPE_DEPTH, capi.BLOCK_SLOTS), max(HASH_THREADS, 1), vd,
-                                                  C.cast(dg, C.c_void_p)), "verify_many(host)")
-            return all(vd[i] == 1 for i in range(count)) and all(bytes(dg)[32 * i:32 * i + 32] == dealer_digest for i in range(count))
+            def host_many(count):
+                arr = (capi.ModpBox * count)(*([hbox] * count))
+                vd = (C.c_int * count)()
+                dg = (C.c_uint8 * (32 * count))()
+                eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_HOST, arr, count, min(PIPE_DEPTH, capi.BLOCK_SLOTS), max(HASH_THREADS, 1), vd,
+                                                      C.cast(dg, C.c_void_p)), "verify_many(host)")
+                return all(vd[i] == 1 for i in range(count)) and all(bytes(dg)[32 * i:32 * i + 32] == dealer_digest for i in range(count))
 
-        assert host_many(16), "host-buffer boxes: verdict or digest wrong"      # every slot grows its pinned staging here
-        torch.cuda.synchronize()
-        t_h = time.perf_counter()
-        ok_h = host_many(args.host_boxes)
-        host_s = (time.perf_counter() - t_h) / args.host_boxes
-        assert ok_h, "host-buffer boxes: verdict or digest wrong"
-        result["host_buffers"] = {"value": n / host_s, "unit": "share verifications/s", "ms_per_box": host_s * 1e3,
-                                  "boxes": args.host_boxes,
-                                  "note": "same boxes, every input in pageable host memory: the library copies them into pinned "
-                                          "staging and over PCIe (3 x n x 256 B per box) inside the timed calls; not `value`"}
-    # ---------------- opt-in variant: registered public keys (include/mpvss_hip.h) ----------------
-    # NOT the headline: `value` above recomputes y_i^r_i from the bare keys in every step.  Here the per-key tables
-    # are built once (timed separately) and the same K steps are repeated against them -- the situation of a verifier
-    # that checks many dealers' boxes against one set of long-lived participant keys.
-    keyset_ok = False
-    if world == 1 and args.registered_keys:
-        tk = time.perf_counter()
-        h = C.c_void_p()
-        try:
-            eng._check(lib.mpvss_modp_keyset_create(ctx, capi.MPVSS_DEVICE, vp(d_pk), n, C.byref(h)), "keyset_create")
-            keyset_ok = True
-        except capi.EngineError as err:      # 622 KB per key: very large key sets do not fit beside the workspaces
-            result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
-    if keyset_ok:
-        try:
+            assert host_many(16), "host-buffer boxes: verdict or digest wrong"      # every slot grows its pinned staging here
             torch.cuda.synchronize()
-            build_s = time.perf_counter() - tk
-            keyset[0] = h
-            for verdict, digest in run_steps(min(args.warmup, 2)) if args.warmup > 0 else []:
-                assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys, warm-up)"
-            barrier()
-            t1 = time.perf_counter()
-            res_k = run_steps(args.steps)
-            barrier()
-            el_k = time.perf_counter() - t1
-            for verdict, digest in res_k:
-                assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys)"
-            keyset[0] = None
-            table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
-            lib.mpvss_modp_keyset_destroy(ctx, h)
-            mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 256 + 63 + 1)
-            result["registered_keys"] = {
-                "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
-                "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
-                "compute_frac": mm_k / (el_k / args.steps) / PEAK_MODMUL_PER_S,
-                "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)) in HBM, built once per key set, "
-                        "a2 = y^r Y^c in 571 products instead of 2620; same verdict and transcript digest; not the headline"}
-        except capi.EngineError as err:
-            keyset[0] = None
-            result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
+            t_h = time.perf_counter()
+            ok_h = host_many(args.host_boxes)
+            host_s = (time.perf_counter() - t_h) / args.host_boxes
+            assert ok_h, "host-buffer boxes: verdict or digest wrong"
+            result["host_buffers"] = {"value": n / host_s, "unit": "share verifications/s", "ms_per_box": host_s * 1e3,
+                                      "boxes": args.host_boxes,
+                                      "note": "same boxes, every input in pageable host memory: the library copies them into pinned "
+                                              "staging and over PCIe (3 x n x 256 B per box) inside the timed calls; not `value`"}
+        # ---------------- opt-in variant: registered public keys (include/mpvss_hip.h) ----------------
+        # NOT the headline: `value` above recomputes y_i^r_i from the bare keys in every step.  Here the per-key tables
+        # are built once (timed separately) and the same K steps are repeated against them -- the situation of a verifier
+        # that checks many dealers' boxes against one set of long-lived participant keys.
+        keyset_ok = False
+        if world == 1 and args.registered_keys:
+            tk = time.perf_counter()
+            h = C.c_void_p()
+            try:
+                eng._check(lib.mpvss_modp_keyset_create(ctx, capi.MPVSS_DEVICE, vp(d_pk), n, C.byref(h)), "keyset_create")
+                keyset_ok = True
+            except capi.EngineError as err:      # 622 KB per key: very large key sets do not fit beside the workspaces
+                result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
+        if keyset_ok:
+            try:
+                torch.cuda.synchronize()
+                build_s = time.perf_counter() - tk
+                keyset[0] = h
+                for verdict, digest in run_steps(min(args.warmup, 2)) if args.warmup > 0 else []:
+                    assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys, warm-up)"
+                barrier()
+                t1 = time.perf_counter()
+                res_k = run_steps(args.steps)
+                barrier()
+                el_k = time.perf_counter() - t1
+                for verdict, digest in res_k:
+                    assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys)"
+                keyset[0] = None
+                table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
+                lib.mpvss_modp_keyset_destroy(ctx, h)
+                mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 256 + 63 + 1)
+                result["registered_keys"] = {
+                    "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
+                    "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
+                    "compute_frac": mm_k / (el_k / args.steps) / PEAK_MODMUL_PER_S,
+                    "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)) in HBM, built once per key set, "
+                            "a2 = y^r Y^c in 571 products instead of 2620; same verdict and transcript digest; not the headline"}
+            except capi.EngineError as err:
+                keyset[0] = None
+                result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
 
-    # ---------------- C3 / C4: the curve groups at n=65536, t=256 (rank 0, N == 1) ----------------
-    if rank == 0 and world == 1 and args.ec_boxes > 0:
-        result["ec"] = {name: bench_ec(eng, name, args) for name in ("secp256k1", "ristretto255")}
+        # ---------------- C3 / C4: the curve groups at n=65536, t=256 (rank 0, N == 1) ----------------
+        if rank == 0 and world == 1 and args.ec_boxes > 0:
+            result["ec"] = {name: bench_ec(eng, name, args) for name in ("secp256k1", "ristretto255")}
 
-    # ---------------- W_B: decrypted-share verifications (participant.rs:361-386), SURVEY 8(d) ----------------
-    # Secondary figure, rank 0 at N=1 only, outside the timed region above: a bounded batch of share boxes
-    # (built with the engine's own extract_shares), inputs resident in HBM, verdicts checked.
-    if rank == 0 and world == 1 and args.wb_shares != 0:
-        m = min(n, args.wb_shares if args.wb_shares > 0 else 16384)
-        sl = slice(0, m * EB)
-        rng_w = random.Random(SEED + 7)
-        wit_b = [keygen(rng_w) for _ in range(m)]
-        xinv = b"".join(fx(pow(x, -1, ORDER)) for x in privs[:m])
-        wit_bytes_b = b"".join(map(fx, wit_b))
-        S, cb = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)            # also warms the path up
-        t_x = time.perf_counter()
-        S2, cb2 = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
-        extract_s = time.perf_counter() - t_x
-        assert (S2, cb2) == (S, cb)
-        result["extract_shares"] = {"value": m / extract_s, "unit": "shares decrypted and proven/s", "batch": m,
-                                    "note": "extract_secret_share for `batch` participants in one synchronous call, host buffers "
-                                            "(participant.rs:294-353): S_i = Y_i^(1/x_i), a1 = G^w_i, a2 = S_i^w_i and the per-share "
-                                            "challenge hash; two dependent full-width exponentiations per share"}
-        rb = b"".join(fx((w - x * int.from_bytes(cb[i * EB:(i + 1) * EB], "big")) % ORDER)
-                      for i, (w, x) in enumerate(zip(wit_b, privs[:m])))                      # dleq.rs:42-50
-        d_S, d_cb, d_rb = dev_u8(S), dev_u8(cb), dev_u8(rb)
-        verd = (C.c_uint8 * m)()
-        torch.cuda.synchronize()
-        reps = 3
-        for it in range(reps + 1):
-            if it == 1:
-                tw = time.perf_counter()
-            eng._check(lib.mpvss_modp_verify_shares(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb), vp(d_rb),
-                                                    m, verd), "verify_shares")
-        wb_s = (time.perf_counter() - tw) / reps
-        assert bytes(verd) == b"\x01" * m, "verify_share verdicts"
-        # the block form: several batches in flight in ONE context (compute = enqueue only, absorb = wait + n verdict bytes)
-        inflight, batches = 4, 12
-        d_verd = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+        # ---------------- W_B: decrypted-share verifications (participant.rs:361-386), SURVEY 8(d) ----------------
+        # Secondary figure, rank 0 at N=1 only, outside the timed region above: a bounded batch of share boxes
+        # (built with the engine's own extract_shares), inputs resident in HBM, verdicts checked.
+        if rank == 0 and world == 1 and args.wb_shares != 0:
+            m = min(n, args.wb_shares if args.wb_shares > 0 else 16384)
+            sl = slice(0, m * EB)
+            rng_w = random.Random(SEED + 7)
+            wit_b = [keygen(rng_w) for _ in range(m)]
+            xinv = b"".join(fx(pow(x, -1, ORDER)) for x in privs[:m])
+            wit_bytes_b = b"".join(map(fx, wit_b))
+            S, cb = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)            # also warms the path up
+            t_x = time.perf_counter()
+            S2, cb2 = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
+            extract_s = time.perf_counter() - t_x
+            assert (S2, cb2) == (S, cb)
+            result["extract_shares"] = {"value": m / extract_s, "unit": "shares decrypted and proven/s", "batch": m,
+                                        "note": "extract_secret_share for `batch` participants in one synchronous call, host buffers "
+                                                "(participant.rs:294-353): S_i = Y_i^(1/x_i), a1 = G^w_i, a2 = S_i^w_i and the per-share "
+                                                "challenge hash; two dependent full-width exponentiations per share"}
+            rb = b"".join(fx((w - x * int.from_bytes(cb[i * EB:(i + 1) * EB], "big")) % ORDER)
+                          for i, (w, x) in enumerate(zip(wit_b, privs[:m])))                      # dleq.rs:42-50
+            d_S, d_cb, d_rb = dev_u8(S), dev_u8(cb), dev_u8(rb)
+            verd = (C.c_uint8 * m)()
+            torch.cuda.synchronize()
+            reps = 3
+            for it in range(reps + 1):
+                if it == 1:
+                    tw = time.perf_counter()
+                eng._check(lib.mpvss_modp_verify_shares(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb), vp(d_rb),
+                                                        m, verd), "verify_shares")
+            wb_s = (time.perf_counter() - tw) / reps
+            assert bytes(verd) == b"\x01" * m, "verify_share verdicts"
+            # the block form: several batches in flight in ONE context (compute = enqueue only, absorb = wait + n verdict bytes)
+            inflight, batches = 4, 12
+            d_verd = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(inflight)]
 
-        def wb_pipelined(count):
-            issued = done = 0
-            while done < count:
-                while issued < count and issued - done < inflight:
-                    eng._check(lib.mpvss_modp_verify_shares_compute(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb),
-                                                                    vp(d_rb), m, vp(d_verd[issued % inflight])), "verify_shares_compute")
-                    issued += 1
-                eng._check(lib.mpvss_modp_verify_shares_absorb(ctx, verd), "verify_shares_absorb")
-                assert bytes(verd) == b"\x01" * m, "verify_share verdicts (block API)"
-                done += 1
+            def wb_pipelined(count):
+                issued = done = 0
+                while done < count:
+                    while issued < count and issued - done < inflight:
+                        eng._check(lib.mpvss_modp_verify_shares_compute(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb),
+                                                                        vp(d_rb), m, vp(d_verd[issued % inflight])), "verify_shares_compute")
+                        issued += 1
+                    eng._check(lib.mpvss_modp_verify_shares_absorb(ctx, verd), "verify_shares_absorb")
+                    assert bytes(verd) == b"\x01" * m, "verify_share verdicts (block API)"
+                    done += 1
 
-        wb_pipelined(inflight)                                # slot workspaces
-        torch.cuda.synchronize()
-        tw = time.perf_counter()
-        wb_pipelined(batches)
-        torch.cuda.synchronize()
-        wbp_s = (time.perf_counter() - tw) / batches
-        assert all(bool((dv == 1).all()) for dv in d_verd), "device verdict tensors"
-        result["verify_share"] = {"value": m / wbp_s, "unit": "share-box verifications/s", "batch": m,
-                                  "batches_in_flight": inflight, "value_synchronous_calls": m / wb_s,
-                                  "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c and the per-share SHA-256 verdict (K7) on the device; "
-                                          "inputs resident in HBM; `value`: mpvss_modp_verify_shares_compute/_absorb with "
-                                          f"{inflight} batches in flight in one context, verdict bytes also left in device tensors; "
-                                          "`value_synchronous_calls`: one mpvss_modp_verify_shares call at a time"}
-    if world == 1:
-        # dealer side in block form: inputs resident in HBM, DEAL_DEPTH boxes in flight, X_i = g^P(i) through the comb,
-        # host hashing of the oldest box beside the GPU work of the next ones; plus the scalar side of one box
-        # (P(i), responses) behind the C ABI, timed separately
-        d_pv, d_wt = dev_u8(pv_bytes), dev_u8(wit_bytes)
-        deal_depth, deal_boxes = 8, 12
+            wb_pipelined(inflight)                                # slot workspaces
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            wb_pipelined(batches)
+            torch.cuda.synchronize()
+            wbp_s = (time.perf_counter() - tw) / batches
+            assert all(bool((dv == 1).all()) for dv in d_verd), "device verdict tensors"
+            result["verify_share"] = {"value": m / wbp_s, "unit": "share-box verifications/s", "batch": m,
+                                      "batches_in_flight": inflight, "value_synchronous_calls": m / wb_s,
+                                      "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c and the per-share SHA-256 verdict (K7) on the device; "
+                                              "inputs resident in HBM; `value`: mpvss_modp_verify_shares_compute/_absorb with "
+                                              f"{inflight} batches in flight in one context, verdict bytes also left in device tensors; "
+                                              "`value_synchronous_calls`: one mpvss_modp_verify_shares call at a time"}
+        if world == 1:
+            # dealer side in block form: inputs resident in HBM, DEAL_DEPTH boxes in flight, X_i = g^P(i) through the comb,
+            # host hashing of the oldest box beside the GPU work of the next ones; plus the scalar side of one box
+            # (P(i), responses) behind the C ABI, timed separately
+            d_pv, d_wt = dev_u8(pv_bytes), dev_u8(wit_bytes)
+            deal_depth, deal_boxes = 8, 12
 
-        def deal_absorb():
-            st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
-            eng._check(lib.mpvss_modp_distribute_absorb(ctx, st, None, None, None, None), "distribute_absorb")
-            return capi.transcript_verdict(bytes(st), bytes(EB))[1]
+            def deal_absorb():
+                st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+                eng._check(lib.mpvss_modp_distribute_absorb(ctx, st, None, None, None, None), "distribute_absorb")
+                return capi.transcript_verdict(bytes(st), bytes(EB))[1]
 
-        def deal_pipelined(count):
-            issued = 0
-            pend, digests = collections.deque(), []
-            while issued < count or pend:
-                if issued < count and len(pend) < deal_depth:
-                    eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pv), vp(d_wt), n,
-                                                                 None, None, None, None), "distribute_compute")
-                    issued += 1
-                    pend.append(hash_pool.submit(deal_absorb))        # absorbs take the blocks in FIFO order
-                else:
-                    digests.append(pend.popleft().result())
-            return digests
+            def deal_pipelined(count):
+                issued = 0
+                pend, digests = collections.deque(), []
+                while issued < count or pend:
+                    if issued < count and len(pend) < deal_depth:
+                        eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pv), vp(d_wt), n,
+                                                                     None, None, None, None), "distribute_compute")
+                        issued += 1
+                        pend.append(hash_pool.submit(deal_absorb))        # absorbs take the blocks in FIFO order
+                    else:
+                        digests.append(pend.popleft().result())
+                return digests
 
-        deal_pipelined(16)                 # every slot's workspace grows to the dealer's size here
-        torch.cuda.synchronize()
-        t_d = time.perf_counter()
-        dg = deal_pipelined(deal_boxes)
-        torch.cuda.synchronize()
-        deal_blk_s = (time.perf_counter() - t_d) / deal_boxes
-        if world == 1 and rank == 0:
-            assert all(x == dealer_digest for x in dg), "dealer block API: transcript digest differs"
-        t_s = time.perf_counter()
-        pv2 = capi.poly_eval(0, b"".join(fx(a) for a in coeffs), positions)
-        rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)
-        scalar_s = time.perf_counter() - t_s
-        assert pv2 == pv_bytes and rs2 == responses, "scalar side (C ABI) differs from the Python integers"
-        result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
-                                "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
-                                "scalar_side_ms_per_box": scalar_s * 1e3,
-                                "note": "dealer side of distribute_secret (participant.rs:160-286): X_i = g^P(i), Y_i = y_i^P(i), "
-                                        "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
-                                        "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
-                                        "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
-                                        "PCIe included); scalar_side: P(i) and the responses for one box through "
-                                        "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`"}
+            deal_pipelined(16)                 # every slot's workspace grows to the dealer's size here
+            torch.cuda.synchronize()
+            t_d = time.perf_counter()
+            dg = deal_pipelined(deal_boxes)
+            torch.cuda.synchronize()
+            deal_blk_s = (time.perf_counter() - t_d) / deal_boxes
+            if world == 1 and rank == 0:
+                assert all(x == dealer_digest for x in dg), "dealer block API: transcript digest differs"
+            t_s = time.perf_counter()
+            pv2 = capi.poly_eval(0, b"".join(fx(a) for a in coeffs), positions)
+            rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)
+            scalar_s = time.perf_counter() - t_s
+            assert pv2 == pv_bytes and rs2 == responses, "scalar side (C ABI) differs from the Python integers"
+            result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
+                                    "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
+                                    "scalar_side_ms_per_box": scalar_s * 1e3,
+                                    "note": "dealer side of distribute_secret (participant.rs:160-286): X_i = g^P(i), Y_i = y_i^P(i), "
+                                            "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
+                                            "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
+                                            "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
+                                            "PCIe included); scalar_side: P(i) and the responses for one box through "
+                                            "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`"}
+    except Exception as exc:      # noqa: BLE001 - reported in the line and through the exit code
+        import traceback
+        secondary_error = "".join(traceback.format_exception_only(type(exc), exc)).strip()
+        result["secondary_error"] = secondary_error
+        traceback.print_exc()
     fd_blocks, fd_fallbacks = eng.fd_stats()
     result["compute"]["fd_blocks"] = fd_blocks
     result["compute"]["fd_fallbacks"] = fd_fallbacks          # boxes whose pipeline gave up and were recomputed by Horner
@@ -863,6 +873,8 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+    if secondary_error:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":
