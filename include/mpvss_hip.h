@@ -301,6 +301,16 @@ int mpvss_ec_distribute(mpvss_ctx* ctx, int group, int space, const uint8_t* com
                         const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
                         const uint8_t* witnesses, size_t n, uint8_t* x_out, uint8_t* y_out, uint8_t* a1_out,
                         uint8_t* a2_out, uint8_t* digest32_out);
+/* The same as a block (the verifier's slots, staging layout and absorbing hash; mpvss_ec_transcript_verdict(state, zero
+ * challenge) yields the dealer's digest): compute enqueues, absorb waits, validates, hashes and hands out X, Y, a1, a2.
+ * commitments == NULL: X_i = P(i) * G through the fixed-base comb (the dealer knows the polynomial; positions unused).
+ * *_dev_out (MPVSS_DEVICE only, optional): the results also stay in HBM. */
+int mpvss_ec_distribute_compute(mpvss_ctx* ctx, int group, int space, const uint8_t* commitments, size_t t,
+                                const int64_t* positions, const uint8_t* pubkeys, const uint8_t* p_values,
+                                const uint8_t* witnesses, size_t n, uint8_t* x_dev_out, uint8_t* y_dev_out,
+                                uint8_t* a1_dev_out, uint8_t* a2_dev_out);
+int mpvss_ec_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,
+                               uint8_t* a1_out_host, uint8_t* a2_out_host);
 /* Group::hash_to_scalar(data), host only; out32 in the group's scalar byte order */
 int mpvss_ec_hash_to_scalar(int group, const uint8_t* data, size_t len, uint8_t out32[32]);
 

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_block_claim", "mpvss_modp_verify_block_absorb_claimed",
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
-    "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_hash_to_scalar",
+    "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_distribute_compute", "mpvss_ec_distribute_absorb", "mpvss_ec_hash_to_scalar",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
@@ -143,6 +143,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_verify_shares_compute.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_ec_verify_shares_absorb.argtypes = [vp, u8p]
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_distribute_compute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_distribute_absorb.argtypes = [vp, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
     lib.mpvss_ec_batch_exp_generator.argtypes = [vp, ci, ci, u8p, sz, u8p]
     lib.mpvss_box_wire_size.argtypes = [ci, sz, sz, sz]
@@ -524,6 +526,28 @@ class Engine:
         self._check(self.lib.mpvss_ec_verify_shares(self.ctx, group, MPVSS_HOST, k[0][1], k[1][1], k[2][1], k[3][1],
                                                     k[4][1], n, pv), "ec_verify_shares")
         return bytes(kv)[:n]
+
+    def ec_distribute_compute(self, group: int, commitments: Optional[bytes], positions: Optional[Sequence[int]],
+                              pubkeys: bytes, p_values: bytes, witnesses: bytes) -> int:
+        """Enqueue one dealer block of a curve group (returns its size).  commitments None: X_i = p_i * G."""
+        e = EC_ENC[group]
+        n = len(pubkeys) // e
+        t = len(commitments) // e if commitments else 0
+        kc, pc = _buf(commitments) if commitments else (None, None)
+        ky, py = _buf(pubkeys); kp, pp = _buf(p_values); kw, pw = _buf(witnesses)
+        pos = (C.c_int64 * max(n, 1))(*(positions or [0] * n))
+        self._check(self.lib.mpvss_ec_distribute_compute(self.ctx, group, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pp, pw,
+                                                         n, None, None, None, None), "ec_distribute_compute")
+        return n
+
+    def ec_distribute_absorb(self, group: int, state: bytes, n: int):
+        """(state, X, Y, a1, a2) of the oldest dealer block"""
+        e = EC_ENC[group]
+        ks, ps = _buf(state)
+        outs = [_out(n * e) for _ in range(4)]
+        self._check(self.lib.mpvss_ec_distribute_absorb(self.ctx, ps, outs[0][1], outs[1][1], outs[2][1], outs[3][1]),
+                    "ec_distribute_absorb")
+        return (bytes(ks),) + tuple(bytes(o[0])[: n * e] for o in outs)
 
     def ec_verify_shares_compute(self, group: int, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes,
                                  verdicts_dev_ptr: int = 0) -> int:

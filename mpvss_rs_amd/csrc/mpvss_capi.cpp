@@ -140,6 +140,7 @@ struct mpvss_ctx {
     bool claimed = false;          // taken by mpvss_block_claim, its absorb call has not started yet
     unsigned ticket = 0;           // value of `tail` when the block was claimed
     unsigned ring_pos = 0;         // ring position the block occupies
+    bool dealer = false;           // kind 2: a dealer's block (flag [1] = polynomial values, [2] = witnesses; t may be 0)
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
@@ -1628,7 +1629,7 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
 namespace {
 
 int ec_verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
-                                  uint8_t* a1_out, uint8_t* a2_out);     // capi_ec.inc
+                                  uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out);     // capi_ec.inc
 
 // issue(b): enqueue box b (called with the context lock held); finish(idx, state): verdict of box idx from its state
 template <class Issue, class Finish>
@@ -1673,7 +1674,7 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
         std::unique_lock<std::mutex> lk(ctx->mu);
         idx = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
         const int kind = ctx->ring_slot(ctx->tail).kind;
-        rc = kind == 2 ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr)
+        rc = kind == 2 ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr)
                        : verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
       }
       if (rc == MPVSS_OK && idx < count) rc = finish(idx, state);
@@ -1957,7 +1958,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
                                     uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out) {
   if (n > 0 && (!pubkeys || !p_values || !witnesses || (commitments && (!positions || t == 0 || t > 0x7fffffff))))
     return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
-  if (commitments && t > n) return fail(ctx, MPVSS_E_INVALID, "distribute: threshold > number of public keys (participant.rs:166)");
+  // (threshold > n is the whole box's business -- mpvss_modp_distribute checks it; a block of a box may be smaller)
   mpvss_ctx::BlockSlot& sl = ctx->head_slot();
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "distribute: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();

@@ -156,6 +156,11 @@ unsafe extern "C" {
     pub fn mpvss_ec_distribute(ctx: *mut mpvss_ctx, group: c_int, space: c_int, commitments: *const u8, t: usize, positions: *const i64,
                                pubkeys: *const u8, p_values: *const u8, witnesses: *const u8, n: usize, x_out: *mut u8, y_out: *mut u8,
                                a1_out: *mut u8, a2_out: *mut u8, digest32_out: *mut u8) -> c_int;
+    pub fn mpvss_ec_distribute_compute(ctx: *mut mpvss_ctx, group: c_int, space: c_int, commitments: *const u8, t: usize,
+        positions: *const i64, pubkeys: *const u8, p_values: *const u8, witnesses: *const u8, n: usize,
+        x_dev_out: *mut u8, y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
+    pub fn mpvss_ec_distribute_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, y_out_host: *mut u8,
+        a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
     pub fn mpvss_ec_hash_to_scalar(group: c_int, data: *const u8, len: usize, out32: *mut u8) -> c_int;
     // ---- extract_secret_share, batched
     pub fn mpvss_modp_extract_shares(ctx: *mut mpvss_ctx, space: c_int, pk: *const u8, y: *const u8, xinv: *const u8, w: *const u8, n: usize,

@@ -310,3 +310,49 @@ def test_ec_verify_many_batches_the_x_paths_of_several_boxes(engine, name):
                                                   C.cast(out, C.c_void_p)), "ec_verify_many(device)")
     raw = bytes(out)
     assert [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(len(seq))] == one_by_one
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
+def test_ec_dealer_blocks(engine, name):
+    """Dealer side of distribute_secret for the curve groups in compute / absorb form (participant.rs:1094-1274,
+    1573-1717): several blocks in flight; X from the commitments or as P(i) * G through the comb (commitments None);
+    outputs and transcript digest equal to the synchronous call and to the oracle's box; one box as two blocks carries
+    the hash state; a witness that is no scalar is reported by the absorbing call and the context stays usable."""
+    fx = json.load(open(os.path.join(HERE, "golden", f"{name}_n8_t4.json")))
+    G, gid = mk(name)
+    order = G.group_order_int()
+    L = G.elem_len
+    sb = G.scalar_to_fixed
+    coeffs = [int(c, 16) for c in fx["inputs"]["coefficients"]]
+    wits = [int(x, 16) for x in fx["inputs"]["witnesses"]]
+    b = fx["box"]
+    cat = lambda hs: bytes.fromhex("".join(hs))
+    cm, pks, positions = cat(b["commitments"]), cat(b["publickeys"]), b["positions"]
+    n = len(positions)
+    pvals = [sum(c * pow(p, j, order) for j, c in enumerate(coeffs)) % order for p in positions]
+    pv, wt = b"".join(map(sb, pvals)), b"".join(map(sb, wits))
+    want = engine.ec_distribute(gid, cm, positions, pks, pv, wt)
+    assert want["Y"] == cat(b["shares"]) and want["digest"] == bytes.fromhex(fx["expected"]["transcript_digest"])
+    engine.ec_distribute_compute(gid, cm, positions, pks, pv, wt)
+    engine.ec_distribute_compute(gid, None, None, pks, pv, wt)
+    for _ in range(2):
+        st, X, Y, a1, a2 = engine.ec_distribute_absorb(gid, capi.transcript_init(), n)
+        assert (X, Y, a1, a2) == (want["X"], want["Y"], want["a1"], want["a2"])
+        assert capi.ec_transcript_verdict(gid, st, bytes(32))[1] == want["digest"]
+    cut = 3
+    engine.ec_distribute_compute(gid, cm, positions[:cut], pks[:cut * L], pv[:cut * 32], wt[:cut * 32])
+    engine.ec_distribute_compute(gid, None, None, pks[cut * L:], pv[cut * 32:], wt[cut * 32:])
+    st = capi.transcript_init()
+    st, X1, Y1, _, _ = engine.ec_distribute_absorb(gid, st, cut)
+    st, X2, Y2, _, _ = engine.ec_distribute_absorb(gid, st, n - cut)
+    assert X1 + X2 == want["X"] and Y1 + Y2 == want["Y"]
+    assert capi.ec_transcript_verdict(gid, st, bytes(32))[1] == want["digest"]
+    big = order.to_bytes(32, "big" if name == "secp256k1" else "little")
+    engine.ec_distribute_compute(gid, cm, positions, pks, pv, wt[:64] + big + wt[96:])
+    engine.ec_distribute_compute(gid, cm, positions, pks, pv, wt)
+    with pytest.raises(capi.EngineError, match="witnesses: scalar 2"):
+        engine.ec_distribute_absorb(gid, capi.transcript_init(), n)
+    st, X, _, _, _ = engine.ec_distribute_absorb(gid, capi.transcript_init(), n)
+    assert X == want["X"]
+    with pytest.raises(capi.EngineError, match="threshold"):
+        engine.ec_distribute(gid, cm, positions[:2], pks[:2 * L], pv[:64], wt[:64])              # a whole box with t = 4 > n = 2
