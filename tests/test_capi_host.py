@@ -71,3 +71,16 @@ def test_rust_ffi_declares_the_exported_symbols():
     declared = set(re.findall(r"pub fn (mpvss_\w+)\(", ffi))
     from mpvss_rs_amd import EXPORTED_SYMBOLS
     assert declared == set(EXPORTED_SYMBOLS), (sorted(declared - set(EXPORTED_SYMBOLS)), sorted(set(EXPORTED_SYMBOLS) - declared))
+
+
+def test_header_is_plain_c_and_cxx():
+    """The boundary is a C ABI: include/mpvss_hip.h must compile on its own as C99 and as C++11 (what cgo / bindgen /
+    a C++ host would feed it to), without warnings."""
+    import shutil
+    import subprocess
+    header = os.path.join(ROOT, "include", "mpvss_hip.h")
+    for cc, args in (("gcc", ["-std=c99", "-x", "c", "-pedantic"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        out = subprocess.run([cc, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", *args, header], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
