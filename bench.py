@@ -276,7 +276,7 @@ def main():
                     help="also time the opt-in registered-key variant at N=1 (0: skip)")
     ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
     ap.add_argument("--ec-boxes", type=int, default=64, help="boxes timed per curve group for the `ec` objects (0: skip)")
-    ap.add_argument("--host-boxes", type=int, default=8, help="boxes verified from HOST buffers (PCIe included) for the "
+    ap.add_argument("--host-boxes", type=int, default=20, help="boxes verified from HOST buffers (PCIe included) for the "
                     "`host_buffers` figure (0: skip)")
     ap.add_argument("--ec-n", type=int, default=65536)
     ap.add_argument("--ec-t", type=int, default=256)
