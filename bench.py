@@ -14,6 +14,48 @@ must verify (verdict True) and reproduce the dealer's transcript digest or the r
 Prints ONE JSON line on rank 0.
 """
 import os as _os
+import sys as _sys
+
+
+def _launch_own_ranks():
+    """`python3 bench.py --gpus N` (N > 1) without a launcher around it: start the N ranks ourselves, as a CHILD
+    process (`python -m torch.distributed.run --nproc-per-node N bench.py ...`), relay rank 0's JSON line and exit with
+    the child's code.  This runs before torch or the engine library is imported, i.e. before anything in this process
+    can have touched the GPU (a process that has initialised HIP must not exec or fork GPU work on this pool)."""
+    if "WORLD_SIZE" in _os.environ or "RANK" in _os.environ:
+        return
+    n = 1
+    argv = _sys.argv[1:]
+    for k, a in enumerate(argv):
+        if a == "--gpus" and k + 1 < len(argv):
+            n = int(argv[k + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(_os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), _os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:          # rank 0 prints ONE JSON line; anything else on stdout goes to stderr
+        if line.startswith("{\"metric\""):
+            _sys.stdout.write(line)
+            _sys.stdout.flush()
+        else:
+            _sys.stderr.write(line)
+    raise SystemExit(proc.wait())
+
+
+if __name__ == "__main__":
+    _launch_own_ranks()
 
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
 # run one after the other.  Every box in flight has its own stream pair, so 8 queues let the latency-bound launches
@@ -265,6 +307,82 @@ def bench_ec(eng, name, args):
     return out
 
 
+def inv_tree_products(m):                                         # simultaneous inversion: 3 products per node
+    total = 0
+    while m > 1:
+        total += 3 * m
+        m = -(-m // 16)
+    return total
+
+
+def sliding_windows(c):
+    """(windows, bit position of the lowest bit of the top window) of the width-4 sliding-window schedule the library
+    makes from a challenge (sliding_schedule in mpvss_capi.cpp)"""
+    c_win, c_top, i = 0, 0, 255
+    while i >= 0:
+        if not (c >> i) & 1:
+            i -= 1
+            continue
+        low = max(i - 3, 0)
+        while not (c >> low) & 1:
+            low += 1
+        c_top = low if c_win == 0 else c_top
+        c_win += 1
+        i = low - 1
+    return c_win, c_top
+
+
+def modp_work(n, t, positions, cs):
+    """Montgomery products (a squaring counts SQ_COST) the kernels execute for ONE verification of a block of n shares at
+    `positions` with t commitments, averaged over the challenges `cs` of the timed boxes; mirrors the choices of
+    eval_x() / verify_block_compute_locked() in mpvss_capi.cpp for a block that is part of a pipelined run."""
+    fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "4096"))
+    if fd:
+        chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(min(2048 // t, n // 8192), n // 16384, 4),
+                            n // (4 * t)))                                   # as eval_x() in mpvss_capi.cpp
+        chain_len = -(-n // chains)
+        w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
+        m0 = chains * t                                                  # the seeds: m0 consecutive positions
+        steps = (chain_len - 1 - w0) + (w0 + t - 1)                      # forward + backward pipeline of every chain
+        two_level = os.environ.get("MPVSS_FD_L1", "1") != "0" and chains > 1
+        if two_level:     # Horner for t seeds only; a stride-1 chain steps through the other (chains-1)*t seed positions
+            seed_work = (horner_modmuls(positions[chains * w0:chains * w0 + t], t) + inv_tree_products(t) + t * (t - 1)
+                         + t * (m0 - 1))
+            seed_txt = f"{t} Horner seeds, a stride-1 chain through the other {m0 - t} seed positions"
+        else:
+            seed_work = horner_modmuls(positions[chains * w0:chains * w0 + m0], t)
+            seed_txt = f"{m0} Horner seeds"
+        mm_x = seed_work + inv_tree_products(m0) + chains * t * (t - 1) + chains * t * steps + n
+        x_path = (f"forward differences: {chains} strided chains stepping both ways from {m0} seeds in their middle "
+                  f"(also outputs; {seed_txt}), inverses by simultaneous inversion, {steps} lock-step products per chain and level")
+    else:
+        mm_x = horner_modmuls(positions, t) + n
+        x_path = "Horner in the exponent"
+    comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
+    gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
+    w6 = os.environ.get("MPVSS_A2_W6", "1") != "0" and n >= 1024   # 6-bit windows for y^r (64-entry table) or 4-bit
+    # X^c and Y^c: 64 fixed 4-bit windows, or -- one c for the whole box, forward-difference path -- the sliding-window
+    # schedule the library makes from it (width 4, odd digits; the tables of X and Y then hold the odd powers only)
+    tot_a2 = tot_dual = tot_tab = 0.0
+    for c in cs:
+        sliding = fd and w6 and os.environ.get("MPVSS_C_SLIDING", "1") != "0" and c > 0
+        c_win, c_top = sliding_windows(c) if sliding else (0, 0)
+        yc = c_win if sliding else 64                          # products with the table of Y (a2) / X (a1; its first is a load)
+        xc_sq, xc = (c_top, c_win - 1) if sliding else (252, 63)
+        a2_products = (2046 * SQ_COST + 341 + yc + 1) if w6 else (2044 * SQ_COST + 511 + 64 + 1)
+        tot_a2 += a2_products
+        tot_dual += n * (a2_products + (xc_sq * SQ_COST + xc + 1 + gr + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
+        tab_xy = (8 + SQ_COST) if sliding else 15              # conversion + b^2 + seven odd powers, or conversion + 14 powers
+        tot_tab += n * (2 * tab_xy + (63 if w6 else 15))       # window tables of X, Y and y (+1 conversion each)
+    k = max(len(cs), 1)
+    return {"mm_total": mm_x + tot_dual / k + tot_tab / k, "mm_x": mm_x, "x_path": x_path, "a2_products": tot_a2 / k, "w6": w6, "fd": fd}
+
+
+class Box:
+    """One dealer's box as this rank holds it: its block of the shares resident in HBM plus what the checks need."""
+    pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +390,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--participants", dest="n", type=int, default=65536, help="participants per GPU")
     ap.add_argument("--threshold", dest="t", type=int, default=256, help="threshold")
+    ap.add_argument("--distinct-boxes", type=int, default=-1, help="different dealers' boxes cycled through by the timed steps "
+                    "(-1: min(steps, 24); every box has its own polynomial, witnesses, challenge)")
     ap.add_argument("--registered-keys", type=int, default=1,
                     help="also time the opt-in registered-key variant at N=1 (0: skip)")
     ap.add_argument("--wb-shares", type=int, default=-1, help="share boxes in the verify_share figure (-1: 16384, 0: skip)")
@@ -282,15 +402,16 @@ def main():
     ap.add_argument("--ec-t", type=int, default=256)
     ap.add_argument("--lone-boxes", type=int, default=2, help="boxes verified one at a time after the timed region "
                                                               "(isolated kernel durations for the roofline; 0: skip)")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the CPU port (-1: 2 per core, 0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the all-core CPU port (-1: 1 per core, 0: skip all CPU legs)")
+    ap.add_argument("--config-boxes", type=int, default=-1, help="boxes timed for the other BASELINE shapes in `configs` "
+                    "(C2 n=4096 t=64, one GPU's slice of C5 n=131072 t=1024; -1: 48 / 6, 0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N needs N ranks: run `python bench.py --gpus N` directly (it starts them) or under torch.distributed.run")
     import torch.distributed as dist
     # MPVSS_BENCH_SMOKE_ONE_GPU=1: run every rank on cuda:0 with the gloo backend -- only to exercise the
     # multi-rank control flow on a single-GPU box; real runs use one GPU per rank and RCCL ("nccl").
@@ -308,7 +429,8 @@ def main():
     torch.cuda.set_device(dev)
     # The running hash state (128 bytes per box and hop) is produced and consumed by host code: it travels over a
     # gloo (CPU) group, so that a hop never waits for a free wave slot on a GPU that is saturated with long-running
-    # workgroups.  The barrier and the max-reduction of the timing stay on RCCL.
+    # workgroups.  The barrier, the max-reduction of the timing and the per-box all-gather of the shares' well-formedness
+    # bytes (device data) go over the default group: RCCL in a real run.
     commdev = torch.device("cpu")
     chain = dist.new_group(backend="gloo") if (world > 1 and not smoke_one_gpu) else None
 
@@ -319,82 +441,155 @@ def main():
     n, t = args.n, args.t
     n_total = n * world
     lo = rank * n
-
-    # ---------------- synthetic honest-dealer box (deterministic) ----------------
-    t_setup = time.time()
-    rng_c = random.Random(SEED)                       # polynomial coefficients: same on every rank
-    coeffs = [rng_c.randrange(ORDER) for _ in range(t)]
-    rng = random.Random(SEED * 1000003 + rank)       # this rank's participants
-    privs = [keygen(rng) for _ in range(n)]
-    wits = [keygen(rng) for _ in range(n)]
-    positions = list(range(lo + 1, lo + n + 1))
-    # P(i) mod (q-1)   (polynomial.rs:50-58 evaluates over Z, the caller reduces; Horner is the same value)
-    pvals = []
-    rc = list(reversed(coeffs))
-    for i in positions:
-        acc = 0
-        for a in rc:
-            acc = acc * i + a
-        pvals.append(acc % ORDER)
-    commitments = eng.batch_exp_fixed_base(fx(4), b"".join(fx(a) for a in coeffs))        # C_j = g^a_j
-    pubkeys = eng.batch_exp_fixed_base(fx(2), b"".join(fx(k) for k in privs))             # y_i = G^x_i
-    pv_bytes, wit_bytes = b"".join(map(fx, pvals)), b"".join(map(fx, wits))
-    dres = eng.distribute(commitments, positions, pubkeys, pv_bytes, wit_bytes)           # also builds the comb tables
-    t_deal = time.perf_counter()
-    dres = eng.distribute(commitments, positions, pubkeys, pv_bytes, wit_bytes)
-    deal_s = time.perf_counter() - t_deal
-    shares = dres["Y"]
-    # dealer transcript over ALL ranks in order -> challenge
-    inter = bytearray()
-    for i in range(n):
-        s = slice(i * EB, (i + 1) * EB)
-        inter += dres["X"][s] + dres["Y"][s] + dres["a1"][s] + dres["a2"][s]
-    if world > 1:
-        if rank == 0:
-            state = capi.transcript_init()
-        else:
-            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
-            dist.recv(buf, src=rank - 1, group=chain)
-            state = bytes(buf.cpu().numpy().tobytes())
-        state = capi.transcript_absorb(state, bytes(inter))
-        if rank + 1 < world:
-            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain)
-            dg = torch.zeros(32, dtype=torch.uint8, device=commdev)
-        else:
-            _, digest = capi.transcript_verdict(state, bytes(EB))
-            dg = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(commdev)
-        dist.broadcast(dg, src=world - 1, group=chain)
-        dealer_digest = bytes(dg.cpu().numpy().tobytes())
-    else:
-        state = capi.transcript_absorb(capi.transcript_init(), bytes(inter))
-        _, dealer_digest = capi.transcript_verdict(state, bytes(EB))
     import hashlib
-    c = int.from_bytes(hashlib.sha256(dealer_digest).digest(), "big") % ((Q - 1) // 2)    # modp.rs:142-148
-    challenge = fx(c)
-    responses = b"".join(fx((w - (p * c) % ORDER) % ORDER) for w, p in zip(wits, pvals))   # dleq.rs:42-50
-    del inter
-    setup_s = time.time() - t_setup
 
-    # ---------------- inputs resident in HBM ----------------
     def dev_u8(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    d_cm, d_pk, d_sh, d_rs = dev_u8(commitments), dev_u8(pubkeys), dev_u8(shares), dev_u8(responses)
-    d_pos = torch.tensor(positions, dtype=torch.int64, device=dev)
-    ch_buf = (C.c_uint8 * EB).from_buffer_copy(challenge)
-    torch.cuda.synchronize()
 
     def vp(tensor):
         return C.c_void_p(tensor.data_ptr())
 
+    def chain_digest(tag, inter):
+        """SHA-256 of the dealer's transcript over ALL ranks' blocks in rank order (the 128-byte state goes rank to rank)"""
+        if world == 1:
+            return capi.transcript_verdict(capi.transcript_absorb(capi.transcript_init(), inter), bytes(EB))[1]
+        if rank == 0:
+            state = capi.transcript_init()
+        else:
+            buf = torch.empty(capi.TRANSCRIPT_STATE_BYTES, dtype=torch.uint8, device=commdev)
+            dist.recv(buf, src=rank - 1, group=chain, tag=tag)
+            state = bytes(buf.cpu().numpy().tobytes())
+        state = capi.transcript_absorb(state, inter)
+        if rank + 1 < world:
+            dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain, tag=tag)
+            dg = torch.zeros(32, dtype=torch.uint8, device=commdev)
+        else:
+            dg = torch.frombuffer(bytearray(capi.transcript_verdict(state, bytes(EB))[1]), dtype=torch.uint8).to(commdev)
+        dist.broadcast(dg, src=world - 1, group=chain)
+        return bytes(dg.cpu().numpy().tobytes())
+
+    # ---------------- synthetic workload (deterministic; DESIGN.md section 7) ----------------
+    # The participants -- private keys, public keys, positions -- are the same for every box (long-lived keys); every
+    # dealer's box has its own polynomial, witnesses, shares, challenge and responses.
+    def make_participants(n_, rank_seed):
+        rng = random.Random(rank_seed)
+        privs = [keygen(rng) for _ in range(n_)]
+        wits = [keygen(rng) for _ in range(n_)]
+        return privs, wits
+
+    def make_box(b, n_, t_, positions, pubkeys, wit_bytes0, python_scalars, tag_base=0):
+        """box number b of the run: polynomial from SEED + b, witnesses w_i * k_b (k_b a unit, so gcd(w, q-1) = 1 stays),
+        dealt by the engine (oracle-checked batch calls), challenge and responses as participant.rs:251-264."""
+        bx = Box()
+        rng_c = random.Random(SEED + 7919 * b)            # polynomial coefficients: same on every rank
+        bx.coeffs = [rng_c.randrange(ORDER) for _ in range(t_)]
+        coeff_bytes = b"".join(fx(a) for a in bx.coeffs)
+        if python_scalars:       # P(i) mod (q-1) with Python integers (polynomial.rs:50-58 evaluates over Z, the caller reduces)
+            pvals = []
+            rc = list(reversed(bx.coeffs))
+            for i in positions:
+                acc = 0
+                for a in rc:
+                    acc = acc * i + a
+                pvals.append(acc % ORDER)
+            bx.pv_bytes = b"".join(map(fx, pvals))
+        else:                    # the same through the C ABI's scalar side (checked against Python integers on box 0)
+            bx.pv_bytes = capi.poly_eval(0, coeff_bytes, positions)
+        if b == 0:
+            bx.wit_bytes = wit_bytes0
+        else:                    # w' = w * k_b = 0 - w * (order - k_b)
+            k_b = keygen(rng_c)
+            bx.wit_bytes = capi.dleq_responses(0, bytes(len(wit_bytes0)), wit_bytes0, fx(ORDER - k_b))
+        bx.commitments = eng.batch_exp_fixed_base(fx(4), coeff_bytes)                     # C_j = g^a_j
+        dres = eng.distribute(bx.commitments, positions, pubkeys, bx.pv_bytes, bx.wit_bytes)
+        bx.shares = dres["Y"]
+        if world == 1:
+            bx.dealer_digest = dres["digest"]
+        else:
+            inter = bytearray()
+            for i in range(n_):
+                s = slice(i * EB, (i + 1) * EB)
+                inter += dres["X"][s] + dres["Y"][s] + dres["a1"][s] + dres["a2"][s]
+            bx.dealer_digest = chain_digest((1 << 20) + tag_base + b, bytes(inter))
+        bx.c = int.from_bytes(hashlib.sha256(bx.dealer_digest).digest(), "big") % ((Q - 1) // 2)    # modp.rs:142-148
+        bx.challenge = fx(bx.c)
+        if python_scalars:
+            bx.responses = b"".join(fx((int.from_bytes(bx.wit_bytes[i * EB:(i + 1) * EB], "big") - (p * bx.c) % ORDER) % ORDER)
+                                    for i, p in enumerate(pvals))                         # dleq.rs:42-50
+        else:
+            bx.responses = capi.dleq_responses(0, bx.wit_bytes, bx.pv_bytes, bx.challenge)
+        bx.dres = dres if b == 0 else None
+        bx.d_cm, bx.d_sh, bx.d_rs = dev_u8(bx.commitments), dev_u8(bx.shares), dev_u8(bx.responses)
+        bx.ch_buf = (C.c_uint8 * EB).from_buffer_copy(bx.challenge)
+        bx.n, bx.t = n_, t_
+        return bx
+
+    t_setup = time.time()
+    privs, wits = make_participants(n, SEED * 1000003 + rank)
+    positions = list(range(lo + 1, lo + n + 1))
+    pubkeys = eng.batch_exp_fixed_base(fx(2), b"".join(fx(k) for k in privs))             # y_i = G^x_i
+    wit_bytes = b"".join(map(fx, wits))
+    d_pk = dev_u8(pubkeys)
+    d_pos = torch.tensor(positions, dtype=torch.int64, device=dev)
+    n_distinct = args.distinct_boxes if args.distinct_boxes > 0 else max(1, min(args.steps, 24))
+    boxes = [make_box(0, n, t, positions, pubkeys, wit_bytes, True)]
+    boxes += [make_box(b, n, t, positions, pubkeys, wit_bytes, False) for b in range(1, n_distinct)]
+    box0 = boxes[0]
+    commitments, shares, responses, challenge, dres = box0.commitments, box0.shares, box0.responses, box0.challenge, box0.dres
+    pv_bytes, coeffs, dealer_digest, c = box0.pv_bytes, box0.coeffs, box0.dealer_digest, box0.c
+    d_cm, d_sh, d_rs, ch_buf = box0.d_cm, box0.d_sh, box0.d_rs, box0.ch_buf
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+
     keyset = [None]      # set for the secondary "registered keys" figure only
 
-    def compute_block():
+    class Cur:           # the participants and boxes the step functions below work on (the headline's; bench_shape swaps them)
+        pass
+    cur = Cur()
+    cur.boxes, cur.d_pk, cur.d_pos, cur.n = boxes, d_pk, d_pos, n
+
+    # N > 1: every box also leaves one well-formedness byte per share in HBM (mpvss_modp_verify_block_compute_flags), and
+    # the ranks all-gather those bytes once per box over the default process group -- RCCL over xGMI in a real run
+    # (SURVEY 8e: the per-share verdict bytes of W_A; they never enter the box verdict, which is the transcript digest).
+    rccl = {"issued": 0, "works": collections.deque(), "bad": 0, "ring": 64, "done": set(), "next": 0}
+
+    def rccl_buffers(n_):
+        cdev = commdev if smoke_one_gpu else dev
+        rccl["mine"] = [torch.zeros(n_, dtype=torch.uint8, device=dev) for _ in range(rccl["ring"])]
+        rccl["all"] = [torch.zeros(n_ * world, dtype=torch.uint8, device=cdev) for _ in range(rccl["ring"])]
+    if world > 1:
+        rccl_buffers(n)
+    enq_boxes = []                  # box behind every block enqueued on this rank, in enqueue (= claim) order
+
+    def rccl_reap(limit):
+        while len(rccl["works"]) > limit:
+            work, slot = rccl["works"].popleft()
+            work.wait()
+            rccl["bad"] += int((rccl["all"][slot] != 1).sum().item())
+
+    def rccl_gather_flags(seq):
+        """box `seq` has been absorbed on this rank: its flag bytes are final -> one all-gather (asynchronous; at most
+        ring/2 outstanding, so a buffer is never reused while its collective is in flight)"""
+        slot = seq % rccl["ring"]
+        rccl_reap(rccl["ring"] // 2 - 1)
+        src = rccl["mine"][slot].cpu() if smoke_one_gpu else rccl["mine"][slot]
+        rccl["works"].append((dist.all_gather_into_tensor(rccl["all"][slot], src, async_op=True), slot))
+        rccl["issued"] += 1
+
+    def compute_block(bx):
+        enq_boxes.append(bx)
+        if world > 1 and keyset[0] is None:
+            slot = (len(enq_boxes) - 1) % rccl["ring"]
+            eng._check(lib.mpvss_modp_verify_block_compute_flags(ctx, capi.MPVSS_DEVICE, vp(bx.d_cm), bx.t, vp(cur.d_pos), vp(cur.d_pk), vp(bx.d_sh),
+                                                                 vp(bx.d_rs), bx.n, C.cast(bx.ch_buf, C.c_void_p), vp(rccl["mine"][slot])),
+                       "verify_block_compute_flags")
+            return
         if keyset[0] is not None:
-            rcode = lib.mpvss_modp_verify_block_compute_keyset(ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), keyset[0], 0,
-                                                               vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p))
+            rcode = lib.mpvss_modp_verify_block_compute_keyset(ctx, capi.MPVSS_DEVICE, vp(bx.d_cm), bx.t, vp(cur.d_pos), keyset[0], 0,
+                                                               vp(bx.d_sh), vp(bx.d_rs), bx.n, C.cast(bx.ch_buf, C.c_void_p))
         else:
-            rcode = lib.mpvss_modp_verify_block_compute(ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_pos), vp(d_pk),
-                                                        vp(d_sh), vp(d_rs), n, C.cast(ch_buf, C.c_void_p))
+            rcode = lib.mpvss_modp_verify_block_compute(ctx, capi.MPVSS_DEVICE, vp(bx.d_cm), bx.t, vp(cur.d_pos), vp(cur.d_pk),
+                                                        vp(bx.d_sh), vp(bx.d_rs), bx.n, C.cast(bx.ch_buf, C.c_void_p))
         eng._check(rcode, "verify_block_compute")
 
     hash_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(HASH_THREADS, 1))
@@ -410,6 +605,7 @@ def main():
             ticket = eng.block_claim()
             seq = box_seq[0]
             box_seq[0] += 1
+            bx = enq_boxes[seq]
         if world == 1 or rank == 0:
             state = capi.transcript_init()
         else:
@@ -421,16 +617,17 @@ def main():
             # hand the state on; only the last rank knows the verdicts, they are broadcast once at the end of run_steps()
             dist.send(torch.frombuffer(bytearray(state), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain, tag=seq)
             return seq, None
-        return seq, capi.transcript_verdict(state, challenge)
+        return seq, capi.transcript_verdict(state, bx.challenge)
 
-    def run_steps_many(k, depth):
-        """N = 1: k complete verifications of the box in ONE library call (mpvss_modp_verify_many): the calling thread
+    def run_steps_many(seq_boxes, depth):
+        """N = 1: complete verifications of the given boxes in ONE library call (mpvss_modp_verify_many): the calling thread
         enqueues the GPU work of up to `depth` boxes ahead, HASH_THREADS library threads absorb (wait for and hash)
         the boxes in order.  No Python in the loop."""
         ks = keyset[0]
-        box = capi.ModpBox(d_cm.data_ptr(), t, d_pos.data_ptr(), None if ks is not None else d_pk.data_ptr(),
-                           d_sh.data_ptr(), d_rs.data_ptr(), n, C.cast(ch_buf, C.c_void_p), ks, 0)
-        arr = (capi.ModpBox * k)(*([box] * k))
+        k = len(seq_boxes)
+        arr = (capi.ModpBox * k)(*[capi.ModpBox(bx.d_cm.data_ptr(), bx.t, cur.d_pos.data_ptr(), None if ks is not None else cur.d_pk.data_ptr(),
+                                                bx.d_sh.data_ptr(), bx.d_rs.data_ptr(), bx.n, C.cast(bx.ch_buf, C.c_void_p), ks, 0)
+                                   for bx in seq_boxes])
         verdicts = (C.c_int * k)()
         digests = (C.c_uint8 * (32 * k))()
         eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_DEVICE, arr, k, depth, max(HASH_THREADS, 1), verdicts,
@@ -438,28 +635,42 @@ def main():
         raw = bytes(digests)
         return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(k)]
 
-    def run_steps(k, depth=None):
-        """k complete verifications of the box, software-pipelined: up to `depth` boxes have their GPU work
-        enqueued while host threads hash the oldest ones.  On one GPU the whole pipeline runs inside the library
-        (run_steps_many); with several ranks the running hash state of every box travels rank to rank, so the blocks
-        are driven from here (compute / claim / absorb_claimed) with HASH_THREADS boxes being absorbed at a time."""
+    def run_steps(k, depth=None, first=0):
+        """k complete verifications -- step s verifies box (first + s) mod (number of distinct boxes) -- software-pipelined:
+        up to `depth` boxes have their GPU work enqueued while host threads hash the oldest ones.  On one GPU the whole
+        pipeline runs inside the library (run_steps_many); with several ranks the running hash state of every box travels
+        rank to rank, so the blocks are driven from here (compute / claim / absorb_claimed) with HASH_THREADS boxes
+        being absorbed at a time.  Returns [(verdict, digest, box)]."""
+        seq_boxes = [cur.boxes[(first + s) % len(cur.boxes)] for s in range(k)]
         if world == 1 and USE_VERIFY_MANY and k > 0:
-            return run_steps_many(k, min(depth or PIPE_DEPTH, capi.BLOCK_SLOTS))
+            res = run_steps_many(seq_boxes, min(depth or PIPE_DEPTH, capi.BLOCK_SLOTS))
+            return [(v, d, bx) for (v, d), bx in zip(res, seq_boxes)]
         # absorbing threads hold the oldest blocks, so leave them slack in the ring of block slots
         depth = min(depth or min(PIPE_DEPTH, 8), capi.BLOCK_SLOTS - max(HASH_THREADS, 1))
         results = []
         issued = 0
+        seq0 = len(enq_boxes)
         while issued < min(depth, k):
-            compute_block()
+            compute_block(seq_boxes[issued])
             issued += 1
         pending = collections.deque(hash_pool.submit(finish_block) for _ in range(issued))
         while pending:
             results.append(pending.popleft().result())
+            if world > 1:                    # gather in box order: the same sequence of collectives on every rank
+                rccl["done"].add(results[-1][0])
+                while rccl["next"] in rccl["done"]:
+                    rccl["done"].discard(rccl["next"])
+                    rccl_gather_flags(rccl["next"])
+                    rccl["next"] += 1
             if issued < k:
-                compute_block()
+                compute_block(seq_boxes[issued])
                 issued += 1
                 pending.append(hash_pool.submit(finish_block))
         results = [r for _, r in sorted(results, key=lambda sr: sr[0])]      # threads claim boxes in order, finish in any
+        assert len(enq_boxes) == seq0 + k
+        if world > 1:
+            rccl_reap(0)
+            assert rccl["bad"] == 0, "a share of an honest box was reported as not well-formed"
         if world > 1:                      # one broadcast of all k verdicts and digests from the last rank
             if rank == world - 1:
                 flat = b"".join(bytes([int(v)]) + d for v, d in results)
@@ -469,7 +680,11 @@ def main():
             dist.broadcast(out, src=world - 1, group=chain)
             raw = bytes(out.cpu().numpy().tobytes())
             results = [(bool(raw[33 * i]), raw[33 * i + 1:33 * i + 33]) for i in range(k)]
-        return results
+        return [(v, d, bx) for (v, d), bx in zip(results, seq_boxes)]
+
+    def gate(results, what):
+        for verdict, digest, bx in results:
+            assert verdict is True and digest == bx.dealer_digest, f"parity gate failed ({what})"
 
     def barrier():
         if world > 1:
@@ -483,10 +698,9 @@ def main():
     # ever have in flight: boxes with GPU work pending + boxes being hashed + slack)
     slot_init = min((PIPE_DEPTH if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8)) + max(HASH_THREADS, 1) + 4,
                     capi.BLOCK_SLOTS - 1)
-    for verdict, digest in run_steps(slot_init, depth=slot_init):
-        assert verdict is True and digest == dealer_digest, "parity gate failed (slot initialisation)"
-    for verdict, digest in run_steps(args.warmup) if args.warmup > 0 else []:
-        assert verdict is True and digest == dealer_digest, "parity gate failed in warm-up"
+    gate(run_steps(slot_init, depth=slot_init), "slot initialisation")
+    if args.warmup > 0:
+        gate(run_steps(args.warmup, first=len(boxes) - args.warmup % len(boxes)), "warm-up")
     eng.pipeline_stats(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -494,8 +708,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     pst = eng.pipeline_stats(reset=True)          # host and kernel accounting of exactly the timed steps
-    for verdict, digest in results:
-        assert verdict is True and digest == dealer_digest, "parity gate failed: GPU box did not verify"
+    gate(results, "timed steps: a GPU box did not verify")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=commdev if smoke_one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -514,8 +727,7 @@ def main():
     lone = None
     if world == 1 and args.lone_boxes > 0:
         torch.cuda.synchronize()
-        for verdict, digest in run_steps(args.lone_boxes, depth=1):
-            assert verdict is True and digest == dealer_digest, "parity gate failed (lone box)"
+        gate(run_steps(args.lone_boxes, depth=1), "lone box")
         lst = eng.pipeline_stats(reset=True)
         lb = max(lst["blocks"], 1)
         lone = {"x_path": lst["kernel_ms"][0] / lb, "a1_comb_dual_exp": lst["kernel_ms"][1] / lb,
@@ -541,60 +753,9 @@ def main():
     a2_one_box_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else None
     a2_launch_ms = alone_ms if alone_ms else (a2_one_box_ms if a2_one_box_ms else a2_launch_ms_overlapped)
 
-    # work accounting: Montgomery products the kernels execute per step on this rank
-    fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "4096"))
-    if fd:
-        chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(min(2048 // t, n // 8192), n // 16384, 4),
-                            n // (4 * t)))                                   # as eval_x() in mpvss_capi.cpp
-        chain_len = -(-n // chains)
-        w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
-        m0 = chains * t                                                  # the seeds: m0 consecutive positions, by Horner
-        def inv_tree_products(m):                                         # simultaneous inversion: 3 products per node
-            total = 0
-            while m > 1:
-                total += 3 * m
-                m = -(-m // 16)
-            return total
-        steps = (chain_len - 1 - w0) + (w0 + t - 1)                      # forward + backward pipeline of every chain
-        two_level = os.environ.get("MPVSS_FD_L1", "1") != "0" and chains > 1
-        if two_level:     # Horner for t seeds only; a stride-1 chain steps through the other (chains-1)*t seed positions
-            seed_work = (horner_modmuls(positions[chains * w0:chains * w0 + t], t) + inv_tree_products(t) + t * (t - 1)
-                         + t * (m0 - 1))
-            seed_txt = f"{t} Horner seeds, a stride-1 chain through the other {m0 - t} seed positions"
-        else:
-            seed_work = horner_modmuls(positions[chains * w0:chains * w0 + m0], t)
-            seed_txt = f"{m0} Horner seeds"
-        mm_x = seed_work + inv_tree_products(m0) + chains * t * (t - 1) + chains * t * steps + n
-        x_path = (f"forward differences: {chains} strided chains stepping both ways from {m0} seeds in their middle "
-                  f"(also outputs; {seed_txt}), inverses by simultaneous inversion, {steps} lock-step products per chain and level")
-    else:
-        mm_x = horner_modmuls(positions, t) + n
-        x_path = "Horner in the exponent"
-    comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
-    gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
-    w6 = os.environ.get("MPVSS_A2_W6", "1") != "0"            # 6-bit windows for y^r (64-entry table) or 4-bit
-    # full-product equivalents: squarings weigh SQ_COST
-    # X^c and Y^c: 64 fixed 4-bit windows, or -- one c for the whole box, forward-difference path -- the sliding-window
-    # schedule the library makes from it (width 4, odd digits; the tables of X and Y then hold the odd powers only)
-    sliding = fd and w6 and os.environ.get("MPVSS_C_SLIDING", "1") != "0" and c > 0
-    c_win, c_top, i = 0, 0, 255
-    while sliding and i >= 0:
-        if not (c >> i) & 1:
-            i -= 1
-            continue
-        low = max(i - 3, 0)
-        while not (c >> low) & 1:
-            low += 1
-        c_top = low if c_win == 0 else c_top
-        c_win += 1
-        i = low - 1
-    yc = c_win if sliding else 64                              # products with the table of Y (a2) / X (a1; its first is a load)
-    xc_sq, xc = (c_top, c_win - 1) if sliding else (252, 63)
-    a2_products = (2046 * SQ_COST + 341 + yc + 1) if w6 else (2044 * SQ_COST + 511 + 64 + 1)
-    mm_dual = n * (a2_products + (xc_sq * SQ_COST + xc + 1 + gr + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
-    tab_xy = (8 + SQ_COST) if sliding else 15                # conversion + b^2 + seven odd powers, or conversion + 14 powers
-    mm_table = n * (2 * tab_xy + (63 if w6 else 15))          # window tables of X, Y and y (+1 conversion each)
-    mm_total = mm_x + mm_dual + mm_table
+    # work accounting: Montgomery products the kernels execute per step on this rank (averaged over the timed boxes)
+    wk = modp_work(n, t, positions, [bx.c for _, _, bx in results])
+    mm_total, w6, a2_products = wk["mm_total"], wk["w6"], wk["a2_products"]
     achieved_modmul = mm_total / (ms_per_step * 1e-3)         # against the step's wall time (kernels overlap)
     peak_modmul = PEAK_MODMUL_PER_S
 
@@ -612,8 +773,12 @@ def main():
         "dtype": "u32 limbs (radix 2^29), u64 accumulators",
         "data": "synthetic",
         "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n} t={t} per GPU "
-                               f"({n_total} participants in the box), honest-dealer box, inputs resident in HBM",
-                   "n_per_gpu": n, "t": t, "parallelism": f"participants sharded x{world}"},
+                               f"({n_total} participants in the box), honest-dealer boxes, inputs resident in HBM",
+                   "n_per_gpu": n, "t": t, "parallelism": f"participants sharded x{world}",
+                   "distinct_boxes": len(boxes),
+                   "boxes": "every timed step verifies another dealer's box (own polynomial, witnesses, shares, challenge, "
+                            "responses) against the same participants' public keys"
+                            + ("" if len(boxes) >= args.steps else f"; {len(boxes)} boxes cycled through {args.steps} steps")},
         "roofline": {
             "bound": "hbm",
             "kernel": a2_kernel,
@@ -637,9 +802,11 @@ def main():
             "achieved": achieved_modmul, "peak": peak_modmul, "unit": "2048-bit Montgomery products/s (all kernels / step wall time; a squaring counts 0.764 of a product, its share of the mads)",
             "frac": achieved_modmul / peak_modmul,
             "modmul_per_share": mm_total / n,
-            "x_path": x_path,
+            "x_path": wk["x_path"],
             "peak_nominal_clock": PEAK_MODMUL_NOMINAL,
             "frac_of_nominal_clock_peak": achieved_modmul / PEAK_MODMUL_NOMINAL,
+            "a2_kernel_alone": ({"products_per_s": a2_products * n / (alone_ms * 1e-3), "frac": a2_products * n / (alone_ms * 1e-3) / peak_modmul,
+                                 "products_per_share": a2_products} if alone_ms else None),
             "kernel_ms_sums": {"x_path": x_ms, "a1_comb_dual_exp": a1_ms, "a2_dual_exp": a2_ms, "tables": tb_ms,
                                "note": "per-kind sums of launch durations per step in the timed region; boxes and kinds "
                                        "overlap, so the sums exceed the step time"},
@@ -656,8 +823,17 @@ def main():
                               else "verify_block_compute / block_claim / absorb_claimed from a Python thread pool"
                                    + ("; the hash state of every box travels rank to rank (gloo, tag = box)" if world > 1 else "")),
                  "slot_init_boxes": slot_init,
+                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                  "setup_s": setup_s},
     }
+    if world > 1:
+        result["rccl"] = {
+            "backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
+            "data_collectives": rccl["issued"], "per_box": 1, "bytes_per_rank_per_box": n,
+            "collective": "all_gather_into_tensor of the shares' well-formedness bytes (device tensors written by "
+                          "mpvss_modp_verify_block_compute_flags), one per box and rank, asynchronous, inside the timed region; "
+                          "every byte of every rank checked == 1",
+            "also": "barrier and max-reduction of the timing over the same group; the 128-byte hash state per box and hop over gloo"}
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape
         try:
@@ -670,7 +846,11 @@ def main():
     # reported in `secondary_error` and the process exits non-zero after printing.
     secondary_error = None
     try:
-        # ---------------- CPU baseline (rank 0, N == 1 only): the C port of the reference sequence ----------------
+        # ---------------- CPU baselines (rank 0, N == 1 only), SURVEY 8(d) ----------------
+        # (i) the C port of the reference's operation sequence on ONE thread -- how src/participant.rs:408 runs (no rayon
+        # on this path); (ii) the same on every free core (`cpu_baseline.value`); (iii) the same sequence with OpenSSL's
+        # BN_mod_exp_mont where libcrypto is present ("strong CPU" line).  About 15 s of wall time altogether; the GPU's
+        # X / a1 / a2 of every sampled share must equal the CPU's.
         if rank == 0 and world == 1 and args.cpu_sample != 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             from concurrent.futures import ThreadPoolExecutor
@@ -679,7 +859,7 @@ def main():
             ref = ModpRef()
             # Threads that really run in parallel here (cpu_count() ignores cgroup quotas): calibrate with
             # short full-width modpows, 1 thread vs many.
-            nthreads = min(os.cpu_count() or 1, 64)
+            nthreads = min(len(os.sched_getaffinity(0)) or 1, 64)
             bb, ee = int.from_bytes(commitments[:EB], "big"), ORDER - 12345
             t1 = time.perf_counter(); ref.modpow(bb, ee); single = time.perf_counter() - t1
             with ThreadPoolExecutor(max_workers=nthreads) as ex:
@@ -687,11 +867,14 @@ def main():
                 list(ex.map(lambda _: ref.modpow(bb, ee), range(2 * nthreads)))
                 par = time.perf_counter() - t1
             cores = max(1, min(nthreads, int(round(2 * nthreads * single / par))))
-            # one share costs ~(sum of exponent bits) * 1.5 Montgomery products; aim for ~15 s of wall time
-            est_share_s = single * (sum(min(17 * j, 2048) for j in range(t)) + 2 * 2048 + 2 * 256) / 2048.0
-            k = args.cpu_sample if args.cpu_sample > 0 else max(cores, min(8 * cores, int(15.0 * cores / max(est_share_s, 1e-3))))
-            k = min(k, n)
-            idx = sorted({int((j + 0.5) * n / k) for j in range(k)})
+            cpu_model = "unknown"
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.lower().startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             # GPU outputs for the sampled shares (one more, untimed, dumped verification)
             X = (C.c_uint8 * (n * EB))(); A1 = (C.c_uint8 * (n * EB))(); A2 = (C.c_uint8 * (n * EB))()
             v = C.c_int(0); dg = (C.c_uint8 * 32)()
@@ -700,22 +883,120 @@ def main():
                                                           dg, X, A1, A2), "verify_distribution(dump)")
             Xb, A1b, A2b = bytes(X), bytes(A1), bytes(A2)
 
+            def spread(k):
+                k = max(1, min(k, n))
+                return sorted({int((j + 0.5) * n / k) for j in range(k)})
+
+            def timed(work, idx, threads):
+                tc = time.perf_counter()
+                if threads == 1:
+                    outs = [work(i) for i in idx]
+                else:
+                    with ThreadPoolExecutor(max_workers=threads) as ex:
+                        outs = list(ex.map(work, idx))
+                secs = time.perf_counter() - tc
+                for i, (x, a1, a2) in zip(idx, outs):
+                    s = slice(i * EB, (i + 1) * EB)
+                    assert (x, a1, a2) == (Xb[s], A1b[s], A2b[s]), f"GPU/CPU mismatch at share {i}"
+                return secs
+
             def work(i):
                 s = slice(i * EB, (i + 1) * EB)
                 return ref.share_work(commitments, positions[i], pubkeys[s], shares[s], responses[s], challenge)
-            tc = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                outs = list(ex.map(work, idx))
-            cpu_s = time.perf_counter() - tc
-            for i, (x, a1, a2) in zip(idx, outs):
-                s = slice(i * EB, (i + 1) * EB)
-                assert (x, a1, a2) == (Xb[s], A1b[s], A2b[s]), f"GPU/CPU mismatch at share {i}"
+            # one share costs ~(sum of exponent bits) * 1.5 products of the port: ~6 s of wall time per leg
+            est_share_s = single * (sum(min(17 * j, 2048) for j in range(t)) + 2 * 2048 + 2 * 256) / 2048.0
+            k1 = max(1, min(4, int(6.0 / max(est_share_s, 1e-3))))
+            idx1 = spread(k1)
+            s1 = timed(work, idx1, 1)
+            k = args.cpu_sample if args.cpu_sample > 0 else max(cores, min(8 * cores, int(6.0 * cores / max(est_share_s, 1e-3))))
+            idx = spread(k)
+            cpu_s = timed(work, idx, cores)
             result["cpu_baseline"] = {
                 "value": len(idx) / cpu_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
+                "cpu_model": cpu_model, "hardware_threads": os.cpu_count(),
                 "sample": f"{len(idx)} of {n} shares (positions spread over [1,{n}], all t={t} commitments), "
                           f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
                           f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
+                "single_thread": {"value": len(idx1) / s1, "unit": "share verifications/s", "cores": 1, "kind": "port",
+                                  "sample": f"{len(idx1)} share(s), same C port on one thread ({s1:.1f}s) -- the reference runs "
+                                            "this path on one thread (src/participant.rs:408-448 has no rayon)"},
             }
+            try:
+                import openssl_ref
+                if openssl_ref.available():
+                    tls = threading.local()
+
+                    def work_ssl(i):
+                        if not hasattr(tls, "ref"):
+                            tls.ref = openssl_ref.OpenSslRef()
+                        s = slice(i * EB, (i + 1) * EB)
+                        return tls.ref.share_work(commitments, positions[i], pubkeys[s], shares[s], responses[s], challenge)
+                    t1 = time.perf_counter(); work_ssl(spread(1)[0]); one = time.perf_counter() - t1
+                    idx_s = spread(max(cores, min(16 * cores, int(3.0 * cores / max(one, 1e-3)))))
+                    ssl_s = timed(work_ssl, idx_s, cores)
+                    result["cpu_baseline"]["openssl"] = {
+                        "value": len(idx_s) / ssl_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
+                        "library": openssl_ref.version(),
+                        "sample": f"{len(idx_s)} shares, the same operation sequence with libcrypto's BN_mod_exp_mont / BN_mod_mul "
+                                  f"(oracle/openssl_ref.py) on {cores} threads, {ssl_s:.1f}s; one share on one thread {one * 1e3:.0f} ms; "
+                                  "GPU X/a1/a2 of those shares checked equal"}
+            except Exception as exc:      # noqa: BLE001 - the strong-CPU line is optional
+                result["cpu_baseline"]["openssl"] = {"value": None, "note": f"skipped: {exc}"}
+        # ---------------- the other MODP shapes of BASELINE.json: C2 and one GPU's slice of C5 ----------------
+        def bench_shape(n_, t_, k, depth, lo_, what):
+            """k boxes of another shape through the same step functions (own participants, up to 4 distinct boxes, the slots
+            grow to the shape in an untimed pass); returns value / ms_per_box / compute of that shape."""
+            saved = (cur.boxes, cur.d_pk, cur.d_pos, cur.n)
+            privs_, wits_ = make_participants(n_, SEED * 1000003 + 977 * t_ + rank)
+            pos_ = list(range(lo_ + 1, lo_ + n_ + 1))
+            pub_ = eng.batch_exp_fixed_base(fx(2), b"".join(fx(x) for x in privs_))
+            witb_ = b"".join(map(fx, wits_))
+            try:
+                cur.d_pk, cur.d_pos, cur.n = dev_u8(pub_), torch.tensor(pos_, dtype=torch.int64, device=dev), n_
+                cur.boxes = [make_box(b, n_, t_, pos_, pub_, witb_, False, tag_base=100000 + 1000 * t_) for b in range(min(k, 4))]
+                if world > 1:
+                    rccl_reap(0)
+                    rccl_buffers(n_)
+                init = min(depth + max(HASH_THREADS, 1) + 2, capi.BLOCK_SLOTS - 1)
+                gate(run_steps(init, depth=init), f"{what}: slot initialisation")
+                eng.pipeline_stats(reset=True)
+                barrier()
+                t_s = time.perf_counter()
+                res_s = run_steps(k, depth=depth)
+                barrier()
+                dt = time.perf_counter() - t_s
+                gate(res_s, what)
+                if world > 1:
+                    tt_ = torch.tensor([dt], dtype=torch.float64, device=commdev if smoke_one_gpu else dev)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    dt = float(tt_.item())
+                wk_ = modp_work(n_, t_, pos_, [bx.c for _, _, bx in res_s])
+                rate = wk_["mm_total"] * k / dt
+                return {"value": n_ * world * k / dt, "unit": "share verifications/s", "ms_per_box": dt / k * 1e3, "boxes": k,
+                        "boxes_in_flight": depth, "distinct_boxes": len(cur.boxes),
+                        "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n_} t={t_} per GPU ({what}), "
+                                               f"honest-dealer boxes, inputs resident in HBM"},
+                        "compute": {"achieved": rate, "peak": PEAK_MODMUL_PER_S, "frac": rate / PEAK_MODMUL_PER_S,
+                                    "modmul_per_share": wk_["mm_total"] / n_, "x_path": wk_["x_path"]}}
+            finally:
+                cur.boxes, cur.d_pk, cur.d_pos, cur.n = saved
+                if world > 1:
+                    rccl_reap(0)
+                    rccl_buffers(n)
+
+        if args.config_boxes != 0 and keyset[0] is None:
+            if world == 1:
+                k2, k5 = (48, 6) if args.config_boxes < 0 else (args.config_boxes, max(2, args.config_boxes // 8))
+                result["configs"] = {
+                    "c2": bench_shape(4096, 64, k2, min(PIPE_DEPTH + 2, 14), 0, "BASELINE config C2"),
+                    "c5_slice": bench_shape(131072, 1024, k5, 6, 0, "one GPU's slice of BASELINE config C5: positions 1..131072 of 1048576"),
+                }
+            elif world == 8 or os.environ.get("MPVSS_BENCH_C5") == "1":
+                # BASELINE config C5 itself: ONE box of world x 131072 participants, t = 1024, every rank its block
+                k5 = 6 if args.config_boxes < 0 else max(2, args.config_boxes)
+                n5 = int(os.environ.get("MPVSS_BENCH_C5_N", "131072"))
+                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 4, rank * n5,
+                                           f"BASELINE config C5: {n5 * world} participants over {world} GPUs")
         # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
         if world == 1 and args.host_boxes > 0:
             pos_arr = (C.c_int64 * n)(*positions)
@@ -759,15 +1040,14 @@ def main():
                 torch.cuda.synchronize()
                 build_s = time.perf_counter() - tk
                 keyset[0] = h
-                for verdict, digest in run_steps(min(args.warmup, 2)) if args.warmup > 0 else []:
-                    assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys, warm-up)"
+                if args.warmup > 0:
+                    gate(run_steps(min(args.warmup, 2)), "registered keys, warm-up")
                 barrier()
                 t1 = time.perf_counter()
                 res_k = run_steps(args.steps)
                 barrier()
                 el_k = time.perf_counter() - t1
-                for verdict, digest in res_k:
-                    assert verdict is True and digest == dealer_digest, "parity gate failed (registered keys)"
+                gate(res_k, "registered keys")
                 keyset[0] = None
                 table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
                 lib.mpvss_modp_keyset_destroy(ctx, h)
@@ -879,6 +1159,9 @@ def main():
             deal_blk_s = (time.perf_counter() - t_d) / deal_boxes
             if world == 1 and rank == 0:
                 assert all(x == dealer_digest for x in dg), "dealer block API: transcript digest differs"
+            t_sync = time.perf_counter()
+            eng.distribute(commitments, positions, pubkeys, pv_bytes, wit_bytes)
+            deal_s = time.perf_counter() - t_sync
             t_s = time.perf_counter()
             pv2 = capi.poly_eval(0, b"".join(fx(a) for a in coeffs), positions)
             rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)

@@ -11,6 +11,7 @@
 using namespace mpvss_host;
 
 int main(int argc, char** argv) {
+  mpvss_process_init();   // before the first HIP call: 8 hardware queues for the block pipeline
   Rng rng(argc > 1 ? strtoull(argv[1], nullptr, 0) : std::random_device{}());
   auto group = ModpGroup::create();
   const std::string secret_message = "Hello MPVSS Example.";

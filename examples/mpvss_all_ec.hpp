@@ -11,6 +11,7 @@ template <class Traits>
 int run_mpvss_all(const char* secret_message_c, int argc, char** argv) {
   using namespace mpvss_host;
   typedef EcParticipant<Traits> P;
+  mpvss_process_init();   // before the first HIP call: 8 hardware queues for the block pipeline
   Rng rng(argc > 1 ? strtoull(argv[1], nullptr, 0) : std::random_device{}());
   auto group = EcGroup<Traits>::create();
   const std::string secret_message = secret_message_c;

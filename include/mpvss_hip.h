@@ -48,6 +48,14 @@ typedef struct mpvss_ctx mpvss_ctx;
 
 /* ---- context ------------------------------------------------------------------------ */
 
+/* Optional, process-wide, and only meaningful BEFORE the process's first HIP call (any library's): puts
+ * GPU_MAX_HW_QUEUES=8 into the environment unless the variable is already set -- the block pipeline keeps one stream
+ * pair per box in flight and wants 8 hardware queues (the runtime's default is 4; 16 or more oversubscribe the
+ * hardware).  Returns 1 when it set the variable, 0 when a value was already there.  Not thread-safe against
+ * concurrent getenv: call it at the top of main, or set the variable in the launcher instead.  The library never
+ * changes the environment on its own. */
+int mpvss_process_init(void);
+
 /* Number of visible HIP devices (0 when there is no GPU; the library never falls back to
  * a CPU path -- every compute entry point then fails with MPVSS_E_DEVICE). */
 int mpvss_device_count(void);
@@ -134,6 +142,16 @@ int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const uint8_t* co
                                     const uint8_t* responses, size_t n, const uint8_t* challenge_host);
 int mpvss_modp_verify_block_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* a1_out_host,
                                    uint8_t* a2_out_host);
+/* mpvss_modp_verify_block_compute that also leaves one well-formedness byte per share in DEVICE memory
+ * (wellformed_dev_out, n bytes, valid once the block has been absorbed): 1 iff 0 < y_i < q, 0 < Y_i < q and
+ * r_i < q - 1, i.e. the three inputs of the share are canonical encodings.  The reference validates nothing here
+ * (src/groups/modp.rs:154-156; src/participant.rs:408-448 hashes whatever comes out), so these bytes never enter the box
+ * verdict: they are the per-share record that the ranks of a sharded verification all-gather over RCCL,
+ * telling every rank which block holds a non-canonical share. */
+int mpvss_modp_verify_block_compute_flags(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                          const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
+                                          const uint8_t* responses, size_t n, const uint8_t* challenge_host,
+                                          uint8_t* wellformed_dev_out);
 /* The same in two steps, for callers whose transcript state arrives from elsewhere (one rank of a sharded verification:
  * the state of box b comes from the previous rank): mpvss_block_claim takes the oldest block in flight (MODP
  * distribution blocks only) and returns its ticket -- tickets count the blocks of this context in enqueue order --,

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
     "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
     "mpvss_modp_distribute_compute", "mpvss_modp_distribute_absorb",
+    "mpvss_process_init", "mpvss_modp_verify_block_compute_flags",
 )
 
 GROUP_SECP256K1 = 1
@@ -129,6 +130,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_transcript_init.restype = None
     lib.mpvss_modp_verify_block_compute.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p]
     lib.mpvss_modp_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
+    lib.mpvss_modp_verify_block_compute_flags.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p]
+    lib.mpvss_process_init.restype = ci
     lib.mpvss_block_claim.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     lib.mpvss_modp_verify_block_absorb_claimed.argtypes = [vp, C.c_ulonglong, u8p, u8p, u8p, u8p]
     lib.mpvss_modp_transcript_verdict.argtypes = [u8p, u8p, C.POINTER(ci), u8p]
@@ -218,6 +221,22 @@ class Engine:
         if rc != 0:
             msg = self.lib.mpvss_last_error(self.ctx)
             raise EngineError(f"{what} failed: rc={rc} {msg.decode() if msg else ''}")
+
+    def last_error(self) -> str:
+        msg = self.lib.mpvss_last_error(self.ctx)
+        return msg.decode() if msg else ""
+
+    def verify_block_compute_flags(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, shares: bytes,
+                                   responses: bytes, challenge: bytes, wellformed_dev_ptr: int) -> None:
+        """mpvss_modp_verify_block_compute that also leaves one well-formedness byte per share at the DEVICE address
+        wellformed_dev_ptr (n bytes, e.g. a torch uint8 tensor's data_ptr(); valid once the block is absorbed)."""
+        n = len(positions)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        bufs = [_buf(x) for x in (commitments, pubkeys, shares, responses, challenge)]
+        self._check(self.lib.mpvss_modp_verify_block_compute_flags(self.ctx, MPVSS_HOST, bufs[0][1], len(commitments) // EB,
+                                                                   C.cast(pos, C.c_void_p), bufs[1][1], bufs[2][1], bufs[3][1], n,
+                                                                   bufs[4][1], C.c_void_p(wellformed_dev_ptr)),
+                    "verify_block_compute_flags")
 
     def kernel_ms(self, kernel_id: int) -> float:
         return self.lib.mpvss_last_kernel_ms(self.ctx, kernel_id)

@@ -42,9 +42,9 @@ static const size_t MAX_CHUNK = max_chunk_init();
 
 // ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); launches of streams that share a queue run
 // one after the other.  The block pipeline wants 8 (measured: 16 or 32 make every kernel 2-3x slower,
-// profiles/r02_ec_streams_ab.txt).  The runtime reads the variable when it initialises, so this only helps when the
-// library is loaded before the process's first HIP call; a value the user has set is left alone.
-__attribute__((constructor)) static void mpvss_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// profiles/r02_ec_streams_ab.txt).  The runtime reads the variable when it initialises, so it has to be in the
+// environment before the process's first HIP call: that is the HOST APPLICATION's business (its launcher, or an explicit
+// mpvss_process_init() at the top of main) -- the library does not touch the environment on its own.
 
 struct DevBuf {
   void* p = nullptr;
@@ -113,6 +113,7 @@ struct mpvss_ctx {
   int prio_high = 0, prio_low = 0;
   DevBuf comb[2];            // fixed-base comb tables of g = 4 (index 0) and G = 2 (index 1), built on first use
   bool comb_ready[2] = {false, false};
+  DevBuf qbounds;            // q and q - 1 as big-endian bytes (bounds of the well-formedness verdicts), built on first use
   DevBuf comb16[2];          // their wide versions (16-bit windows, 2.5 GB each), built on first large batch
   bool comb16_ready[2] = {false, false};
   // pinned host staging
@@ -523,6 +524,11 @@ int exp_dev(mpvss_ctx* ctx, const uint8_t* bases_dev, const uint8_t* exps_dev, s
 
 // -------------------------------------------------------------------------------------------
 
+extern "C" int mpvss_process_init(void) {
+  if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+  return setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0 ? 1 : MPVSS_E_INVALID;
+}
+
 extern "C" int mpvss_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -594,7 +600,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto& sl : ctx->slot) work_destroy(sl.work, true);
   work_destroy(ctx->work0, ctx->own_stream);
-  for (DevBuf* b : {&ctx->comb[0], &ctx->comb[1], &ctx->comb16[0], &ctx->comb16[1]})
+  for (DevBuf* b : {&ctx->comb[0], &ctx->comb[1], &ctx->comb16[0], &ctx->comb16[1], &ctx->qbounds})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : ctx->ecwork.all())
     if (b->p) (void)hipFree(b->p);
@@ -1131,13 +1137,33 @@ namespace {
 
 static_assert(sizeof(mpvss::Sha256) <= MPVSS_TRANSCRIPT_STATE_BYTES, "transcript state size");
 
+// q | q - 1 as 2 x 256 big-endian bytes in HBM (once per context)
+int wellformed_bounds(mpvss_ctx* ctx, const uint8_t** out) {
+  if (!ctx->qbounds.p) {
+    uint8_t hb[2 * EB];
+    modq_modulus_bytes(hb);
+    memcpy(hb + EB, hb, EB);
+    hb[2 * EB - 1] -= 1;                       // q is odd: q - 1 only changes the last byte
+    DevBuf b;
+    hipError_t e = hipMalloc(&b.p, sizeof(hb));
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipMalloc(bounds)", e);
+    e = hipMemcpy(b.p, hb, sizeof(hb), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(b.p); return fail(ctx, MPVSS_E_DEVICE, "hipMemcpy(bounds)", e); }
+    b.cap = sizeof(hb);
+    ctx->qbounds = b;
+  }
+  *out = (const uint8_t*)ctx->qbounds.p;
+  return 0;
+}
+
 int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                 const uint8_t* responses, size_t n, const uint8_t* challenge_host,
-                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0) {
+                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr) {
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
-  if (n > 0 && (!commitments || !positions || (!pubkeys && !ks) || !shares || !responses || t == 0 || t > 0x7fffffff))
-    return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1)");
+  if (n > 0 && (!commitments || !positions || (!pubkeys && !ks) || !shares || !responses || t == 0 || t > 0x7fffffff ||
+                n > 0x7fffffff))
+    return fail(ctx, MPVSS_E_INVALID, "verify: bad argument (t must be >= 1, n < 2^31)");
   if (ks && (key_offset > ks->n || n > ks->n - key_offset))
     return fail(ctx, MPVSS_E_INVALID, "verify: shares outside the registered key set");
   int key_space = space;
@@ -1168,11 +1194,18 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   if (space == MPVSS_HOST) RET_IF(check_positions_host(ctx, positions, n));
   // this block runs in its slot's own workspace and stream pair, so that boxes overlap on the GPU
   RET_IF(work_init(ctx, sl.work, nullptr));
-  struct Restore {
+  struct Restore {       // also: an early (error) return leaves nothing of this block running on the slot's streams
     mpvss_ctx* c;
     hipStream_t a, b;
-    ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
-  } restore{ctx, ctx->stream, ctx->stream_b};
+    mpvss_ctx::BlockSlot* sl;
+    ~Restore() {
+      if (!sl->busy) {
+        if (sl->work.sa) (void)hipStreamSynchronize(sl->work.sa);
+        if (sl->work.sb) (void)hipStreamSynchronize(sl->work.sb);
+      }
+      c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b;
+    }
+  } restore{ctx, ctx->stream, ctx->stream_b, &sl};
   ctx->w = &sl.work;
   sl.work.fd_used = false;
   ctx->stream = sl.work.sa;
@@ -1244,6 +1277,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     RET_IF(stage_in(ctx, key_space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
     RET_IF(stage_in(ctx, space, shares + off * EB, cnt * EB, ctx->w->in_b, &dY));
     RET_IF(stage_in(ctx, space, responses + off * EB, cnt * EB, ctx->w->in_c, &dr));
+    if (wf_dev_out) {    // per-share well-formedness bytes for the caller's all-gather (never part of the box verdict)
+      const uint8_t* dq;
+      RET_IF(wellformed_bounds(ctx, &dq));
+      LAUNCHCHK(ctx, verdict_launch_modp_wellformed((const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, dq, (int)cnt,
+                                                    wf_dev_out + off, ctx->stream));
+    }
     RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
     RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
     RET_IF(ensure(ctx, ctx->w->out2, cnt * EB));
@@ -1417,7 +1456,15 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
     return MPVSS_OK;
   }
   sl.absorbing = true;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  {
+    const hipError_t e_dev = hipSetDevice(ctx->device);
+    if (e_dev != hipSuccess) {               // give the slot back: the block is lost, the ring is not
+      ctx->release(sl);
+      sl.absorbing = false;
+      ctx->gpu_done.fetch_add(1);
+      return fail(ctx, MPVSS_E_DEVICE, "absorb: hipSetDevice", e_dev);
+    }
+  }
   lk.unlock();
   const auto t_w0 = std::chrono::steady_clock::now();
   const hipError_t e = hipEventSynchronize(sl.done);
@@ -1514,6 +1561,16 @@ extern "C" int mpvss_modp_verify_block_compute(mpvss_ctx* ctx, int space, const 
   std::lock_guard<std::mutex> lk(ctx->mu);
   return verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
                                      challenge_host);
+}
+
+extern "C" int mpvss_modp_verify_block_compute_flags(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
+                                                     const int64_t* positions, const uint8_t* pubkeys,
+                                                     const uint8_t* shares, const uint8_t* responses, size_t n,
+                                                     const uint8_t* challenge_host, uint8_t* wellformed_dev_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
+                                     challenge_host, nullptr, 0, wellformed_dev_out);
 }
 
 // ---- registered public keys -------------------------------------------------------------------------
@@ -1646,12 +1703,14 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    size_t issued = 0, claimed = 0, low = 0;   // low: boxes 0 .. low-1 are finished (their block slots are free)
+    size_t issued = 0, claimed = 0, skipped = 0, low = 0;   // skipped: malformed boxes (no block); low: boxes 0 .. low-1 are finished (their block slots are free)
     std::vector<char> finished;
+    std::vector<size_t> order;  // order[k]: the box behind the k-th block enqueued by this run (malformed boxes enqueue none)
     bool stop = false;          // no more boxes will be issued
     int rc = MPVSS_OK;
   } sh;
   sh.finished.assign(count, 0);
+  sh.order.reserve(count);
   const unsigned base_tail = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->tail; }();
   // `depth` bounds the boxes whose GPU work is pending; a box whose GPU work is done but whose transcript is still being
   // hashed keeps its slot (the ring has NSLOT of them) without holding back the enqueueing of the next one
@@ -1668,16 +1727,25 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
       }
       uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
       mpvss_transcript_init(state);
-      size_t idx;
+      size_t idx, seq;
       int rc;
       {
         std::unique_lock<std::mutex> lk(ctx->mu);
-        idx = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
+        seq = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
         const int kind = ctx->ring_slot(ctx->tail).kind;
         rc = kind == 2 ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr)
                        : verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
       }
-      if (rc == MPVSS_OK && idx < count) rc = finish(idx, state);
+      {
+        std::lock_guard<std::mutex> l(sh.m);
+        idx = seq < sh.order.size() ? sh.order[seq] : count;
+      }
+      // A box the engine rejects as malformed (an invalid curve encoding, a scalar that is not reduced, a negative
+      // position in device memory) is THAT box's business: its verdict stays 0 -- the reference answers `false` to
+      // structural problems, participant.rs:415-420 -- and the other boxes of the run are verified as usual
+      // (mpvss_last_error still names the reason).  Only device and allocation errors end the run.
+      if (rc == MPVSS_E_INVALID) rc = MPVSS_OK;
+      else if (rc == MPVSS_OK && idx < count) rc = finish(idx, state);
       {
         std::lock_guard<std::mutex> l(sh.m);
         if (idx < count) sh.finished[idx] = 1;
@@ -1697,9 +1765,9 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
       // slots are a ring: box b may be enqueued once box b - NSLOT has been absorbed (the threads finish in any order)
       auto may_issue = [&] {
         if (sh.rc != MPVSS_OK) return true;
-        if (!issue_on_gpu_done) return sh.issued - sh.low < (size_t)depth;
+        if (!issue_on_gpu_done) return sh.issued + sh.skipped - sh.low < (size_t)depth;
         const size_t pending_gpu = sh.issued - (size_t)(ctx->gpu_done.load() - gpu_done0);
-        return pending_gpu < (size_t)depth && sh.issued - sh.low < (size_t)mpvss_ctx::NSLOT - 1;
+        return pending_gpu < (size_t)depth && sh.issued + sh.skipped - sh.low < (size_t)mpvss_ctx::NSLOT - 1;
       };
       while (!may_issue()) sh.cv.wait_for(l, std::chrono::microseconds(200));
       if (sh.rc != MPVSS_OK) break;
@@ -1711,9 +1779,15 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
     }
     {
       std::lock_guard<std::mutex> l(sh.m);
-      if (rc != MPVSS_OK) {
+      if (rc == MPVSS_E_INVALID) {          // malformed box: nothing was enqueued, verdict 0, the run goes on
+        sh.finished[b] = 1;
+        ++sh.skipped;
+        while (sh.low < count && sh.finished[sh.low]) ++sh.low;
+        rc = MPVSS_OK;
+      } else if (rc != MPVSS_OK) {
         if (sh.rc == MPVSS_OK) sh.rc = rc;
       } else {
+        sh.order.push_back(b);
         ++sh.issued;
       }
     }
@@ -1742,6 +1816,7 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
       return fail(ctx, MPVSS_E_INVALID, "verify_many: blocks of the block API are in flight, absorb them first");
   }
   for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
+  if (digests32) memset(digests32, 0, 32 * count);       // a malformed box has no transcript: verdict 0, digest zero
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
       [&](size_t b) {
@@ -1797,7 +1872,7 @@ namespace {
 
 int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, const uint8_t* s, const uint8_t* y,
                                  const uint8_t* c, const uint8_t* r, size_t n, uint8_t* verdicts_dev_out) {
-  if (n > 0 && (!pk || !s || !y || !c || !r)) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
+  if (n > 0 && (!pk || !s || !y || !c || !r || n > 0x7fffffff)) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
   mpvss_ctx::BlockSlot& sl = ctx->head_slot();
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify_shares: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
@@ -1818,11 +1893,18 @@ int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, c
     return MPVSS_OK;
   }
   RET_IF(work_init(ctx, sl.work, nullptr));
-  struct Restore {
+  struct Restore {       // also: an early (error) return leaves nothing of this block running on the slot's streams
     mpvss_ctx* c;
     hipStream_t a, b;
-    ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
-  } restore{ctx, ctx->stream, ctx->stream_b};
+    mpvss_ctx::BlockSlot* sl;
+    ~Restore() {
+      if (!sl->busy) {
+        if (sl->work.sa) (void)hipStreamSynchronize(sl->work.sa);
+        if (sl->work.sb) (void)hipStreamSynchronize(sl->work.sb);
+      }
+      c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b;
+    }
+  } restore{ctx, ctx->stream, ctx->stream_b, &sl};
   ctx->w = &sl.work;
   ctx->stream = sl.work.sa;
   ctx->stream_b = sl.work.sb;
@@ -1892,7 +1974,15 @@ int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk
     return MPVSS_OK;
   }
   sl.absorbing = true;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  {
+    const hipError_t e_dev = hipSetDevice(ctx->device);
+    if (e_dev != hipSuccess) {               // give the slot back: the block is lost, the ring is not
+      ctx->release(sl);
+      sl.absorbing = false;
+      ctx->gpu_done.fetch_add(1);
+      return fail(ctx, MPVSS_E_DEVICE, "absorb: hipSetDevice", e_dev);
+    }
+  }
   lk.unlock();
   const auto t_w0 = std::chrono::steady_clock::now();
   const hipError_t e = hipEventSynchronize(sl.done);
@@ -1956,7 +2046,7 @@ namespace {
 int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t, const int64_t* positions,
                                     const uint8_t* pubkeys, const uint8_t* p_values, const uint8_t* witnesses, size_t n,
                                     uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out) {
-  if (n > 0 && (!pubkeys || !p_values || !witnesses || (commitments && (!positions || t == 0 || t > 0x7fffffff))))
+  if (n > 0 && (!pubkeys || !p_values || !witnesses || n > 0x7fffffff || (commitments && (!positions || t == 0 || t > 0x7fffffff))))
     return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
   // (threshold > n is the whole box's business -- mpvss_modp_distribute checks it; a block of a box may be smaller)
   mpvss_ctx::BlockSlot& sl = ctx->head_slot();
@@ -1980,11 +2070,18 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   }
   if (commitments && space == MPVSS_HOST) RET_IF(check_positions_host(ctx, positions, n));
   RET_IF(work_init(ctx, sl.work, nullptr));
-  struct Restore {
+  struct Restore {       // also: an early (error) return leaves nothing of this block running on the slot's streams
     mpvss_ctx* c;
     hipStream_t a, b;
-    ~Restore() { c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b; }
-  } restore{ctx, ctx->stream, ctx->stream_b};
+    mpvss_ctx::BlockSlot* sl;
+    ~Restore() {
+      if (!sl->busy) {
+        if (sl->work.sa) (void)hipStreamSynchronize(sl->work.sa);
+        if (sl->work.sb) (void)hipStreamSynchronize(sl->work.sb);
+      }
+      c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b;
+    }
+  } restore{ctx, ctx->stream, ctx->stream_b, &sl};
   ctx->w = &sl.work;
   sl.work.fd_used = false;
   ctx->stream = sl.work.sa;

@@ -9,6 +9,9 @@ extern "C" {
 /* verdict[i] = hash_to_scalar(SHA256(framed(h1_i) framed(h2_i) framed(a1_i) framed(a2_i))) == c_i; all arrays [count][256] */
 int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2, const uint8_t* c,
                         int count, uint8_t* verdict, hipStream_t s);
+/* out[i] = 1 iff 0 < y_i < q, 0 < Y_i < q, r_i < q-1 (canonical encodings); bounds = [q | q-1], 2 x 256 big-endian bytes */
+int verdict_launch_modp_wellformed(const uint8_t* y, const uint8_t* Y, const uint8_t* r, const uint8_t* bounds, int count,
+                                   uint8_t* out, hipStream_t s);
 /* group 1 = secp256k1 (33-byte elements), 2 = ristretto255 (32-byte); c, r: [count][32] in the group's byte order;
  * ok[i] = 0 when c_i or r_i is not below the group order */
 int verdict_launch_ec(int group, const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,

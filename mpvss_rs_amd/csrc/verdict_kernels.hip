@@ -236,6 +236,45 @@ __device__ __forceinline__ bool below_order(const u32 (&w)[8]) {
   return lt;
 }
 
+
+// Per-share well-formedness of a MODP distribution block (the verdict bytes a sharded verification
+// all-gathers for W_A): out[i] = 1 iff 0 < y_i < q, 0 < Y_i < q and r_i < q - 1.  The reference does not validate its
+// inputs (src/groups/modp.rs:154-156 decodes anything, src/participant.rs:408-448 hashes whatever it computed), so this
+// byte never changes the box verdict; it tells an operator which rank holds a share that is not a canonical encoding.
+// 16 lanes per number: a lane compares its 16-byte piece, the pieces are combined through a ballot (piece 0 = the most
+// significant bytes of the big-endian encoding).  bounds: [2][256] = q, q - 1 as big-endian bytes.
+__device__ __forceinline__ void cmp16(const uint8_t* v, const uint8_t* b, int& c, bool& nz) {
+  c = 0;
+  nz = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int x = v[k], y = b[k];
+    nz = nz || x != 0;
+    if (c == 0) c = x < y ? -1 : (x > y ? 1 : 0);
+  }
+}
+__global__ void __launch_bounds__(256) k_modp_wellformed(const uint8_t* __restrict__ y, const uint8_t* __restrict__ Y,
+                                                         const uint8_t* __restrict__ r, const uint8_t* __restrict__ bounds,
+                                                         int n, uint8_t* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int share = gid >> 4, part = gid & 15;
+  const int s = share < n ? share : n - 1;
+  const int sh = (threadIdx.x & 63) & 48;
+  bool good = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const uint8_t* arr = a == 0 ? y : (a == 1 ? Y : r);
+    int c;
+    bool nz;
+    cmp16(arr + (size_t)s * 256 + 16 * part, bounds + (a == 2 ? 256 : 0) + 16 * part, c, nz);
+    const u32 ne = (u32)(__ballot(c != 0) >> sh) & 0xffffu;
+    const u32 lt = (u32)(__ballot(c < 0) >> sh) & 0xffffu;
+    const u32 any = (u32)(__ballot(nz) >> sh) & 0xffffu;
+    const bool below = ne != 0 && ((lt >> (__ffs((int)ne) - 1)) & 1u);
+    good = good && below && (a == 2 || any != 0);
+  }
+  if (share < n && part == 0) out[share] = good ? 1 : 0;
+}
 }  // namespace
 
 // ---- MODP-2048 ---------------------------------------------------------------------------------------------
@@ -377,6 +416,12 @@ extern "C" __global__ void k_secp_check_scalars(const uint8_t* s, int count, int
 extern "C" __global__ void k_rist_check_scalars(const uint8_t* s, int count, int* first_bad) { check_scalars_body<2>(s, count, first_bad); }
 
 // ---- launchers ------------------------------------------------------------------------------------------------
+extern "C" int verdict_launch_modp_wellformed(const uint8_t* y, const uint8_t* Y, const uint8_t* r, const uint8_t* bounds,
+                                              int count, uint8_t* out, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_wellformed, dim3((count + 15) / 16), dim3(256), 0, s, y, Y, r, bounds, count, out);
+  return (int)hipGetLastError();
+}
 extern "C" int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,
                                    const uint8_t* c, int count, uint8_t* verdict, hipStream_t s) {
   if (count <= 0) return 0;

@@ -10,6 +10,9 @@ What is exchanged, and why:
     running state (point-to-point send/recv).  Each rank enqueues its GPU work first and only
     then waits for the state, so the wait overlaps compute.  The verdict of the last rank is
     broadcast, and a per-rank status record is all-gathered (one small collective per box).
+    On request the ranks also all-gather one well-formedness byte per share (canonical encodings
+    of y_i, Y_i, r_i) -- the per-share verdict bytes of W_A that SURVEY 8(e) describes; they never
+    enter the box verdict.
   * `verify_share` (src/participant.rs:361-386) has one verdict per share box: each rank verifies
     its block and the per-share verdict bytes are all-gathered -- the collective the north star
     names.
@@ -71,14 +74,32 @@ class ShardedVerifier:
 
     # -- verify_distribution_shares ---------------------------------------------------------
     def verify_distribution(self, commitments: bytes, positions: Sequence[int], pubkeys: bytes, shares: bytes,
-                            responses: bytes, challenge: bytes):
+                            responses: bytes, challenge: bytes, block: Optional[int] = None,
+                            ec_group: Optional[int] = None):
         """Arguments are THIS rank's block (commitments and challenge are replicated).
-        Returns (verdict, digest, counts) on every rank; raises ShardError on every rank if any rank failed."""
+        Returns (verdict, digest, counts) on every rank; raises ShardError on every rank if any rank failed.
+        ec_group: capi.GROUP_SECP256K1 / GROUP_RISTRETTO255 for the curve groups (src/participant.rs:1384-1442,
+        1827-1885; None: MODP-2048, :399-455).
+        block (MODP): the padded block length (equal on all ranks).  Then every rank also produces one well-formedness byte
+        per share of its block -- 1 iff y_i, Y_i, r_i are canonical encodings (0 < y, Y < q, r < q - 1) -- and the bytes of
+        ALL ranks are all-gathered (RCCL when the group is "nccl": the engine writes them into the device tensor that is
+        gathered, mpvss_modp_verify_block_compute_flags); the call returns (verdict, digest, counts, wellformed) with the
+        padding removed.  The reference validates nothing at this point (src/groups/modp.rs:154-156), so these bytes are
+        a per-share record for the operator and never part of the box verdict, which is the transcript comparison."""
         eng, rank, world = self.engine, self.rank, self.world
         error: Optional[Exception] = None
         enqueued = False
+        n = len(positions)
+        flags = torch.zeros(block, dtype=torch.uint8, device=self.dev) if block is not None else None
         try:
-            eng.verify_block_compute(commitments, positions, pubkeys, shares, responses, challenge)
+            if ec_group:
+                eng.ec_verify_block_compute(ec_group, commitments, positions, pubkeys, shares, responses, challenge)
+            elif flags is not None and self.dev.type == "cuda" and hasattr(eng, "verify_block_compute_flags"):
+                eng.verify_block_compute_flags(commitments, positions, pubkeys, shares, responses, challenge, flags.data_ptr())
+            else:
+                eng.verify_block_compute(commitments, positions, pubkeys, shares, responses, challenge)
+                if flags is not None and n:
+                    flags[:n] = torch.frombuffer(bytearray(eng.wellformed(pubkeys, shares, responses)), dtype=torch.uint8).to(self.dev)
             enqueued = True
         except Exception as exc:      # still join the chain below
             error = exc
@@ -91,8 +112,8 @@ class ShardedVerifier:
             raw = bytes(buf.cpu().numpy().tobytes())
             state, poisoned = raw[:STATE], bool(raw[STATE])
         if enqueued:
-            try:
-                state = eng.verify_block_absorb(state)          # also frees the block slot when the chain is poisoned
+            try:      # also frees the block slot when the chain is poisoned
+                state = eng.ec_verify_block_absorb(state) if ec_group else eng.verify_block_absorb(state)
             except Exception as exc:
                 error = error or exc
         poisoned = poisoned or error is not None
@@ -103,15 +124,24 @@ class ShardedVerifier:
         else:
             if poisoned:
                 verdict, digest = False, bytes(32)
+            elif ec_group:
+                verdict, digest = capi.ec_transcript_verdict(ec_group, state, challenge)
             else:
                 verdict, digest = capi.transcript_verdict(state, challenge)
             out = torch.frombuffer(bytearray(bytes([int(verdict), int(poisoned)]) + digest), dtype=torch.uint8).to(self.dev)
         dist.broadcast(out, src=world - 1, group=self.group)
         raw = bytes(out.cpu().numpy().tobytes())
-        counts, failed = self._gather_status(len(positions), error is not None)   # one small all-gather per box
+        allf = None
+        if flags is not None:         # the block has been absorbed: the engine's flag bytes are final
+            allf = torch.zeros(block * world, dtype=torch.uint8, device=self.dev)
+            dist.all_gather_into_tensor(allf, flags, group=self.group)        # RCCL all-gather of per-share verdict bytes (W_A)
+        counts, failed = self._gather_status(n, error is not None)   # one small all-gather per box
         if failed:
             raise ShardError(f"verify_distribution failed on rank(s) {failed}" + (f": {error}" if error else "")) from error
-        return bool(raw[0]), raw[2:34], counts
+        if allf is None:
+            return bool(raw[0]), raw[2:34], counts
+        rawf = bytes(allf.cpu().numpy().tobytes())
+        return bool(raw[0]), raw[2:34], counts, b"".join(rawf[k * block: k * block + cnt] for k, cnt in enumerate(counts))
 
     # -- verify_share, batched ------------------------------------------------------------------
     def verify_shares(self, pk: bytes, s: bytes, y: bytes, c: bytes, r: bytes, block: int,

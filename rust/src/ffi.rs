@@ -78,6 +78,7 @@ pub struct mpvss_box_view {
 #[link(name = "mpvss_hip")]
 unsafe extern "C" {
     // ---- context
+    pub fn mpvss_process_init() -> c_int;
     pub fn mpvss_device_count() -> c_int;
     pub fn mpvss_ctx_create(device_id: c_int, out: *mut *mut mpvss_ctx) -> c_int;
     pub fn mpvss_ctx_destroy(ctx: *mut mpvss_ctx);
@@ -100,6 +101,9 @@ unsafe extern "C" {
     pub fn mpvss_modp_verify_block_compute(ctx: *mut mpvss_ctx, space: c_int, commitments: *const u8, t: usize, positions: *const i64,
                                            pubkeys: *const u8, shares: *const u8, responses: *const u8, n: usize, challenge_host: *const u8) -> c_int;
     pub fn mpvss_modp_verify_block_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
+    pub fn mpvss_modp_verify_block_compute_flags(ctx: *mut mpvss_ctx, space: c_int, commitments: *const u8, t: usize, positions: *const i64,
+                                                 pubkeys: *const u8, shares: *const u8, responses: *const u8, n: usize, challenge_host: *const u8,
+                                                 wellformed_dev_out: *mut u8) -> c_int;
     pub fn mpvss_block_claim(ctx: *mut mpvss_ctx, ticket_out: *mut c_ulonglong) -> c_int;
     pub fn mpvss_modp_verify_block_absorb_claimed(ctx: *mut mpvss_ctx, ticket: c_ulonglong, state: *mut u8,
         x_out_host: *mut u8, a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;

@@ -20,3 +20,10 @@ pub mod groups;
 
 pub use engine::{Engine, EngineError};
 pub use groups::{HipModpGroup, HipRistretto255Group, HipSecp256k1Group};
+
+/// Call once at the top of `main`, before anything in the process touches HIP: asks the ROCm runtime for the 8 hardware
+/// queues the block pipeline is tuned for (sets `GPU_MAX_HW_QUEUES=8` unless the variable is already set; the library
+/// never edits the environment by itself).  Returns true when it set the variable.
+pub fn process_init() -> bool {
+    unsafe { ffi::mpvss_process_init() == 1 }
+}

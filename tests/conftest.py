@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the block pipeline wants 8 hardware queues; the variable must be in the environment before the first HIP call of the
+# process -- the library no longer sets it when it is loaded
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # torch ships its own HIP runtime: load it BEFORE libmpvss_hip.so pulls in the system one, otherwise a later
 # torch.cuda initialisation in the same process finds no GPU (bench.py imports torch first for the same reason).
 try:

@@ -140,6 +140,7 @@ static void test_wire_format_round_trip(std::shared_ptr<ModpGroup> group) {
 }
 
 int main() {
+  mpvss_process_init();   // before the first HIP call: 8 hardware queues for the block pipeline
   auto group = ModpGroup::create();
   test_wire_format_round_trip(group);
   test_group_basics(group);

@@ -24,20 +24,33 @@ def _run(ranks, steps, n, depth, timeout=900):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps",
            str(steps), "--warmup", "1", "--participants", str(n), "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0",
-           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0"]
+           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0", "--config-boxes", "0"]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
-def test_two_ranks_share_one_box_through_bench_py():
-    out = _run(2, 3, 16384, 3)
+def test_the_drivers_own_command_starts_its_ranks():
+    """Exactly what the driver runs for N > 1 -- `python3 bench.py --gpus 2 --steps 3 --warmup 1`, no launcher around it:
+    bench.py starts its two ranks itself (a child `torch.distributed.run`, before the parent touches the GPU), relays
+    rank 0's ONE JSON line and its exit code.  Headline shape per rank (65536, 256), three different dealers' boxes; each
+    box's per-share well-formedness bytes are all-gathered over the default process group (gloo here, RCCL on a real
+    node) and the line says how many ranks that group had."""
+    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH="3")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")]
-    assert len(lines) == 1, out.stdout[-2000:]           # rank 0 prints ONE line
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{\"metric\""), out.stdout[-2000:]           # ONE line on stdout
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
-    assert res["config"]["n_per_gpu"] == 16384 and "32768 participants in the box" in res["config"]["workload"]
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["n_per_gpu"] == 65536 and "131072 participants in the box" in res["config"]["workload"]
+    assert res["config"]["distinct_boxes"] == 3
     assert res["value"] > 0 and res["compute"]["fd_fallbacks"] == 0
     assert res["host"]["pipeline"].startswith("verify_block_compute / block_claim / absorb_claimed")
+    # one data collective per box over a group of two ranks: slot initialisation + warm-up + timed boxes at least
+    assert res["rccl"]["rccl_world_size"] == 2 and res["rccl"]["per_box"] == 1 and res["rccl"]["data_collectives"] >= 3 + 1
+    assert res["rccl"]["bytes_per_rank_per_box"] == 65536
 
 
 def test_four_ranks_many_boxes_every_rank_absorbing_several_at_once():
@@ -49,3 +62,4 @@ def test_four_ranks_many_boxes_every_rank_absorbing_several_at_once():
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
     assert res["n_gpus"] == 4 and res["steps"] == 14 and "16384 participants in the box" in res["config"]["workload"]
     assert res["host"]["hash_threads"] >= 2 and res["compute"]["fd_fallbacks"] == 0
+    assert res["rccl"]["rccl_world_size"] == 4 and res["rccl"]["data_collectives"] >= 14

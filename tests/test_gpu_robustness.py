@@ -209,7 +209,7 @@ def test_claimed_blocks_are_absorbed_by_ticket(engine):
 
 def test_verify_many_pipelines_boxes_inside_the_library(engine):
     """mpvss_modp_verify_many == one verify_distribution per box, in box order: honest, tampered, empty and
-    different-sized boxes mixed; more boxes than block slots; an invalid box aborts the call with its error."""
+    different-sized boxes mixed; more boxes than block slots; a malformed box gets verdict False and the run goes on."""
     g, privs, pks, coeffs, ws, box = make_modp_instance(12, 4, 21)
     flat = O.box_to_flat(g, box)
     g2, _, _, _, _, box2 = make_modp_instance(5, 3, 22)
@@ -232,7 +232,39 @@ def test_verify_many_pipelines_boxes_inside_the_library(engine):
     assert st["blocks"] == 3 * sum(1 for b in boxes if b["positions"])
     assert st["hash_ms"] > 0 and st["enqueue_ms"] > 0
     bad = as_box(flat, positions=[-1] + flat["positions"][1:])
-    with pytest.raises(capi.EngineError):
-        engine.verify_many([as_box(flat)] * 3 + [bad] + [as_box(flat)] * 3, depth=4, hash_threads=2)
+    # a malformed box (the reference would panic on its negative exponent) costs only itself: verdict False, zero digest
+    assert engine.verify_many([bad] + [as_box(flat)] * 3 + [bad] + [as_box(flat)] * 3 + [bad], depth=4, hash_threads=2) == \
+        [(False, bytes(32))] + [want[0]] * 3 + [(False, bytes(32))] + [want[0]] * 3 + [(False, bytes(32))]
+    assert "negative position" in engine.last_error()
     # the engine is usable afterwards (no slot left busy)
     assert engine.verify_many([as_box(flat)], depth=1, hash_threads=1) == [want[0]]
+
+
+def test_block_wellformedness_bytes(engine):
+    """mpvss_modp_verify_block_compute_flags: one byte per share in device memory, 1 iff y_i, Y_i, r_i are canonical
+    encodings (0 < y, Y < q, r < q - 1); the box verdict and digest are those of the plain call (the reference validates
+    nothing here, src/groups/modp.rs:154-156) -- an honest box gives all ones."""
+    import torch
+    g, privs, pks, coeffs, ws, box = make_modp_instance(40, 3, 31)
+    flat = O.box_to_flat(g, box)
+    n, q = 40, g.q
+    dev = torch.device("cuda", 0)
+
+    def run(pk, sh, rs):
+        flags = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        engine.verify_block_compute_flags(flat["commitments"], flat["positions"], pk, sh, rs, flat["challenge"], flags.data_ptr())
+        st = engine.verify_block_absorb(capi.transcript_init())
+        return list(flags.cpu().numpy()), capi.transcript_verdict(st, flat["challenge"])
+
+    good, verdict = run(flat["publickeys"], flat["shares"], flat["responses"])
+    assert good == [1] * n and verdict == (True, box["_digest"])
+    pk, sh, rs = bytearray(flat["publickeys"]), bytearray(flat["shares"]), bytearray(flat["responses"])
+    fx = lambda v: v.to_bytes(256, "big")
+    pk[0:256] = fx(0); pk[256:512] = fx(q); pk[512:768] = fx(q - 1)               # 0: no, q: no, q-1: yes
+    sh[3 * 256:4 * 256] = fx(q + 1); sh[4 * 256:5 * 256] = fx(2**2048 - 1); sh[5 * 256:6 * 256] = fx(1)   # no, no, yes
+    rs[6 * 256:7 * 256] = fx(q - 1); rs[7 * 256:8 * 256] = fx(q - 2); rs[8 * 256:9 * 256] = fx(0)       # no, yes, yes
+    rs[39 * 256:40 * 256] = fx(q)
+    got, verdict = run(bytes(pk), bytes(sh), bytes(rs))
+    assert got == [0, 0, 1, 0, 0, 1, 0, 1, 1] + [1] * 30 + [0]
+    ref = engine.verify_distribution(flat["commitments"], flat["positions"], bytes(pk), bytes(sh), bytes(rs), flat["challenge"])
+    assert verdict == (ref["verdict"], ref["digest"]) and verdict[0] is False

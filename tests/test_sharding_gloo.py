@@ -41,6 +41,32 @@ class OracleBlockEngine:
         self._pending = b""
         return st
 
+    def wellformed(self, pubkeys, shares, responses):
+        """include/mpvss_hip.h, mpvss_modp_verify_block_compute_flags: canonical encodings of y_i, Y_i, r_i"""
+        q = self.G.q
+        sp = lambda b: [int.from_bytes(b[i:i + 256], "big") for i in range(0, len(b), 256)]
+        return bytes(int(0 < y < q and 0 < Y < q and r < q - 1) for y, Y, r in zip(sp(pubkeys), sp(shares), sp(responses)))
+
+    def ec_verify_block_compute(self, group, commitments, positions, pubkeys, shares, responses, challenge):
+        O = self.O
+        E = O.GROUPS["secp256k1" if group == 1 else "ristretto255"]()
+        L = E.elem_len
+        el = lambda b: [E.element_from_fixed(b[i:i + L]) for i in range(0, len(b), L)]
+        sc = lambda b: [E.scalar_from_fixed(b[i:i + 32]) for i in range(0, len(b), 32)]
+        cm, c = el(commitments), E.scalar_from_fixed(challenge)
+        out = bytearray()
+        for i, y, Y, r in zip(positions, el(pubkeys), el(shares), sc(responses)):
+            X = O.commitment_eval(E, cm, i)
+            a1, a2 = O.dleq_verifier_commitments(E, E.subgroup_generator(), X, y, Y, r, c)
+            for e in (X, Y, a1, a2):
+                out += E.element_to_bytes(e)
+        self._pending_ec = (group, bytes(out))
+
+    def ec_verify_block_absorb(self, state):
+        from mpvss_rs_amd import capi
+        group, data = self._pending_ec
+        return capi.ec_transcript_absorb(group, state, data)
+
     def verify_shares(self, pk, s, y, c, r):
         O, G = self.O, self.G
         sp = lambda b: [int.from_bytes(b[i:i + 256], "big") for i in range(0, len(b), 256)]
@@ -81,6 +107,19 @@ def _worker(rank, world, port, tamper, q):
         verdict, digest, counts = sv.verify_distribution(flat["commitments"], flat["positions"][lo:hi],
                                                          flat["publickeys"][sl], flat["shares"][sl],
                                                          flat["responses"][sl], flat["challenge"])
+        # the same box once more with the per-share well-formedness bytes all-gathered: share 2's public key is replaced
+        # by q (not a canonical encoding) and share 4's response by q - 1; the box verdict is then False for a reason of
+        # its own (the transcript changes), the flags say where
+        block7 = max(block_range(n, world, k)[1] - block_range(n, world, k)[0] for k in range(world))
+        pkb, rsb = bytearray(flat["publickeys"]), bytearray(flat["responses"])
+        pkb[2 * 256:3 * 256] = g.q.to_bytes(256, "big")
+        rsb[4 * 256:5 * 256] = (g.q - 1).to_bytes(256, "big")
+        _, _, _, wf = sv.verify_distribution(flat["commitments"], flat["positions"][lo:hi], bytes(pkb)[sl], flat["shares"][sl],
+                                             bytes(rsb)[sl], flat["challenge"], block=block7)
+        assert list(wf) == [1, 1, 0, 1, 0, 1, 1], list(wf)
+        v4 = sv.verify_distribution(flat["commitments"], flat["positions"][lo:hi], flat["publickeys"][sl], flat["shares"][sl],
+                                    flat["responses"][sl], flat["challenge"], block=block7)
+        assert (v4[0], v4[1], list(v4[3])) == (verdict, digest, [1] * n)
         # share-box verdicts, all-gathered
         rng = random.Random(5)
         sbs = [O.extract_secret_share(g, box, k, modp_keygen(g, rng)) for k in privs]
@@ -109,6 +148,14 @@ def _worker(rank, world, port, tamper, q):
         eblock = max(block_range(5, world, k)[1] - block_range(5, world, k)[0] for k in range(world))
         ev = sv.verify_shares(enc(epks[elo:ehi]), enc([x["share"] for x in esb[elo:ehi]]), enc(eY[elo:ehi]),
                               scb([x["challenge"] for x in esb[elo:ehi]]), scb(er[elo:ehi]), eblock, ec_group=1)
+        # verify_distribution_shares of a curve group, sharded the same way (participant.rs:1384-1442)
+        eflat = O.box_to_flat(E, ebox)
+        esl = slice(elo * E.elem_len, ehi * E.elem_len)
+        ever = sv.verify_distribution(eflat["commitments"], eflat["positions"][elo:ehi], eflat["publickeys"][esl],
+                                      eflat["shares"][esl], eflat["responses"][elo * 32:ehi * 32], eflat["challenge"], ec_group=1)
+        etr = {}
+        assert O.verify_distribution_shares(E, ebox, etr) is True
+        assert ever[0] is True and ever[1] == etr["digest"] and ever[2] == [ehi - elo if k == rank else 5 - (ehi - elo) for k in range(world)]
         q.put((rank, verdict, digest, counts, list(allv), list(ev)))
     finally:
         dist.destroy_process_group()
