@@ -52,6 +52,13 @@ size_t modp_keyset_words_per_key(void);
 int modp_launch_keyset_build(const uint8_t* pk_be, int count, uint32_t* ks, const void* cs, hipStream_t s);
 int modp_launch_keyset_dual_exp(const uint32_t* ks, const uint32_t* tab2, const uint8_t* r, const uint8_t* c, int count,
                                 uint8_t* out, const void* cs, hipStream_t s);
+/* pair layout (modp_pair_kernels.hip): a2 = y^r Y^c with the Montgomery reduction on the matrix cores; same tables, same
+   exponents, same schedule conventions as modp_launch_dual_exp_w6 / _sched (c_sched null: fixed windows of c, c null too:
+   y^r alone).  pair_tables: device copy of the constant digit matrices (modp_pair_tables_upload, once per context). */
+int modp_pair_tables_upload(void** dev_tables);
+int modp_launch_dual_exp_w6_pair(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
+                                 size_t c_stride, const uint16_t* c_sched, int count, uint8_t* out, const void* cs,
+                                 const void* pair_tables, hipStream_t s);
 int modp_occupancy_report(int* out5);
 /* forward-difference evaluation of X_i for consecutive positions (see modp_kernels.hip) */
 int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_t* cm_b, int split, int t, const int64_t* positions,

@@ -1,0 +1,241 @@
+// MODP-2048 kernels in the "pair" layout: the Montgomery REDUCTION runs on the matrix cores (bn_pair.h).
+//
+//   reference:  DLEQ verifier commitment a2 = y^r * Y^c   src/dleq.rs:79-81 (two ModpGroup::exp, one ::mul,
+//               src/groups/modp.rs:122-132), the dominant kernel of verify_distribution_shares (src/participant.rs:399-455)
+//
+// Why a second layout.  bn_quad.h spends 36 v_mad_u64_u32 per row and lane, 18 of them (of 27.5 for a squaring) on m*N.
+// N never changes, so m*N over the 32 numbers of a wave is a matrix product against a constant matrix: two int8 GEMMs on
+// v_mfma_i32_32x32x32_i8 (T_lo*N' mod R, then m*N), 114 MFMAs per product, beside 18.5 (squaring) / 36 (product) VALU
+// mads per row for a*b.  Measured on MI355X (tools/mfma_mont/ubench): 5.0 G squarings/s against 3.7-3.8 G/s for the
+// VALU-only chain, bit-exact.  The instruction mix, the value bounds and the constant matrices come from the exact integer
+// model tools/mfma_mont/model.py.
+//
+// Layout: one wave = 32 numbers; a number lives in lanes j and j+32 (limbs 36h .. 36h+35 in lane half h).  A workgroup is
+// PAIR_WAVES waves that share one copy of the constant matrices in LDS (39 KB) and own one operand slot per number each.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "bn_pair.h"
+#include "modp_kernels.h"
+
+#ifndef PAIR_WAVES
+#define PAIR_WAVES 8            // waves per workgroup: one workgroup (119 KB of LDS) per CU, two waves per SIMD at 230 VGPRs
+#endif
+
+namespace {
+
+using namespace mm;
+
+struct ModpConsts {             // same layout as in modp_kernels.hip: N, R^2 mod N, R mod N, plain 1
+  u32 n[L];
+  u32 r2[L];
+  u32 one_m[L];
+  u32 one[L];
+};
+
+#ifndef PAIR_LDS_PAD
+#define PAIR_LDS_PAD 0          // bytes of unused LDS per workgroup: lowers the number of workgroups a CU holds (tuning)
+#endif
+
+struct PairShared {
+  Tables tb;
+  __attribute__((aligned(16))) u32 slots[PAIR_WAVES][32 * SLOTW];
+  u32 junk[PAIR_WAVES][L];
+#if PAIR_LDS_PAD > 0
+  u32 pad[PAIR_LDS_PAD / 4];
+#endif
+};
+
+__device__ __forceinline__ void tables_to_lds(Tables* dst, const Tables* __restrict__ src) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += blockDim.x) d4[i] = s4[i];
+  __syncthreads();
+}
+
+// this lane's half (36 limbs = 9 x 16 bytes) of a 72-limb number in global memory -> the number's LDS slot
+__device__ __forceinline__ void slot_fill_pair(u32* slot, const u32* __restrict__ g, const PairLane& pl) {
+  const uint4* g4 = reinterpret_cast<const uint4*>(g + LP * pl.h);
+  uint4* s4 = reinterpret_cast<uint4*>(slot + LP * pl.h);
+#pragma unroll
+  for (int c = 0; c < LP / 4; ++c) s4[c] = g4[c];
+}
+
+__device__ __forceinline__ void slot_store_pair(u32* slot, const u32 (&a)[LP], const PairLane& pl) {
+  uint4* s4 = reinterpret_cast<uint4*>(slot + LP * pl.h);
+#pragma unroll
+  for (int c = 0; c < LP / 4; ++c) s4[c] = make_uint4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+}
+
+__device__ __forceinline__ void load_pair_limbs(u32 (&a)[LP], const u32* __restrict__ g, const PairLane& pl) {
+  const uint4* g4 = reinterpret_cast<const uint4*>(g + LP * pl.h);
+#pragma unroll
+  for (int c = 0; c < LP / 4; ++c) {
+    const uint4 v = g4[c];
+    a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+  }
+}
+
+// plain almost-normalised value < 2N in `a` -> canonical residue in [0, N) as 256 big-endian bytes (as
+// store_canonical_be256 of modp_kernels.hip: exact carry propagation, one conditional subtraction, done by lane half 0)
+__device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, const u32 (&a)[LP], u32* slot,
+                                                     const ModpConsts* __restrict__ cs, const PairLane& pl, bool write) {
+  slot_store_pair(slot, a, pl);
+  __builtin_amdgcn_wave_barrier();
+  if (pl.h == 0) {
+    u32 c = 0;
+#pragma nounroll
+    for (int j = 0; j < L; ++j) {
+      const u32 v = slot[j] + c;
+      slot[j] = v & MASK;
+      c = v >> W;
+    }
+    int ge = 1;
+#pragma nounroll
+    for (int j = L - 1; j >= 0; --j) {
+      const u32 x = slot[j], y = cs->n[j];
+      if (x != y) { ge = x > y; break; }
+    }
+    if (ge) {
+      u32 borrow = 0;
+#pragma nounroll
+      for (int j = 0; j < L; ++j) {
+        const u32 d = slot[j] - cs->n[j] - borrow;
+        borrow = (d >> 31) & 1;
+        slot[j] = d & MASK;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (write) {
+    // lane half h emits the little-endian 32-bit words 32h .. 32h+31 (byte-swapped, mirrored position)
+    u32* out32 = reinterpret_cast<u32*>(out);
+#pragma nounroll
+    for (int i = 0; i < 32; ++i) {
+      const int wd = (int)pl.h * 32 + i;
+      const int bit = 32 * wd;
+      const int j = bit / W, s = bit % W;
+      u64 two = (u64)slot[j] | ((u64)(j + 1 < L ? slot[j + 1] : 0u) << W);
+      two >>= s;
+      if (2 * W - s < 32) two |= (u64)(j + 2 < L ? slot[j + 2] : 0u) << (2 * W - s);
+      out32[63 - wd] = __builtin_bswap32((u32)two);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// a2 = y^r * Y^c (dleq.rs:79-81): the same left-to-right schedule as k_modp_dual_exp_w6 (modp_kernels.hip) -- 6-bit
+// windows of r against the 64-entry table of y, the windows of c (fixed 4-bit, or the host's sliding-window schedule when the
+// box has ONE challenge) against the table of Y -- on the pair layout.  tab1 [count][64][72], tab2 [count][16][72] in
+// Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
+                        const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
+                        const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched,
+                        const Tables* __restrict__ gtab) {
+  __shared__ PairShared sh;
+  tables_to_lds(&sh.tb, gtab);
+  const PairLane pl = make_pair_lane();
+  const int wave = threadIdx.x >> 6;
+  const int xi = (blockIdx.x * PAIR_WAVES + wave) * 32 + (int)(pl.lane & 31);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = &sh.slots[wave][(pl.lane & 31) * SLOTW];
+  u32* junk = sh.junk[wave];
+  const Tables* tb = &sh.tb;
+  u32 acc[LP];
+  const u32* t1 = tab1 + (size_t)x * 64 * L;
+  const u32* t2 = tab2 + (size_t)x * 16 * L;
+  const uint8_t* e1 = e1_be + (size_t)x * 256;
+  const uint8_t* c_be = c_all + (size_t)x * c_stride;
+  auto digit6 = [&](int w) -> u32 {
+    const int o = 6 * w, k = o >> 3;
+    const u32 lo = e1[255 - k];
+    const u32 hi = (k + 1 < 256) ? e1[254 - k] : 0u;
+    return ((lo | (hi << 8)) >> (o & 7)) & 63u;
+  };
+  load_pair_limbs(acc, t1 + (size_t)digit6(341) * L, pl);
+  int cur = 2046;
+  int s = 0;                       // 0: square, 1: product with tab1, 2: product with tab2, 3: leave the Montgomery domain
+  int si = 0;
+  const int sn = c_sched ? (int)c_sched[0] : 0;
+  while (true) {
+    const u32* fill = nullptr;
+    bool skip = false;
+    if (s == 0) {
+      --cur;
+    } else if (s == 1) {
+      if (cur % 6 == 0) fill = t1 + (size_t)digit6(cur / 6) * L; else skip = true;
+    } else if (s == 2) {
+      if (c_sched != nullptr) {
+        if (si < sn && cur == (int)c_sched[1 + 2 * si]) {
+          fill = t2 + (size_t)c_sched[2 + 2 * si] * L;
+          ++si;
+        } else {
+          skip = true;
+        }
+      } else if ((cur & 3) == 0 && cur < 256 && c_all != nullptr) {
+        const u32 byte = c_be[255 - (cur >> 3)];
+        fill = t2 + (size_t)((cur & 4) ? (byte >> 4) : (byte & 15)) * L;
+      } else {
+        skip = true;
+      }
+    } else {
+      fill = cs->one;
+    }
+    if (!skip) {
+      u64 T[LP];
+      if (s == 0) {
+        slot_store_pair(slot, acc, pl);
+        __builtin_amdgcn_wave_barrier();
+        phase_a<true>(T, acc, slot, junk, pl);
+      } else {
+        slot_fill_pair(slot, fill, pl);
+        __builtin_amdgcn_wave_barrier();
+        phase_a<false>(T, acc, slot, junk, pl);
+      }
+      u32 r[LP];
+      reduce(r, T, slot, tb, pl);                 // ONE copy of the reduction in the kernel
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < LP; ++k) acc[k] = r[k];
+    }
+    if (s == 3) break;
+    s = (s == 2) ? (cur == 0 ? 3 : 0) : s + 1;
+  }
+  store_canonical_pair(out_be + (size_t)x * 256, acc, slot, cs, pl, live);
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int modp_pair_tables_upload(void** dev_tables) {
+  static_assert(sizeof(MM_A1) == sizeof(Tables::a1) && sizeof(MM_A2) == sizeof(Tables::a2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
+                    sizeof(MM_C2) == sizeof(Tables::c2), "generated tables do not match bn_pair.h");
+  Tables* h = new Tables;
+  memcpy(h->a1, MM_A1, sizeof(MM_A1));
+  memcpy(h->a2, MM_A2, sizeof(MM_A2));
+  memcpy(h->c1, MM_C1, sizeof(MM_C1));       // [R][h][16] ints = v16i [2 R + h]
+  memcpy(h->c2, MM_C2, sizeof(MM_C2));
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, sizeof(Tables));
+  if (e == hipSuccess) e = hipMemcpy(d, h, sizeof(Tables), hipMemcpyHostToDevice);
+  delete h;
+  if (e != hipSuccess) return (int)e;
+  *dev_tables = d;
+  return 0;
+}
+
+static inline int pair_grid(int count) { return (count + 32 * PAIR_WAVES - 1) / (32 * PAIR_WAVES); }
+
+extern "C" int modp_launch_dual_exp_w6_pair(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
+                                            size_t c_stride, const uint16_t* c_sched, int count, uint8_t* out, const void* cs,
+                                            const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_dual_exp_w6_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab1, tab2, e1, c, c_stride, count,
+                     out, (const ModpConsts*)cs, c_sched, (const Tables*)pair_tables);
+  return (int)hipGetLastError();
+}

@@ -75,6 +75,7 @@ struct mpvss_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   void* consts = nullptr;
+  void* pair_tables = nullptr;   // constant digit matrices of the pair-layout kernels (bn_pair.h), one device copy per context
   std::string err;
   mutable std::mutex err_mu;     // guards `err` alone: mpvss_last_error may run beside calls of other threads
   std::mutex mu;
@@ -585,7 +586,7 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
   ctx->own_stream = true;
   if (work_init(ctx, ctx->work0, ctx->stream) != 0 ||
       hipDeviceGetStreamPriorityRange(&ctx->prio_low, &ctx->prio_high) != hipSuccess ||
-      modp_consts_upload(&ctx->consts) != 0) {
+      modp_consts_upload(&ctx->consts) != 0 || modp_pair_tables_upload(&ctx->pair_tables) != 0) {
     delete ctx;
     return MPVSS_E_DEVICE;
   }
@@ -621,6 +622,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
+  if (ctx->pair_tables) (void)hipFree(ctx->pair_tables);
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : ctx->slot) {
     if (sl.pin) (void)hipHostFree(sl.pin);
@@ -1037,6 +1039,24 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
 
 // ---- DLEQ verifier commitments -------------------------------------------------------------------
 namespace {
+// a = B1^r * B2^c with the 64-entry table of B1.  Two kernels compute it: the VALU-only one (modp_kernels.hip) and the
+// pair-layout one whose Montgomery reduction runs on the matrix cores (modp_pair_kernels.hip: 37.7 against 48.9 ms for the
+// 65536 shares of a headline box when the launch has the chip to itself).  The pair kernel's workgroups are large (8 waves,
+// 230 VGPRs, 119 KB of LDS: a whole CU) and do not share a CU with the single-wave workgroups of the other kernels, so in a
+// run of many boxes in flight it gains nothing (profiles/r03_pair_ab.txt): MPVSS_A2_PAIR = 1 (default) uses it for calls
+// that have the GPU to themselves, 2 always, 0 never.
+// c_sched: sliding-window schedule of ONE shared challenge (then c_dev is unused), else fixed 4-bit windows of c_dev
+// (stride c_stride; null: B1^r alone).
+int launch_dual_exp_w6(mpvss_ctx* ctx, const uint32_t* t1, const uint32_t* t2, const uint8_t* r_dev, const uint8_t* c_dev,
+                       size_t c_stride, const uint16_t* c_sched, size_t cnt, uint8_t* out_dev) {
+  static const int pair = fd_env("MPVSS_A2_PAIR", 1);
+  if (pair >= 2 || (pair == 1 && !ctx->busy_with_others() && cnt >= 4096))
+    return modp_launch_dual_exp_w6_pair(t1, t2, r_dev, c_dev, c_stride, c_sched, (int)cnt, out_dev, ctx->consts, ctx->pair_tables,
+                                        ctx->stream);
+  if (c_sched) return modp_launch_dual_exp_w6_sched(t1, t2, r_dev, c_sched, (int)cnt, out_dev, ctx->consts, ctx->stream);
+  return modp_launch_dual_exp_w6(t1, t2, r_dev, c_dev, c_stride, (int)cnt, out_dev, ctx->consts, ctx->stream);
+}
+
 // a = B1^r * B2^c for `cnt` shares.  tab_b1: shared table (stride 0) or nullptr -> per-number tables
 // from b1_dev.  c: device pointer, stride c_stride (0 shared).
 int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, const uint8_t* b2_dev,
@@ -1055,8 +1075,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
     // per-share base with a full-width exponent and 256-bit second exponent(s): 6-bit windows for B1^r
     RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
     TIMED_LAUNCH(ctx, 2, modp_launch_build_table64(b1_dev, (int)cnt, (uint32_t*)ctx->w->tab1.p, ctx->consts, ctx->stream));
-    TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6((const uint32_t*)ctx->w->tab1.p, t2, r_dev, c_dev, c_stride, (int)cnt, out_dev,
-                                                 ctx->consts, ctx->stream));
+    TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, (const uint32_t*)ctx->w->tab1.p, t2, r_dev, c_dev, c_stride, nullptr, cnt, out_dev));
     return 0;
   }
   if (shared_b1) {
@@ -1353,10 +1372,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
-          if (dsched) TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6_sched(t1p, t2p, (const uint8_t*)dr, dsched, (int)cnt, da2,
-                                                                         ctx->consts, ctx->stream));
-          else TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, (int)cnt, da2,
-                                                            ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
@@ -2148,8 +2164,8 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
                                                   bk + cnt * bw, dY, da2, ctx->consts, ctx->stream));
       } else if (cnt >= 1024) {   // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
         TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dp, nullptr, 0, (int)cnt, dY, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_w6(ty, ty, (const uint8_t*)dw, nullptr, 0, (int)cnt, da2, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, ty, ty, (const uint8_t*)dp, nullptr, 0, nullptr, cnt, dY));
+        TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, ty, ty, (const uint8_t*)dw, nullptr, 0, nullptr, cnt, da2));
       } else {
         TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
         TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dY,
