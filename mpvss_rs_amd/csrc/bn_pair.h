@@ -40,10 +40,12 @@ constexpr int SLOTW = 76;                 // LDS words per number slot (72 limbs
 constexpr u32 MASK = (1u << W) - 1;
 constexpr u32 XM = 0x00808080u;           // bytes 0..2 of an operand word are unsigned digits (minus 128 for the MFMA), byte 3 is signed
 
-struct __attribute__((aligned(64))) Tables {   // constant, one copy in LDS per workgroup
-  v4i a1[9 * 64];                         // tile d = R - C of GEMM 1: [lane] 16 bytes of the A operand
-  v4i a2[MM_NA2 * 64];                    // distinct tiles of GEMM 2 (MM_A2IDX[9 R + C], -1: all zero)
-  v16i c1[9 * 2];                         // C-init of tile R for lane half h: [2 R + h]
+struct __attribute__((aligned(64))) Tables {   // constant, one copy in LDS per workgroup (17 KB)
+  // 16-byte A-operand records of the two Toeplitz digit matrices: gt[e][x], x = (row limb) - (8 C + 4 h') + 4, bytes
+  // [4 j' + f] = digit e of limb x - 4 - j' of (N' or N) << 8 f  (tools/mfma_mont/model.py checks every tile and lane)
+  v4i gt1[4 * MM_GT1_X];
+  v4i gt2[4 * MM_GT2_X];
+  v16i c1[9 * 2];                         // C-init of tile R for lane half h: [2 R + h], register 4 e + g
   v16i c2[9 * 2];
 };
 
@@ -52,6 +54,9 @@ struct PairLane {
   u32 m0, m1;   // all ones in lane half 0 / 1
   u32 lane;     // 0..63
   int k16, one; // 65536 and 1 in VGPRs, opaque to the optimiser: "x * k16 + y" stays one v_mad_i64_i32
+  // this lane's A-operand record of tile (R, C): GEMM 1 at rec1 + 8 (R - C), GEMM 2 at rec2 + (4 R - 8 C + 64) (tile 8: rec2g,
+  // whose row rho = 71 is the guard limb 71 instead of limb 143)
+  u32 rec1, rec2, rec2g;
 };
 
 __device__ __forceinline__ PairLane make_pair_lane() {
@@ -62,6 +67,12 @@ __device__ __forceinline__ PairLane make_pair_lane() {
   pl.m0 = ~pl.m1;
   pl.k16 = 65536;
   pl.one = 1;
+  {
+    const u32 row = pl.lane & 31, g = row & 3, hr = (row >> 2) & 1, e = row >> 3, hp = pl.lane >> 5;
+    pl.rec1 = e * MM_GT1_X + 4 * hr + g - 4 * hp + 4;
+    pl.rec2 = e * MM_GT2_X + 76 + 36 * hr + g - 4 * hp - 64;
+    pl.rec2g = pl.rec2 - ((hr == 1 && g == 3) ? 72u : 0u);
+  }
   asm volatile("" : "+v"(pl.m0), "+v"(pl.m1), "+v"(pl.k16), "+v"(pl.one));
   return pl;
 }
@@ -142,6 +153,9 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
   // Software pipeline, one stage per row tile: the (dependent) MFMA chain of tile R runs on the matrix pipe while the VALU
   // does the epilogue of tile R-1; a scheduling barrier between the stages keeps the compiler from unrolling the whole GEMM
   // into eight accumulators at once (it does, and then spills).
+  // T_lo and m'' stay in registers (2 x 36): taking the data operand of every MFMA from the LDS slot instead was built and
+  // measured (170 instead of 197 VGPRs, but 4.2 instead of 4.8 G squarings/s, and 0.96 instead of 1.03 M share
+  // verifications/s in the pipeline: profiles/r03_pair_ab.txt).
   v4i xw[9], mw[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) xw[c] = *reinterpret_cast<const v4i*>(slot + 8 * c + 4 * pl.h);
@@ -153,7 +167,7 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
     ac = c1[2 * R];
 #pragma unroll
     for (int C = 0; C <= R; ++C) {
-      const v4i A = tb->a1[64 * (R - C) + pl.lane];
+      const v4i A = tb->gt1[pl.rec1 + 8 * (R - C)];
       ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, xw[C], ac, 0, 0, 0);
     }
   };
@@ -161,7 +175,7 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
     u32 lo[4], hi[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int p01 = ac[4 * g] + (ac[4 * g + 1] << 8), p23 = ac[4 * g + 2] + (ac[4 * g + 3] << 8);
+      const int p01 = ac[g] + (ac[4 + g] << 8), p23 = ac[8 + g] + (ac[12 + g] << 8);     // register 4 e + g: byte e of limb g
       const i64 V = (i64)p23 * pl.k16 + (i64)p01;          // v_mad_i64_i32 (the constant is opaque: no 64-bit shift-and-add)
       lo[g] = (u32)V & MASK;
       hi[g] = __builtin_amdgcn_alignbit((u32)((u64)V >> 32), (u32)V, W);     // low 32 bits of V >> 29 (|V| < 2^47)
@@ -192,16 +206,15 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
     ac = c2[2 * R];
 #pragma unroll
     for (int C = 0; C < 9; ++C) {
-      const int id = MM_A2IDX[9 * R + C];
-      if (id < 0) continue;
-      const v4i A = tb->a2[64 * id + pl.lane];
+      if (MM_SKIP2[9 * R + C]) continue;
+      const v4i A = tb->gt2[(R == 8 ? pl.rec2g : pl.rec2) + (4 * R - 8 * C + 64)];
       ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, mw[C], ac, 0, 0, 0);
     }
   };
   auto epi2 = [&](int R, const v16i& ac) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int p01 = ac[4 * g] + (ac[4 * g + 1] << 8), p23 = ac[4 * g + 2] + (ac[4 * g + 3] << 8);
+      const int p01 = ac[g] + (ac[4 + g] << 8), p23 = ac[8 + g] + (ac[12 + g] << 8);
       if (R == 8 && g == 3) {
         // half 0: result limb 35 as usual; half 1: the guard limb (absolute limb 71) -> carry of the low half into limb 0
         const i64 V = (i64)p23 * pl.k16 + (i64)p01;

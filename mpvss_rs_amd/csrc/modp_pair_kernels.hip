@@ -11,7 +11,7 @@
 // model tools/mfma_mont/model.py.
 //
 // Layout: one wave = 32 numbers; a number lives in lanes j and j+32 (limbs 36h .. 36h+35 in lane half h).  A workgroup is
-// PAIR_WAVES waves that share one copy of the constant matrices in LDS (39 KB) and own one operand slot per number each.
+// PAIR_WAVES waves that share one copy of the constant digit records in LDS (17 KB) and own one operand slot per number each.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -20,7 +20,12 @@
 #include "modp_kernels.h"
 
 #ifndef PAIR_WAVES
-#define PAIR_WAVES 8            // waves per workgroup: one workgroup (119 KB of LDS) per CU, two waves per SIMD at 230 VGPRs
+#define PAIR_WAVES 1            // waves per workgroup.  ONE, as for the quad kernels: a single-wave workgroup (27 KB of LDS: 17 KB
+                                // of constant records + the wave's operand slots) fits any CU with a free wave slot, and the
+                                // pipeline mixes it with the other kernels' waves -- with 4 or 8 waves per workgroup the kernel
+                                // is faster alone (37.7 instead of 43.4 ms) but the pipeline is SLOWER than with the VALU-only
+                                // kernel, because such a workgroup only starts on a CU the single-wave workgroups have left
+                                // empty (profiles/r03_pair_ab.txt: 0.91 / 0.98 / 1.04 M for 4 / 2 / 1 waves, 0.98 M VALU-only)
 #endif
 
 namespace {
@@ -213,11 +218,11 @@ k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ ta
 
 // ---------------------------------------------------------------------------------------
 extern "C" int modp_pair_tables_upload(void** dev_tables) {
-  static_assert(sizeof(MM_A1) == sizeof(Tables::a1) && sizeof(MM_A2) == sizeof(Tables::a2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
+  static_assert(sizeof(MM_GT1) == sizeof(Tables::gt1) && sizeof(MM_GT2) == sizeof(Tables::gt2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
                     sizeof(MM_C2) == sizeof(Tables::c2), "generated tables do not match bn_pair.h");
   Tables* h = new Tables;
-  memcpy(h->a1, MM_A1, sizeof(MM_A1));
-  memcpy(h->a2, MM_A2, sizeof(MM_A2));
+  memcpy(h->gt1, MM_GT1, sizeof(MM_GT1));
+  memcpy(h->gt2, MM_GT2, sizeof(MM_GT2));
   memcpy(h->c1, MM_C1, sizeof(MM_C1));       // [R][h][16] ints = v16i [2 R + h]
   memcpy(h->c2, MM_C2, sizeof(MM_C2));
   void* d = nullptr;

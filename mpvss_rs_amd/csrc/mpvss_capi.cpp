@@ -1039,18 +1039,15 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
 
 // ---- DLEQ verifier commitments -------------------------------------------------------------------
 namespace {
-// a = B1^r * B2^c with the 64-entry table of B1.  Two kernels compute it: the VALU-only one (modp_kernels.hip) and the
-// pair-layout one whose Montgomery reduction runs on the matrix cores (modp_pair_kernels.hip: 37.7 against 48.9 ms for the
-// 65536 shares of a headline box when the launch has the chip to itself).  The pair kernel's workgroups are large (8 waves,
-// 230 VGPRs, 119 KB of LDS: a whole CU) and do not share a CU with the single-wave workgroups of the other kernels, so in a
-// run of many boxes in flight it gains nothing (profiles/r03_pair_ab.txt): MPVSS_A2_PAIR = 1 (default) uses it for calls
-// that have the GPU to themselves, 2 always, 0 never.
+// a = B1^r * B2^c with the 64-entry table of B1.  Two kernels compute it: the pair-layout one, whose Montgomery reduction
+// runs on the matrix cores (modp_pair_kernels.hip; default), and the VALU-only one (modp_kernels.hip; MPVSS_A2_PAIR=0).
+// Same tables, exponents and results; measured in the headline pipeline 1.03 against 0.92-0.98 M share verifications/s.
 // c_sched: sliding-window schedule of ONE shared challenge (then c_dev is unused), else fixed 4-bit windows of c_dev
 // (stride c_stride; null: B1^r alone).
 int launch_dual_exp_w6(mpvss_ctx* ctx, const uint32_t* t1, const uint32_t* t2, const uint8_t* r_dev, const uint8_t* c_dev,
                        size_t c_stride, const uint16_t* c_sched, size_t cnt, uint8_t* out_dev) {
   static const int pair = fd_env("MPVSS_A2_PAIR", 1);
-  if (pair >= 2 || (pair == 1 && !ctx->busy_with_others() && cnt >= 4096))
+  if (pair)
     return modp_launch_dual_exp_w6_pair(t1, t2, r_dev, c_dev, c_stride, c_sched, (int)cnt, out_dev, ctx->consts, ctx->pair_tables,
                                         ctx->stream);
   if (c_sched) return modp_launch_dual_exp_w6_sched(t1, t2, r_dev, c_sched, (int)cnt, out_dev, ctx->consts, ctx->stream);

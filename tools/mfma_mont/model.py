@@ -136,43 +136,44 @@ if __name__ == "__main__":
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Tables for the kernel (tools/mfma_mont/mont_tables.h).  MFMA v_mfma_i32_32x32x32_i8, D = A*B + C:
+# Tables for the kernel (mpvss_rs_amd/csrc/modp_mfma_tables.h).  MFMA v_mfma_i32_32x32x32_i8, D = A*B + C:
 #   A (constant digit matrix): lane l holds A[row = l & 31][k = 16 (l >> 5) + jj], jj = 0..15   (16 bytes)
 #   B (data):                  lane l holds B[k = 16 (l >> 5) + jj][col = l & 31]                (col = the number)
 #   C/D:                       lane l, register reg: row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), col = l & 31
-# Row / k conventions of both GEMMs (h = lane half, g = reg >> 2, e = reg & 3; h' = half of the k index, j', f):
+# Row / k conventions of both GEMMs (h = lane half of the RESULT, g = reg & 3, e = reg >> 2; h' = half of the k index):
 #   k index 16 h' + 4 j' + f   <->  data limb i = 8 C + 4 h' + j', byte f          (K-block C = 0..8)
-#   GEMM 1 tile R: row e + 8 g + 4 h  <->  limb k = 8 R + 4 h + g of m, byte e     (so that the results ARE the next operand)
-#   GEMM 2 tile R: row e + 8 g + 4 h  <->  result limb rho = 36 h + 4 R + g (absolute limb 72 + rho), byte e;
-#                  (R, h, g) = (8, 1, 3), i.e. rho = 71, is the guard limb: absolute limb 71.
-def tile_bytes(entry):
-    """entry(row, kidx) -> 1024 bytes in A-operand order: lane l = row + 32 h', 16 bytes jj"""
-    out = bytearray(1024)
-    for lane in range(64):
-        row, hp = lane & 31, lane >> 5
-        for jj in range(16):
-            out[16 * lane + jj] = entry(row, 16 * hp + jj) & 0xFF
+#   row r = g + 8 e + 4 h of tile R:
+#     GEMM 1: limb k = 8 R + 4 h + g of m, byte e          (so that the results ARE the next operand)
+#     GEMM 2: result limb rho = 36 h + 4 R + g (absolute limb 72 + rho), byte e;
+#             (R, h, g) = (8, 1, 3), i.e. rho = 71, is the guard limb: absolute limb 71.
+# Both matrices are Toeplitz in the limb index: entry (row, k) = digit e of limb (k_row - i) of (N' or N) << 8 f.  So a lane's
+# 16 A-operand bytes of ANY tile are one 16-byte record GT[e][x], x = k_row - (8 C + 4 h'):  bytes [4 j' + f] =
+# digit(f, x - j', e) -- 5 KB (GEMM 1) + 9.5 KB (GEMM 2, zero-padded so that no lane ever needs a clamp) instead of
+# 36 one-kilobyte tiles.  Lanes 0..7 of a wave (g = 0..3, h = 0..1, e = 0) read 8 consecutive records: conflict-free.
+GT1_X = 81          # records per e of GEMM 1: x = -4 .. 76
+GT2_X = 148         # records per e of GEMM 2: x = -4 .. 143
+
+
+def gv(G, f, d, e):
+    return G[f][d][e] if 0 <= d <= L else 0
+
+
+def gt_bytes(G, nx):
+    out = bytearray()
+    for e in range(4):
+        for xi in range(nx):
+            x = xi - 4
+            for jp in range(4):
+                for f in range(4):
+                    out.append(gv(G, f, x - jp, e) & 0xFF)
     return bytes(out)
 
 
 def row_geh(row):
-    e = row & 3
+    g = row & 3
     h = (row >> 2) & 1
-    g = row >> 3
+    e = row >> 3
     return g, e, h
-
-
-def k_ijf(kidx, C):
-    hp, jp, f = kidx >> 4, (kidx >> 2) & 3, kidx & 3
-    return 8 * C + 4 * hp + jp, f
-
-
-def gemm1_tile(d):       # depends on R - C only; computed for C = 0
-    def entry(row, kidx):
-        g, e, h = row_geh(row)
-        i, f = k_ijf(kidx, 0)
-        return g1(8 * d + 4 * h + g, e, i, f) if 8 * d + 4 * h + g < L else 0
-    return tile_bytes(entry)
 
 
 def gemm2_row_limb(R, h, g):
@@ -180,41 +181,39 @@ def gemm2_row_limb(R, h, g):
     return L - 1 if rho == 71 else L + rho
 
 
-def gemm2_tile(R, C):
-    def entry(row, kidx):
-        g, e, h = row_geh(row)
-        i, f = k_ijf(kidx, C)
-        return g2(gemm2_row_limb(R, h, g), e, i, f)
-    return tile_bytes(entry)
-
-
 def emit(path):
-    a1 = [gemm1_tile(d) for d in range(9)]
-    # sanity: tile (R, C) of GEMM 1 equals the tile of R - C
-    def g1_tile_rc(R, C):
-        def entry(row, kidx):
-            g, e, h = row_geh(row)
-            i, f = k_ijf(kidx, C)
-            return g1(8 * R + 4 * h + g, e, i, f)
-        return tile_bytes(entry)
-    for R, C in ((3, 1), (8, 8), (8, 0), (5, 4)):
-        assert g1_tile_rc(R, C) == a1[R - C]
-    a2, a2idx, seen = [], [[-1] * 9 for _ in range(9)], {}
+    gt1, gt2 = gt_bytes(G1, GT1_X), gt_bytes(G2, GT2_X)
+    # the record addressing of the kernel against the matrix definitions g1 / g2, every tile, every lane
+    skip2 = [[1] * 9 for _ in range(9)]
     for R in range(9):
         for C in range(9):
-            t = gemm2_tile(R, C)
-            if not any(t):
-                continue
-            if t not in seen:
-                seen[t] = len(a2)
-                a2.append(t)
-            a2idx[R][C] = seen[t]
+            for lane in range(64):
+                row, hp = lane & 31, lane >> 5
+                g, e, h = row_geh(row)
+                if C <= R:
+                    xi = 4 * h + g - 4 * hp + 4 + 8 * (R - C)
+                    assert 0 <= xi < GT1_X
+                    rec = gt1[(e * GT1_X + xi) * 16:(e * GT1_X + xi) * 16 + 16]
+                    for jp in range(4):
+                        for f in range(4):
+                            want = g1(8 * R + 4 * h + g, e, 8 * C + 4 * hp + jp, f)
+                            assert rec[4 * jp + f] == want & 0xFF
+                k = gemm2_row_limb(R, h, g)
+                xi = k - 8 * C - 4 * hp + 4
+                assert 0 <= xi < GT2_X
+                rec = gt2[(e * GT2_X + xi) * 16:(e * GT2_X + xi) * 16 + 16]
+                for jp in range(4):
+                    for f in range(4):
+                        want = g2(k, e, 8 * C + 4 * hp + jp, f)
+                        assert rec[4 * jp + f] == want & 0xFF
+                        if want:
+                            skip2[R][C] = 0
     def cinit(rowlimb, gfun):
         out = []
         for R in range(9):
             for h in range(2):
                 for reg in range(16):
-                    g, e = reg >> 2, reg & 3
+                    g, e = reg & 3, reg >> 2
                     k = rowlimb(R, h, g)
                     out.append(128 * sum(gfun(k, e, i, f) for i in range(L) for f in range(3)))
         return out
@@ -222,26 +221,25 @@ def emit(path):
     c2 = cinit(gemm2_row_limb, g2)
     assert all(-(1 << 31) <= v < (1 << 31) for v in c1 + c2)
     n_mfma1 = sum(R + 1 for R in range(9))
-    n_mfma2 = sum(1 for R in range(9) for C in range(9) if a2idx[R][C] >= 0)
+    n_mfma2 = sum(1 for R in range(9) for C in range(9) if not skip2[R][C])
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/mfma_mont/model.py -- constant digit matrices of N' and N for the int8 MFMA reduction.\n")
+        f.write("// GENERATED by tools/mfma_mont/model.py -- constant digit records of N' and N for the int8 MFMA reduction (bn_pair.h).\n")
         f.write("#pragma once\n#include <stdint.h>\n")
-        f.write(f"#define MM_NA2 {len(a2)}\n#define MM_MFMA1 {n_mfma1}\n#define MM_MFMA2 {n_mfma2}\n")
+        f.write(f"#define MM_GT1_X {GT1_X}\n#define MM_GT2_X {GT2_X}\n#define MM_MFMA1 {n_mfma1}\n#define MM_MFMA2 {n_mfma2}\n")
         def arr(name, data, ctype="uint8_t"):
             f.write(f"static const {ctype} {name}[{len(data)}] = {{\n")
             for o in range(0, len(data), 32):
                 f.write("  " + ",".join(str(v) for v in data[o:o + 32]) + ",\n")
             f.write("};\n")
-        arr("MM_A1", b"".join(a1))
-        arr("MM_A2", b"".join(a2))
+        arr("MM_GT1", gt1)
+        arr("MM_GT2", gt2)
         arr("MM_C1", c1, "int32_t")
         arr("MM_C2", c2, "int32_t")
-        f.write("static constexpr int8_t MM_A2IDX[81] = {" + ",".join(str(v) for row in a2idx for v in row) + "};\n")
-    print(f"wrote {path}: {len(a2)} distinct GEMM-2 tiles, {n_mfma1} + {n_mfma2} MFMAs per product")
+        f.write("static constexpr int8_t MM_SKIP2[81] = {" + ",".join(str(v) for row in skip2 for v in row) + "};\n")
+    print(f"wrote {path}: {len(gt1)} + {len(gt2)} bytes of records, {n_mfma1} + {n_mfma2} MFMAs per product")
 
 
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "emit":
     import os
     here = os.path.dirname(os.path.abspath(__file__))
-    emit(os.path.join(here, "mont_tables.h"))
     emit(os.path.join(here, "..", "..", "mpvss_rs_amd", "csrc", "modp_mfma_tables.h"))

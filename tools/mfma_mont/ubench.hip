@@ -12,7 +12,7 @@
 
 #include "../../mpvss_rs_amd/csrc/bn_quad.h"
 #include "../../mpvss_rs_amd/csrc/modp2048_consts.h"
-#include "mont_pair.h"
+#include "../../mpvss_rs_amd/csrc/bn_pair.h"
 
 #define CHECK(x)                                                                       \
   do {                                                                                 \
@@ -25,8 +25,11 @@
 #endif
 constexpr int WAVES = UB_WAVES;   // waves per workgroup of the pair kernel (one workgroup per CU: the tables take 39 KB of LDS)
 
+#ifndef UB_WPE
+#define UB_WPE 2
+#endif
 template <bool MUL>
-__global__ void __launch_bounds__(64 * WAVES) k_chain_pair(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(UB_WPE, UB_WPE))) k_chain_pair(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
                                                           int S, const mm::Tables* __restrict__ gt) {
   __shared__ mm::Tables tb;
   __shared__ __attribute__((aligned(16))) uint32_t slots[WAVES][32 * mm::SLOTW];
@@ -154,10 +157,9 @@ int main(int argc, char** argv) {
   printf("selftest (MFMA i8 32x32x32 lane maps, permlane32_swap): %s (%d)\n", hbad == 0 ? "ok" : "MISMATCH", hbad);
   if (hbad != 0) return 3;
   mm::Tables* ht = new mm::Tables;
-  static_assert(sizeof(MM_A1) == sizeof(ht->a1) && sizeof(MM_A2) == sizeof(ht->a2) && sizeof(MM_C1) == sizeof(ht->c1), "tables");
-  // MM_C1 / MM_C2 are [R][h][16] ints = v16i[2 R + h]
-  memcpy(ht->a1, MM_A1, sizeof(MM_A1));
-  memcpy(ht->a2, MM_A2, sizeof(MM_A2));
+  static_assert(sizeof(MM_GT1) == sizeof(ht->gt1) && sizeof(MM_GT2) == sizeof(ht->gt2) && sizeof(MM_C1) == sizeof(ht->c1), "tables");
+  memcpy(ht->gt1, MM_GT1, sizeof(MM_GT1));
+  memcpy(ht->gt2, MM_GT2, sizeof(MM_GT2));
   memcpy(ht->c1, MM_C1, sizeof(MM_C1));
   memcpy(ht->c2, MM_C2, sizeof(MM_C2));
   mm::Tables* dt;
