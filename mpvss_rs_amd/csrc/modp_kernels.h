@@ -59,6 +59,14 @@ int modp_pair_tables_upload(void** dev_tables);
 int modp_launch_dual_exp_w6_pair(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
                                  size_t c_stride, const uint16_t* c_sched, int count, uint8_t* out, const void* cs,
                                  const void* pair_tables, hipStream_t s);
+/* pair-layout forms of the table builders (entries 64, or 16 with odd_only), of the wide-comb exponentiation g^e1 (mode 1
+   of modp_launch_comb_dual_exp_split with the 16-bit comb) and of p_m * B2^c for a scheduled shared c (modp_launch_comb_dual_exp_sched) */
+int modp_launch_build_table_pair(const uint8_t* base_be, int count, uint32_t* tab, int entries, int odd_only, const void* cs,
+                                 const void* pair_tables, hipStream_t s);
+int modp_launch_comb16_exp_pair(const uint32_t* comb16, const uint8_t* e1, int count, uint32_t* p_m, const void* cs,
+                                const void* pair_tables, hipStream_t s);
+int modp_launch_sched_exp_mul_pair(const uint32_t* tab2, size_t tab2_stride, const uint16_t* c_sched, const uint32_t* p_m,
+                                   int count, uint8_t* out, const void* cs, const void* pair_tables, hipStream_t s);
 int modp_occupancy_report(int* out5);
 /* forward-difference evaluation of X_i for consecutive positions (see modp_kernels.hip) */
 int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_t* cm_b, int split, int t, const int64_t* positions,

@@ -217,6 +217,185 @@ k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ ta
 }
 
 // ---------------------------------------------------------------------------------------
+// One Montgomery operation of a kernel's main loop.  Every kernel below calls this from ONE place: the straight-line code of
+// a product (12 KB), of a squaring (9 KB) and of the reduction (10 KB) must exist once per kernel, or the loop outgrows the
+// instruction cache.  sq: acc = acc^2; else acc = acc * b with b = `fill` (72 limbs in global memory) or, if fill is null,
+// the 36 limbs per lane in `breg`.
+// ---------------------------------------------------------------------------------------
+namespace {
+template <bool HAS_SQ>
+__device__ __forceinline__ void pair_step(u32 (&acc)[LP], bool sq, const u32* fill, const u32 (&breg)[LP], u32* slot, u32* junk,
+                                          const Tables* tb, const PairLane& pl) {
+  u64 T[LP];
+  if (HAS_SQ && sq) {
+    slot_store_pair(slot, acc, pl);
+    __builtin_amdgcn_wave_barrier();
+    phase_a<true>(T, acc, slot, junk, pl);
+  } else {
+    if (fill != nullptr) slot_fill_pair(slot, fill, pl); else slot_store_pair(slot, breg, pl);
+    __builtin_amdgcn_wave_barrier();
+    phase_a<false>(T, acc, slot, junk, pl);
+  }
+  u32 r[LP];
+  reduce(r, T, slot, tb, pl);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < LP; ++k) acc[k] = r[k];
+}
+
+// limb j (W bits at bit offset W j) of a 256-byte big-endian integer (as be256_limb of modp_kernels.hip)
+__device__ __forceinline__ u32 be256_limb_pair(const uint8_t* __restrict__ be, int j) {
+  const int o = W * j;
+  const int p = o >> 3, sft = o & 7;
+  u64 w = 0;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int idx = 255 - (p + t);
+    if (idx >= 0) w |= (u64)be[idx] << (8 * t);
+  }
+  return (u32)(w >> sft) & MASK;
+}
+
+__device__ __forceinline__ void load_be256_pair(u32 (&a)[LP], const uint8_t* __restrict__ be, const PairLane& pl) {
+#pragma unroll
+  for (int k = 0; k < LP; ++k) a[k] = be256_limb_pair(be, (int)pl.h * LP + k);
+}
+
+__device__ __forceinline__ void store_pair_limbs(u32* __restrict__ g, const u32 (&a)[LP], const PairLane& pl) {
+  uint4* g4 = reinterpret_cast<uint4*>(g + LP * pl.h);
+#pragma unroll
+  for (int c = 0; c < LP / 4; ++c) g4[c] = make_uint4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+}
+
+struct PairCtx {          // what every pair kernel sets up the same way
+  PairLane pl;
+  int x;
+  bool live;
+  u32* slot;
+  u32* junk;
+  const Tables* tb;
+};
+}  // namespace
+
+#define PAIR_KERNEL_PROLOGUE(gtab, count)                                                  \
+  __shared__ PairShared sh;                                                                \
+  tables_to_lds(&sh.tb, gtab);                                                             \
+  PairCtx pc;                                                                              \
+  pc.pl = make_pair_lane();                                                                \
+  {                                                                                        \
+    const int wave_ = threadIdx.x >> 6;                                                    \
+    const int xi_ = (blockIdx.x * PAIR_WAVES + wave_) * 32 + (int)(pc.pl.lane & 31);       \
+    pc.live = xi_ < (count);                                                               \
+    pc.x = pc.live ? xi_ : (count)-1;                                                      \
+    pc.slot = &sh.slots[wave_][(pc.pl.lane & 31) * SLOTW];                                 \
+    pc.junk = sh.junk[wave_];                                                              \
+    pc.tb = &sh.tb;                                                                        \
+  }
+
+// ---------------------------------------------------------------------------------------
+// Window tables of per-share bases (part of ModpGroup::exp, modp.rs:122-128), pair layout.  Same HBM format as the quad
+// builders: tab[x][entries][72] Montgomery limbs, entry e = base^e.
+//   entries == 64: all powers 0..63 (k_modp_build_table64: the 6-bit windows of y^r)
+//   entries == 16, odd_only: 0, 1, 3, 5, .. 15 (k_modp_build_table(odd): what a sliding-window schedule asks for)
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+k_modp_build_table_pair(const uint8_t* __restrict__ base_be, int count, u32* __restrict__ tab, int entries, int odd_only,
+                        const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  u32 acc[LP], b[LP];
+  load_be256_pair(acc, base_be + (size_t)pc.x * 256, pl);
+  u32* my = tab + (size_t)pc.x * entries * L;
+  // it 0: base -> Montgomery form (times R^2); it 1 (odd_only): b <- b^2 after saving entry 1; then acc *= b, store
+  int e = 1;
+  for (int it = 0;; ++it) {
+    const u32* fill = it == 0 ? cs->r2 : nullptr;
+    pair_step<false>(acc, false, fill, b, pc.slot, pc.junk, pc.tb, pl);
+    if (it == 0) {
+#pragma unroll
+      for (int k = 0; k < LP; ++k) b[k] = acc[k];
+      if (pc.live) {
+        u32 one[LP];
+        load_pair_limbs(one, cs->one_m, pl);
+        store_pair_limbs(my, one, pl);
+        store_pair_limbs(my + L, acc, pl);
+      }
+      if (!odd_only) continue;
+    } else if (odd_only && it == 1) {        // acc = base^2: becomes the multiplier; the chain restarts from base
+      u32 t[LP];
+#pragma unroll
+      for (int k = 0; k < LP; ++k) { t[k] = acc[k]; acc[k] = b[k]; b[k] = t[k]; }
+      continue;
+    }
+    if (it > 0) {
+      e += odd_only ? 2 : 1;
+      if (pc.live) store_pair_limbs(my + (size_t)e * L, acc, pl);
+      if (e >= entries - 1) break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// p_m[x] = g^e1[x] in Montgomery form through the wide fixed-base comb (comb16[k][d] = g^(d 65536^k), 128 rows): 127
+// products, no squarings -- mode 1 of k_modp_comb_dual_exp.  The g^r half of a1 = g^r X^c (dleq.rs:75-77).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+k_modp_comb16_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict__ e1_be, int count, u32* __restrict__ p_m,
+                       const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  const uint8_t* e1 = e1_be + (size_t)pc.x * 256;
+  auto entry = [&](int k) { return comb16 + ((size_t)k * 65536 + (((u32)e1[254 - 2 * k] << 8) | e1[255 - 2 * k])) * L; };
+  u32 acc[LP], dummy[LP];
+  load_pair_limbs(acc, entry(0), pl);
+#pragma unroll
+  for (int k = 0; k < LP; ++k) dummy[k] = 0;
+  for (int k = 1; k < 128; ++k) pair_step<false>(acc, false, entry(k), dummy, pc.slot, pc.junk, pc.tb, pl);
+  if (pc.live) store_pair_limbs(p_m + (size_t)pc.x * L, acc, pl);
+}
+
+// ---------------------------------------------------------------------------------------
+// out[x] = p_m[x] * B2[x]^c for ONE shared exponent c given as a sliding-window schedule (mode 2 of
+// k_modp_comb_dual_exp with c_sched): a1 = g^r * X^c (dleq.rs:75-77) once X is known.  tab2: odd-power tables of X.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, const uint16_t* __restrict__ c_sched,
+                          const u32* __restrict__ p_m, int count, uint8_t* __restrict__ out_be,
+                          const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  const u32* t2 = tab2 + (size_t)pc.x * tab2_stride;
+  const int sn = (int)c_sched[0];
+  u32 acc[LP], dummy[LP];
+#pragma unroll
+  for (int k = 0; k < LP; ++k) dummy[k] = 0;
+  load_pair_limbs(acc, t2 + (size_t)c_sched[2] * L, pl);     // top window: load instead of multiply
+  int cur = (int)c_sched[1], si = 1;
+  int stage = 0;          // 0: square down one bit (or go on to the last two products at weight 0), 1: window product
+  int tail = 0;           // 1: times the stored g^r, 2: leave the Montgomery domain
+  while (true) {
+    bool sq = false;
+    const u32* fill = nullptr;
+    if (tail == 0) {
+      if (stage == 0) {
+        if (cur == 0) { tail = 1; fill = p_m + (size_t)pc.x * L; }
+        else { sq = true; --cur; stage = 1; }
+      } else {
+        stage = 0;
+        if (si < sn && cur == (int)c_sched[1 + 2 * si]) { fill = t2 + (size_t)c_sched[2 + 2 * si] * L; ++si; }
+        else continue;
+      }
+    } else {
+      fill = cs->one;
+      tail = 2;
+    }
+    pair_step<true>(acc, sq, fill, dummy, pc.slot, pc.junk, pc.tb, pl);
+    if (tail == 2) break;
+  }
+  store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);
+}
+
+// ---------------------------------------------------------------------------------------
 extern "C" int modp_pair_tables_upload(void** dev_tables) {
   static_assert(sizeof(MM_GT1) == sizeof(Tables::gt1) && sizeof(MM_GT2) == sizeof(Tables::gt2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
                     sizeof(MM_C2) == sizeof(Tables::c2), "generated tables do not match bn_pair.h");
@@ -242,5 +421,29 @@ extern "C" int modp_launch_dual_exp_w6_pair(const uint32_t* tab1, const uint32_t
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_dual_exp_w6_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab1, tab2, e1, c, c_stride, count,
                      out, (const ModpConsts*)cs, c_sched, (const Tables*)pair_tables);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_build_table_pair(const uint8_t* base_be, int count, uint32_t* tab, int entries, int odd_only, const void* cs,
+                                            const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_build_table_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, base_be, count, tab, entries, odd_only,
+                     (const ModpConsts*)cs, (const Tables*)pair_tables);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_comb16_exp_pair(const uint32_t* comb16, const uint8_t* e1, int count, uint32_t* p_m, const void* cs,
+                                           const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_comb16_exp_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, comb16, e1, count, p_m,
+                     (const ModpConsts*)cs, (const Tables*)pair_tables);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_sched_exp_mul_pair(const uint32_t* tab2, size_t tab2_stride, const uint16_t* c_sched, const uint32_t* p_m,
+                                              int count, uint8_t* out, const void* cs, const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_sched_exp_mul_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab2, tab2_stride, c_sched, p_m,
+                     count, out, (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }

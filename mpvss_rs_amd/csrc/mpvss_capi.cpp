@@ -1044,10 +1044,28 @@ namespace {
 // Same tables, exponents and results; measured in the headline pipeline 1.03 against 0.92-0.98 M share verifications/s.
 // c_sched: sliding-window schedule of ONE shared challenge (then c_dev is unused), else fixed 4-bit windows of c_dev
 // (stride c_stride; null: B1^r alone).
+// MPVSS_PAIR: which kernels of the verifier's block path take the pair layout (bit 0: a2 = y^r Y^c, bit 1: the window tables,
+// bit 2: g^r through the wide comb, bit 3: a1 = g^r X^c).  Default 1: a2 only.  A pair wave (230 VGPRs, two per SIMD at
+// most) leaves its SIMD idle while it waits for its MFMA chains and LDS reads; the quad kernels' waves (135 VGPRs) of the
+// other boxes in flight fill those gaps.  With every wide kernel in the pair layout there is nothing left to fill them:
+// measured on one box 1.063 M share verifications/s for a2 alone, 1.044 M with the tables, 1.022 M with all four,
+// 0.942 M with none (profiles/r03_pair_ab.txt).  MPVSS_A2_PAIR=0 clears bit 0 (older switch).
+int pair_mask() {
+  static const int m = fd_env("MPVSS_PAIR", 1) & (fd_env("MPVSS_A2_PAIR", 1) ? 15 : 14);
+  return m;
+}
+int launch_table_odd(mpvss_ctx* ctx, const uint8_t* base_dev, size_t cnt, uint32_t* tab) {
+  if (pair_mask() & 2) return modp_launch_build_table_pair(base_dev, (int)cnt, tab, 16, 1, ctx->consts, ctx->pair_tables, ctx->stream);
+  return modp_launch_build_table_odd(base_dev, (int)cnt, tab, ctx->consts, ctx->stream);
+}
+int launch_table64(mpvss_ctx* ctx, const uint8_t* base_dev, size_t cnt, uint32_t* tab) {
+  if (pair_mask() & 2) return modp_launch_build_table_pair(base_dev, (int)cnt, tab, 64, 0, ctx->consts, ctx->pair_tables, ctx->stream);
+  return modp_launch_build_table64(base_dev, (int)cnt, tab, ctx->consts, ctx->stream);
+}
+
 int launch_dual_exp_w6(mpvss_ctx* ctx, const uint32_t* t1, const uint32_t* t2, const uint8_t* r_dev, const uint8_t* c_dev,
                        size_t c_stride, const uint16_t* c_sched, size_t cnt, uint8_t* out_dev) {
-  static const int pair = fd_env("MPVSS_A2_PAIR", 1);
-  if (pair)
+  if (pair_mask() & 1)
     return modp_launch_dual_exp_w6_pair(t1, t2, r_dev, c_dev, c_stride, c_sched, (int)cnt, out_dev, ctx->consts, ctx->pair_tables,
                                         ctx->stream);
   if (c_sched) return modp_launch_dual_exp_w6_sched(t1, t2, r_dev, c_sched, (int)cnt, out_dev, ctx->consts, ctx->stream);
@@ -1071,7 +1089,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
   if (!shared_b1 && w6 && c_windows == 64 && cnt >= 1024) {
     // per-share base with a full-width exponent and 256-bit second exponent(s): 6-bit windows for B1^r
     RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
-    TIMED_LAUNCH(ctx, 2, modp_launch_build_table64(b1_dev, (int)cnt, (uint32_t*)ctx->w->tab1.p, ctx->consts, ctx->stream));
+    TIMED_LAUNCH(ctx, 2, launch_table64(ctx, b1_dev, cnt, (uint32_t*)ctx->w->tab1.p));
     TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, (const uint32_t*)ctx->w->tab1.p, t2, r_dev, c_dev, c_stride, nullptr, cnt, out_dev));
     return 0;
   }
@@ -1358,7 +1376,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, sl.work.root[0].csched, (1 + 2 * (size_t)sl.work.root[0].csched[0]) * 2,
                                      hipMemcpyHostToDevice, ctx->stream));
         uint32_t* t2p = (uint32_t*)ctx->w->tab2.p;
-        if (dsched) TIMED_LAUNCH(ctx, 2, modp_launch_build_table_odd((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
+        if (dsched) TIMED_LAUNCH(ctx, 2, launch_table_odd(ctx, (const uint8_t*)dY, cnt, t2p));
         else TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
         if (use_keys) {
           // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
@@ -1368,7 +1386,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         } else if (a2_w6 && c_windows == 64) {
           // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
-          TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 2, launch_table64(ctx, (const uint8_t*)dy, cnt, t1p));
           TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
@@ -1383,9 +1401,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           HIPCHK(ctx, hipEventRecord(mine, ctx->stream));
         }
         // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase
-        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
-                                                             (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
-                                                             ctx->stream));
+        if ((pair_mask() & 4) && comb_bits_of(ctx, cg) == 16)
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, (const uint8_t*)dr, (int)cnt, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
+                                                           ctx->pair_tables, ctx->stream));
+        else
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
+                                                               (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
+                                                               ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
       mark(2);
@@ -1396,13 +1418,16 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         const uint32_t* tx;
         if (dsched) {
           RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
-          TIMED_LAUNCH(ctx, 2, modp_launch_build_table_odd(dX, (int)cnt, (uint32_t*)ctx->w->tab3.p, ctx->consts, ctx->stream));
+          TIMED_LAUNCH(ctx, 2, launch_table_odd(ctx, dX, cnt, (uint32_t*)ctx->w->tab3.p));
           tx = (const uint32_t*)ctx->w->tab3.p;
         } else {
           RET_IF(number_tables(ctx, dX, cnt, ctx->w->tab3, &tx));
         }
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_gr, 0));
-        if (dsched)
+        if (dsched && (pair_mask() & 8))
+          TIMED_LAUNCH(ctx, 1, modp_launch_sched_exp_mul_pair(tx, TABW, dsched, (const uint32_t*)ctx->w->gr_m.p, (int)cnt, da1, ctx->consts,
+                                                              ctx->pair_tables, ctx->stream));
+        else if (dsched)
           TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_sched(cg, tx, TABW, dsched, (int)cnt, da1, (uint32_t*)ctx->w->gr_m.p,
                                                                comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
         else
@@ -1448,10 +1473,14 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
 // own transcript; a 65536-share box is 40 ms of SHA-256).  Blocks are handed out in FIFO order at entry.
 int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
                                uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr,
-                               const unsigned long long* ticket = nullptr) {
+                               const unsigned long long* ticket = nullptr, bool by_position = false) {
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
   mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ticket ? (unsigned)*ticket : ctx->tail);
-  if (ticket) {
+  if (ticket && by_position) {       // the library's own pipeline: the block at ring position *ticket, whatever the FIFO order
+    if (!sl.busy || sl.absorbing || sl.claimed) return fail(ctx, MPVSS_E_INVALID, "absorb: no block at this position");
+    if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the block at this position is not a MODP distribution block");
+    if ((int)((unsigned)*ticket + 1u - ctx->tail) > 0) ctx->tail = (unsigned)*ticket + 1u;
+  } else if (ticket) {
     if (!sl.busy || !sl.claimed || sl.ticket != (unsigned)*ticket)
       return fail(ctx, MPVSS_E_INVALID, "absorb: no block was claimed with this ticket");
     if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the claimed block is not a MODP distribution block");
@@ -1702,6 +1731,8 @@ int ec_verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& 
                                   uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out);     // capi_ec.inc
 
 // issue(b): enqueue box b (called with the context lock held); finish(idx, state): verdict of box idx from its state
+// issue(b, &parts): enqueue box b as `parts` consecutive blocks (called with the context lock held; a box in several parts
+// has its transcript absorbed part by part, in order, by ONE worker); finish(idx, state): verdict of box idx from its state
 template <class Issue, class Finish>
 int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, Issue issue, Finish finish) {
   if (hash_threads < 1) hash_threads = 1;
@@ -1713,57 +1744,75 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
     Hint(mpvss_ctx* c_, bool on) : c(c_) { std::lock_guard<std::mutex> lk(c->mu); was = c->pipelined_hint; if (on) c->pipelined_hint = true; }
     ~Hint() { std::lock_guard<std::mutex> lk(c->mu); c->pipelined_hint = was; }
   } hint(ctx, count > 2 && depth > 1);
+  struct Ent { size_t box; unsigned parts; bool bad; };      // one entry per enqueued block; parts: blocks of its box (first entry)
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    size_t issued = 0, claimed = 0, skipped = 0, low = 0;   // skipped: malformed boxes (no block); low: boxes 0 .. low-1 are finished (their block slots are free)
-    std::vector<char> finished;
-    std::vector<size_t> order;  // order[k]: the box behind the k-th block enqueued by this run (malformed boxes enqueue none)
-    bool stop = false;          // no more boxes will be issued
+    size_t issued = 0, claimed = 0, low = 0;   // blocks enqueued / handed to workers; low: blocks 0 .. low-1 are absorbed (their ring positions are free)
+    std::vector<Ent> order;                     // order[k]: the k-th block enqueued by this run
+    std::vector<char> blk_done;
+    bool stop = false;                          // no more boxes will be issued
     int rc = MPVSS_OK;
   } sh;
-  sh.finished.assign(count, 0);
-  sh.order.reserve(count);
+  sh.order.reserve(count + 8);
+  sh.blk_done.reserve(count + 8);
   const unsigned base_tail = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->tail; }();
-  // `depth` bounds the boxes whose GPU work is pending; a box whose GPU work is done but whose transcript is still being
+  // `depth` bounds the blocks whose GPU work is pending; a block whose GPU work is done but whose transcript is still being
   // hashed keeps its slot (the ring has NSLOT of them) without holding back the enqueueing of the next one
   static const int issue_on_gpu_done = fd_env("MPVSS_ISSUE_ON_GPU_DONE", 1);
   const unsigned long long gpu_done0 = ctx->gpu_done.load();
 
   auto worker = [&]() {
     for (;;) {
+      size_t seq0;
+      Ent ent;
       {
         std::unique_lock<std::mutex> l(sh.m);
         sh.cv.wait(l, [&] { return sh.claimed < sh.issued || sh.stop; });
         if (sh.claimed >= sh.issued) return;       // stop and nothing left
-        ++sh.claimed;
+        seq0 = sh.claimed;
+        ent = sh.order[seq0];
+        sh.claimed += ent.parts;                   // the parts of a box are enqueued (and counted in `issued`) together
       }
       uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
       mpvss_transcript_init(state);
-      size_t idx, seq;
-      int rc;
-      {
-        std::unique_lock<std::mutex> lk(ctx->mu);
-        seq = (size_t)(ctx->tail - base_tail);     // blocks are handed out in FIFO order under the context lock
-        const int kind = ctx->ring_slot(ctx->tail).kind;
-        rc = kind == 2 ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr)
-                       : verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr);
+      int rc = MPVSS_OK;
+      bool malformed = ent.bad;
+      size_t box = ent.box;
+      for (unsigned p = 0; p < ent.parts; ++p) {
+        size_t seq = seq0 + p;
+        int prc;
+        {
+          std::unique_lock<std::mutex> lk(ctx->mu);
+          const unsigned long long pos = (unsigned long long)(base_tail + (unsigned)seq);
+          if (ctx->ring_slot((unsigned)pos).kind == 2 || ctx->ring_slot(ctx->tail).kind == 2) {
+            // curve-group blocks are handed out in FIFO order under the context lock (always one block per box)
+            seq = (size_t)(ctx->tail - base_tail);
+            prc = ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr);
+          } else {
+            prc = verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr, &pos, true);
+          }
+        }
+        {
+          std::lock_guard<std::mutex> l(sh.m);
+          if (seq < sh.order.size()) {
+            if (ent.parts == 1) box = sh.order[seq].box, malformed = sh.order[seq].bad;
+            sh.blk_done[seq] = 1;
+          }
+          while (sh.low < sh.blk_done.size() && sh.blk_done[sh.low]) ++sh.low;
+        }
+        sh.cv.notify_all();
+        // A box the engine rejects as malformed (an invalid curve encoding, a scalar that is not reduced, a negative
+        // position in device memory) is THAT box's business: its verdict stays 0 -- the reference answers `false` to
+        // structural problems, participant.rs:415-420 -- and the other boxes of the run are verified as usual
+        // (mpvss_last_error still names the reason).  Only device and allocation errors end the run.
+        if (prc == MPVSS_E_INVALID) malformed = true;
+        else if (prc != MPVSS_OK && rc == MPVSS_OK) rc = prc;
       }
-      {
+      if (rc == MPVSS_OK && !malformed && box < count) rc = finish(box, state);
+      if (rc != MPVSS_OK) {
         std::lock_guard<std::mutex> l(sh.m);
-        idx = seq < sh.order.size() ? sh.order[seq] : count;
-      }
-      // A box the engine rejects as malformed (an invalid curve encoding, a scalar that is not reduced, a negative
-      // position in device memory) is THAT box's business: its verdict stays 0 -- the reference answers `false` to
-      // structural problems, participant.rs:415-420 -- and the other boxes of the run are verified as usual
-      // (mpvss_last_error still names the reason).  Only device and allocation errors end the run.
-      if (rc == MPVSS_E_INVALID) rc = MPVSS_OK;
-      else if (rc == MPVSS_OK && idx < count) rc = finish(idx, state);
-      {
-        std::lock_guard<std::mutex> l(sh.m);
-        if (idx < count) sh.finished[idx] = 1;
-        while (sh.low < count && sh.finished[sh.low]) ++sh.low;
-        if (rc != MPVSS_OK && sh.rc == MPVSS_OK) sh.rc = rc;
+        if (sh.rc == MPVSS_OK) sh.rc = rc;
       }
       sh.cv.notify_all();
     }
@@ -1775,33 +1824,35 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   for (size_t b = 0; b < count; ++b) {
     {
       std::unique_lock<std::mutex> l(sh.m);
-      // slots are a ring: box b may be enqueued once box b - NSLOT has been absorbed (the threads finish in any order)
+      // slots are a ring: a block may be enqueued once the block NSLOT positions before it has been absorbed (the threads
+      // finish in any order); a box takes at most 8 positions
       auto may_issue = [&] {
         if (sh.rc != MPVSS_OK) return true;
-        if (!issue_on_gpu_done) return sh.issued + sh.skipped - sh.low < (size_t)depth;
+        if (!issue_on_gpu_done) return sh.issued - sh.low < (size_t)depth;
         const size_t pending_gpu = sh.issued - (size_t)(ctx->gpu_done.load() - gpu_done0);
-        return pending_gpu < (size_t)depth && sh.issued + sh.skipped - sh.low < (size_t)mpvss_ctx::NSLOT - 1;
+        return pending_gpu < (size_t)depth && sh.issued - sh.low + 8 < (size_t)mpvss_ctx::NSLOT;
       };
       while (!may_issue()) sh.cv.wait_for(l, std::chrono::microseconds(200));
       if (sh.rc != MPVSS_OK) break;
     }
     int rc;
+    unsigned parts = 0;                      // blocks actually enqueued for this box (also when a later part was rejected)
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
-      rc = issue(b);
+      rc = issue(b, &parts);
     }
     {
       std::lock_guard<std::mutex> l(sh.m);
-      if (rc == MPVSS_E_INVALID) {          // malformed box: nothing was enqueued, verdict 0, the run goes on
-        sh.finished[b] = 1;
-        ++sh.skipped;
-        while (sh.low < count && sh.finished[sh.low]) ++sh.low;
+      const bool bad = rc == MPVSS_E_INVALID;     // malformed box: verdict 0, the run goes on (what was enqueued is still absorbed)
+      if (rc == MPVSS_OK || bad) {
+        for (unsigned p = 0; p < parts; ++p) {
+          sh.order.push_back(Ent{b, p == 0 ? parts : 0u, bad});
+          sh.blk_done.push_back(0);
+        }
+        sh.issued += parts;
         rc = MPVSS_OK;
-      } else if (rc != MPVSS_OK) {
-        if (sh.rc == MPVSS_OK) sh.rc = rc;
-      } else {
-        sh.order.push_back(b);
-        ++sh.issued;
+      } else if (sh.rc == MPVSS_OK) {
+        sh.rc = rc;
       }
     }
     sh.cv.notify_all();
@@ -1830,12 +1881,31 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   }
   for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
   if (digests32) memset(digests32, 0, 32 * count);       // a malformed box has no transcript: verdict 0, digest zero
+  // Optional (MPVSS_TAIL_PARTS > 1, off by default): the last MPVSS_TAIL_BOXES boxes of a run are enqueued in MPVSS_TAIL_PARTS
+  // parts of consecutive shares each, absorbed in order by one worker -- nothing follows them, so their transcript hashes (40 ms
+  // per 65536 shares, strictly sequential: dleq.rs:87-99) otherwise start when the GPU has nothing left to do; in parts, the
+  // hash of part k runs beside the GPU work of part k+1.  Measured at K = 20 (profiles/r03_tail_ab.txt): the last box in 4
+  // parts is within the run-to-run noise of the plain run (1.006 against 1.007 M, three runs each); the last 12 boxes in 2 or 4
+  // parts LOSE a third (0.59-0.75 M: quarter-size blocks are inefficient on the forward-difference path).
+  static const int tail_parts = fd_env("MPVSS_TAIL_PARTS", 1);
+  static const size_t tail_boxes = (size_t)fd_env("MPVSS_TAIL_BOXES", 1);
+  static const size_t tail_min_part = (size_t)fd_env("MPVSS_TAIL_MIN_PART", 8192);     // shares per part at least (tests lower it)
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
-      [&](size_t b) {
+      [&](size_t b, unsigned* parts) {
         const mpvss_modp_box& bx = boxes[b];
-        return verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
-                                           bx.n, bx.challenge_host, bx.keyset, bx.key_offset);
+        const size_t P = (b + tail_boxes >= count && count >= 3 && tail_parts > 1 && tail_parts <= 8 && bx.n >= (size_t)tail_parts * tail_min_part &&
+                          bx.commitments && bx.positions && (bx.pubkeys || bx.keyset) && bx.shares && bx.responses)
+                             ? (size_t)tail_parts : 1;
+        for (size_t p = 0; p < P; ++p) {
+          const size_t lo = (bx.n * p / P) & ~(size_t)15, hi = p + 1 == P ? bx.n : ((bx.n * (p + 1) / P) & ~(size_t)15);
+          const int rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions + lo,
+                                                     bx.pubkeys ? bx.pubkeys + lo * EB : nullptr, bx.shares + lo * EB,
+                                                     bx.responses + lo * EB, hi - lo, bx.challenge_host, bx.keyset, bx.key_offset + lo);
+          if (rc != MPVSS_OK) return rc;
+          ++*parts;
+        }
+        return (int)MPVSS_OK;
       },
       [&](size_t idx, const uint8_t* state) {
         return mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],

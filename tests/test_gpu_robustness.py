@@ -268,3 +268,41 @@ def test_block_wellformedness_bytes(engine):
     assert got == [0, 0, 1, 0, 0, 1, 0, 1, 1] + [1] * 30 + [0]
     ref = engine.verify_distribution(flat["commitments"], flat["positions"], bytes(pk), bytes(sh), bytes(rs), flat["challenge"])
     assert verdict == (ref["verdict"], ref["digest"]) and verdict[0] is False
+
+
+def test_last_box_of_a_run_is_absorbed_in_parts():
+    """mpvss_modp_verify_many enqueues the LAST box of a run in MPVSS_TAIL_PARTS parts of consecutive shares, absorbed in
+    order by one worker (so that its transcript hash overlaps its own GPU work).  Same verdicts and digests as one
+    verify_distribution per box -- honest, tampered in the first / a middle / the last part, a negative position in a late
+    part (the box is malformed: verdict False, zero digest), with host and keyset-free boxes.  The switches are read once
+    per process, so the run happens in a child process with small parts."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mpvss_oracle as O
+from helpers import make_modp_instance
+from mpvss_rs_amd import Engine
+eng = Engine(0)
+g, privs, pks, coeffs, ws, box = make_modp_instance(203, 5, 77)
+flat = O.box_to_flat(g, box)
+as_box = lambda f, **kw: dict({"commitments": f["commitments"], "positions": f["positions"], "pubkeys": f["publickeys"],
+                               "shares": f["shares"], "responses": f["responses"], "challenge": f["challenge"]}, **kw)
+def tamper(share):
+    b = bytearray(flat["responses"]); b[share * 256 + 100] ^= 1; return as_box(flat, responses=bytes(b))
+good = as_box(flat)
+one = lambda b: (lambda r: (r["verdict"], r["digest"]))(eng.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
+want_good = one(good)
+assert want_good == (True, box["_digest"])
+for last in (good, tamper(3), tamper(101), tamper(202)):
+    for depth, threads in ((2, 1), (8, 4)):
+        got = eng.verify_many([good, tamper(7), good, last], depth=depth, hash_threads=threads)
+        assert got == [want_good, one(tamper(7)), want_good, one(last)], (got, depth)
+neg = as_box(flat, positions=flat["positions"][:150] + [-5] + flat["positions"][151:])
+assert eng.verify_many([good, good, neg], depth=4, hash_threads=2) == [want_good, want_good, (False, bytes(32))]
+assert eng.verify_many([good, good, good], depth=4, hash_threads=2) == [want_good] * 3
+assert eng.blocks_in_flight() == (0, 0)
+print("parts ok")
+""" % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MPVSS_TAIL_PARTS="4", MPVSS_TAIL_MIN_PART="16")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "parts ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
