@@ -244,6 +244,20 @@ def bench_ec(eng, name, args):
            "host_per_box_ms": {"enqueue": pst["enqueue_ms"] / nb, "wait_for_gpu": pst["wait_ms"] / nb,
                                "sha256_transcript": pst["hash_ms"] / nb},
            "distribute_shares_per_s": n / deal_s}
+    # counter evidence of the same shape (profiles/r03_ec_counters.json: SQ_INSTS_VALU and FETCH/WRITE per verified box, PMC
+    # passes of tools/run_profiles_ec.sh; profiles/r03_pmc_traffic.json: bytes per launch of the dominant kernel)
+    try:
+        if (n, t) == (65536, 256):
+            ecc = json.load(open(os.path.join(ROOT, "profiles", "r03_ec_counters.json")))[name]
+            slots = ecc["valu_wave_insts_per_box"] / dt
+            out["compute"] = {"bound": "valu issue", "achieved": slots, "peak": PEAK_VALU_SLOTS_PER_S, "frac": slots / PEAK_VALU_SLOTS_PER_S,
+                              "unit": "VALU wave-instruction issue slots/s (SQ_INSTS_VALU per verified box x boxes/s)",
+                              "valu_wave_insts_per_box": ecc["valu_wave_insts_per_box"],
+                              "hbm_bytes_per_box": ecc["hbm_bytes_per_box"], "hbm_gb_per_s": ecc["hbm_bytes_per_box"] / dt / 1e9}
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"] + "_bytes_per_launch")
+    except (OSError, KeyError, ValueError):
+        pass
     # dealer side in block form (mpvss_ec_distribute_compute / _absorb): inputs resident in HBM, X_i = P(i) G through the
     # comb, 8 blocks in flight, absorbed (validated + hashed) by a few host threads; the digest must be the dealer's
     import concurrent.futures
@@ -332,10 +346,25 @@ def sliding_windows(c):
     return c_win, c_top
 
 
+# VALU wave-instruction issue slots per number and Montgomery operation (what bounds these kernels: every VALU instruction
+# costs one issue slot of ~4 cycles per SIMD whatever it is; profiles/r01_ubench_*):
+#   quad layout (bn_quad.h):  72 rows x 41 (product) / 32.5 (squaring) instructions + ~110 for the final passes, 16 numbers per wave
+#   pair layout (bn_pair.h):  3 690 (product) / 2 501 (squaring) VALU instructions per wave of 32 numbers, counted in the ISA
+#                             (tools/mfma_mont/count_isa.py), + 114 MFMAs that each hold the SIMD's issue for 2 slots
+QUAD_MUL_SLOTS, QUAD_SQ_SLOTS = (72 * 41 + 110) / 16.0, (72 * 32.5 + 110) / 16.0
+PAIR_MUL_SLOTS, PAIR_SQ_SLOTS = (3690 + 2 * 114) / 32.0, (2501 + 2 * 114) / 32.0
+PEAK_VALU_SLOTS_PER_S = 1024 / (MAD_NS_PER_SIMD * 1e-9)        # 256 CUs x 4 SIMDs, one wave-instruction per 2.07 ns per SIMD
+PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "1")) & (15 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 14)
+
+
 def modp_work(n, t, positions, cs):
-    """Montgomery products (a squaring counts SQ_COST) the kernels execute for ONE verification of a block of n shares at
-    `positions` with t commitments, averaged over the challenges `cs` of the timed boxes; mirrors the choices of
-    eval_x() / verify_block_compute_locked() in mpvss_capi.cpp for a block that is part of a pipelined run."""
+    """Montgomery operations the kernels execute for ONE verification of a block of n shares at `positions` with t
+    commitments, averaged over the challenges `cs` of the timed boxes; mirrors the choices of eval_x() /
+    verify_block_compute_locked() in mpvss_capi.cpp for a block that is part of a pipelined run.  Two accountings:
+    mm_total -- product equivalents (a squaring counts SQ_COST, its share of the mads of the quad layout), as in rounds 1-2;
+    slots    -- VALU issue slots, per layout of the kernel that does the work (the a2 kernel runs in the pair layout)."""
+    sq_n = {"x": 0.0, "a1": 0.0, "a2": 0.0, "tab": 0.0}
+    mul_n = {"x": 0.0, "a1": 0.0, "a2": 0.0, "tab": 0.0}
     fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "4096"))
     if fd:
         chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(min(2048 // t, n // 8192), n // 16384, 4),
@@ -358,24 +387,39 @@ def modp_work(n, t, positions, cs):
     else:
         mm_x = horner_modmuls(positions, t) + n
         x_path = "Horner in the exponent"
+    mul_n["x"] = mm_x                                          # (Horner's squarings are folded in at SQ_COST: a few % of the X path)
     comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
     gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
     w6 = os.environ.get("MPVSS_A2_W6", "1") != "0" and n >= 1024   # 6-bit windows for y^r (64-entry table) or 4-bit
     # X^c and Y^c: 64 fixed 4-bit windows, or -- one c for the whole box, forward-difference path -- the sliding-window
     # schedule the library makes from it (width 4, odd digits; the tables of X and Y then hold the odd powers only)
-    tot_a2 = tot_dual = tot_tab = 0.0
+    tot_a2 = 0.0
     for c in cs:
         sliding = fd and w6 and os.environ.get("MPVSS_C_SLIDING", "1") != "0" and c > 0
         c_win, c_top = sliding_windows(c) if sliding else (0, 0)
         yc = c_win if sliding else 64                          # products with the table of Y (a2) / X (a1; its first is a load)
         xc_sq, xc = (c_top, c_win - 1) if sliding else (252, 63)
-        a2_products = (2046 * SQ_COST + 341 + yc + 1) if w6 else (2044 * SQ_COST + 511 + 64 + 1)
-        tot_a2 += a2_products
-        tot_dual += n * (a2_products + (xc_sq * SQ_COST + xc + 1 + gr + 2))   # a2: Straus chain; a1: comb for g^r + X^c windows
-        tab_xy = (8 + SQ_COST) if sliding else 15              # conversion + b^2 + seven odd powers, or conversion + 14 powers
-        tot_tab += n * (2 * tab_xy + (63 if w6 else 15))       # window tables of X, Y and y (+1 conversion each)
+        a2_sq, a2_mul = (2046, 341 + yc + 1) if w6 else (2044, 511 + 64 + 1)
+        tot_a2 += a2_sq * SQ_COST + a2_mul
+        sq_n["a2"] += n * a2_sq
+        mul_n["a2"] += n * a2_mul
+        sq_n["a1"] += n * xc_sq
+        mul_n["a1"] += n * (xc + 1 + gr + 2)                   # a1: comb for g^r + X^c windows + the two closing products
+        sq_n["tab"] += n * (2 if sliding else 0)               # b^2 of the two odd-power tables
+        mul_n["tab"] += n * ((2 * 8 if sliding else 2 * 15) + (63 if w6 else 15))   # tables of X, Y and y (+1 conversion each)
     k = max(len(cs), 1)
-    return {"mm_total": mm_x + tot_dual / k + tot_tab / k, "mm_x": mm_x, "x_path": x_path, "a2_products": tot_a2 / k, "w6": w6, "fd": fd}
+    for d in (sq_n, mul_n):
+        for key in ("a1", "a2", "tab"):
+            d[key] /= k
+    mm_total = sum(mul_n.values()) + SQ_COST * sum(sq_n.values())
+    pair_bit = {"a2": 1, "tab": 2, "a1": 8}                     # MPVSS_PAIR bits (g^r, bit 2, is counted with a1)
+    slots = 0.0
+    for key in ("x", "a1", "a2", "tab"):
+        pair = bool(PAIR_MASK & pair_bit.get(key, 0)) and n >= 16
+        slots += sq_n[key] * (PAIR_SQ_SLOTS if pair else QUAD_SQ_SLOTS) + mul_n[key] * (PAIR_MUL_SLOTS if pair else QUAD_MUL_SLOTS)
+    return {"mm_total": mm_total, "mm_x": mm_x, "x_path": x_path, "a2_products": tot_a2 / k, "w6": w6, "fd": fd, "slots": slots,
+            "a2_slots": sq_n["a2"] * (PAIR_SQ_SLOTS if PAIR_MASK & 1 else QUAD_SQ_SLOTS) + mul_n["a2"] * (PAIR_MUL_SLOTS if PAIR_MASK & 1 else QUAD_MUL_SLOTS),
+            "ops": {"squarings": sum(sq_n.values()) / n, "products": sum(mul_n.values()) / n}}
 
 
 class Box:
@@ -719,7 +763,8 @@ def main():
     nb = max(pst["blocks"], 1)
     x_ms, a1_ms, tb_ms, a2_ms = (pst["kernel_ms"][k] / nb for k in (0, 1, 2, 3))    # overlapped: boxes share the chip
     a2_n = max(pst["kernel_launches"][3] / nb, 1.0)   # a2 launches per step (1 unless the box is split)
-    a2_kernel = "k_modp_dual_exp_w6" if os.environ.get("MPVSS_A2_W6", "1") != "0" else "k_modp_dual_exp"
+    a2_kernel = (("k_modp_dual_exp_w6_pair" if PAIR_MASK & 1 else "k_modp_dual_exp_w6") if os.environ.get("MPVSS_A2_W6", "1") != "0"
+                 else "k_modp_dual_exp")
     shares_per_a2_launch = n / a2_n
     # Isolated launches: the same box verified alone (one box in flight, nothing else on the GPU) after the timed
     # region -- the duration of a launch that has the chip to itself is what a roofline can be read from; in the timed
@@ -798,14 +843,24 @@ def main():
             "shares_per_launch": shares_per_a2_launch,
         },
         "compute": {
-            "bound": "valu v_mad_u64_u32 issue",
-            "achieved": achieved_modmul, "peak": peak_modmul, "unit": "2048-bit Montgomery products/s (all kernels / step wall time; a squaring counts 0.764 of a product, its share of the mads)",
-            "frac": achieved_modmul / peak_modmul,
+            "bound": "valu issue",
+            "achieved": wk["slots"] / (ms_per_step * 1e-3), "peak": PEAK_VALU_SLOTS_PER_S,
+            "unit": "VALU wave-instruction issue slots/s (all kernels / step wall time; one slot = one wave64 VALU instruction on one "
+                    "SIMD, 2.07 ns measured; an MFMA holds the issue for two slots)",
+            "frac": wk["slots"] / (ms_per_step * 1e-3) / PEAK_VALU_SLOTS_PER_S,
+            "valu_slots_per_share": wk["slots"] / n,
+            "slots_per_operation": {"quad_product": QUAD_MUL_SLOTS, "quad_squaring": QUAD_SQ_SLOTS, "pair_product": PAIR_MUL_SLOTS,
+                                    "pair_squaring": PAIR_SQ_SLOTS,
+                                    "note": "per number; quad = bn_quad.h (VALU only), pair = bn_pair.h (Montgomery reduction on the "
+                                            "matrix cores); MPVSS_PAIR bit mask in use: %d" % PAIR_MASK},
+            "operations_per_share": wk["ops"],
             "modmul_per_share": mm_total / n,
+            "modmul_equivalents": {"achieved": achieved_modmul, "peak_valu_only": peak_modmul, "frac_of_valu_only_peak": achieved_modmul / peak_modmul,
+                                   "note": "rounds 1-2 accounting: product equivalents per second (a squaring 0.764) against what the VALU-only "
+                                           "product can reach (3.05 G/s); with the reduction on the matrix cores this ratio may exceed the old ceiling 0.88"},
             "x_path": wk["x_path"],
-            "peak_nominal_clock": PEAK_MODMUL_NOMINAL,
-            "frac_of_nominal_clock_peak": achieved_modmul / PEAK_MODMUL_NOMINAL,
-            "a2_kernel_alone": ({"products_per_s": a2_products * n / (alone_ms * 1e-3), "frac": a2_products * n / (alone_ms * 1e-3) / peak_modmul,
+            "a2_kernel_alone": ({"ms": alone_ms, "valu_slots_per_s": wk["a2_slots"] / (alone_ms * 1e-3),
+                                 "frac": wk["a2_slots"] / (alone_ms * 1e-3) / PEAK_VALU_SLOTS_PER_S,
                                  "products_per_share": a2_products} if alone_ms else None),
             "kernel_ms_sums": {"x_path": x_ms, "a1_comb_dual_exp": a1_ms, "a2_dual_exp": a2_ms, "tables": tb_ms,
                                "note": "per-kind sums of launch durations per step in the timed region; boxes and kinds "
@@ -834,7 +889,7 @@ def main():
                           "mpvss_modp_verify_block_compute_flags), one per box and rank, asynchronous, inside the timed region; "
                           "every byte of every rank checked == 1",
             "also": "barrier and max-reduction of the timing over the same group; the 128-byte hash state per box and hop over gloo"}
-    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape
         try:
             result["roofline"]["traffic"] = json.load(open(traffic_file)).get(a2_kernel + "_bytes_per_launch")
@@ -971,12 +1026,13 @@ def main():
                     dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                     dt = float(tt_.item())
                 wk_ = modp_work(n_, t_, pos_, [bx.c for _, _, bx in res_s])
-                rate = wk_["mm_total"] * k / dt
+                rate = wk_["slots"] * k / dt
                 return {"value": n_ * world * k / dt, "unit": "share verifications/s", "ms_per_box": dt / k * 1e3, "boxes": k,
                         "boxes_in_flight": depth, "distinct_boxes": len(cur.boxes),
                         "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n_} t={t_} per GPU ({what}), "
                                                f"honest-dealer boxes, inputs resident in HBM"},
-                        "compute": {"achieved": rate, "peak": PEAK_MODMUL_PER_S, "frac": rate / PEAK_MODMUL_PER_S,
+                        "compute": {"bound": "valu issue", "achieved": rate, "peak": PEAK_VALU_SLOTS_PER_S, "frac": rate / PEAK_VALU_SLOTS_PER_S,
+                                    "unit": "VALU wave-instruction issue slots/s", "valu_slots_per_share": wk_["slots"] / n_,
                                     "modmul_per_share": wk_["mm_total"] / n_, "x_path": wk_["x_path"]}}
             finally:
                 cur.boxes, cur.d_pk, cur.d_pos, cur.n = saved
@@ -1167,15 +1223,55 @@ def main():
             rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)
             scalar_s = time.perf_counter() - t_s
             assert pv2 == pv_bytes and rs2 == responses, "scalar side (C ABI) differs from the Python integers"
+            # ... and the dealer END TO END: per box the scalar side before (P(i) for the box's own polynomial: forward
+            # differences in Z/(q-1) on host threads, H2D of the values) and after the group work (challenge from the
+            # transcript digest, responses r_i = w_i - P(i) c), pipelined over the boxes on host threads beside the GPU
+            e2e_boxes = 10
+            coeff_sets = [b"".join(fx(a) for a in boxes[b % len(boxes)].coeffs) for b in range(e2e_boxes)]
+            scalar_pool = concurrent.futures.ThreadPoolExecutor(max_workers=3)
+            absorb_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)      # blocks are absorbed in FIFO order
+
+            def e2e_post(pv):
+                digest = deal_absorb()
+                cc = fx(int.from_bytes(hashlib.sha256(digest).digest(), "big") % ((Q - 1) // 2))
+                return digest, scalar_pool.submit(capi.dleq_responses, 0, wit_bytes, pv, cc)
+
+            def deal_e2e(count):
+                pre = [scalar_pool.submit(capi.poly_eval, 0, coeff_sets[b], positions) for b in range(count)]
+                post, keep = [], collections.deque()
+                for b in range(count):
+                    pv = pre[b].result()
+                    d_pvb = dev_u8(pv)
+                    keep.append(d_pvb)
+                    while len(post) - sum(f.done() for f in post) >= deal_depth:      # at most deal_depth boxes in flight
+                        time.sleep(0.0005)
+                    eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pvb), vp(d_wt), n,
+                                                                 None, None, None, None), "distribute_compute")
+                    post.append(absorb_pool.submit(e2e_post, pv))
+                outs = [f.result() for f in post]
+                return [(dgst, fut.result()) for dgst, fut in outs]
+
+            deal_e2e(3)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            e2e = deal_e2e(e2e_boxes)
+            torch.cuda.synchronize()
+            e2e_s = (time.perf_counter() - t_e) / e2e_boxes
+            assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer: box 0 differs"
+            scalar_pool.shutdown()
+            absorb_pool.shutdown()
             result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
                                     "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
                                     "scalar_side_ms_per_box": scalar_s * 1e3,
+                                    "value_end_to_end": n / e2e_s, "end_to_end_ms_per_box": e2e_s * 1e3,
                                     "note": "dealer side of distribute_secret (participant.rs:160-286): X_i = g^P(i), Y_i = y_i^P(i), "
                                             "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
                                             "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
                                             "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
                                             "PCIe included); scalar_side: P(i) and the responses for one box through "
-                                            "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`"}
+                                            "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`; `value_end_to_end`: "
+                                            "every box with its own polynomial -- P(i) by forward differences in Z/(q-1), upload, the group "
+                                            "work, the transcript hash, the challenge and the responses -- pipelined over host threads"}
     except Exception as exc:      # noqa: BLE001 - reported in the line and through the exit code
         import traceback
         secondary_error = "".join(traceback.format_exception_only(type(exc), exc)).strip()

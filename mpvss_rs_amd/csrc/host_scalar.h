@@ -120,6 +120,14 @@ struct Modulus {
     reduce(r, t, N + 1);
   }
   // (a - b) mod m for a, b < m
+  // r = (a + b) mod m for a, b < m: one add, one subtract, a branch-free choice
+  void addmod(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
+    uint64_t s[N], d[N];
+    const uint64_t carry = add_n<N>(s, a, b);
+    const uint64_t borrow = sub_n<N>(d, s, m);
+    const uint64_t take_d = (uint64_t)0 - (uint64_t)(carry | (borrow ^ 1));     // a + b >= m
+    for (int i = 0; i < N; ++i) r[i] = (d[i] & take_d) | (s[i] & ~take_d);
+  }
   void submod(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
     if (sub_n<N>(r, a, b)) add_n<N>(r, r, m);
   }

@@ -110,3 +110,22 @@ def modp_reference_x(args):
     cm, position = args
     G = O.ModpGroup()
     return O.commitment_eval(G, cm, position)
+
+
+def modp_fast_share(args):
+    """(X_i, a1_i, a2_i) of one MODP share as 256-byte strings by the FAST form of the reference's arithmetic: X_i by Horner's
+    rule in the exponent, X = (..(C_{t-1}^i * C_{t-2})^i ..)^i * C_0 -- the same group element as the loop of
+    src/participant.rs:423-434 (tests/test_oracle_reference_kats.py pins that equivalence against the reference-order
+    oracle) -- and a1 = g^r X^c, a2 = y^r Y^c (src/dleq.rs:66-84) with CPython's pow.  A share costs ~0.1 s at t = 1024
+    instead of ~30 core-seconds in the reference order, so a full 1 % sample of the largest boxes is affordable.
+    args: (commitments bytes, position, y, Y, r, c) with 256-byte big-endian fields; picklable for parallel_map."""
+    cm, i, y, Y, r, c = args
+    q = MODP_Q
+    t = len(cm) // 256
+    x = int.from_bytes(cm[(t - 1) * 256:t * 256], "big") % q
+    for j in range(t - 2, -1, -1):
+        x = pow(x, i, q) * int.from_bytes(cm[j * 256:(j + 1) * 256], "big") % q
+    yi, Yi, ri, ci = (int.from_bytes(v, "big") for v in (y, Y, r, c))
+    a1 = pow(4, ri, q) * pow(x, ci, q) % q
+    a2 = pow(yi, ri, q) * pow(Yi, ci, q) % q
+    return tuple(v.to_bytes(256, "big") for v in (x, a1, a2))

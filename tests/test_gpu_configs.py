@@ -11,8 +11,8 @@ import random
 import pytest
 
 import mpvss_oracle as O
-from helpers import (EB, MODP_ORDER as ORDER, MODP_Q as Q, ec_reference_share, ec_reference_x, parallel_map, poly_values,
-                     worker_count)
+from helpers import (EB, MODP_ORDER as ORDER, MODP_Q as Q, ec_reference_share, ec_reference_x, modp_fast_share, parallel_map,
+                     poly_values, worker_count)
 from mpvss_rs_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -44,7 +44,7 @@ def make_modp_box(engine, n, t, seed):
     return {"cm": cm, "pos": positions, "pk": pks, "Y": d["Y"], "r": responses, "c": fx(c), "d": d}
 
 
-def check_modp_box(engine, box, sample_idx):
+def check_modp_box(engine, box, sample_idx, fast_idx=()):
     """round trip, three tampers, and the C port (reference operation sequence) on the sampled shares"""
     n = len(box["pos"])
     res = engine.verify_distribution(box["cm"], box["pos"], box["pk"], box["Y"], box["r"], box["c"], dump=True)
@@ -71,6 +71,16 @@ def check_modp_box(engine, box, sample_idx):
     for i, (x, a1, a2) in zip(sample_idx, outs):
         s = slice(i * EB, (i + 1) * EB)
         assert (x, a1, a2) == (res["X"][s], res["a1"][s], res["a2"][s]), f"share {i} of {n}"
+    if fast_idx:
+        # a full 1 % sample through the fast form of the same arithmetic (Horner in the exponent + CPython pow), on spawned
+        # oracle-only processes
+        def arg(i):
+            s = slice(i * EB, (i + 1) * EB)
+            return (box["cm"], box["pos"][i], box["pk"][s], box["Y"][s], box["r"][s], box["c"])
+        outs = parallel_map(modp_fast_share, [arg(i) for i in fast_idx])
+        for i, (x, a1, a2) in zip(fast_idx, outs):
+            s = slice(i * EB, (i + 1) * EB)
+            assert (x, a1, a2) == (res["X"][s], res["a1"][s], res["a2"][s]), f"share {i} of {n} (fast form)"
 
 
 def test_c2_every_share_against_the_c_port(engine):
@@ -90,7 +100,8 @@ def test_headline_shape_seeded_one_percent_sample(engine):
 def test_c5_slice_of_one_gpu(engine):
     """BASELINE config C5 is n=2^20, t=1024 over 8 GPUs: this is ONE GPU's block (131072 consecutive positions, the
     block of rank 3, so positions start at 393217) -- multi-GPU run itself is the driver's.  48 seeded shares against
-    the C port (a share costs the reference sequence ~30 core-seconds at t=1024)."""
+    the C port in the reference order (~30 core-seconds per share at t=1024) and a seeded 1 % (1311 shares) against the
+    fast form of the same arithmetic (helpers.modp_fast_share)."""
     n, t, lo = 131072, 1024, 3 * 131072
     rng = random.Random(1024 + n)
     coeffs = [rng.randrange(ORDER) for _ in range(t)]
@@ -105,10 +116,44 @@ def test_c5_slice_of_one_gpu(engine):
     responses = b"".join(fx((w - p * c) % ORDER) for w, p in zip(wits, pvals))
     box = {"cm": cm, "pos": positions, "pk": pks, "Y": d["Y"], "r": responses, "c": fx(c), "d": d}
     idx = sorted(set(random.Random(7).sample(range(n), 46)) | {0, n - 1})
+    fast = sorted(random.Random(8).sample(range(n), 1311))          # 1 % of the slice, fast form (SURVEY 8d's gate)
     blocks0, fallbacks0 = engine.fd_stats()
-    check_modp_box(engine, box, idx)
+    check_modp_box(engine, box, idx, fast)
     blocks1, fallbacks1 = engine.fd_stats()
     assert blocks1 > blocks0 and fallbacks1 == fallbacks0      # the forward-difference path ran and held
+
+
+def test_forward_differences_hold_with_a_dozen_boxes_in_flight(engine):
+    """The forward-difference pipelines are chains of single-wave stages that must all be resident; their stage time-outs
+    would only bite on a saturated GPU.  Thirteen headline-shape blocks (65536, 256) are enqueued back to back through the
+    block API -- the chip is then as full as bench.py ever makes it -- and absorbed in order: no block may fall back to
+    Horner's rule, every transcript must be the dealer's, and the X / a1 / a2 of a block from the middle of the queue must
+    equal the fast form of the reference arithmetic on a seeded sample (and the dealer's outputs everywhere)."""
+    import ctypes as C
+    n, t, in_flight, probe = 65536, 256, 13, 6
+    box = make_modp_box(engine, n, t, seed=n + 256 + 1)
+    blocks0, fallbacks0 = engine.fd_stats()
+    engine.lib.mpvss_ctx_synchronize(engine.ctx)
+    for _ in range(in_flight):
+        engine.verify_block_compute(box["cm"], box["pos"], box["pk"], box["Y"], box["r"], box["c"])
+    X, A1, A2 = ((C.c_uint8 * (n * EB))() for _ in range(3))
+    for b in range(in_flight):
+        st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+        outs = (X, A1, A2) if b == probe else (None, None, None)
+        engine._check(engine.lib.mpvss_modp_verify_block_absorb(engine.ctx, st, *outs), "verify_block_absorb")
+        assert capi.transcript_verdict(bytes(st), box["c"]) == (True, box["d"]["digest"]), f"block {b}"
+    blocks1, fallbacks1 = engine.fd_stats()
+    assert blocks1 - blocks0 == in_flight and fallbacks1 == fallbacks0, "a forward-difference pipeline gave up under load"
+    Xb, A1b, A2b = bytes(X), bytes(A1), bytes(A2)
+    assert (Xb, A1b, A2b) == (box["d"]["X"], box["d"]["a1"], box["d"]["a2"])
+    idx = sorted(random.Random(13).sample(range(n), 96))
+
+    def arg(i):
+        s = slice(i * EB, (i + 1) * EB)
+        return (box["cm"], box["pos"][i], box["pk"][s], box["Y"][s], box["r"][s], box["c"])
+    for i, (x, a1, a2) in zip(idx, parallel_map(modp_fast_share, [arg(i) for i in idx])):
+        s = slice(i * EB, (i + 1) * EB)
+        assert (x, a1, a2) == (Xb[s], A1b[s], A2b[s]), f"share {i}"
 
 
 GID = {"secp256k1": capi.GROUP_SECP256K1, "ristretto255": capi.GROUP_RISTRETTO255}

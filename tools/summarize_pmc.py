@@ -37,7 +37,7 @@ doc = {
                   "these kernels are outside the calibrated pattern, so treat as indicative)",
 }
 for k in sorted(f):
-    if not k.startswith("k_modp"):
+    if not k.startswith("k_"):
         continue
     fk, grid, calls = f[k]
     wk = w.get(k, (0.0, 0, 0))[0]
