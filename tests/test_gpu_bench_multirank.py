@@ -19,12 +19,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(ranks, steps, n, depth, timeout=900):
-    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH=str(depth), MASTER_ADDR="127.0.0.1")
+def _run(ranks, steps, n, depth, timeout=900, extra_env=None, config_boxes="0"):
+    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH=str(depth), MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps",
            str(steps), "--warmup", "1", "--participants", str(n), "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0",
-           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0", "--config-boxes", "0"]
+           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0", "--config-boxes", config_boxes]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
@@ -63,3 +63,18 @@ def test_four_ranks_many_boxes_every_rank_absorbing_several_at_once():
     assert res["n_gpus"] == 4 and res["steps"] == 14 and "16384 participants in the box" in res["config"]["workload"]
     assert res["host"]["hash_threads"] >= 2 and res["compute"]["fd_fallbacks"] == 0
     assert res["rccl"]["rccl_world_size"] == 4 and res["rccl"]["data_collectives"] >= 14
+
+
+def test_the_c5_object_of_an_eight_gpu_run_in_small():
+    """At N = 8 the line also carries `c5`: ONE box of 8 x 131072 participants, t = 1024, every rank its block.  That leg
+    cannot run here at size; the same code path with two ranks, 2 x 16384 participants and t = 64 (MPVSS_BENCH_C5*): own
+    participants per rank, boxes dealt across the ranks (the dealer's transcript chained rank to rank), slots grown in an
+    untimed pass, per-box flag gather with re-sized buffers, and the headline figure of the same run untouched."""
+    out = _run(2, 3, 8192, 3, extra_env={"MPVSS_BENCH_C5": "1", "MPVSS_BENCH_C5_N": "16384", "MPVSS_BENCH_C5_T": "64"},
+               config_boxes="3")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+    assert "secondary_error" not in res
+    c5 = res["c5"]
+    assert c5["boxes"] == 3 and c5["value"] > 0 and "32768 participants over 2 GPUs" in c5["config"]["workload"]
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["rccl"]["data_collectives"] >= 3 + 3

@@ -334,3 +334,48 @@ def test_rejects_bad_arguments(engine):
         engine.commit_eval(fx(4), [-1])
     with pytest.raises(EngineError):
         engine.distribute(cat(G, [4, 4, 4]), [1, 2], cat(G, [2, 2]), cat(G, [1, 1]), cat(G, [1, 1]))   # t > n
+
+
+def test_every_pair_layout_kernel_against_the_dealer_and_the_fast_form():
+    """MPVSS_PAIR=15 sends the window tables, g^r and a1 through the pair layout as well (by default only a2 goes there: the
+    pipeline is faster that way).  An 8200-share box is dealt and verified with dumps in a child process under that
+    switch (it is read once per process): verdict, the dealer's digest, X / a1 / a2 equal to the dealer's everywhere and to
+    the fast form of the reference arithmetic on a sample; one flipped response bit is rejected."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, random, hashlib, math
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import MODP_Q as Q, MODP_ORDER as ORDER, modp_fast_share, poly_values
+from mpvss_rs_amd import Engine
+fx = lambda v: v.to_bytes(256, "big")
+eng = Engine(0)
+rng = random.Random(515)
+n, t = 8200, 17
+def keygen():
+    while True:
+        k = rng.randrange(Q)
+        if math.gcd(k, ORDER) == 1: return k
+coeffs = [rng.randrange(ORDER) for _ in range(t)]
+privs = [keygen() for _ in range(n)]; wits = [keygen() for _ in range(n)]
+pos = list(range(11, 11 + n))
+pv = poly_values(coeffs, pos, ORDER)
+cm = eng.batch_exp_fixed_base(fx(4), b"".join(map(fx, coeffs)))
+pk = eng.batch_exp_fixed_base(fx(2), b"".join(map(fx, privs)))
+d = eng.distribute(cm, pos, pk, b"".join(map(fx, pv)), b"".join(map(fx, wits)))
+c = int.from_bytes(hashlib.sha256(d["digest"]).digest(), "big") %% ((Q - 1) // 2)
+r = b"".join(fx((w - p * c) %% ORDER) for w, p in zip(wits, pv))
+res = eng.verify_distribution(cm, pos, pk, d["Y"], r, fx(c), dump=True)
+assert res["verdict"] is True and res["digest"] == d["digest"]
+assert (res["X"], res["a1"], res["a2"]) == (d["X"], d["a1"], d["a2"])
+for i in sorted(random.Random(3).sample(range(n), 12)) + [0, n - 1]:
+    s = slice(i * 256, (i + 1) * 256)
+    assert modp_fast_share((cm, pos[i], pk[s], d["Y"][s], r[s], fx(c))) == (res["X"][s], res["a1"][s], res["a2"][s]), i
+bad = bytearray(r); bad[7321 * 256 + 200] ^= 8
+assert eng.verify_distribution(cm, pos, pk, d["Y"], bytes(bad), fx(c))["verdict"] is False
+print("pair15 ok")
+""" % (root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MPVSS_PAIR="15"), timeout=900)
+    assert out.returncode == 0 and "pair15 ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
