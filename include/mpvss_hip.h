@@ -342,6 +342,14 @@ int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_t* pk, cons
                               const uint8_t* w, size_t n, uint8_t* s_out, uint8_t* c_out_host);
 int mpvss_ec_extract_shares(mpvss_ctx* ctx, int group, int space, const uint8_t* pk, const uint8_t* y,
                             const uint8_t* xinv, const uint8_t* w, size_t n, uint8_t* s_out, uint8_t* c_out_host);
+/* MODP, in two steps, so that several batches are in flight (they share the MPVSS_BLOCK_SLOTS block slots and the FIFO order of
+ * the other block calls): `compute` forms e2 = w / x mod (q-1) on host threads and only ENQUEUES the GPU work -- S and a2 from
+ * one chain of squarings, a1 through the comb, and the challenge hash of every proof on the device (K7) --, `absorb` waits for
+ * the oldest batch and hands out S and c (n x 256 bytes each).  Host buffers.  A batch with an encrypted share that is 0 mod q
+ * (no group element) is refused with MPVSS_E_UNSUPPORTED: it belongs to mpvss_modp_extract_shares. */
+int mpvss_modp_extract_shares_compute(mpvss_ctx* ctx, const uint8_t* pk, const uint8_t* y, const uint8_t* xinv, const uint8_t* w,
+                                      size_t n);
+int mpvss_modp_extract_shares_absorb(mpvss_ctx* ctx, uint8_t* s_out_host, uint8_t* c_out_host);
 
 /* ---- scalar-field side (host only, no context needed) ------------------------------------------------------------
  * The reference's scalar rings: Z/(q-1) for MODP-2048 (256-byte big-endian scalars), Z/n for secp256k1 (32-byte

@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
     "mpvss_modp_distribute_compute", "mpvss_modp_distribute_absorb",
     "mpvss_process_init", "mpvss_modp_verify_block_compute_flags",
+    "mpvss_modp_extract_shares_compute", "mpvss_modp_extract_shares_absorb",
 )
 
 GROUP_SECP256K1 = 1
@@ -132,6 +133,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_verify_block_absorb.argtypes = [vp, u8p, u8p, u8p, u8p]
     lib.mpvss_modp_verify_block_compute_flags.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p]
     lib.mpvss_process_init.restype = ci
+    lib.mpvss_modp_extract_shares_compute.argtypes = [vp, u8p, u8p, u8p, u8p, sz]
+    lib.mpvss_modp_extract_shares_absorb.argtypes = [vp, u8p, u8p]
     lib.mpvss_block_claim.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     lib.mpvss_modp_verify_block_absorb_claimed.argtypes = [vp, C.c_ulonglong, u8p, u8p, u8p, u8p]
     lib.mpvss_modp_transcript_verdict.argtypes = [u8p, u8p, C.POINTER(ci), u8p]
@@ -401,6 +404,18 @@ class Engine:
         self._check(self.lib.mpvss_modp_verify_block_absorb_claimed(self.ctx, ticket, ps, None, None, None),
                     "verify_block_absorb_claimed")
         return bytes(ks)
+
+    def extract_shares_compute(self, pk: bytes, y: bytes, xinv: bytes, w: bytes) -> int:
+        """enqueue one batch of extract_secret_share (returns its size); absorb with extract_shares_absorb(n)"""
+        n = len(pk) // EB
+        k = [_buf(x) for x in (pk, y, xinv, w)]
+        self._check(self.lib.mpvss_modp_extract_shares_compute(self.ctx, k[0][1], k[1][1], k[2][1], k[3][1], n), "extract_shares_compute")
+        return n
+
+    def extract_shares_absorb(self, n: int) -> Tuple[bytes, bytes]:
+        ks, ps = _out(n * EB); kc, pc = _out(n * EB)
+        self._check(self.lib.mpvss_modp_extract_shares_absorb(self.ctx, ps, pc), "extract_shares_absorb")
+        return bytes(ks)[: n * EB], bytes(kc)[: n * EB]
 
     def extract_shares(self, pk: bytes, y: bytes, xinv: bytes, w: bytes) -> Tuple[bytes, bytes]:
         n = len(pk) // EB

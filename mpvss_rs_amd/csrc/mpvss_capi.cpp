@@ -2437,6 +2437,170 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
   return MPVSS_OK;
 }
 
+// ---- extract_secret_share in block form -------------------------------------------------------------------------
+// compute: host -> e2 = w / x mod (q-1) on host threads, then ONLY enqueues: S and a2 = S^w from one chain of squarings (the
+// dealer's bucket kernels), a1 = G^w through the comb, the challenge c_i by K7 on the device, D2H of S and c into the slot's
+// pinned staging.  absorb: waits for the oldest batch and hands out S (n x 256) and c (n x 256, big-endian scalars).
+// Batches share the block slots and the FIFO order with the other block calls (slot kind 4).  Host buffers; every Y must be
+// a unit mod q (the shared chain is exact for units only: a batch with Y = 0 mod q returns MPVSS_E_UNSUPPORTED and belongs to
+// mpvss_modp_extract_shares).
+namespace {
+
+int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8_t* y, const uint8_t* xinv, const uint8_t* w,
+                                  size_t n) {
+  if (n == 0 || !pk || !y || !xinv || !w || n > 0x7fffffff) return fail(ctx, MPVSS_E_INVALID, "extract_shares_compute: bad argument");
+  mpvss_ctx::BlockSlot& sl = ctx->head_slot();
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "extract_shares_compute: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
+  if (n > MAX_CHUNK) return fail(ctx, MPVSS_E_UNSUPPORTED, "extract_shares_compute: batch larger than one chunk");
+  {
+    uint8_t qb[EB];
+    modq_modulus_bytes(qb);
+    static const uint8_t zero[EB] = {0};
+    for (size_t i = 0; i < n; ++i)
+      if (memcmp(y + i * EB, zero, EB) == 0 || memcmp(y + i * EB, qb, EB) == 0)
+        return fail(ctx, MPVSS_E_UNSUPPORTED, "extract_shares_compute: an encrypted share is 0 mod q (use mpvss_modp_extract_shares)");
+  }
+  const auto t_enq0 = std::chrono::steady_clock::now();
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!sl.done) {
+    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+  }
+  sl.n = n;
+  sl.kind = 4;
+  sl.check_positions = false;
+  sl.fd_used = false;
+  sl.fd_chunks = 0;
+  sl.enqueue_ms = 0;
+  RET_IF(work_init(ctx, sl.work, nullptr));
+  struct Restore {       // also: an early (error) return leaves nothing of this block running on the slot's streams
+    mpvss_ctx* c;
+    hipStream_t a, b;
+    mpvss_ctx::BlockSlot* sl;
+    ~Restore() {
+      if (!sl->busy) {
+        if (sl->work.sa) (void)hipStreamSynchronize(sl->work.sa);
+        if (sl->work.sb) (void)hipStreamSynchronize(sl->work.sb);
+      }
+      c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b;
+    }
+  } restore{ctx, ctx->stream, ctx->stream_b, &sl};
+  ctx->w = &sl.work;
+  ctx->stream = sl.work.sa;
+  ctx->stream_b = sl.work.sb;
+  ctx->sp = &sl.spans;
+  spans_reset(ctx);
+  // pinned staging: outputs S [n][256], c [n][32]; inputs pk, y, xinv, w, e2 [n][256] each
+  const size_t need = n * EB + n * 32 + 5 * n * EB;
+  if (need > sl.cap) {
+    if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
+    sl.pin = nullptr;
+    sl.cap = 0;
+    hipError_t e = hipHostMalloc(&sl.pin, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(block staging)", e);
+    sl.cap = need;
+  }
+  uint8_t* hS = (uint8_t*)sl.pin;
+  uint8_t* hc = hS + n * EB;
+  uint8_t* in = hc + n * 32;
+  uint8_t *hpk = in, *hy = in + n * EB, *hxi = in + 2 * n * EB, *hw = in + 3 * n * EB, *he2 = in + 4 * n * EB;
+  memcpy(hpk, pk, n * EB);
+  memcpy(hy, y, n * EB);
+  memcpy(hxi, xinv, n * EB);
+  memcpy(hw, w, n * EB);
+  {
+    const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < nt; ++k)
+      pool.emplace_back([&, k] {
+        for (size_t i = k; i < n; i += nt) mpvss_modp_scalar_mul(hw + i * EB, hxi + i * EB, he2 + i * EB);     // w * (1/x) mod (q-1)
+      });
+    for (auto& th : pool) th.join();
+  }
+  const uint32_t* cG;
+  RET_IF(comb_table(ctx, 1, &cG, n));
+  const void *dpk, *dy, *dxi, *dw, *de2;
+  RET_IF(stage_in(ctx, MPVSS_HOST, hpk, n * EB, ctx->w->in_a, &dpk));
+  RET_IF(stage_in(ctx, MPVSS_HOST, hy, n * EB, ctx->w->in_b, &dy));
+  RET_IF(stage_in(ctx, MPVSS_HOST, hxi, n * EB, ctx->w->in_c, &dxi));
+  RET_IF(stage_in(ctx, MPVSS_HOST, hw, n * EB, ctx->w->in_d, &dw));
+  RET_IF(stage_in(ctx, MPVSS_HOST, he2, n * EB, ctx->w->in_e, &de2));
+  RET_IF(ensure(ctx, ctx->w->xbe, n * EB));
+  RET_IF(ensure(ctx, ctx->w->out1, n * EB));
+  RET_IF(ensure(ctx, ctx->w->out2, n * EB));
+  RET_IF(ensure(ctx, ctx->w->verd, n * 32));
+  uint8_t *dS = (uint8_t*)ctx->w->xbe.p, *da1 = (uint8_t*)ctx->w->out1.p, *da2 = (uint8_t*)ctx->w->out2.p, *dc = (uint8_t*)ctx->w->verd.p;
+  const size_t bw = modp_twin_exp_bucket_words();
+  RET_IF(ensure(ctx, ctx->w->tab1, n * (bw + 2) * 4));
+  uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
+  // S = Y^(1/x) and a2 = S^w = Y^(w/x) from one chain of squarings (participant.rs:310-314, dleq.rs:213-216)
+  TIMED_LAUNCH(ctx, 3, modp_launch_twin_exp((const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, (int)n, bk, bk + n * bw, dS, da2,
+                                            ctx->consts, ctx->stream));
+  TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)n, da1,
+                                                 comb_bits_of(ctx, cG), ctx->consts, ctx->stream));                         // a1 = G^w
+  // c_i = hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1_i) framed(a2_i)))   (participant.rs:329-343), K7
+  TIMED_LAUNCH(ctx, 0, verdict_launch_modp_challenge((const uint8_t*)dpk, (const uint8_t*)dy, da1, da2, (int)n, dc, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(hS, dS, n * EB, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(hc, dc, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+  sl.busy = true;
+  sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
+  ctx->commit_head(sl);
+  return MPVSS_OK;
+}
+
+int extract_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* s_out_host, uint8_t* c_out_host) {
+  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
+  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "extract_shares_absorb: no batch in flight");
+  if (sl.kind != 4) return fail(ctx, MPVSS_E_INVALID, "extract_shares_absorb: the oldest block in flight belongs to another entry point");
+  const size_t n = sl.n;
+  ++ctx->tail;
+  sl.absorbing = true;
+  {
+    const hipError_t e_dev = hipSetDevice(ctx->device);
+    if (e_dev != hipSuccess) {
+      ctx->release(sl);
+      sl.absorbing = false;
+      ctx->gpu_done.fetch_add(1);
+      return fail(ctx, MPVSS_E_DEVICE, "absorb: hipSetDevice", e_dev);
+    }
+  }
+  lk.unlock();
+  const hipError_t e = hipEventSynchronize(sl.done);
+  ctx->gpu_done.fetch_add(1);
+  if (e == hipSuccess) {
+    const uint8_t* hS = (const uint8_t*)sl.pin;
+    const uint8_t* hc = hS + n * EB;
+    if (s_out_host) memcpy(s_out_host, hS, n * EB);
+    if (c_out_host)
+      for (size_t i = 0; i < n; ++i) {             // 256-byte big-endian scalars, as mpvss_modp_hash_to_scalar writes them
+        memset(c_out_host + i * EB, 0, EB - 32);
+        memcpy(c_out_host + i * EB + EB - 32, hc + i * 32, 32);
+      }
+  }
+  lk.lock();
+  ctx->release(sl);
+  sl.absorbing = false;
+  if (e != hipSuccess) return fail(ctx, MPVSS_E_DEVICE, "extract_shares_absorb: hipEventSynchronize", e);
+  RET_IF(spans_sum(ctx, sl.spans, ctx->kernel_ms));
+  return MPVSS_OK;
+}
+
+}  // namespace
+
+extern "C" int mpvss_modp_extract_shares_compute(mpvss_ctx* ctx, const uint8_t* pk, const uint8_t* y, const uint8_t* xinv,
+                                                 const uint8_t* w, size_t n) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return extract_shares_compute_locked(ctx, pk, y, xinv, w, n);
+}
+
+extern "C" int mpvss_modp_extract_shares_absorb(mpvss_ctx* ctx, uint8_t* s_out_host, uint8_t* c_out_host) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  return extract_shares_absorb_locked(ctx, lk, s_out_host, c_out_host);
+}
+
 // Elliptic-curve groups (secp256k1, ristretto255): same translation unit, separate file
 #include "capi_ec.inc"
 // scalar-field entry points and reconstruct

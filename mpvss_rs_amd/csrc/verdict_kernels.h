@@ -9,6 +9,10 @@ extern "C" {
 /* verdict[i] = hash_to_scalar(SHA256(framed(h1_i) framed(h2_i) framed(a1_i) framed(a2_i))) == c_i; all arrays [count][256] */
 int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2, const uint8_t* c,
                         int count, uint8_t* verdict, hipStream_t s);
+/* c_out32[i] = SHA256(SHA256(framed(h1_i) framed(h2_i) framed(a1_i) framed(a2_i))) as 32 big-endian bytes: the challenge of a
+ * share-box proof (hash_to_scalar of the transcript digest, participant.rs:329-343; the mod (q-1)/2 is the identity) */
+int verdict_launch_modp_challenge(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2, int count,
+                                  uint8_t* c_out32, hipStream_t s);
 /* out[i] = 1 iff 0 < y_i < q, 0 < Y_i < q, r_i < q-1 (canonical encodings); bounds = [q | q-1], 2 x 256 big-endian bytes */
 int verdict_launch_modp_wellformed(const uint8_t* y, const uint8_t* Y, const uint8_t* r, const uint8_t* bounds, int count,
                                    uint8_t* out, hipStream_t s);

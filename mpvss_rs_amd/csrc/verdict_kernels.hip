@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_modp_wellformed(const uint8_t* __restri
 extern "C" __global__ void __launch_bounds__(64)
 k_modp_share_verdict(const uint8_t* __restrict__ h1, const uint8_t* __restrict__ h2, const uint8_t* __restrict__ a1,
                      const uint8_t* __restrict__ a2, const uint8_t* __restrict__ c, int count,
-                     uint8_t* __restrict__ verdict) {
+                     uint8_t* __restrict__ verdict, uint8_t* __restrict__ c_out32) {
   __shared__ u32 lds[16 * 64];
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= count) return;
@@ -299,6 +299,12 @@ k_modp_share_verdict(const uint8_t* __restrict__ h1, const uint8_t* __restrict__
   sha256_of_digest(hs, digest);                         // modp.rs:142-148 hashes the digest again
   // c as a 256-byte big-endian integer must equal the 256-bit hash: the top 224 bytes are zero, the rest matches.
   // (mod (q-1)/2 is the identity on 256-bit values; a challenge >= 2^256 can never match.)
+  if (c_out32 != nullptr) {      // the prover's side (extract_secret_share, participant.rs:329-343): hand the challenge out
+    u32* o = reinterpret_cast<u32*>(c_out32 + (size_t)x * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = __builtin_bswap32(hs[k]);
+    return;
+  }
   const u32* c32 = reinterpret_cast<const u32*>(c + off);
   u32 diff = 0;
   for (int k = 0; k < 56; ++k) diff |= c32[k];
@@ -425,7 +431,15 @@ extern "C" int verdict_launch_modp_wellformed(const uint8_t* y, const uint8_t* Y
 extern "C" int verdict_launch_modp(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,
                                    const uint8_t* c, int count, uint8_t* verdict, hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_share_verdict, dim3((count + 63) / 64), dim3(64), 0, s, h1, h2, a1, a2, c, count, verdict);
+  hipLaunchKernelGGL(k_modp_share_verdict, dim3((count + 63) / 64), dim3(64), 0, s, h1, h2, a1, a2, c, count, verdict,
+                     (uint8_t*)nullptr);
+  return (int)hipGetLastError();
+}
+extern "C" int verdict_launch_modp_challenge(const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2, int count,
+                                             uint8_t* c_out32, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_share_verdict, dim3((count + 63) / 64), dim3(64), 0, s, h1, h2, a1, a2, (const uint8_t*)nullptr, count,
+                     (uint8_t*)nullptr, c_out32);
   return (int)hipGetLastError();
 }
 extern "C" int verdict_launch_ec(int group, const uint8_t* h1, const uint8_t* h2, const uint8_t* a1, const uint8_t* a2,

@@ -171,6 +171,8 @@ unsafe extern "C" {
                                      s_out: *mut u8, c_out_host: *mut u8) -> c_int;
     pub fn mpvss_ec_extract_shares(ctx: *mut mpvss_ctx, group: c_int, space: c_int, pk: *const u8, y: *const u8, xinv: *const u8, w: *const u8,
                                    n: usize, s_out: *mut u8, c_out_host: *mut u8) -> c_int;
+    pub fn mpvss_modp_extract_shares_compute(ctx: *mut mpvss_ctx, pk: *const u8, y: *const u8, xinv: *const u8, w: *const u8, n: usize) -> c_int;
+    pub fn mpvss_modp_extract_shares_absorb(ctx: *mut mpvss_ctx, s_out_host: *mut u8, c_out_host: *mut u8) -> c_int;
     // ---- scalar-field side (host only)
     pub fn mpvss_modp_scalar_mul(a256: *const u8, b256: *const u8, out256: *mut u8) -> c_int;
     pub fn mpvss_ec_scalar_mul(group: c_int, a32: *const u8, b32: *const u8, out32: *mut u8) -> c_int;

@@ -27,6 +27,41 @@ def test_modp_extract_shares(engine):
     assert list(engine.verify_shares(cat(g, pks), S, cat(g, Y), c, cat(g, r))) == [1] * 7
 
 
+def test_modp_extract_shares_block_form(engine):
+    """mpvss_modp_extract_shares_compute / _absorb: three batches in flight (320 participants each, other witnesses per
+    batch), absorbed in order -- S and c equal to the synchronous call's, a few shares against the oracle, the proofs verify;
+    a batch holding an encrypted share that is 0 mod q is refused (it is no group element) and the context stays usable."""
+    n, t = 320, 4
+    g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, 29)
+    keys = [g.element_to_bytes(p) for p in pks]
+    Y = [box["shares"][k] for k in keys]
+    xinv = cat(g, [O.mod_inverse(x, g.group_order_int()) for x in privs])
+    pkb, Yb = cat(g, pks), cat(g, Y)
+    batches = []
+    for b in range(3):
+        rng = random.Random(100 + b)
+        batches.append([modp_keygen(g, rng) for _ in privs])
+    for wit in batches:
+        assert engine.extract_shares_compute(pkb, Yb, xinv, cat(g, wit)) == n
+    assert engine.blocks_in_flight()[0] == 3
+    got = [engine.extract_shares_absorb(n) for _ in batches]
+    assert engine.blocks_in_flight() == (0, 0)
+    for b, (wit, (S, c)) in enumerate(zip(batches, got)):
+        # the synchronous call takes the two dependent exponentiations at this size: a second path to the same bytes
+        assert (S, c) == engine.extract_shares(pkb, Yb, xinv, cat(g, wit)), f"batch {b}"
+        for i in (0, 7, n - 1):
+            e = O.extract_secret_share(g, box, privs[i], wit[i])                          # participant.rs:294-353
+            assert split(S)[i] == e["share"] and split(c)[i] == e["challenge"]
+        r = [O.dleq_response(g, w, x, ci) for w, x, ci in zip(wit, privs, split(c))]
+        assert list(engine.verify_shares(pkb, S, Yb, c, cat(g, r))) == [1] * n
+    zero = bytearray(Yb); zero[5 * 256:6 * 256] = g.q.to_bytes(256, "big")
+    with pytest.raises(capi.EngineError, match="0 mod q"):
+        engine.extract_shares_compute(pkb, bytes(zero), xinv, cat(g, batches[0]))
+    assert engine.blocks_in_flight() == (0, 0)
+    assert engine.extract_shares_compute(pkb, Yb, xinv, cat(g, batches[0])) == n
+    assert engine.extract_shares_absorb(n)[0] == engine.extract_shares(pkb, Yb, xinv, cat(g, batches[0]))[0]
+
+
 @pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
 def test_ec_extract_shares(engine, name):
     G = O.GROUPS[name]()
