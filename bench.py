@@ -1013,7 +1013,12 @@ def main():
                     rccl_reap(0)
                     rccl_buffers(n_)
                 init = min(depth + max(HASH_THREADS, 1) + 2, capi.BLOCK_SLOTS - 1)
-                gate(run_steps(init, depth=init), f"{what}: slot initialisation")
+                if world == 1 and n_ <= 16384:
+                    # small boxes travel in groups (one block for a run of boxes, mpvss_modp_verify_many): the same run, untimed,
+                    # grows exactly the slots the timed one uses
+                    gate(run_steps(k, depth=depth), f"{what}: slot initialisation")
+                else:
+                    gate(run_steps(init, depth=init), f"{what}: slot initialisation")
                 eng.pipeline_stats(reset=True)
                 barrier()
                 t_s = time.perf_counter()
@@ -1027,7 +1032,10 @@ def main():
                     dt = float(tt_.item())
                 wk_ = modp_work(n_, t_, pos_, [bx.c for _, _, bx in res_s])
                 rate = wk_["slots"] * k / dt
+                st_ = eng.pipeline_stats()
                 return {"value": n_ * world * k / dt, "unit": "share verifications/s", "ms_per_box": dt / k * 1e3, "boxes": k,
+                        "host_ms_per_box": {"enqueue": st_["enqueue_ms"] / max(st_["blocks"], 1), "wait": st_["wait_ms"] / max(st_["blocks"], 1),
+                                            "hash": st_["hash_ms"] / max(st_["blocks"], 1)},
                         "boxes_in_flight": depth, "distinct_boxes": len(cur.boxes),
                         "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n_} t={t_} per GPU ({what}), "
                                                f"honest-dealer boxes, inputs resident in HBM"},
@@ -1043,10 +1051,14 @@ def main():
         if args.config_boxes != 0 and keyset[0] is None:
             if world == 1:
                 k2, k5 = (48, 6) if args.config_boxes < 0 else (args.config_boxes, max(2, args.config_boxes // 8))
-                result["configs"] = {
-                    "c2": bench_shape(4096, 64, k2, min(PIPE_DEPTH + 2, 14), 0, "BASELINE config C2"),
-                    "c5_slice": bench_shape(131072, 1024, k5, 6, 0, "one GPU's slice of BASELINE config C5: positions 1..131072 of 1048576"),
-                }
+                only = os.environ.get("MPVSS_BENCH_CONFIGS", "c2,c5_slice").split(",")
+                result["configs"] = {}
+                if "c2" in only:
+                    result["configs"]["c2"] = bench_shape(4096, 64, k2, int(os.environ.get("MPVSS_BENCH_C2_DEPTH", "14")), 0,
+                                                          "BASELINE config C2")
+                if "c5_slice" in only:
+                    result["configs"]["c5_slice"] = bench_shape(131072, 1024, k5, 6, 0,
+                                                                "one GPU's slice of BASELINE config C5: positions 1..131072 of 1048576")
             elif world == 8 or os.environ.get("MPVSS_BENCH_C5") == "1":
                 # BASELINE config C5 itself: ONE box of world x 131072 participants, t = 1024, every rank its block
                 k5 = 6 if args.config_boxes < 0 else max(2, args.config_boxes)

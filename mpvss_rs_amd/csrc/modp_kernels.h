@@ -90,6 +90,21 @@ int modp_launch_fd_step(const uint32_t* state, const uint32_t* state_back, int c
                         hipStream_t s);
 int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,
                           hipStream_t s);
+/* the same phases for a GROUP of same-shaped boxes in one launch each (box b = blockIdx.y; box_*: strides from one box to the next,
+   in 32-bit words for limb buffers, in elements for positions and output rows) */
+int modp_launch_commit_eval_boxes(const uint32_t* cm, int t, const int64_t* positions, size_t box_positions, int count, int boxes,
+                                  uint32_t* x_m, uint8_t* x_be, size_t box_out, const int* gate, int want, const void* cs,
+                                  hipStream_t s);
+int modp_launch_fd_check_positions_boxes(const int64_t* positions, size_t box_positions, int count, int boxes, int* flag,
+                                         hipStream_t s);
+int modp_launch_fd_table_boxes(const uint32_t* x, size_t box_x, const uint32_t* x_inv, size_t box_xinv, int chains, int t,
+                               uint32_t* state, uint32_t* state_back, size_t box_state, uint32_t* hand, size_t box_hand, int boxes,
+                               int* gate, int inject_fault, const void* cs, hipStream_t s);
+int modp_launch_fd_step_boxes(const uint32_t* state, const uint32_t* state_back, size_t box_state, int chains, int t, int w0,
+                              int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand, size_t box_hand, int boxes,
+                              int* gate, int inject_fault, const void* cs, hipStream_t s);
+int modp_launch_gather_rows(const uint32_t* src, size_t src_stride_words, size_t row_words, int boxes, uint32_t* dst, hipStream_t s);
+int modp_launch_spread_rows(const uint8_t* rows, int group, int count, uint8_t* out, hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

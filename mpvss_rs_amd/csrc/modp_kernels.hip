@@ -10,6 +10,7 @@
 // every product staged in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "bn_quad.h"
 #include "modp_kernels.h"
 
@@ -212,8 +213,14 @@ extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
 k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, int split, int t,
                    const int64_t* __restrict__ positions, int count, uint8_t* __restrict__ x_be,
                    u32* __restrict__ x_m, const int* __restrict__ gate, int gate_want,
-                   const ModpConsts* __restrict__ cs) {
+                   const ModpConsts* __restrict__ cs, size_t box_cm_words, size_t box_positions, size_t box_out) {
   __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_BLOCK + MODP_WPB) * SLOT_WORDS];
+  // blockIdx.y: box of a group of same-shaped boxes evaluated by one launch (own commitments, positions and output rows)
+  cm_a += blockIdx.y * box_cm_words;
+  cm_b += blockIdx.y * box_cm_words;
+  positions += blockIdx.y * box_positions;
+  if (x_be != nullptr) x_be += blockIdx.y * box_out * 256;
+  if (x_m != nullptr) x_m += blockIdx.y * box_out * L;
   // gate: the forward-difference path (below) and this kernel exclude each other through a device flag,
   // so that the choice needs no host synchronisation
   if (gate != nullptr && *gate != gate_want) return;
@@ -317,7 +324,8 @@ k_modp_commit_eval(const u32* __restrict__ cm_a, const u32* __restrict__ cm_b, i
 
 // flag = 1 iff positions[i] == positions[0] + i for all i (and no negative / overflowing value)
 extern "C" __global__ void k_modp_fd_check_positions(const int64_t* __restrict__ positions, int count,
-                                                      int* __restrict__ flag) {
+                                                      int* __restrict__ flag, size_t box_positions) {
+  positions += blockIdx.y * box_positions;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const int64_t p0 = positions[0];
@@ -472,7 +480,14 @@ __device__ __forceinline__ bool hand_receive(const u32* __restrict__ src, u32* d
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int chains, int t, int tpad,
                 u32* __restrict__ state, u32* __restrict__ state_back, u32* __restrict__ hand, int* __restrict__ gate,
-                int inject_fault, const ModpConsts* __restrict__ cs) {
+                int inject_fault, const ModpConsts* __restrict__ cs, size_t box_x, size_t box_xinv, size_t box_state,
+                size_t box_hand) {
+  // blockIdx.y: box of a group (word strides; the stages of one box keep their dispatch order, x runs fastest)
+  x += blockIdx.y * box_x;
+  x_inv += blockIdx.y * box_xinv;
+  state += blockIdx.y * box_state;
+  state_back += blockIdx.y * box_state;
+  hand += blockIdx.y * box_hand;
   // state[c][l]      = E_l[0]                       = D_l at the first seed: the chain that steps forward
   // state_back[c][l] = (l even ? E_l : F_l)[t-1-l]  = g^((-1)^l nabla^l P) at the last seed: with H_l(i-1) = H_l(i) H_{l+1}(i)
   //                    the same recurrence steps BACKWARD from the last seed, H_0 being X (one seed window serves
@@ -559,7 +574,11 @@ k_modp_fd_table(const u32* __restrict__ x, const u32* __restrict__ x_inv, int ch
 extern "C" __global__ void __launch_bounds__(64) WAVES_ATTR
 k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back, int chains, int t, int tpad, int w0,
                int chain_len, int count, u32* __restrict__ x_m, u32* __restrict__ hand, int* __restrict__ gate,
-               int inject_fault, const ModpConsts* __restrict__ cs) {
+               int inject_fault, const ModpConsts* __restrict__ cs, size_t box_state, size_t box_xm, size_t box_hand) {
+  state += blockIdx.y * box_state;
+  state_back += blockIdx.y * box_state;
+  x_m += blockIdx.y * box_xm;
+  hand += blockIdx.y * box_hand;
   __shared__ __attribute__((aligned(16))) u32 lds[(NUMS_PER_WAVE + 2) * SLOT_WORDS];
   if (*gate != 1) return;
   __builtin_amdgcn_s_setprio(MODP_SETPRIO);   // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
@@ -1403,7 +1422,7 @@ extern "C" int modp_launch_commit_eval(const uint32_t* cm, int t, const int64_t*
                                        uint32_t* x_m, uint8_t* x_be, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, cm, cm, 0x7fffffff, t,
-                     positions, count, x_be, x_m, (const int*)nullptr, 0, (const ModpConsts*)cs);
+                     positions, count, x_be, x_m, (const int*)nullptr, 0, (const ModpConsts*)cs, (size_t)0, (size_t)0, (size_t)0);
   return (int)hipGetLastError();
 }
 
@@ -1413,7 +1432,42 @@ extern "C" int modp_launch_commit_eval_gated(const uint32_t* cm_a, const uint32_
                                              const int* gate, int want, const void* cs, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, cm_a, cm_b, split, t,
-                     positions, count, x_be, x_m, gate, want, (const ModpConsts*)cs);
+                     positions, count, x_be, x_m, gate, want, (const ModpConsts*)cs, (size_t)0, (size_t)0, (size_t)0);
+  return (int)hipGetLastError();
+}
+// the same for `boxes` same-shaped boxes in one launch: box b reads cm + b * t rows, positions + b * box_positions, and
+// writes its `count` results from row b * box_out of x_m / x_be
+extern "C" int modp_launch_commit_eval_boxes(const uint32_t* cm, int t, const int64_t* positions, size_t box_positions, int count,
+                                             int boxes, uint32_t* x_m, uint8_t* x_be, size_t box_out, const int* gate, int want,
+                                             const void* cs, hipStream_t s) {
+  if (count <= 0 || boxes <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_commit_eval, dim3(grid_for(count), boxes), dim3(BLOCK_THREADS), 0, s, cm, cm, 0x7fffffff, t,
+                     positions, count, x_be, x_m, gate, want, (const ModpConsts*)cs, (size_t)t * L, box_positions, box_out);
+  return (int)hipGetLastError();
+}
+// dst[b][0 .. row_words) = src[b * src_stride_words ..): the seeds of a group's boxes side by side for one simultaneous inversion
+__global__ void k_modp_gather_rows(const u32* __restrict__ src, size_t src_stride_words, size_t row_words, u32* __restrict__ dst) {
+  const u32* from = src + blockIdx.y * src_stride_words;
+  u32* to = dst + blockIdx.y * row_words;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_words; i += (size_t)gridDim.x * blockDim.x) to[i] = from[i];
+}
+extern "C" int modp_launch_gather_rows(const uint32_t* src, size_t src_stride_words, size_t row_words, int boxes, uint32_t* dst,
+                                       hipStream_t s) {
+  if (boxes <= 0 || row_words == 0) return 0;
+  const unsigned gx = (unsigned)std::min<size_t>((row_words + 255) / 256, 64);
+  hipLaunchKernelGGL(k_modp_gather_rows, dim3(gx, boxes), dim3(256), 0, s, src, src_stride_words, row_words, dst);
+  return (int)hipGetLastError();
+}
+// out[x] = rows[x / group]: one 256-byte challenge per box spread to one per share
+__global__ void k_modp_spread_rows(const uint8_t* __restrict__ rows, int group, int count, uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte piece each
+  if (i >= (size_t)count * 16) return;
+  const size_t x = i / 16, piece = i % 16;
+  ((uint4*)out)[i] = ((const uint4*)rows)[(x / group) * 16 + piece];
+}
+extern "C" int modp_launch_spread_rows(const uint8_t* rows, int group, int count, uint8_t* out, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_spread_rows, dim3(((size_t)count * 16 + 255) / 256), dim3(256), 0, s, rows, group, count, out);
   return (int)hipGetLastError();
 }
 
@@ -1424,7 +1478,13 @@ extern "C" int modp_fd_tpad(int t) {
 }
 
 extern "C" int modp_launch_fd_check_positions(const int64_t* positions, int count, int* flag, hipStream_t s) {
-  hipLaunchKernelGGL(k_modp_fd_check_positions, dim3((count + 255) / 256), dim3(256), 0, s, positions, count, flag);
+  hipLaunchKernelGGL(k_modp_fd_check_positions, dim3((count + 255) / 256), dim3(256), 0, s, positions, count, flag, (size_t)0);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_check_positions_boxes(const int64_t* positions, size_t box_positions, int count, int boxes, int* flag,
+                                                    hipStream_t s) {
+  hipLaunchKernelGGL(k_modp_fd_check_positions, dim3((count + 255) / 256, boxes), dim3(256), 0, s, positions, count, flag,
+                     box_positions);
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_binv_up(const uint32_t* a, int m, int G, uint32_t* prefix, uint32_t* totals, const int* gate,
@@ -1457,7 +1517,16 @@ extern "C" int modp_launch_fd_table(const uint32_t* x, const uint32_t* x_inv, in
                                     hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
   hipLaunchKernelGGL(k_modp_fd_table, dim3(chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, x, x_inv, chains, t, tpad,
-                     state, state_back, hand, gate, inject_fault, (const ModpConsts*)cs);
+                     state, state_back, hand, gate, inject_fault, (const ModpConsts*)cs, (size_t)0, (size_t)0, (size_t)0, (size_t)0);
+  return (int)hipGetLastError();
+}
+// `boxes` boxes in one launch; box_*: word strides from one box to the next (state and state_back share box_state)
+extern "C" int modp_launch_fd_table_boxes(const uint32_t* x, size_t box_x, const uint32_t* x_inv, size_t box_xinv, int chains, int t,
+                                          uint32_t* state, uint32_t* state_back, size_t box_state, uint32_t* hand, size_t box_hand,
+                                          int boxes, int* gate, int inject_fault, const void* cs, hipStream_t s) {
+  const int tpad = modp_fd_tpad(t);
+  hipLaunchKernelGGL(k_modp_fd_table, dim3(chains * (tpad / NUMS_PER_WAVE), boxes), dim3(64), 0, s, x, x_inv, chains, t, tpad,
+                     state, state_back, hand, gate, inject_fault, (const ModpConsts*)cs, box_x, box_xinv, box_state, box_hand);
   return (int)hipGetLastError();
 }
 // x_m: base of the chains (position index 0); w0: index of the first seed inside every chain
@@ -1466,7 +1535,17 @@ extern "C" int modp_launch_fd_step(const uint32_t* state, const uint32_t* state_
                                    const void* cs, hipStream_t s) {
   const int tpad = modp_fd_tpad(t);
   hipLaunchKernelGGL(k_modp_fd_step, dim3(2 * chains * (tpad / NUMS_PER_WAVE)), dim3(64), 0, s, state, state_back, chains,
-                     t, tpad, w0, chain_len, count, x_m, hand, gate, inject_fault, (const ModpConsts*)cs);
+                     t, tpad, w0, chain_len, count, x_m, hand, gate, inject_fault, (const ModpConsts*)cs, (size_t)0, (size_t)0,
+                     (size_t)0);
+  return (int)hipGetLastError();
+}
+extern "C" int modp_launch_fd_step_boxes(const uint32_t* state, const uint32_t* state_back, size_t box_state, int chains, int t,
+                                         int w0, int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand,
+                                         size_t box_hand, int boxes, int* gate, int inject_fault, const void* cs, hipStream_t s) {
+  const int tpad = modp_fd_tpad(t);
+  hipLaunchKernelGGL(k_modp_fd_step, dim3(2 * chains * (tpad / NUMS_PER_WAVE), boxes), dim3(64), 0, s, state, state_back, chains,
+                     t, tpad, w0, chain_len, count, x_m, hand, gate, inject_fault, (const ModpConsts*)cs, box_state, box_xm,
+                     box_hand);
   return (int)hipGetLastError();
 }
 extern "C" int modp_launch_from_mont(const uint32_t* x_m, int count, uint8_t* out_be, const int* gate, const void* cs,

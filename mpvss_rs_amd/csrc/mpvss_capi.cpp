@@ -84,7 +84,7 @@ struct mpvss_ctx {
   // flight on the GPU at once (the serial phases of one box overlap the wide phases of the next).
   struct Work {
     DevBuf in_a, in_b, in_c, in_d, in_e, pos, cm, xbe, out1, out2, tab1, tab2, tabg, cbuf;
-    DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root, fd_hand_t, fd_hand_s;   // forward differences
+    DevBuf fd_flag, fd_state, fd_xm, fd_xinv, fd_pre, fd_tot, fd_totinv, fd_root, fd_hand_t, fd_hand_s, fd_gather;   // forward differences
     DevBuf tab3, gr_m;   // X tables of a1; gr_m: g^r_i in Montgomery form
     DevBuf verd;         // per-share verdict bytes of verify_share batches (K7)
     DevBuf csched;       // sliding-window schedule of the box's challenge
@@ -104,7 +104,7 @@ struct mpvss_ctx {
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
-              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &tab3, &gr_m, &verd,
+              &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &fd_gather, &tab3, &gr_m, &verd,
               &csched};
     }
   };
@@ -146,6 +146,7 @@ struct mpvss_ctx {
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
     bool check_positions = false;
+    unsigned nbox = 1;             // kind 0: boxes of one shape in this block (a group enqueued by mpvss_modp_verify_many), n / nbox shares each
     int kind = 0;                  // 0: block of verify_distribution_shares, 1: batch of verify_share proofs (W_B),
                                    // 2: block of a curve group's verify_distribution_shares, 3: a curve group's verify_share batch
     int group = 0;                 // kind 2: MPVSS_GROUP_*
@@ -850,10 +851,18 @@ bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
   return fd;
 }
 
-int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX) {
+// boxes > 1: a GROUP of same-shaped boxes in one set of launches -- box b has its commitments at w.cm + b * t rows, its `cnt`
+// positions at dpos + b * box_positions (0: the boxes share one array) and its X at dX + b * cnt rows; one flag for the group.
+int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX, size_t boxes = 1,
+           size_t box_positions = 0) {
+  const int B = (int)boxes;
   static const int fd_chains_env = fd_env("MPVSS_FD_CHAINS", 0);
   const bool fd = fd_applies(t, hpos, cnt);
   if (!fd) {
+    if (B > 1)
+      TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval_boxes((const uint32_t*)ctx->w->cm.p, (int)t, dpos, box_positions, (int)cnt, B,
+                                                         nullptr, dX, cnt, nullptr, 0, ctx->consts, ctx->stream));
+    else
     TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval((const uint32_t*)ctx->w->cm.p, (int)t, dpos, (int)cnt, nullptr, dX,
                                                  ctx->consts, ctx->stream));
     return 0;
@@ -903,7 +912,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   w.fd_used = true;
   RET_IF(ensure(ctx, w.fd_flag, 64));
   RET_IF(ensure(ctx, w.fd_root, 4 * EB));
-  RET_IF(ensure(ctx, w.fd_xm, cnt * MODP_L * 4));
+  RET_IF(ensure(ctx, w.fd_xm, boxes * cnt * MODP_L * 4));
   // The configuration (chains, seeding levels) depends on whether other blocks are in flight, and a slot sees both
   // over its life: the buffers are sized for the largest of them at once -- growing one later means hipFree, which
   // waits for the device (58-87 ms inside the enqueue of a timed box, measured with MPVSS_TRACE_ENQUEUE).
@@ -914,18 +923,18 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
     for (int c = 0; c < 3; ++c) {
       const int Sc = cands[c] < 1 ? 1 : cands[c];
       const int m0c = (int)(Sc * t), clc = (int)((cnt + Sc - 1) / Sc);
-      const std::vector<int> msc = tree_sizes(m0c);
+      const std::vector<int> msc = tree_sizes(m0c * B);
       size_t prec = 0, totc = 0;
       for (size_t l = 0; l + 1 < msc.size(); ++l) prec += (size_t)msc[l];
       for (size_t l = 1; l < msc.size(); ++l) totc += (size_t)msc[l];
       const size_t l1t = Sc > 1 ? modp_fd_table_hand_words(1, (int)t) * 4 : 0;
       const size_t l1s = Sc > 1 ? modp_fd_step_hand_words(1, (int)t, m0c) * 4 : 0;
-      need_b.xinv = std::max(need_b.xinv, (size_t)m0c * MODP_L * 4);
+      need_b.xinv = std::max(need_b.xinv, boxes * m0c * MODP_L * 4);
       need_b.pre = std::max(need_b.pre, prec * MODP_L * 4);
       need_b.tot = std::max(need_b.tot, totc * MODP_L * 4);
-      need_b.state = std::max(need_b.state, (size_t)2 * m0c * MODP_L * 4);
-      need_b.hand_t = std::max(need_b.hand_t, modp_fd_table_hand_words(Sc, (int)t) * 4 + l1t);
-      need_b.hand_s = std::max(need_b.hand_s, modp_fd_step_hand_words(Sc, (int)t, clc) * 4 + l1s);
+      need_b.state = std::max(need_b.state, boxes * 2 * m0c * MODP_L * 4);
+      need_b.hand_t = std::max(need_b.hand_t, boxes * (modp_fd_table_hand_words(Sc, (int)t) * 4 + l1t));
+      need_b.hand_s = std::max(need_b.hand_s, boxes * (modp_fd_step_hand_words(Sc, (int)t, clc) * 4 + l1s));
     }
   }
   RET_IF(ensure(ctx, w.fd_xinv, need_b.xinv));
@@ -933,6 +942,7 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   RET_IF(ensure(ctx, w.fd_tot, need_b.tot));
   RET_IF(ensure(ctx, w.fd_totinv, need_b.tot));
   RET_IF(ensure(ctx, w.fd_state, need_b.state));
+  if (B > 1) RET_IF(ensure(ctx, w.fd_gather, need_b.xinv));
   if (!w.root) return fail(ctx, MPVSS_E_DEVICE, "eval_x: workspace not initialised");
   int* flag = (int*)w.fd_flag.p;
   int* dok = flag + 1;
@@ -974,40 +984,54 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   const size_t hand_t = modp_fd_table_hand_words(S, (int)t) * 4, hand_s = modp_fd_step_hand_words(S, (int)t, chain_len) * 4;
   const size_t hand_t1 = two_level ? modp_fd_table_hand_words(1, (int)t) * 4 : 0;
   const size_t hand_s1 = two_level ? modp_fd_step_hand_words(1, (int)t, m0) * 4 : 0;
-  RET_IF(ensure(ctx, w.fd_hand_t, std::max(need_b.hand_t, hand_t + hand_t1)));
-  RET_IF(ensure(ctx, w.fd_hand_s, std::max(need_b.hand_s, hand_s + hand_s1)));
+  RET_IF(ensure(ctx, w.fd_hand_t, std::max(need_b.hand_t, boxes * (hand_t + hand_t1))));
+  RET_IF(ensure(ctx, w.fd_hand_s, std::max(need_b.hand_s, boxes * (hand_s + hand_s1))));
+  // strides from one box of the group to the next, in 32-bit words
+  const size_t bx_xm = cnt * MODP_L, bx_state = (size_t)2 * m0 * MODP_L, bx_hand_t = (hand_t + hand_t1) / 4, bx_hand_s = (hand_s + hand_s1) / 4;
+  // the seeds of the group's boxes side by side (one simultaneous inversion for all of them); a lone box's are already
+  auto seeds_together = [&](int per_box) -> const uint32_t* {
+    if (B == 1) return xseed;
+    if (modp_launch_gather_rows(xseed, bx_xm, (size_t)per_box * MODP_L, B, (uint32_t*)w.fd_gather.p, ctx->stream) != 0) return nullptr;
+    return (const uint32_t*)w.fd_gather.p;
+  };
   w.root[0].one = 1;     // pinned: the copy below is asynchronous and reads it in stream order
   HIPCHK(ctx, hipMemcpyAsync(flag, &w.root[0].one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RET_IF(span_begin(ctx, 0));
-  if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions(dpos, (int)cnt, flag, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_t.p, 0, hand_t + hand_t1, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, hand_s + hand_s1, ctx->stream));
+  if (!hpos) LAUNCHCHK(ctx, modp_launch_fd_check_positions_boxes(dpos, box_positions, (int)cnt, box_positions ? B : 1, flag, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_t.p, 0, boxes * (hand_t + hand_t1), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(w.fd_hand_s.p, 0, boxes * (hand_s + hand_s1), ctx->stream));
   // seeds: X at the S*t positions from seed0, kept in Montgomery form
   if (two_level) {
-    LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
-                                                 dpos + seed0, (int)t, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
-    RET_IF(invert_batch(xseed, (int)t, (uint32_t*)w.fd_xinv.p, &w.root[1]));
+    LAUNCHCHK(ctx, modp_launch_commit_eval_boxes((const uint32_t*)w.cm.p, (int)t, dpos + seed0, box_positions, (int)t, B, xseed, nullptr,
+                                                 cnt, flag, 1, ctx->consts, ctx->stream));
+    const uint32_t* seeds1 = seeds_together((int)t);
+    if (!seeds1) return fail(ctx, MPVSS_E_DEVICE, "eval_x: gather launch");
+    RET_IF(invert_batch(seeds1, B * (int)t, (uint32_t*)w.fd_xinv.p, &w.root[1]));
     // one chain of stride 1 over the seed window: tables from its first t values, then m0 - 1 steps forward
-    LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, 1, (int)t, state_fwd, state_bwd,
-                                        (uint32_t*)((uint8_t*)w.fd_hand_t.p + hand_t), flag, 0, ctx->consts, ctx->stream));
-    LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, 1, (int)t, 0, m0, m0, xseed,
-                                       (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), flag, inject_fault == 3 ? 1 : 0, ctx->consts,
-                                       ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_fd_table_boxes(xseed, bx_xm, (const uint32_t*)w.fd_xinv.p, t * MODP_L, 1, (int)t, state_fwd, state_bwd,
+                                              bx_state, (uint32_t*)((uint8_t*)w.fd_hand_t.p + hand_t), bx_hand_t, B, flag, 0,
+                                              ctx->consts, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_fd_step_boxes(state_fwd, state_bwd, bx_state, 1, (int)t, 0, m0, m0, xseed, bx_xm,
+                                             (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), bx_hand_s, B, flag,
+                                             inject_fault == 3 ? 1 : 0, ctx->consts, ctx->stream));
   } else {
-    LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t,
-                                                 dpos + seed0, m0, xseed, nullptr, flag, 1, ctx->consts, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_commit_eval_boxes((const uint32_t*)w.cm.p, (int)t, dpos + seed0, box_positions, m0, B, xseed, nullptr,
+                                                 cnt, flag, 1, ctx->consts, ctx->stream));
   }
-  RET_IF(invert_batch(xseed, m0, (uint32_t*)w.fd_xinv.p, &w.root[0]));
+  const uint32_t* seeds2 = seeds_together(m0);
+  if (!seeds2) return fail(ctx, MPVSS_E_DEVICE, "eval_x: gather launch");
+  RET_IF(invert_batch(seeds2, B * m0, (uint32_t*)w.fd_xinv.p, &w.root[0]));
   // difference tables, stepping, conversion -- all gated on flag == 1.  Both kernels are pipelines of single-wave
   // stages that hand numbers down through zeroed buffers (see modp_kernels.hip).
-  LAUNCHCHK(ctx, modp_launch_fd_table(xseed, (const uint32_t*)w.fd_xinv.p, S, (int)t, state_fwd, state_bwd,
-                                      (uint32_t*)w.fd_hand_t.p, flag, inject_fault, ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_step(state_fwd, state_bwd, S, (int)t, w0, chain_len, (int)cnt, xm,
-                                     (uint32_t*)w.fd_hand_s.p, flag, inject_fault, ctx->consts, ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_from_mont(xm, (int)cnt, dX, flag, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_table_boxes(xseed, bx_xm, (const uint32_t*)w.fd_xinv.p, (size_t)m0 * MODP_L, S, (int)t, state_fwd,
+                                            state_bwd, bx_state, (uint32_t*)w.fd_hand_t.p, bx_hand_t, B, flag, inject_fault, ctx->consts,
+                                            ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_fd_step_boxes(state_fwd, state_bwd, bx_state, S, (int)t, w0, chain_len, (int)cnt, xm, bx_xm,
+                                           (uint32_t*)w.fd_hand_s.p, bx_hand_s, B, flag, inject_fault, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_from_mont(xm, B * (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
-  LAUNCHCHK(ctx, modp_launch_commit_eval_gated((const uint32_t*)w.cm.p, (const uint32_t*)w.cm.p, 0x7fffffff, (int)t, dpos,
-                                               (int)cnt, nullptr, dX, flag, 0, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, modp_launch_commit_eval_boxes((const uint32_t*)w.cm.p, (int)t, dpos, box_positions, (int)cnt, B, nullptr, dX, cnt, flag,
+                                               0, ctx->consts, ctx->stream));
   RET_IF(span_end(ctx));
   return 0;
 }
@@ -1216,6 +1240,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   }
   sl.n = n;
   sl.kind = 0;
+  sl.nbox = 1;
   sl.check_positions = false;
   sl.fd_used = false;
   sl.fd_chunks = 0;
@@ -1468,14 +1493,208 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   return MPVSS_OK;
 }
 
+// ---- a GROUP of small boxes as one block ------------------------------------------------------------------------------
+// A 4096-share box is 128 waves of the a2 kernel and a chain of latency-bound launches for X; the device runs eight
+// launches at a time (its hardware queues; sixteen or more make everything slower) and each of those waves works for the
+// same 27 ms whatever the box size: boxes of BASELINE config C2's size, one block each, reach 0.68-0.71 M share
+// verifications/s with the chip mostly empty, and fewer with more of them in flight (profiles/r03_c2_ab.txt).
+// mpvss_modp_verify_many therefore enqueues runs of consecutive boxes of ONE shape (same n and t; their own commitments,
+// keys, positions, shares, responses and challenges) as ONE block: every launch of the block path covers all of them.
+//   X path   : forward differences with the box as the second grid dimension (eval_x: box b's chains read its own
+//              commitments; one simultaneous inversion for the seeds of all boxes; one flag for the group)
+//   c        : one challenge per box, spread to one per share (fixed 4-bit windows instead of the lone box's sliding
+//              schedule: about 38 products per share more)
+//   absorb   : one transcript per box over its rows of the block's staging
+// Same bytes as one block per box (tests/test_gpu_configs.py::test_c2_boxes_share_one_a2_launch).
+size_t group_shares_max() {
+  static const size_t v = (size_t)fd_env("MPVSS_GROUP_SHARES", 32768);      // 0: every box its own block; measured on C2: 16384 and 32768 -> 1.06-1.07 M, 65536 -> 0.97-1.00 M
+  return v < MAX_CHUNK ? v : MAX_CHUNK;
+}
+bool box_groupable(const mpvss_modp_box& bx, size_t n, size_t t, int space) {
+  static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
+  static const size_t max_n = (size_t)fd_env("MPVSS_GROUP_MAX_BOX", 16384);
+  if (!(two_streams && bx.n == n && bx.t == t && n <= max_n && 2 * n <= group_shares_max() && !bx.keyset && bx.commitments &&
+        bx.positions && bx.pubkeys && bx.shares && bx.responses && bx.challenge_host && fits_256_bits(bx.challenge_host) &&
+        fd_applies(t, nullptr, n)))
+    return false;
+  if (space == MPVSS_HOST)           // a box with a negative position is rejected on its own, with its own message
+    for (size_t i = 0; i < n; ++i)
+      if (bx.positions[i] < 0) return false;
+  return true;
+}
+
+int verify_group_compute_locked(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t B) {
+  const size_t n = boxes[0].n, t = boxes[0].t, N = B * n;
+  mpvss_ctx::BlockSlot& sl = ctx->head_slot();
+  if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
+  const auto t_enq0 = std::chrono::steady_clock::now();
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!sl.done) {
+    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+  }
+  sl.n = N;
+  sl.nbox = (unsigned)B;
+  sl.kind = 0;
+  sl.check_positions = false;
+  sl.fd_used = false;
+  sl.fd_chunks = 0;
+  sl.enqueue_ms = 0;
+  RET_IF(work_init(ctx, sl.work, nullptr));
+  struct Restore {       // an early (error) return leaves nothing of this block running on the slot's streams
+    mpvss_ctx* c;
+    hipStream_t a, b;
+    mpvss_ctx::BlockSlot* sl;
+    ~Restore() {
+      if (!sl->busy) {
+        if (sl->work.sa) (void)hipStreamSynchronize(sl->work.sa);
+        if (sl->work.sb) (void)hipStreamSynchronize(sl->work.sb);
+        sl->nbox = 1;
+      }
+      c->sp = &c->main_spans; c->w = &c->work0; c->stream = a; c->stream_b = b;
+    }
+  } restore{ctx, ctx->stream, ctx->stream_b, &sl};
+  mpvss_ctx::Work& w = sl.work;
+  ctx->w = &w;
+  w.fd_used = false;
+  ctx->stream = w.sa;
+  ctx->stream_b = w.sb;
+  ctx->sp = &sl.spans;
+  spans_reset(ctx);
+  // pinned staging as for a lone block (X | Y | a1 | a2 | positions | flags | host inputs), then the boxes' challenges
+  constexpr size_t FLAGS = 64;
+  const size_t out_bytes = N * EB * 4 + N * 8 + FLAGS * 4;
+  const size_t in_bytes = space == MPVSS_HOST ? 3 * N * EB + B * t * EB : 0;
+  const size_t need = out_bytes + in_bytes + B * EB;
+  if (need > sl.cap) {
+    if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
+    sl.pin = nullptr;
+    sl.cap = 0;
+    hipError_t e = hipHostMalloc(&sl.pin, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(block staging)", e);
+    sl.cap = need;
+  }
+  uint8_t* hX = (uint8_t*)sl.pin;
+  uint8_t* hY = hX + N * EB;
+  uint8_t* h1 = hY + N * EB;
+  uint8_t* h2 = h1 + N * EB;
+  int64_t* hpos = (int64_t*)(h2 + N * EB);
+  int* hflags = (int*)((uint8_t*)sl.pin + N * EB * 4 + N * 8);
+  uint8_t* hin = (uint8_t*)sl.pin + out_bytes;
+  uint8_t* hch = hin + in_bytes;
+  RET_IF(ensure(ctx, w.in_a, N * EB));
+  RET_IF(ensure(ctx, w.in_b, N * EB));
+  RET_IF(ensure(ctx, w.in_c, N * EB));
+  RET_IF(ensure(ctx, w.in_d, B * EB));
+  RET_IF(ensure(ctx, w.in_e, N * EB));
+  RET_IF(ensure(ctx, w.cbuf, B * t * EB));
+  RET_IF(ensure(ctx, w.cm, B * t * MODP_L * 4));
+  RET_IF(ensure(ctx, w.pos, N * 8));
+  RET_IF(ensure(ctx, w.xbe, N * EB));
+  RET_IF(ensure(ctx, w.out1, N * EB));
+  RET_IF(ensure(ctx, w.out2, N * EB));
+  RET_IF(ensure(ctx, w.tab1, N * TABW * 4 * 4));
+  RET_IF(ensure(ctx, w.tab2, N * TABW * 4));
+  RET_IF(ensure(ctx, w.tab3, N * TABW * 4));
+  RET_IF(ensure(ctx, w.gr_m, N * MODP_L * 4));
+  uint8_t *dy = (uint8_t*)w.in_a.p, *dY = (uint8_t*)w.in_b.p, *dr = (uint8_t*)w.in_c.p, *dcm = (uint8_t*)w.cbuf.p;
+  int64_t* dpos = (int64_t*)w.pos.p;
+  for (size_t b = 0; b < B; ++b) {
+    const mpvss_modp_box& bx = boxes[b];
+    memcpy(hch + b * EB, bx.challenge_host, EB);
+    if (space == MPVSS_HOST) {
+      memcpy(hin + b * n * EB, bx.pubkeys, n * EB);
+      memcpy(hin + (N + b * n) * EB, bx.shares, n * EB);
+      memcpy(hin + (2 * N + b * n) * EB, bx.responses, n * EB);
+      memcpy(hin + 3 * N * EB + b * t * EB, bx.commitments, t * EB);
+      memcpy(hpos + b * n, bx.positions, n * 8);
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(dy + b * n * EB, bx.pubkeys, n * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(dY + b * n * EB, bx.shares, n * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(dr + b * n * EB, bx.responses, n * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(dcm + b * t * EB, bx.commitments, t * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(dpos + b * n, bx.positions, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  if (space == MPVSS_HOST) {
+    HIPCHK(ctx, hipMemcpyAsync(dy, hin, N * EB, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dY, hin + N * EB, N * EB, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dr, hin + 2 * N * EB, N * EB, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dcm, hin + 3 * N * EB, B * t * EB, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dpos, hpos, N * 8, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    // device-resident positions are validated when the block is absorbed (no host sync here)
+    HIPCHK(ctx, hipMemcpyAsync(hpos, dpos, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    sl.check_positions = true;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(w.in_d.p, hch, B * EB, hipMemcpyHostToDevice, ctx->stream));
+  const uint8_t* dchal = (const uint8_t*)w.in_e.p;        // one challenge per share
+  LAUNCHCHK(ctx, modp_launch_spread_rows((const uint8_t*)w.in_d.p, (int)n, (int)N, (uint8_t*)w.in_e.p, ctx->stream));
+  w.cm_bytes_dev = dcm;
+  LAUNCHCHK(ctx, modp_launch_to_mont(dcm, (uint32_t*)w.cm.p, (int)(B * t), ctx->consts, ctx->stream));
+  const uint32_t* cg;
+  RET_IF(comb_table(ctx, 0, &cg, N));
+  uint8_t *dX = (uint8_t*)w.xbe.p, *da1 = (uint8_t*)w.out1.p, *da2 = (uint8_t*)w.out2.p;
+  struct Swap {
+    mpvss_ctx* c; hipStream_t a;
+    Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
+    ~Swap() { c->stream = a; }
+  };
+  HIPCHK(ctx, hipEventRecord(w.ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(w.sb, w.ev_fork, 0));
+  {
+    Swap sw(ctx, w.sb);      // a2 = y^r Y^c and g^r beside the X path, as in a lone block
+    uint32_t *t1p = (uint32_t*)w.tab1.p, *t2p = (uint32_t*)w.tab2.p;
+    TIMED_LAUNCH(ctx, 2, modp_launch_build_table(dY, (int)N, t2p, ctx->consts, ctx->stream));
+    TIMED_LAUNCH(ctx, 2, launch_table64(ctx, dy, N, t1p));
+    TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, dr, dchal, EB, nullptr, N, da2));
+    HIPCHK(ctx, hipEventRecord(w.ev_a2, ctx->stream));
+    if ((pair_mask() & 4) && comb_bits_of(ctx, cg) == 16)
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, dr, (int)N, (uint32_t*)w.gr_m.p, ctx->consts, ctx->pair_tables, ctx->stream));
+    else
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, dr, dchal, 0, 0, (int)N, nullptr, 1, (uint32_t*)w.gr_m.p,
+                                                           comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(w.ev_gr, ctx->stream));
+  }
+  RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
+  {
+    const uint32_t* tx;
+    RET_IF(number_tables(ctx, dX, N, w.tab3, &tx));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, w.ev_gr, 0));
+    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, tx, TABW, dr, dchal, EB, 64, (int)N, da1, 2, (uint32_t*)w.gr_m.p,
+                                                         comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, w.ev_a2, 0));
+  HIPCHK(ctx, hipMemcpyAsync(hX, dX, N * EB, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(hY, dY, N * EB, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h1, da1, N * EB, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h2, da2, N * EB, hipMemcpyDeviceToHost, ctx->stream));
+  if (w.fd_used) {
+    sl.fd_used = true;
+    HIPCHK(ctx, hipMemcpyAsync(hflags, w.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    sl.fd_chunks = 1;
+  }
+  HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+  sl.busy = true;
+  sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
+  ctx->commit_head(sl);
+  return MPVSS_OK;
+}
+
 // Called with `lk` (the context lock) held.  The lock is RELEASED while this thread waits for the block's GPU work
 // and hashes it, so that other host threads can enqueue blocks or absorb the next ones meanwhile (every box has its
 // own transcript; a 65536-share box is 40 ms of SHA-256).  Blocks are handed out in FIFO order at entry.
 int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
                                uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr,
-                               const unsigned long long* ticket = nullptr, bool by_position = false) {
+                               const unsigned long long* ticket = nullptr, bool by_position = false,
+                               unsigned states = 1, char* box_bad = nullptr) {
+  // states > 1: `state` holds that many transcript states, one per box of a GROUP block (its nbox); box_bad[b] = 1 marks a
+  // box with a negative position (device-resident positions are looked at here)
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
   mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ticket ? (unsigned)*ticket : ctx->tail);
+  // only the library's own pipeline makes groups and knows how many states to bring; nothing is consumed otherwise
+  if (sl.busy && sl.kind == 0 && ((sl.nbox ? sl.nbox : 1u) != states || (states > 1 && (x_out || a1_out || a2_out || y_out))))
+    return fail(ctx, MPVSS_E_INVALID, "absorb: the block is a group of boxes (one transcript state per box)");
   if (ticket && by_position) {       // the library's own pipeline: the block at ring position *ticket, whatever the FIFO order
     if (!sl.busy || sl.absorbing || sl.claimed) return fail(ctx, MPVSS_E_INVALID, "absorb: no block at this position");
     if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the block at this position is not a MODP distribution block");
@@ -1491,6 +1710,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
     ++ctx->tail;
   }
   const size_t n = sl.n;
+  const size_t nbox = sl.nbox ? sl.nbox : 1;
   if (n == 0) {
     ctx->release(sl);
     sl.absorbing = false;
@@ -1518,11 +1738,30 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   const uint8_t* h2 = h1 + n * EB;
   bool positions_ok = true;
   if (e == hipSuccess) {
-    if (sl.check_positions) {
+    if (sl.check_positions && nbox == 1) {
       const int64_t* pos = (const int64_t*)(h2 + n * EB);
       for (size_t i = 0; i < n && positions_ok; ++i) positions_ok = pos[i] >= 0;
     }
-    if (positions_ok) {
+    if (nbox > 1) {
+      const size_t per = n / nbox;
+      const int64_t* pos = (const int64_t*)(h2 + n * EB);
+      for (size_t b = 0; b < nbox; ++b) {
+        bool ok = true;
+        if (sl.check_positions)
+          for (size_t i = b * per; i < (b + 1) * per && ok; ++i) ok = pos[i] >= 0;
+        if (box_bad) box_bad[b] = ok ? 0 : 1;
+        if (!ok) continue;
+        mpvss::Sha256 tr;
+        memcpy(&tr, state + b * MPVSS_TRANSCRIPT_STATE_BYTES, sizeof(tr));
+        for (size_t i = b * per; i < (b + 1) * per; ++i) {
+          frame_update(tr, hX + i * EB);
+          frame_update(tr, hY + i * EB);
+          frame_update(tr, h1 + i * EB);
+          frame_update(tr, h2 + i * EB);
+        }
+        memcpy(state + b * MPVSS_TRANSCRIPT_STATE_BYTES, &tr, sizeof(tr));
+      }
+    } else if (positions_ok) {
       mpvss::Sha256 tr;
       memcpy(&tr, state, sizeof(tr));
       for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99, share order = array order
@@ -1561,7 +1800,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
       ps.kernel_ms[k] += ctx->kernel_ms[k];
       ps.kernel_launches[k] += (unsigned long long)ctx->kernel_launches[k];
     }
-    ++ps.blocks;
+    ps.blocks += (unsigned long long)nbox;      // a group block counts as its boxes
   }
   return MPVSS_OK;
 }
@@ -1744,7 +1983,7 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
     Hint(mpvss_ctx* c_, bool on) : c(c_) { std::lock_guard<std::mutex> lk(c->mu); was = c->pipelined_hint; if (on) c->pipelined_hint = true; }
     ~Hint() { std::lock_guard<std::mutex> lk(c->mu); c->pipelined_hint = was; }
   } hint(ctx, count > 2 && depth > 1);
-  struct Ent { size_t box; unsigned parts; bool bad; };      // one entry per enqueued block; parts: blocks of its box (first entry)
+  struct Ent { size_t box; unsigned parts; bool bad; unsigned nbox; };   // one entry per enqueued block; parts: blocks of its box (first entry); nbox > 1: a group block of boxes box .. box+nbox-1
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
@@ -1774,9 +2013,41 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
         ent = sh.order[seq0];
         sh.claimed += ent.parts;                   // the parts of a box are enqueued (and counted in `issued`) together
       }
+      int rc = MPVSS_OK;
+      if (ent.nbox > 1) {          // a group of boxes in one block: one transcript each
+        std::vector<uint8_t> states((size_t)ent.nbox * MPVSS_TRANSCRIPT_STATE_BYTES);
+        std::vector<char> bad(ent.nbox, 0);
+        for (unsigned i = 0; i < ent.nbox; ++i) mpvss_transcript_init(states.data() + (size_t)i * MPVSS_TRANSCRIPT_STATE_BYTES);
+        int prc;
+        {
+          std::unique_lock<std::mutex> lk(ctx->mu);
+          const unsigned long long pos = (unsigned long long)(base_tail + (unsigned)seq0);
+          prc = verify_block_absorb_locked(ctx, lk, states.data(), nullptr, nullptr, nullptr, nullptr, &pos, true, ent.nbox, bad.data());
+        }
+        {
+          std::lock_guard<std::mutex> l(sh.m);
+          sh.blk_done[seq0] = 1;
+          while (sh.low < sh.blk_done.size() && sh.blk_done[sh.low]) ++sh.low;
+        }
+        sh.cv.notify_all();
+        if (prc != MPVSS_OK) rc = prc;
+        for (unsigned i = 0; i < ent.nbox && rc == MPVSS_OK; ++i) {
+          if (bad[i]) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            (void)fail(ctx, MPVSS_E_INVALID, "negative position (the reference panics: negative exponent)");
+            continue;
+          }
+          if (ent.box + i < count) rc = finish(ent.box + i, states.data() + (size_t)i * MPVSS_TRANSCRIPT_STATE_BYTES);
+        }
+        if (rc != MPVSS_OK) {
+          std::lock_guard<std::mutex> l(sh.m);
+          if (sh.rc == MPVSS_OK) sh.rc = rc;
+        }
+        sh.cv.notify_all();
+        continue;
+      }
       uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
       mpvss_transcript_init(state);
-      int rc = MPVSS_OK;
       bool malformed = ent.bad;
       size_t box = ent.box;
       for (unsigned p = 0; p < ent.parts; ++p) {
@@ -1821,7 +2092,8 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   pool.reserve((size_t)hash_threads);
   for (int i = 0; i < hash_threads; ++i) pool.emplace_back(worker);
 
-  for (size_t b = 0; b < count; ++b) {
+  unsigned nbox = 1;
+  for (size_t b = 0; b < count; b += nbox) {
     {
       std::unique_lock<std::mutex> l(sh.m);
       // slots are a ring: a block may be enqueued once the block NSLOT positions before it has been absorbed (the threads
@@ -1837,16 +2109,18 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
     }
     int rc;
     unsigned parts = 0;                      // blocks actually enqueued for this box (also when a later part was rejected)
+    nbox = 1;                                // boxes this call enqueued (> 1: one group block)
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
-      rc = issue(b, &parts);
+      rc = issue(b, &parts, &nbox);
     }
+    if (nbox < 1) nbox = 1;
     {
       std::lock_guard<std::mutex> l(sh.m);
       const bool bad = rc == MPVSS_E_INVALID;     // malformed box: verdict 0, the run goes on (what was enqueued is still absorbed)
       if (rc == MPVSS_OK || bad) {
         for (unsigned p = 0; p < parts; ++p) {
-          sh.order.push_back(Ent{b, p == 0 ? parts : 0u, bad});
+          sh.order.push_back(Ent{b, p == 0 ? parts : 0u, bad, nbox});
           sh.blk_done.push_back(0);
         }
         sh.issued += parts;
@@ -1892,8 +2166,21 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   static const size_t tail_min_part = (size_t)fd_env("MPVSS_TAIL_MIN_PART", 8192);     // shares per part at least (tests lower it)
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
-      [&](size_t b, unsigned* parts) {
+      [&](size_t b, unsigned* parts, unsigned* nbox) {
         const mpvss_modp_box& bx = boxes[b];
+        // a run of consecutive boxes of this box's shape (small ones): ONE block for all of them
+        if (bx.n > 0 && 2 * bx.n <= group_shares_max() && box_groupable(bx, bx.n, bx.t, space)) {
+          const size_t cap = group_shares_max() / bx.n;
+          size_t B = 1;
+          while (B < cap && b + B < count && box_groupable(boxes[b + B], bx.n, bx.t, space)) ++B;
+          if (B >= 2) {
+            const int rc = verify_group_compute_locked(ctx, space, boxes + b, B);
+            if (rc != MPVSS_OK) return rc;
+            *parts = 1;
+            *nbox = (unsigned)B;
+            return (int)MPVSS_OK;
+          }
+        }
         const size_t P = (b + tail_boxes >= count && count >= 3 && tail_parts > 1 && tail_parts <= 8 && bx.n >= (size_t)tail_parts * tail_min_part &&
                           bx.commitments && bx.positions && (bx.pubkeys || bx.keyset) && bx.shares && bx.responses)
                              ? (size_t)tail_parts : 1;
@@ -2142,6 +2429,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   }
   sl.n = n;
   sl.kind = 0;                 // absorbed like a verifier's block: same staging layout, same hash
+  sl.nbox = 1;
   sl.check_positions = false;
   sl.fd_used = false;
   sl.fd_chunks = 0;

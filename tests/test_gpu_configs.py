@@ -89,6 +89,77 @@ def test_c2_every_share_against_the_c_port(engine):
     check_modp_box(engine, box, list(range(4096)))
 
 
+def test_c2_boxes_grouped_into_one_block(engine):
+    """mpvss_modp_verify_many enqueues runs of consecutive small boxes of one shape as ONE block (every launch covers all of
+    them: the box is the second grid dimension of the forward-difference kernels, one challenge per box spread to one per
+    share, fixed windows of c instead of the lone box's sliding schedule, one transcript per box at the end).  21 boxes of
+    BASELINE config C2's shape with other shapes in between -- three dealers' boxes, one of them tampered in a response, one
+    in a share, a (4100, 64) box that ends a run, a box whose challenge does not fit 256 bits, a box with two participants
+    swapped (positions not consecutive: the whole group falls back to Horner's rule on the device) -- give exactly the
+    verdicts and transcript digests of one verify_distribution per box; the honest ones are the dealer's digests."""
+    b0, b1, b2 = (make_modp_box(engine, 4096, 64, 60 + i) for i in range(3))
+    other = make_modp_box(engine, 4100, 64, 63)
+    as_box = lambda b, **kw: dict({"commitments": b["cm"], "positions": b["pos"], "pubkeys": b["pk"], "shares": b["Y"],
+                                   "responses": b["r"], "challenge": b["c"]}, **kw)
+    rs = bytearray(b1["r"]); rs[4095 * EB + 255] ^= 1
+    sh = bytearray(b2["Y"]); sh[2000 * EB + 17] ^= 0x40
+    wide = (int.from_bytes(b0["c"], "big") + (1 << 300)).to_bytes(EB, "big")
+
+    def swapped(b, i, j):
+        out = as_box(b)
+        out["positions"] = list(b["pos"]); out["positions"][i], out["positions"][j] = b["pos"][j], b["pos"][i]
+        for key, src in (("pubkeys", b["pk"]), ("shares", b["Y"]), ("responses", b["r"])):
+            buf = bytearray(src)
+            buf[i * EB:(i + 1) * EB], buf[j * EB:(j + 1) * EB] = src[j * EB:(j + 1) * EB], src[i * EB:(i + 1) * EB]
+            out[key] = bytes(buf)
+        return out
+
+    boxes = ([as_box(b0), as_box(b1), as_box(b1, responses=bytes(rs)), as_box(b2)] * 4 + [as_box(other), as_box(b0)] +
+             [as_box(b2, shares=bytes(sh)), as_box(b0, challenge=wide), as_box(b1), swapped(b2, 5, 4000), as_box(b0)])
+    one = lambda b: (lambda r: (r["verdict"], r["digest"]))(engine.verify_distribution(
+        b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
+    want = [one(b) for b in boxes[:4]] * 4 + [one(b) for b in boxes[16:]]
+    assert want[0] == (True, b0["d"]["digest"]) and want[1] == (True, b1["d"]["digest"]) and want[3] == (True, b2["d"]["digest"])
+    assert want[2][0] is False and want[16] == (True, other["d"]["digest"]) and want[18][0] is False and want[19][0] is False
+    assert want[21][0] is False and want[21][1] != b2["d"]["digest"]       # every share verifies, the transcript order differs
+    before = engine.fd_stats()
+    for depth, threads in ((24, 6), (3, 2)):
+        assert engine.verify_many(boxes, depth=depth, hash_threads=threads) == want
+    assert engine.blocks_in_flight() == (0, 0)
+    after = engine.fd_stats()
+    assert after[1] - before[1] == 2              # the group with the swapped box fell back (once per run), no other block did
+
+
+def test_grouped_boxes_in_device_memory_with_a_negative_position(engine):
+    """Groups of boxes handed over in HBM (what bench.py's `configs.c2` times): positions are only looked at when the block
+    is absorbed -- a negative one costs its own box (verdict False, zero digest; the reference would panic) and nothing
+    else of the group."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    bs = [make_modp_box(engine, 4096, 64, 70 + i) for i in range(2)]
+    u8 = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    pos_ok = torch.tensor(bs[0]["pos"], dtype=torch.int64, device=dev)
+    pos_bad = pos_ok.clone(); pos_bad[4095] = -4096
+    keep, arr = [], (capi.ModpBox * 5)()
+    for i, (b, pos) in enumerate([(bs[0], pos_ok), (bs[1], pos_bad), (bs[1], pos_ok), (bs[0], pos_ok), (bs[1], pos_ok)]):
+        t = [u8(b[k]) for k in ("cm", "pk", "Y", "r")]
+        ch = (C.c_uint8 * EB).from_buffer_copy(b["c"])
+        keep.append((t, ch))
+        arr[i] = capi.ModpBox(t[0].data_ptr(), 64, pos.data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), 4096,
+                              C.cast(ch, C.c_void_p), None, 0)
+    torch.cuda.synchronize()
+    verdicts, digests = (C.c_int * 5)(), (C.c_uint8 * 160)()
+    engine._check(engine.lib.mpvss_modp_verify_many(engine.ctx, capi.MPVSS_DEVICE, arr, 5, 4, 2, verdicts, C.cast(digests, C.c_void_p)),
+                  "verify_many")
+    raw = bytes(digests)
+    got = [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(5)]
+    d0, d1 = bs[0]["d"]["digest"], bs[1]["d"]["digest"]
+    assert got == [(True, d0), (False, bytes(32)), (True, d1), (True, d0), (True, d1)]
+    assert "negative position" in engine.last_error()
+    assert engine.blocks_in_flight() == (0, 0)
+
+
 def test_headline_shape_seeded_one_percent_sample(engine):
     """n=65536, t=256 (the metric's shape): 656 seeded shares (1 %) against the C port, plus the first and last."""
     n = 65536
