@@ -1258,7 +1258,7 @@ def main():
             # ... and the dealer END TO END: per box the scalar side before (P(i) for the box's own polynomial: forward
             # differences in Z/(q-1) on host threads, H2D of the values) and after the group work (challenge from the
             # transcript digest, responses r_i = w_i - P(i) c), pipelined over the boxes on host threads beside the GPU
-            e2e_boxes = 10
+            e2e_boxes = 16
             coeff_sets = [b"".join(fx(a) for a in boxes[b % len(boxes)].coeffs) for b in range(e2e_boxes)]
             scalar_pool = concurrent.futures.ThreadPoolExecutor(max_workers=3)
             absorb_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)      # blocks are absorbed in FIFO order
@@ -1288,22 +1288,70 @@ def main():
             t_e = time.perf_counter()
             e2e = deal_e2e(e2e_boxes)
             torch.cuda.synchronize()
-            e2e_s = (time.perf_counter() - t_e) / e2e_boxes
+            e2e_host_s = (time.perf_counter() - t_e) / e2e_boxes
             assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer: box 0 differs"
             scalar_pool.shutdown()
+
+            # ... and with the scalar side on the device as well: P(i) mod (q-1) by mpvss_modp_poly_eval_device into HBM, the
+            # group work on those values, the challenge from the transcript digest, r_i by mpvss_modp_dleq_responses_device --
+            # nothing of a box but its t coefficients, its digest and its challenge crosses the bus
+            ring = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(deal_depth + 3)]
+
+            resp_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+            d_rs = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(deal_depth + 3)]
+
+            def e2e_resp(b, d_pvb, cc):
+                d_r = d_rs[b % len(d_rs)]
+                eng.dleq_responses_device(d_wt.data_ptr(), d_pvb.data_ptr(), cc, n, d_r.data_ptr())
+                return bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None
+
+            def e2e_post_dev(b, d_pvb, ticket):
+                st = eng.verify_block_absorb_claimed(ticket, capi.transcript_init())       # dealer blocks are absorbed like verifier blocks
+                digest = capi.transcript_verdict(st, bytes(EB))[1]
+                cc = fx(int.from_bytes(hashlib.sha256(digest).digest(), "big") % ((Q - 1) // 2))
+                return digest, resp_pool.submit(e2e_resp, b, d_pvb, cc)      # the responses wait for wave slots, not the next absorb
+
+            def deal_e2e_dev(count):
+                post = []
+                for b in range(count):
+                    d_pvb = ring[b % len(ring)]
+                    while len(post) - sum(f.done() for f in post) >= deal_depth:      # at most deal_depth boxes in flight
+                        time.sleep(0.0005)
+                    eng.deal_compute(coeff_sets[b], cur.d_pos.data_ptr(), d_pk.data_ptr(), d_wt.data_ptr(), n, d_pvb.data_ptr())
+                    post.append(hash_pool.submit(e2e_post_dev, b, d_pvb, eng.block_claim()))     # several boxes are hashed at a time
+                outs = [f.result() for f in post]
+                return [(dgst, fut.result()) for dgst, fut in outs]
+
+            deal_e2e_dev(3)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            e2e = deal_e2e_dev(e2e_boxes)
+            torch.cuda.synchronize()
+            e2e_s = (time.perf_counter() - t_e) / e2e_boxes
+            assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer (device scalars): box 0 differs"
             absorb_pool.shutdown()
+            resp_pool.shutdown()
+            t_s = time.perf_counter()
+            eng.poly_eval_device(coeff_sets[0], cur.d_pos.data_ptr(), n, ring[0].data_ptr())
+            eng.dleq_responses_device(d_wt.data_ptr(), ring[0].data_ptr(), challenge, n, d_rs[0].data_ptr())
+            scalar_dev_s = time.perf_counter() - t_s
+            assert bytes(d_rs[0].cpu().numpy().tobytes()) == responses, "device scalar side differs from the Python integers"
             result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
                                     "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
-                                    "scalar_side_ms_per_box": scalar_s * 1e3,
+                                    "scalar_side_ms_per_box": scalar_s * 1e3, "scalar_side_on_device_ms_per_box": scalar_dev_s * 1e3,
                                     "value_end_to_end": n / e2e_s, "end_to_end_ms_per_box": e2e_s * 1e3,
+                                    "value_end_to_end_host_scalars": n / e2e_host_s,
                                     "note": "dealer side of distribute_secret (participant.rs:160-286): X_i = g^P(i), Y_i = y_i^P(i), "
                                             "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
                                             "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
                                             "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
                                             "PCIe included); scalar_side: P(i) and the responses for one box through "
                                             "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`; `value_end_to_end`: "
-                                            "every box with its own polynomial -- P(i) by forward differences in Z/(q-1), upload, the group "
-                                            "work, the transcript hash, the challenge and the responses -- pipelined over host threads"}
+                                            "every box with its own polynomial -- P(i) mod (q-1) and the responses on the device "
+                                            "(mpvss_modp_poly_eval_device / _dleq_responses_device: residues mod (q-1)/2 in the Montgomery "
+                                            "kernels, parity beside), the group work, the transcript hash and the challenge, boxes pipelined; "
+                                            "`value_end_to_end_host_scalars`: the same with P(i) (forward differences in Z/(q-1)) and the "
+                                            "responses on host threads and the values uploaded"}
     except Exception as exc:      # noqa: BLE001 - reported in the line and through the exit code
         import traceback
         secondary_error = "".join(traceback.format_exception_only(type(exc), exc)).strip()

@@ -247,6 +247,15 @@ int mpvss_modp_distribute_compute(mpvss_ctx* ctx, int space, const uint8_t* comm
                                   uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out);
 int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,
                                  uint8_t* a1_out_host, uint8_t* a2_out_host);
+/* The dealer's block with the polynomial evaluation on the device as well (participant.rs:196-249 for one box or one block of
+ * it): `compute` takes the t coefficients (host memory; 256-byte big-endian scalars) and n positions, public keys and witnesses
+ * in HBM, evaluates p_i = P(position_i) mod (q-1) into p_dev_out (n x 256 bytes in HBM, kept for
+ * mpvss_modp_dleq_responses_device) on the block's own stream and goes on as mpvss_modp_distribute_compute with
+ * commitments == NULL: X_i = g^p_i, Y_i = y_i^p_i, a1_i = g^w_i, a2_i = y_i^w_i.  Absorbed by mpvss_modp_distribute_absorb (a
+ * negative position fails the block there).  n <= 262144 shares per call. */
+int mpvss_modp_deal_compute(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
+                            const uint8_t* pubkeys_dev, const uint8_t* witnesses_dev, size_t n, uint8_t* p_dev_out,
+                            uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out);
 
 /* ---- elliptic-curve groups --------------------------------------------------------------------
  * The same entry points for the reference's two curve groups, selected by `group`:
@@ -372,6 +381,15 @@ int mpvss_ec_dleq_responses(int group, const uint8_t* w, const uint8_t* alpha, c
  * by the caller's `% order` (participant.rs:202, 1155-1157, 1619-1621).  MODP positions must be >= 0. */
 int mpvss_modp_poly_eval(const uint8_t* coeffs, size_t t, const int64_t* positions, size_t n, uint8_t* out, int threads);
 int mpvss_ec_poly_eval(int group, const uint8_t* coeffs, size_t t, const int64_t* positions, size_t n, uint8_t* out, int threads);
+/* The MODP pair on the DEVICE (2048-bit scalars: the host loops above cost more than the group work of a box): P(i) for
+ * positions in HBM (>= 0) from the dealer's coefficients in host memory, results in HBM as 256-byte big-endian scalars in
+ * [0, q-1) (what mpvss_modp_distribute_compute takes as p_values); and r[i] = w[i] - alpha[i] c mod (q-1) for ONE shared c
+ * (host), w, alpha and r in HBM.  Same values as the host functions (src/polynomial.rs:50-58, src/dleq.rs:42-50);
+ * synchronous: the results are complete when the call returns. */
+int mpvss_modp_poly_eval_device(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev, size_t n,
+                                uint8_t* out_dev);
+int mpvss_modp_dleq_responses_device(mpvss_ctx* ctx, const uint8_t* w_dev, const uint8_t* alpha_dev, const uint8_t* c_host, size_t n,
+                                     uint8_t* r_dev_out);
 
 /* ---- reconstruct ---------------------------------------------------------------------------------------------------
  * G^s = prod_i S_i^lambda_i from m >= t decrypted shares S_i at pairwise different positions (host int64):

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
     "mpvss_modp_scalar_mul", "mpvss_modp_scalar_sub", "mpvss_ec_scalar_mul", "mpvss_ec_scalar_sub",
     "mpvss_modp_dleq_responses", "mpvss_ec_dleq_responses", "mpvss_modp_poly_eval", "mpvss_ec_poly_eval",
+    "mpvss_modp_poly_eval_device", "mpvss_modp_dleq_responses_device", "mpvss_modp_deal_compute",
     "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
     "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
     "mpvss_modp_distribute_compute", "mpvss_modp_distribute_absorb",
@@ -165,6 +166,9 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_dleq_responses.argtypes = [u8p, u8p, u8p, ci, sz, u8p, ci]
     lib.mpvss_ec_dleq_responses.argtypes = [ci, u8p, u8p, u8p, ci, sz, u8p, ci]
     lib.mpvss_modp_poly_eval.argtypes = [u8p, sz, i64p, sz, u8p, ci]
+    lib.mpvss_modp_poly_eval_device.argtypes = [vp, u8p, sz, vp, sz, vp]
+    lib.mpvss_modp_dleq_responses_device.argtypes = [vp, vp, vp, u8p, sz, vp]
+    lib.mpvss_modp_deal_compute.argtypes = [vp, u8p, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp]
     lib.mpvss_ec_poly_eval.argtypes = [ci, u8p, sz, i64p, sz, u8p, ci]
     lib.mpvss_modp_reconstruct.argtypes = [vp, ci, i64p, u8p, sz, u8p, u8p]
     lib.mpvss_ec_reconstruct.argtypes = [vp, ci, ci, i64p, u8p, sz, u8p, u8p]
@@ -369,6 +373,25 @@ class Engine:
                     "verify_many")
         raw = bytes(kd)
         return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(len(boxes))]
+
+    def poly_eval_device(self, coeffs: bytes, positions_dev_ptr: int, n: int, out_dev_ptr: int) -> None:
+        """P(i) mod (q-1) for n positions in HBM (int64) into n x 256 bytes in HBM; the coefficients are host bytes"""
+        kc, pc = _buf(coeffs)
+        self._check(self.lib.mpvss_modp_poly_eval_device(self.ctx, pc, len(coeffs) // EB, positions_dev_ptr, n, out_dev_ptr),
+                    "poly_eval_device")
+
+    def deal_compute(self, coeffs: bytes, positions_dev_ptr: int, pubkeys_dev_ptr: int, witnesses_dev_ptr: int, n: int,
+                     p_dev_out_ptr: int) -> None:
+        """one dealer's block, P(i) included, enqueued (absorb with distribute_absorb / mpvss_modp_distribute_absorb)"""
+        kc, pc = _buf(coeffs)
+        self._check(self.lib.mpvss_modp_deal_compute(self.ctx, pc, len(coeffs) // EB, positions_dev_ptr, pubkeys_dev_ptr,
+                                                     witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None), "deal_compute")
+
+    def dleq_responses_device(self, w_dev_ptr: int, alpha_dev_ptr: int, c: bytes, n: int, out_dev_ptr: int) -> None:
+        """r[i] = w[i] - alpha[i] c mod (q-1), everything but the shared c in HBM"""
+        kc, pc = _buf(c)
+        self._check(self.lib.mpvss_modp_dleq_responses_device(self.ctx, w_dev_ptr, alpha_dev_ptr, pc, n, out_dev_ptr),
+                    "dleq_responses_device")
 
     def pipeline_stats(self, reset: bool = False) -> dict:
         st = PipelineStats()

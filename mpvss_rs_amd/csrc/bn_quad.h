@@ -101,7 +101,9 @@ __device__ __forceinline__ Lane make_lane() {
 // local indices are equal -- and every square once, in all four lanes by the same instructions: 9.5 instead of 18
 // mads per row for the a*a half, 24 % fewer mads per squaring.  (Needs an even number of limbs per lane only in
 // the sense that the rule is lane-independent; bounds: tests/test_limb_model.py.)
-template <u32 N0INV, bool SQ = false>
+// OUTER < L / LPL: only the low 18 OUTER limbs of b take part (b < 2^(522 OUTER)) and the result is a b 2^(-522 OUTER) mod N --
+// the scalar-ring kernels multiply by small numbers this way (a quarter of a product per Horner step).
+template <u32 N0INV, bool SQ = false, int OUTER = L / LPL>
 __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], const u32* __restrict__ b,
                                          const u32 (&n)[LPL], const Lane& ln) {
   u64 T[LPL];
@@ -109,7 +111,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
   for (int k = 0; k < LPL; ++k) T[k] = 0;
   u32 bnext = b[0];   // software prefetch of the next b limb (one LDS read in flight)
 #pragma nounroll
-  for (int o = 0; o < L / LPL; ++o) {
+  for (int o = 0; o < OUTER; ++o) {
 #pragma unroll
     for (int rr = 0; rr < LPL; ++rr) {
       // local position k lives in T[(k + rr) % LPL]

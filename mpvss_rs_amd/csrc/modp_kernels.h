@@ -103,6 +103,12 @@ int modp_launch_fd_table_boxes(const uint32_t* x, size_t box_x, const uint32_t* 
 int modp_launch_fd_step_boxes(const uint32_t* state, const uint32_t* state_back, size_t box_state, int chains, int t, int w0,
                               int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand, size_t box_hand, int boxes,
                               int* gate, int inject_fault, const void* cs, hipStream_t s);
+/* scalar ring Z/(q-1) on the device (constants of q' = (q-1)/2: modq_consts_upload) */
+int modq_consts_upload(void** dev_consts);
+int modq_launch_poly_eval(const uint32_t* coef, int t, const int64_t* positions, int count, int par_even, int par_odd, uint8_t* out_be,
+                          const void* cs_q, hipStream_t s);
+int modq_launch_responses(const uint8_t* w_be, const uint8_t* alpha_be, const uint8_t* cneg_be, int c_parity, int count,
+                          uint8_t* out_be, const void* cs_q, hipStream_t s);
 int modp_launch_gather_rows(const uint32_t* src, size_t src_stride_words, size_t row_words, int boxes, uint32_t* dst, hipStream_t s);
 int modp_launch_spread_rows(const uint8_t* rows, int group, int count, uint8_t* out, hipStream_t s);
 #ifdef __cplusplus

@@ -90,7 +90,9 @@ __device__ __forceinline__ void to_mont(u32 (&a)[LPL], u32* slot, const ModpCons
 // [0, N) written as 256 big-endian bytes.  Uses the LDS slot as scratch.
 __device__ __forceinline__ void store_canonical_be256(uint8_t* __restrict__ out, u32 (&a)[LPL], bool from_montgomery,
                                                       u32* slot, const ModpConsts* __restrict__ cs,
-                                                      const u32 (&n)[LPL], const Lane& ln, bool write) {
+                                                      const u32 (&n)[LPL], const Lane& ln, bool write, int lift_parity = -1) {
+  // lift_parity 0 / 1 (scalar ring, cs = the constants of q'): the canonical residue v in [0, q') is lifted to the
+  // number in [0, 2q') = [0, q-1) of that parity, v or v + q' (Chinese remainders; q' is odd)
   if (from_montgomery) {
     slot_fill_from_global(slot, cs->one, ln);
     __builtin_amdgcn_wave_barrier();
@@ -122,6 +124,15 @@ __device__ __forceinline__ void store_canonical_be256(uint8_t* __restrict__ out,
         const u32 d = slot[j] - cs->n[j] - borrow;
         borrow = (d >> 31) & 1;  // operands < 2^W, so a wrap sets the top bit
         slot[j] = d & MASK;
+      }
+    }
+    if (lift_parity >= 0 && (int)(slot[0] & 1u) != lift_parity) {
+      u32 carry = 0;
+#pragma nounroll
+      for (int j = 0; j < L; ++j) {
+        const u32 v = slot[j] + cs->n[j] + carry;
+        slot[j] = v & MASK;
+        carry = v >> W;
       }
     }
   }
@@ -195,6 +206,88 @@ k_modp_to_mont(const uint8_t* __restrict__ in_be, u32* __restrict__ out_m, int c
   load_be256(a, in_be + (size_t)x * 256, ln);
   to_mont(a, slot, cs, n, ln);
   if (live) store_lane_limbs(out_m + (size_t)x * L, a, ln);
+}
+
+// =======================================================================================
+// The scalar ring Z/(q-1) of the MODP group on the device (the dealer's P(i) and responses; src/polynomial.rs:50-58,
+// src/dleq.rs:42-50).  q - 1 = 2 q' with q' = (q-1)/2 an odd prime: a scalar is kept as its residue mod q' -- in the
+// Montgomery machinery above with the constants of q' (also -1 mod 2^29) -- and its parity, and lifted to [0, q-1) when
+// it is written (store_canonical_be256, lift_parity).
+// =======================================================================================
+
+// a += b limb by limb, then carries inside the lane and one hand-over to the next lane: almost normalised again
+__device__ __forceinline__ void add_limbs(u32 (&a)[LPL], const u32 (&b)[LPL], const Lane& ln) {
+  u32 c = 0;
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) {
+    const u32 v = a[k] + b[k] + c;
+    a[k] = v & MASK;
+    c = v >> W;
+  }
+  a[0] += quad_from_prev(c) & ln.not_low;       // values stay far below 2^2088: the top lane has no carry-out
+}
+
+// out[x] = P(positions[x]) mod (q-1), P = sum_j a_j X^j.  Horner's rule with the position as a SMALL multiplier: 18 rows of
+// the Montgomery product instead of 72 (positions < 2^63 are three limbs), which leaves a factor 2^-522 per step -- the
+// caller hands the coefficients over as a'_j = a_j 2^(522 j) mod q' (plain limbs), so the factors cancel.
+//   coef        : [t][72] limbs of a'_j
+//   par_even/odd: parity of P at even / odd positions (a_0 resp. the sum of all a_j, mod 2)
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modq_poly_eval(const u32* __restrict__ coef, int t, const int64_t* __restrict__ positions, int count, int par_even, int par_odd,
+                 uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  const u64 pos = (u64)positions[x];
+  u32 n[LPL], acc[LPL], cj[LPL];
+  load_lane_limbs(n, cs->n, ln);
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) {
+    const int j = (int)ln.q * LPL + k;
+    slot[j] = j < 3 ? (u32)(pos >> (W * j)) & MASK : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+  load_lane_limbs(acc, coef + (size_t)(t - 1) * L, ln);
+  for (int j = t - 2; j >= 0; --j) {
+    load_lane_limbs(cj, coef + (size_t)j * L, ln);
+    mont_mul<MODP_N0INV_C, false, 1>(acc, acc, slot, n, ln);
+    add_limbs(acc, cj, ln);
+  }
+  __builtin_amdgcn_wave_barrier();
+  store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live, (pos & 1) ? par_odd : par_even);
+}
+
+// r[x] = w[x] - alpha[x] c mod (q-1) for one shared c (dleq.rs:42-50, participant.rs:255-264).
+//   cneg_be : (q' - c mod q') mod q' as 256 big-endian bytes, c_parity = c mod 2
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modq_responses(const uint8_t* __restrict__ w_be, const uint8_t* __restrict__ alpha_be, const uint8_t* __restrict__ cneg_be,
+                 int c_parity, int count, uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], a[LPL], b[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(a, alpha_be + (size_t)x * 256, ln);
+  const int parity = (int)((w_be[(size_t)x * 256 + 255] ^ (alpha_be[(size_t)x * 256 + 255] & (uint8_t)c_parity)) & 1u);
+  to_mont(a, slot, cs, n, ln);                       // alpha R mod q'
+  load_be256(b, cneg_be, ln);
+  slot_store(slot, b, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);         // -alpha c mod q' (plain, < 2q')
+  __builtin_amdgcn_wave_barrier();
+  load_be256(b, w_be + (size_t)x * 256, ln);
+  add_limbs(a, b, ln);                               // w - alpha c, < 2^2050
+  slot_fill_from_global(slot, cs->one_m, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);         // times R R^-1: the same residue, below 2q'
+  __builtin_amdgcn_wave_barrier();
+  store_canonical_be256(out_be + (size_t)x * 256, a, false, slot, cs, n, ln, live, parity);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1388,6 +1481,39 @@ extern "C" int modp_consts_upload(void** dev_consts) {
   if (e != hipSuccess) return (int)e;
   *dev_consts = d;
   return 0;
+}
+
+static inline int grid_for(int count);
+// the same four rows for q' = (q-1)/2, the modulus of the scalar-ring kernels
+extern "C" int modq_consts_upload(void** dev_consts) {
+  ModpConsts h;
+  for (int j = 0; j < L; ++j) {
+    h.n[j] = MODQH_N_LIMBS[j];
+    h.r2[j] = MODQH_R2_LIMBS[j];
+    h.one_m[j] = MODQH_ONE_M_LIMBS[j];
+    h.one[j] = (j == 0) ? 1u : 0u;
+  }
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, sizeof(ModpConsts));
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpy(d, &h, sizeof(ModpConsts), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return (int)e;
+  *dev_consts = d;
+  return 0;
+}
+extern "C" int modq_launch_poly_eval(const uint32_t* coef, int t, const int64_t* positions, int count, int par_even, int par_odd,
+                                     uint8_t* out_be, const void* cs_q, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modq_poly_eval, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, coef, t, positions, count, par_even, par_odd,
+                     out_be, (const ModpConsts*)cs_q);
+  return (int)hipGetLastError();
+}
+extern "C" int modq_launch_responses(const uint8_t* w_be, const uint8_t* alpha_be, const uint8_t* cneg_be, int c_parity, int count,
+                                     uint8_t* out_be, const void* cs_q, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modq_responses, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, w_be, alpha_be, cneg_be, c_parity, count,
+                     out_be, (const ModpConsts*)cs_q);
+  return (int)hipGetLastError();
 }
 
 // Residency report for tuning: max resident workgroups per CU the runtime computes for each kernel.

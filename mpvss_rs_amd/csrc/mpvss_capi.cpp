@@ -75,6 +75,13 @@ struct mpvss_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   void* consts = nullptr;
+  void* consts_q = nullptr;     // the same rows for q' = (q-1)/2 (scalar-ring kernels), uploaded on first use
+  // staging of the stand-alone scalar-ring calls (capi_scalar.inc): their own stream, a ring of small pinned + device buffers
+  struct ScalarEntry { void* pin = nullptr; size_t cap = 0; DevBuf dev; hipEvent_t done = nullptr; };
+  static constexpr unsigned SCALAR_RING = 16;
+  ScalarEntry scalar_ring[SCALAR_RING];
+  unsigned scalar_seq = 0;
+  hipStream_t scalar_stream = nullptr;
   void* pair_tables = nullptr;   // constant digit matrices of the pair-layout kernels (bn_pair.h), one device copy per context
   std::string err;
   mutable std::mutex err_mu;     // guards `err` alone: mpvss_last_error may run beside calls of other threads
@@ -623,6 +630,13 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
+  if (ctx->consts_q) (void)hipFree(ctx->consts_q);
+  for (auto& e : ctx->scalar_ring) {
+    if (e.pin) (void)hipHostFree(e.pin);
+    if (e.dev.p) (void)hipFree(e.dev.p);
+    if (e.done) (void)hipEventDestroy(e.done);
+  }
+  if (ctx->scalar_stream) (void)hipStreamDestroy(ctx->scalar_stream);
   if (ctx->pair_tables) (void)hipFree(ctx->pair_tables);
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : ctx->slot) {
@@ -2413,9 +2427,26 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
 //                             forward-difference chain);  a1_i = g^w_i (dleq.rs:207-211) through the comb.
 namespace {
 
+// the dealer's polynomial for a block whose P(i) is computed on the device, ahead of the group work and in the same stream
+struct DealPoly {
+  const uint8_t* coeffs_host;     // t x 256 bytes
+  size_t t;
+  const int64_t* positions_dev;   // n positions (validated when the block is absorbed)
+  uint8_t* p_dev_out;             // n x 256 bytes: P(i) mod (q-1), kept by the caller for the responses
+};
+void modq_poly_limbs(const uint8_t* coeffs_host, size_t t, uint32_t* limbs, int* par_even, int* par_odd);   // capi_scalar.inc
+int modq_consts(mpvss_ctx* ctx);
+
 int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t, const int64_t* positions,
                                     const uint8_t* pubkeys, const uint8_t* p_values, const uint8_t* witnesses, size_t n,
-                                    uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out) {
+                                    uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out,
+                                    const DealPoly* poly = nullptr) {
+  if (poly) {
+    if (space != MPVSS_DEVICE || commitments || !poly->coeffs_host || !poly->positions_dev || !poly->p_dev_out || poly->t == 0 ||
+        poly->t > 0x7fffffff || n > MAX_CHUNK)
+      return fail(ctx, MPVSS_E_INVALID, "deal: bad argument (device buffers, t >= 1, one chunk of shares)");
+    p_values = poly->p_dev_out;
+  }
   if (n > 0 && (!pubkeys || !p_values || !witnesses || n > 0x7fffffff || (commitments && (!positions || t == 0 || t > 0x7fffffff))))
     return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
   // (threshold > n is the whole box's business -- mpvss_modp_distribute checks it; a block of a box may be smaller)
@@ -2461,7 +2492,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   spans_reset(ctx);
   constexpr size_t FLAGS = 64;
   const size_t out_bytes = n * EB * 4 + n * 8 + FLAGS * 4;
-  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + (commitments ? t * EB : 0) : 0);
+  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + (commitments ? t * EB : 0) : 0) + (poly ? poly->t * MODP_L * 4 : 0);
   if (need > sl.cap) {
     if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
     sl.pin = nullptr;
@@ -2476,6 +2507,19 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   uint8_t* h2 = h1 + n * EB;
   int64_t* hpos = (int64_t*)(h2 + n * EB);
   int* hflags = (int*)((uint8_t*)sl.pin + n * EB * 4 + n * 8);
+  if (poly) {
+    // P(i) mod (q-1) first, on this block's own stream: the group work below reads it in stream order (k_modq_poly_eval)
+    RET_IF(modq_consts(ctx));
+    uint32_t* hl = (uint32_t*)((uint8_t*)sl.pin + out_bytes);
+    int par_even, par_odd;
+    modq_poly_limbs(poly->coeffs_host, poly->t, hl, &par_even, &par_odd);
+    RET_IF(ensure(ctx, ctx->w->cm, poly->t * MODP_L * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->cm.p, hl, poly->t * MODP_L * 4, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCHCHK(ctx, modq_launch_poly_eval((const uint32_t*)ctx->w->cm.p, (int)poly->t, poly->positions_dev, (int)n, par_even, par_odd,
+                                         poly->p_dev_out, ctx->consts_q, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hpos, poly->positions_dev, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    sl.check_positions = true;          // a negative position fails the block when it is absorbed
+  }
   if (space == MPVSS_HOST) {
     uint8_t* in = (uint8_t*)sl.pin + out_bytes;
     memcpy(in, pubkeys, n * EB); pubkeys = in;
@@ -2590,6 +2634,17 @@ extern "C" int mpvss_modp_distribute_compute(mpvss_ctx* ctx, int space, const ui
   std::lock_guard<std::mutex> lk(ctx->mu);
   return distribute_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, p_values, witnesses, n, x_dev_out,
                                          y_dev_out, a1_dev_out, a2_dev_out);
+}
+
+extern "C" int mpvss_modp_deal_compute(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
+                                       const uint8_t* pubkeys_dev, const uint8_t* witnesses_dev, size_t n, uint8_t* p_dev_out,
+                                       uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return fail(ctx, MPVSS_E_INVALID, "deal_compute: no shares");
+  const DealPoly poly{coeffs_host, t, positions_dev, p_dev_out};
+  return distribute_block_compute_locked(ctx, MPVSS_DEVICE, nullptr, 0, nullptr, pubkeys_dev, p_dev_out, witnesses_dev, n, x_dev_out,
+                                         y_dev_out, a1_dev_out, a2_dev_out, &poly);
 }
 
 extern "C" int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,

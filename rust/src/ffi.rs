@@ -133,6 +133,9 @@ unsafe extern "C" {
                                          y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
     pub fn mpvss_modp_distribute_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, y_out_host: *mut u8, a1_out_host: *mut u8,
                                         a2_out_host: *mut u8) -> c_int;
+    pub fn mpvss_modp_deal_compute(ctx: *mut mpvss_ctx, coeffs_host: *const u8, t: usize, positions_dev: *const i64, pubkeys_dev: *const u8,
+                                   witnesses_dev: *const u8, n: usize, p_dev_out: *mut u8, x_dev_out: *mut u8, y_dev_out: *mut u8,
+                                   a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
     // ---- curve groups
     pub fn mpvss_ec_batch_exp(ctx: *mut mpvss_ctx, group: c_int, space: c_int, bases: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn mpvss_ec_batch_mul(ctx: *mut mpvss_ctx, group: c_int, space: c_int, a: *const u8, b: *const u8, n: usize, out: *mut u8) -> c_int;
@@ -183,6 +186,8 @@ unsafe extern "C" {
                                    threads: c_int) -> c_int;
     pub fn mpvss_modp_poly_eval(coeffs: *const u8, t: usize, positions: *const i64, n: usize, out: *mut u8, threads: c_int) -> c_int;
     pub fn mpvss_ec_poly_eval(group: c_int, coeffs: *const u8, t: usize, positions: *const i64, n: usize, out: *mut u8, threads: c_int) -> c_int;
+    pub fn mpvss_modp_poly_eval_device(ctx: *mut mpvss_ctx, coeffs_host: *const u8, t: usize, positions_dev: *const i64, n: usize, out_dev: *mut u8) -> c_int;
+    pub fn mpvss_modp_dleq_responses_device(ctx: *mut mpvss_ctx, w_dev: *const u8, alpha_dev: *const u8, c_host: *const u8, n: usize, r_dev_out: *mut u8) -> c_int;
     // ---- reconstruct
     pub fn mpvss_modp_reconstruct(ctx: *mut mpvss_ctx, space: c_int, positions_host: *const i64, shares: *const u8, m: usize, gs_out256: *mut u8,
                                   mask_out32: *mut u8) -> c_int;

@@ -1,0 +1,124 @@
+"""The MODP scalar ring Z/(q-1) on the device: mpvss_modp_poly_eval_device (src/polynomial.rs:50-58 followed by the caller's
+`% order`, participant.rs:202) and mpvss_modp_dleq_responses_device (src/dleq.rs:42-50) against Python integers and against
+the host functions of the same C ABI.  The kernels work mod q' = (q-1)/2 with the parity on the side, so the cases aim at
+both halves of the Chinese remainder: even / odd positions and coefficients, values just below q-1, operands that are not
+reduced."""
+import random
+
+import pytest
+import torch
+
+from helpers import EB, MODP_ORDER as ORDER
+from mpvss_rs_amd import capi
+from mpvss_rs_amd.capi import EngineError
+
+pytestmark = pytest.mark.gpu
+fx = lambda v: v.to_bytes(EB, "big")
+QH = ORDER // 2
+
+
+def dev_u8(b):
+    return torch.frombuffer(bytearray(b), dtype=torch.uint8).to("cuda:0")
+
+
+def poly_eval_device(engine, coeffs, positions):
+    n = len(positions)
+    d_pos = torch.tensor(positions, dtype=torch.int64, device="cuda:0")
+    out = torch.full((n * EB,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    engine.poly_eval_device(b"".join(map(fx, coeffs)), d_pos.data_ptr(), n, out.data_ptr())
+    raw = bytes(out.cpu().numpy().tobytes())
+    return [int.from_bytes(raw[i * EB:(i + 1) * EB], "big") for i in range(n)]
+
+
+@pytest.mark.parametrize("t", [1, 2, 7, 64])
+def test_poly_eval_device_against_integers(engine, t):
+    rng = random.Random(100 + t)
+    positions = ([0, 1, 2, 3, 4, 65535, 65536, 2**29 - 1, 2**29, 2**29 + 1, 2**40 + 5, 2**58, 2**62 + 3, 2**63 - 1] +
+                 [rng.randrange(1, 1 << 20) for _ in range(37)])
+    specials = [0, 1, ORDER - 1, QH, QH + 1, QH - 1, 2**2048 - 1, ORDER, ORDER + 1]          # the last three are not reduced
+    for trial in range(3):
+        coeffs = [rng.randrange(ORDER) for _ in range(t)]
+        for k in range(min(t, 3)):
+            if trial:
+                coeffs[rng.randrange(t)] = specials[(trial * 3 + k) % len(specials)]
+        want = [sum(a * pow(i, j, ORDER) for j, a in enumerate(coeffs)) % ORDER for i in positions]
+        assert poly_eval_device(engine, coeffs, positions) == want
+        if all(a < 2**2048 for a in coeffs):
+            host = capi.poly_eval(0, b"".join(map(fx, coeffs)), positions)
+            assert [int.from_bytes(host[i * EB:(i + 1) * EB], "big") for i in range(len(positions))] == want
+
+
+def test_poly_eval_device_of_a_full_box(engine):
+    """the dealer's shape: 65536 consecutive positions, t = 256 -- every value equal to the host function's (which takes the
+    forward-difference route for such a run)"""
+    rng = random.Random(7)
+    coeffs = [rng.randrange(ORDER) for _ in range(256)]
+    positions = list(range(1, 65537))
+    got = poly_eval_device(engine, coeffs, positions)
+    host = capi.poly_eval(0, b"".join(map(fx, coeffs)), positions)
+    assert got == [int.from_bytes(host[i * EB:(i + 1) * EB], "big") for i in range(65536)]
+    for i in (1, 2, 40000, 65536):
+        assert got[i - 1] == sum(a * pow(i, j, ORDER) for j, a in enumerate(coeffs)) % ORDER
+
+
+def test_poly_eval_device_rejects_a_negative_position(engine):
+    with pytest.raises(EngineError):
+        poly_eval_device(engine, [5, 6], [1, 2, -3, 4])
+    assert "negative position" in engine.last_error()
+    assert poly_eval_device(engine, [5, 6], [1, 2]) == [11, 17]
+
+
+def test_dleq_responses_device_against_integers(engine):
+    rng = random.Random(11)
+    n = 203
+    w = [rng.randrange(ORDER) for _ in range(n)]
+    a = [rng.randrange(ORDER) for _ in range(n)]
+    w[:6] = [0, ORDER - 1, 1, QH, 2**2048 - 1, 0]
+    a[:6] = [0, ORDER - 1, QH, QH, ORDER - 1, 1]
+    d_w, d_a = dev_u8(b"".join(map(fx, w))), dev_u8(b"".join(map(fx, a)))
+    for c in (rng.randrange(1 << 256), rng.randrange(1 << 256) | 1, 0, 1, 2, QH, QH + 1, ORDER - 1, ORDER, 2**2048 - 1, rng.randrange(ORDER)):
+        out = torch.full((n * EB,), 0x5A, dtype=torch.uint8, device="cuda:0")
+        engine.dleq_responses_device(d_w.data_ptr(), d_a.data_ptr(), fx(c), n, out.data_ptr())
+        raw = bytes(out.cpu().numpy().tobytes())
+        got = [int.from_bytes(raw[i * EB:(i + 1) * EB], "big") for i in range(n)]
+        assert got == [(wi - ai * c) % ORDER for wi, ai in zip(w, a)], f"c = {c:#x}"
+        if c < ORDER and max(w) < ORDER:
+            pass
+    host = capi.dleq_responses(0, b"".join(map(fx, [x % ORDER for x in w])), b"".join(map(fx, a)), fx(12345))
+    out = torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0")
+    engine.dleq_responses_device(dev_u8(b"".join(map(fx, [x % ORDER for x in w]))).data_ptr(), d_a.data_ptr(), fx(12345), n, out.data_ptr())
+    assert bytes(out.cpu().numpy().tobytes()) == host
+
+
+def test_deal_compute_is_the_oracles_dealer(engine):
+    """mpvss_modp_deal_compute + mpvss_modp_distribute_absorb + mpvss_modp_dleq_responses_device == the oracle's
+    distribute_secret (participant.rs:160-286) for the same polynomial and witnesses: X, Y, a1, a2 of every share, the
+    transcript digest, the challenge and the responses; two blocks in flight; a negative position fails its block at absorb."""
+    import hashlib
+    import mpvss_oracle as O
+    from helpers import make_modp_instance
+    n, t = 23, 4
+    g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, 41)
+    flat = O.box_to_flat(g, box)
+    d_pos = torch.tensor(flat["positions"], dtype=torch.int64, device="cuda:0")
+    d_pk, d_w = dev_u8(flat["publickeys"]), dev_u8(b"".join(map(fx, ws)))
+    d_p = [torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    cb = b"".join(map(fx, coeffs))
+    engine.deal_compute(cb, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[0].data_ptr())
+    engine.deal_compute(cb, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[1].data_ptr())
+    for k in range(2):
+        st, X, Y, a1, a2 = engine.distribute_absorb(capi.transcript_init(), n)
+        digest = capi.transcript_verdict(st, bytes(EB))[1]
+        assert digest == box["_digest"] and Y == flat["shares"]
+        assert bytes(d_p[k].cpu().numpy().tobytes()) == b"".join(fx(sum(a * pow(i, j, ORDER) for j, a in enumerate(coeffs)) % ORDER)
+                                                                   for i in flat["positions"])
+        c = int.from_bytes(hashlib.sha256(digest).digest(), "big") % QH
+        assert fx(c) == flat["challenge"]
+        d_r = torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0")
+        engine.dleq_responses_device(d_w.data_ptr(), d_p[k].data_ptr(), fx(c), n, d_r.data_ptr())
+        assert bytes(d_r.cpu().numpy().tobytes()) == flat["responses"]
+    bad = d_pos.clone(); bad[7] = -8
+    engine.deal_compute(cb, bad.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[0].data_ptr())
+    with pytest.raises(EngineError):
+        engine.distribute_absorb(capi.transcript_init(), n)
+    assert "negative position" in engine.last_error() and engine.blocks_in_flight() == (0, 0)
