@@ -1181,7 +1181,7 @@ k_modp_dual_exp_w6(const u32* __restrict__ tab1, const u32* __restrict__ tab2, c
 // is private to its quad), a 32-bit occupancy mask per exponent stays in a register: a bucket's first factor is stored,
 // not multiplied.  ~2 500 product equivalents for both results instead of ~3 870 for two 6-bit-window ladders.
 // ---------------------------------------------------------------------------------------
-constexpr int BK_W = 5;                       // window bits
+constexpr int BK_W = MODP_BUCKET_W;            // window bits (5; modp_kernels.h -- the pair-layout bucket kernel uses the same)
 constexpr int BK_ENT = (1 << BK_W) - 1;       // buckets per exponent (digit 0 has none)
 constexpr int BK_WINDOWS = (2048 + BK_W - 1) / BK_W;
 
@@ -1740,6 +1740,14 @@ extern "C" int modp_launch_twin_exp(const uint8_t* base_be, const uint8_t* e1, c
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_twin_exp_buckets, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, base_be, e1, e2, count,
                      buckets, occupancy, (const ModpConsts*)cs);
+  hipLaunchKernelGGL(k_modp_bucket_combine, dim3(grid_for(2 * count)), dim3(BLOCK_THREADS), 0, s, buckets, occupancy, count,
+                     out1, out2, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
+}
+// the second phase alone (after the pair-layout bucket kernel, modp_pair_kernels.hip)
+extern "C" int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupancy, int count, uint8_t* out1, uint8_t* out2,
+                                          const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_bucket_combine, dim3(grid_for(2 * count)), dim3(BLOCK_THREADS), 0, s, buckets, occupancy, count,
                      out1, out2, (const ModpConsts*)cs);
   return (int)hipGetLastError();

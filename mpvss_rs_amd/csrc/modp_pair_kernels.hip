@@ -396,6 +396,77 @@ k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, cons
 }
 
 // ---------------------------------------------------------------------------------------
+// One base, two exponents (the dealer: Y_i = y_i^P(i) and a2_i = y_i^w_i, participant.rs:219, dleq.rs:213-216; the
+// participant: S_i = Y_i^(1/x_i) and a2_i = S_i^w_i, participant.rs:310-314): the right-to-left bucket phase of
+// k_modp_twin_exp_buckets (modp_kernels.hip -- same windows, same buckets and occupancy masks in HBM, the same combine kernel
+// afterwards) on the pair layout: 2 045 squarings and 820 bucket products per share at 85 / 122 instead of 153 / 191 issue
+// slots.  A number whose digit is 0, or whose bucket is still empty, multiplies by a harmless operand and drops the result
+// (a bucket's first factor is stored, not multiplied), so that the wave stays in step.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be,
+                             int count, u32* __restrict__ buckets, u32* __restrict__ occupancy, const ModpConsts* __restrict__ cs,
+                             const Tables* __restrict__ gtab) {
+  constexpr int BW = MODP_BUCKET_W, BENT = (1 << BW) - 1, BWIN = (2048 + BW - 1) / BW;
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  u32 cur[LP];
+  load_be256_pair(cur, base_be + (size_t)pc.x * 256, pl);
+  u32* mine = buckets + (size_t)pc.x * 2 * BENT * L;
+  const uint8_t* ex[2] = {e1_be + (size_t)pc.x * 256, e2_be + (size_t)pc.x * 256};
+  auto digit = [&](const uint8_t* e, int k) -> u32 {
+    const int o = BW * k, b = o >> 3;
+    const u32 lo = e[255 - b];
+    const u32 hi = (b + 1 < 256) ? e[254 - b] : 0u;
+    return ((lo | (hi << 8)) >> (o & 7)) & (u32)BENT;
+  };
+  u32 occ[2] = {0, 0};
+  // op 0: the base into Montgomery form; per window k: ops 1, 2 = the bucket products of the two exponents, ops 3 .. 2+BW the
+  // squarings.  ONE product site, one squaring site and one reduction in the loop (instruction cache).
+  int k = 0, op = 0;
+  while (true) {
+    const bool sq = op >= 3;
+    const u32* fill = cs->r2;
+    u32* bk = nullptr;
+    bool has = false;
+    if (op == 1 || op == 2) {
+      const u32 d = digit(ex[op - 1], k);
+      has = (occ[op - 1] >> d) & 1u;
+      if (d != 0) {
+        bk = mine + ((size_t)(op - 1) * BENT + (d - 1)) * L;
+        occ[op - 1] |= 1u << d;
+      }
+      fill = (bk != nullptr && has) ? bk : cs->one_m;
+    }
+    u64 T[LP];
+    if (sq) {
+      slot_store_pair(pc.slot, cur, pl);
+      __builtin_amdgcn_wave_barrier();
+      phase_a<true>(T, cur, pc.slot, pc.junk, pl);
+    } else {
+      slot_fill_pair(pc.slot, fill, pl);
+      __builtin_amdgcn_wave_barrier();
+      phase_a<false>(T, cur, pc.slot, pc.junk, pl);
+    }
+    u32 r[LP];
+    reduce(r, T, pc.slot, pc.tb, pl);
+    __builtin_amdgcn_wave_barrier();
+    if (sq || op == 0) {
+#pragma unroll
+      for (int i = 0; i < LP; ++i) cur[i] = r[i];
+    } else if (bk != nullptr && pc.live) {
+      if (has) store_pair_limbs(bk, r, pl); else store_pair_limbs(bk, cur, pl);
+    }
+    if (op == 2 && k == BWIN - 1) break;
+    if (op == 2 + BW) { op = 1; ++k; } else ++op;
+  }
+  if (pc.live && pl.h == 0) {
+    occupancy[(size_t)pc.x * 2] = occ[0];
+    occupancy[(size_t)pc.x * 2 + 1] = occ[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 extern "C" int modp_pair_tables_upload(void** dev_tables) {
   static_assert(sizeof(MM_GT1) == sizeof(Tables::gt1) && sizeof(MM_GT2) == sizeof(Tables::gt2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
                     sizeof(MM_C2) == sizeof(Tables::c2), "generated tables do not match bn_pair.h");
@@ -446,4 +517,14 @@ extern "C" int modp_launch_sched_exp_mul_pair(const uint32_t* tab2, size_t tab2_
   hipLaunchKernelGGL(k_modp_sched_exp_mul_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab2, tab2_stride, c_sched, p_m,
                      count, out, (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* e1, const uint8_t* e2, int count, uint32_t* buckets,
+                                         uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables,
+                                         hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_twin_exp_buckets_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, base_be, e1, e2, count, buckets,
+                     occupancy, (const ModpConsts*)cs, (const Tables*)pair_tables);
+  if (hipGetLastError() != hipSuccess) return 1;
+  return modp_launch_bucket_combine(buckets, occupancy, count, out1, out2, cs, s);
 }

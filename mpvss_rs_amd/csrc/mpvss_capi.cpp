@@ -1083,13 +1083,15 @@ namespace {
 // c_sched: sliding-window schedule of ONE shared challenge (then c_dev is unused), else fixed 4-bit windows of c_dev
 // (stride c_stride; null: B1^r alone).
 // MPVSS_PAIR: which kernels of the verifier's block path take the pair layout (bit 0: a2 = y^r Y^c, bit 1: the window tables,
-// bit 2: g^r through the wide comb, bit 3: a1 = g^r X^c).  Default 1: a2 only.  A pair wave (230 VGPRs, two per SIMD at
+// bit 2: g^r through the wide comb, bit 3: a1 = g^r X^c, bit 4: the bucket phase of the dealer's / participant's twin
+// exponentiation -- 58.6 against 87.8 ms per 65536 shares alone on the chip, dealer 0.85 -> 0.92 M shares/s,
+// profiles/r03_dealer_ab.txt).  Default 17: a2 and the twin exponentiation.  A pair wave (230 VGPRs, two per SIMD at
 // most) leaves its SIMD idle while it waits for its MFMA chains and LDS reads; the quad kernels' waves (135 VGPRs) of the
 // other boxes in flight fill those gaps.  With every wide kernel in the pair layout there is nothing left to fill them:
 // measured on one box 1.063 M share verifications/s for a2 alone, 1.044 M with the tables, 1.022 M with all four,
 // 0.942 M with none (profiles/r03_pair_ab.txt).  MPVSS_A2_PAIR=0 clears bit 0 (older switch).
 int pair_mask() {
-  static const int m = fd_env("MPVSS_PAIR", 1) & (fd_env("MPVSS_A2_PAIR", 1) ? 15 : 14);
+  static const int m = fd_env("MPVSS_PAIR", 17) & (fd_env("MPVSS_A2_PAIR", 1) ? 31 : 30);
   return m;
 }
 int launch_table_odd(mpvss_ctx* ctx, const uint8_t* base_dev, size_t cnt, uint32_t* tab) {
@@ -1108,6 +1110,14 @@ int launch_dual_exp_w6(mpvss_ctx* ctx, const uint32_t* t1, const uint32_t* t2, c
                                         ctx->stream);
   if (c_sched) return modp_launch_dual_exp_w6_sched(t1, t2, r_dev, c_sched, (int)cnt, out_dev, ctx->consts, ctx->stream);
   return modp_launch_dual_exp_w6(t1, t2, r_dev, c_dev, c_stride, (int)cnt, out_dev, ctx->consts, ctx->stream);
+}
+
+// one base, two exponents, two results: the bucket phase in the pair layout when bit 4 of MPVSS_PAIR is set
+int launch_twin_exp(mpvss_ctx* ctx, const uint8_t* base, const uint8_t* e1, const uint8_t* e2, size_t cnt, uint32_t* buckets,
+                    uint32_t* occupancy, uint8_t* out1, uint8_t* out2) {
+  if (pair_mask() & 16)
+    return modp_launch_twin_exp_pair(base, e1, e2, (int)cnt, buckets, occupancy, out1, out2, ctx->consts, ctx->pair_tables, ctx->stream);
+  return modp_launch_twin_exp(base, e1, e2, (int)cnt, buckets, occupancy, out1, out2, ctx->consts, ctx->stream);
 }
 
 // a = B1^r * B2^c for `cnt` shares.  tab_b1: shared table (stride 0) or nullptr -> per-number tables
@@ -2559,8 +2569,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
         const size_t bw = modp_twin_exp_bucket_words();
         RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + 2) * 4));
         uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
-        TIMED_LAUNCH(ctx, 3, modp_launch_twin_exp((const uint8_t*)dy, (const uint8_t*)dp, (const uint8_t*)dw, (int)cnt, bk,
-                                                  bk + cnt * bw, dY, da2, ctx->consts, ctx->stream));
+        TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dp, (const uint8_t*)dw, cnt, bk, bk + cnt * bw, dY, da2));
       } else if (cnt >= 1024) {   // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
         TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
         TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, ty, ty, (const uint8_t*)dp, nullptr, 0, nullptr, cnt, dY));
@@ -2744,8 +2753,7 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
       const size_t bw = modp_twin_exp_bucket_words();
       RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + 2) * 4));
       uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
-      TIMED_LAUNCH(ctx, 3, modp_launch_twin_exp((const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, (int)cnt, bk,
-                                                bk + cnt * bw, dS, da2, ctx->consts, ctx->stream));
+      TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, cnt, bk, bk + cnt * bw, dS, da2));
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
                                                      da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));              // a1 = G^w
     } else {
@@ -2877,8 +2885,7 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
   RET_IF(ensure(ctx, ctx->w->tab1, n * (bw + 2) * 4));
   uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
   // S = Y^(1/x) and a2 = S^w = Y^(w/x) from one chain of squarings (participant.rs:310-314, dleq.rs:213-216)
-  TIMED_LAUNCH(ctx, 3, modp_launch_twin_exp((const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, (int)n, bk, bk + n * bw, dS, da2,
-                                            ctx->consts, ctx->stream));
+  TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, n, bk, bk + n * bw, dS, da2));
   TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)n, da1,
                                                  comb_bits_of(ctx, cG), ctx->consts, ctx->stream));                         // a1 = G^w
   // c_i = hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1_i) framed(a2_i)))   (participant.rs:329-343), K7

@@ -337,7 +337,7 @@ def test_rejects_bad_arguments(engine):
 
 
 def test_every_pair_layout_kernel_against_the_dealer_and_the_fast_form():
-    """MPVSS_PAIR=15 sends the window tables, g^r and a1 through the pair layout as well (by default only a2 goes there: the
+    """MPVSS_PAIR=31 sends the window tables, g^r and a1 through the pair layout as well (by default only a2 goes there: the
     pipeline is faster that way).  An 8200-share box is dealt and verified with dumps in a child process under that
     switch (it is read once per process): verdict, the dealer's digest, X / a1 / a2 equal to the dealer's everywhere and to
     the fast form of the reference arithmetic on a sample; one flipped response bit is rejected."""
@@ -377,5 +377,5 @@ bad = bytearray(r); bad[7321 * 256 + 200] ^= 8
 assert eng.verify_distribution(cm, pos, pk, d["Y"], bytes(bad), fx(c))["verdict"] is False
 print("pair15 ok")
 """ % (root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MPVSS_PAIR="15"), timeout=900)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MPVSS_PAIR="31"), timeout=900)
     assert out.returncode == 0 and "pair15 ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
