@@ -1295,10 +1295,10 @@ def main():
             # ... and with the scalar side on the device as well: P(i) mod (q-1) by mpvss_modp_poly_eval_device into HBM, the
             # group work on those values, the challenge from the transcript digest, r_i by mpvss_modp_dleq_responses_device --
             # nothing of a box but its t coefficients, its digest and its challenge crosses the bus
-            ring = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(deal_depth + 3)]
+            ring = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]     # P(i) of a box lives until its responses are out
 
             resp_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
-            d_rs = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(deal_depth + 3)]
+            d_rs = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]
 
             def e2e_resp(b, d_pvb, cc):
                 d_r = d_rs[b % len(d_rs)]

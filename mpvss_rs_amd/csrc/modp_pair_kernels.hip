@@ -28,6 +28,21 @@
                                 // empty (profiles/r03_pair_ab.txt: 0.91 / 0.98 / 1.04 M for 4 / 2 / 1 waves, 0.98 M VALU-only)
 #endif
 
+// Waves per SIMD the register allocator aims for.  The straight-line product keeps 230-256 arch VGPRs live and the MFMA
+// accumulators take 32 AGPRs more: left alone the kernels end up at 260-294 registers, ONE wave per SIMD (the unified file
+// holds 512 per lane).  Two waves -- 256 registers in all -- let one wave's VALU rows run under the other's MFMA chains and
+// LDS round trips.  Applied where it costs no spills (a2 = y^r Y^c: 240 registers, headline pipeline 1.02 -> 1.08 M share
+// verifications/s although the launch alone on the chip gets slower, 43 -> 54 ms); the table builder and the twin
+// exponentiation would spill (the dealer loses 8 %) and keep their one wave (profiles/r03_pair_occupancy_ab.txt).
+#ifndef PAIR_WAVES_PER_EU
+#define PAIR_WAVES_PER_EU 2
+#endif
+#if PAIR_WAVES_PER_EU > 0
+#define PAIR_OCC_ATTR __attribute__((amdgpu_waves_per_eu(PAIR_WAVES_PER_EU, PAIR_WAVES_PER_EU)))
+#else
+#define PAIR_OCC_ATTR
+#endif
+
 namespace {
 
 using namespace mm;
@@ -138,7 +153,7 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
 // box has ONE challenge) against the table of Y -- on the pair layout.  tab1 [count][64][72], tab2 [count][16][72] in
 // Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
 k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
                         const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
                         const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched,
@@ -339,7 +354,7 @@ k_modp_build_table_pair(const uint8_t* __restrict__ base_be, int count, u32* __r
 // p_m[x] = g^e1[x] in Montgomery form through the wide fixed-base comb (comb16[k][d] = g^(d 65536^k), 128 rows): 127
 // products, no squarings -- mode 1 of k_modp_comb_dual_exp.  The g^r half of a1 = g^r X^c (dleq.rs:75-77).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
 k_modp_comb16_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict__ e1_be, int count, u32* __restrict__ p_m,
                        const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
   PAIR_KERNEL_PROLOGUE(gtab, count)
@@ -358,7 +373,7 @@ k_modp_comb16_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict
 // out[x] = p_m[x] * B2[x]^c for ONE shared exponent c given as a sliding-window schedule (mode 2 of
 // k_modp_comb_dual_exp with c_sched): a1 = g^r * X^c (dleq.rs:75-77) once X is known.  tab2: odd-power tables of X.
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
 k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, const uint16_t* __restrict__ c_sched,
                           const u32* __restrict__ p_m, int count, uint8_t* __restrict__ out_be,
                           const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
