@@ -20,12 +20,14 @@
 #include "modp_kernels.h"
 
 #ifndef PAIR_WAVES
-#define PAIR_WAVES 1            // waves per workgroup.  ONE, as for the quad kernels: a single-wave workgroup (27 KB of LDS: 17 KB
-                                // of constant records + the wave's operand slots) fits any CU with a free wave slot, and the
-                                // pipeline mixes it with the other kernels' waves -- with 4 or 8 waves per workgroup the kernel
-                                // is faster alone (37.7 instead of 43.4 ms) but the pipeline is SLOWER than with the VALU-only
-                                // kernel, because such a workgroup only starts on a CU the single-wave workgroups have left
-                                // empty (profiles/r03_pair_ab.txt: 0.91 / 0.98 / 1.04 M for 4 / 2 / 1 waves, 0.98 M VALU-only)
+#define PAIR_WAVES 2            // waves per workgroup: they share one copy of the constant records (17 KB) and own 9 KB of operand
+                                // slots each, so two waves make 36 KB and a CU holds four such workgroups = TWO waves per SIMD
+                                // (one-wave workgroups of 27 KB: five per CU).  Measured in the headline pipeline with the a2
+                                // kernel's registers allocated for two waves per SIMD (PAIR_WAVES_PER_EU below; interleaved runs,
+                                // profiles/r03_pair_occupancy_ab.txt): 1.03 / 1.08 / 1.02 M share verifications/s for 1 / 2 / 4
+                                // waves, 1.02 M with one wave per SIMD.  (At one wave per SIMD bigger workgroups LOSE, 0.91 /
+                                // 0.98 / 1.04 M for 4 / 2 / 1: they only start on CUs the single-wave workgroups of the other
+                                // kernels have left empty, profiles/r03_pair_ab.txt.)
 #endif
 
 // Waves per SIMD the register allocator aims for.  The straight-line product keeps 230-256 arch VGPRs live and the MFMA
