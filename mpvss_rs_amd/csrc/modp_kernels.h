@@ -105,6 +105,8 @@ int modp_launch_fd_step_boxes(const uint32_t* state, const uint32_t* state_back,
                               int* gate, int inject_fault, const void* cs, hipStream_t s);
 /* twin exponentiation (one base, two exponents): bucket phase on the pair layout + the shared combine phase */
 #define MODP_BUCKET_W 5
+#define MODP_TWIN_SLACK_BYTES 65536   /* once per buffer: running powers of the padding lanes of the last workgroup */
+#define MODP_TWIN_EXTRA_WORDS 80      /* per share behind the buckets: 2 occupancy masks, padding, the running power (pair kernel) */
 int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* e1, const uint8_t* e2, int count, uint32_t* buckets,
                               uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s);
 int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupancy, int count, uint8_t* out1, uint8_t* out2,

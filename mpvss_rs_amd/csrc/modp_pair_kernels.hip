@@ -420,15 +420,23 @@ k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, cons
 // slots.  A number whose digit is 0, or whose bucket is still empty, multiplies by a harmless operand and drops the result
 // (a bucket's first factor is stored, not multiplied), so that the wave stays in step.
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES)
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
 k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be,
-                             int count, u32* __restrict__ buckets, u32* __restrict__ occupancy, const ModpConsts* __restrict__ cs,
-                             const Tables* __restrict__ gtab) {
+                             int count, u32* __restrict__ buckets, u32* __restrict__ occupancy, u32* __restrict__ curbuf,
+                             const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
   constexpr int BW = MODP_BUCKET_W, BENT = (1 << BW) - 1, BWIN = (2048 + BW - 1) / BW;
   PAIR_KERNEL_PROLOGUE(gtab, count)
   const PairLane& pl = pc.pl;
-  u32 cur[LP];
-  load_be256_pair(cur, base_be + (size_t)pc.x * 256, pl);
+  // The running power cur = y^(2^(5k)) is an operand of both bucket products of a window and of the next squaring: kept in
+  // registers across a product it would be live beside T and the result (36 + 72 + 36 + the rows' temporaries: 284
+  // registers, one wave per SIMD).  It lives in HBM instead (288 bytes per number, L2-resident: one store and three loads of
+  // a window against its seven Montgomery operations), every operation starts from a fresh copy, and the kernel fits the 256
+  // registers of two waves per SIMD without spilling.
+  // (indexed by the lane's own number, also for the padding lanes past `count`: those repeat the last share's work in step with
+  // nothing, and a slot of their own keeps them from writing into the live one's)
+  u32* mycur = curbuf + (size_t)((blockIdx.x * PAIR_WAVES + (threadIdx.x >> 6)) * 32 + (int)(pl.lane & 31)) * L;
+  u32 acc[LP];
+  load_be256_pair(acc, base_be + (size_t)pc.x * 256, pl);
   u32* mine = buckets + (size_t)pc.x * 2 * BENT * L;
   const uint8_t* ex[2] = {e1_be + (size_t)pc.x * 256, e2_be + (size_t)pc.x * 256};
   auto digit = [&](const uint8_t* e, int k) -> u32 {
@@ -454,27 +462,31 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
         occ[op - 1] |= 1u << d;
       }
       fill = (bk != nullptr && has) ? bk : cs->one_m;
+      load_pair_limbs(acc, mycur, pl);
+      if (bk != nullptr && !has && pc.live) store_pair_limbs(bk, acc, pl);        // a bucket's first factor is stored, not multiplied
     }
     u64 T[LP];
     if (sq) {
-      slot_store_pair(pc.slot, cur, pl);
+      slot_store_pair(pc.slot, acc, pl);
       __builtin_amdgcn_wave_barrier();
-      phase_a<true>(T, cur, pc.slot, pc.junk, pl);
+      phase_a<true>(T, acc, pc.slot, pc.junk, pl);
     } else {
       slot_fill_pair(pc.slot, fill, pl);
       __builtin_amdgcn_wave_barrier();
-      phase_a<false>(T, cur, pc.slot, pc.junk, pl);
+      phase_a<false>(T, acc, pc.slot, pc.junk, pl);
     }
     u32 r[LP];
     reduce(r, T, pc.slot, pc.tb, pl);
     __builtin_amdgcn_wave_barrier();
     if (sq || op == 0) {
 #pragma unroll
-      for (int i = 0; i < LP; ++i) cur[i] = r[i];
-    } else if (bk != nullptr && pc.live) {
-      if (has) store_pair_limbs(bk, r, pl); else store_pair_limbs(bk, cur, pl);
+      for (int i = 0; i < LP; ++i) acc[i] = r[i];
+      if (op == 0 || op == 2 + BW) store_pair_limbs(mycur, acc, pl);               // the window's cur
+    } else if (bk != nullptr && has && pc.live) {
+      store_pair_limbs(bk, r, pl);
     }
     if (op == 2 && k == BWIN - 1) break;
+    if (op == 2) load_pair_limbs(acc, mycur, pl);                                  // back to the chain of squarings
     if (op == 2 + BW) { op = 1; ++k; } else ++op;
   }
   if (pc.live && pl.h == 0) {
@@ -540,8 +552,12 @@ extern "C" int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* 
                                          uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables,
                                          hipStream_t s) {
   if (count <= 0) return 0;
+  // the running powers (72 words per share) sit behind the occupancy masks: callers size the buffer with
+  // modp_twin_exp_bucket_words() + MODP_TWIN_EXTRA_WORDS words per share
+  // (one per lane of the grid: up to 32 PAIR_WAVES - 1 more than `count`, MODP_TWIN_SLACK_BYTES at the end of the buffer)
+  uint32_t* curbuf = occupancy + (((size_t)2 * count + 3) & ~(size_t)3);
   hipLaunchKernelGGL(k_modp_twin_exp_buckets_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, base_be, e1, e2, count, buckets,
-                     occupancy, (const ModpConsts*)cs, (const Tables*)pair_tables);
+                     occupancy, curbuf, (const ModpConsts*)cs, (const Tables*)pair_tables);
   if (hipGetLastError() != hipSuccess) return 1;
   return modp_launch_bucket_combine(buckets, occupancy, count, out1, out2, cs, s);
 }

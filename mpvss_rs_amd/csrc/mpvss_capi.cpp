@@ -2567,7 +2567,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
       if (cnt >= 1024 && twin) {
         // same base, two exponents: right-to-left buckets share the 2 045 squarings (tab1 holds buckets + occupancy)
         const size_t bw = modp_twin_exp_bucket_words();
-        RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + 2) * 4));
+        RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
         uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
         TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dp, (const uint8_t*)dw, cnt, bk, bk + cnt * bw, dY, da2));
       } else if (cnt >= 1024) {   // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
@@ -2751,7 +2751,7 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
       RET_IF(stage_in(ctx, space, e2.data(), cnt * EB, ctx->w->in_d, &de2));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // e2 is a local buffer: its copy must have left before it dies
       const size_t bw = modp_twin_exp_bucket_words();
-      RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + 2) * 4));
+      RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
       uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
       TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, cnt, bk, bk + cnt * bw, dS, da2));
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
@@ -2882,7 +2882,7 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
   RET_IF(ensure(ctx, ctx->w->verd, n * 32));
   uint8_t *dS = (uint8_t*)ctx->w->xbe.p, *da1 = (uint8_t*)ctx->w->out1.p, *da2 = (uint8_t*)ctx->w->out2.p, *dc = (uint8_t*)ctx->w->verd.p;
   const size_t bw = modp_twin_exp_bucket_words();
-  RET_IF(ensure(ctx, ctx->w->tab1, n * (bw + 2) * 4));
+  RET_IF(ensure(ctx, ctx->w->tab1, n * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
   uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
   // S = Y^(1/x) and a2 = S^w = Y^(w/x) from one chain of squarings (participant.rs:310-314, dleq.rs:213-216)
   TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, n, bk, bk + n * bw, dS, da2));
