@@ -207,7 +207,7 @@ def bench_ec(eng, name, args):
     dual_ms = lone["dual_win"] / max(lone["dual_win_launches"], 1)
     # timed: K boxes through the library's pipeline (mpvss_ec_verify_many): EC_DEPTH boxes in flight in ONE context
     k = args.ec_boxes
-    depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "46")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "6"))
+    depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "16")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "6"))
     box = capi.EcBox(d_cm.data_ptr(), t, d_pos.data_ptr(), d_pk.data_ptr(), d_Y.data_ptr(), d_r.data_ptr(), n,
                      C.cast(chal, C.c_void_p))
 
@@ -354,7 +354,7 @@ def sliding_windows(c):
 QUAD_MUL_SLOTS, QUAD_SQ_SLOTS = (72 * 41 + 110) / 16.0, (72 * 32.5 + 110) / 16.0
 PAIR_MUL_SLOTS, PAIR_SQ_SLOTS = (3690 + 2 * 114) / 32.0, (2501 + 2 * 114) / 32.0
 PEAK_VALU_SLOTS_PER_S = 1024 / (MAD_NS_PER_SIMD * 1e-9)        # 256 CUs x 4 SIMDs, one wave-instruction per 2.07 ns per SIMD
-PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "1")) & (15 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 14)
+PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "17")) & (31 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 30)
 
 
 def modp_work(n, t, positions, cs):
