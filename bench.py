@@ -113,8 +113,8 @@ def keygen(rng: random.Random) -> int:
             return k
 
 
-PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "12"))  # boxes with GPU work pending (the engine has capi.BLOCK_SLOTS block slots)
-HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "6"))   # host threads absorbing (hashing) boxes at N=1
+PIPE_DEPTH = int(os.environ.get("MPVSS_BENCH_DEPTH", "10"))  # boxes with GPU work pending (the engine has capi.BLOCK_SLOTS block slots)
+HASH_THREADS = int(os.environ.get("MPVSS_BENCH_HASH_THREADS", "8"))   # host threads absorbing (hashing) boxes at N=1
 USE_VERIFY_MANY = os.environ.get("MPVSS_BENCH_VERIFY_MANY", "1") != "0"   # N=1: the library's own pipeline (0: Python threads)
 
 

@@ -1,13 +1,6 @@
 exec < /dev/null
-timeout 1500 bash tools/run_profiles.sh > gpurun_out/run_profiles.log 2>&1
-tail -3 gpurun_out/run_profiles.log | cut -c1-300
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_full_line.json 2> gpurun_out/prof/bench_full_err.txt
-tail -2 gpurun_out/prof/bench_full_err.txt | cut -c1-300
-python3 -c "
-import json
-d=json.load(open('gpurun_out/prof/bench_full_line.json'))
-print(d['value'], d['ms_per_step'], d.get('secondary_error'))
-print({k:(round(v['value']) if isinstance(v,dict) and 'value' in v else None) for k,v in d.items() if isinstance(v,dict)})
-print({k:round(v['value']) for k,v in d.get('configs',{}).items()})
-"
-ls gpurun_out/prof | head -30
+mkdir -p gpurun_out/r03_hash
+rm -f gpurun_out/r03_hash/ab.txt
+for rep in 1 2 3; do
+timeout 600 tools/ab_bench.sh r03_hash/ab.txt -r 1 -- h6 MPVSS_BENCH_HASH_THREADS=6 -- h12 MPVSS_BENCH_HASH_THREADS=12 -- h12_d16 MPVSS_BENCH_HASH_THREADS=12 MPVSS_BENCH_DEPTH=16 -- h8_d10 MPVSS_BENCH_HASH_THREADS=8 MPVSS_BENCH_DEPTH=10
+done

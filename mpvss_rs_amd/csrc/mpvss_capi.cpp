@@ -1999,7 +1999,7 @@ int ec_verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& 
 template <class Issue, class Finish>
 int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, Issue issue, Finish finish) {
   if (hash_threads < 1) hash_threads = 1;
-  if (hash_threads > 8) hash_threads = 8;
+  if (hash_threads > 16) hash_threads = 16;
   if (depth < 1) depth = 1;
   if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
   struct Hint {
