@@ -601,6 +601,7 @@ def main():
         cdev = commdev if smoke_one_gpu else dev
         rccl["mine"] = [torch.zeros(n_, dtype=torch.uint8, device=dev) for _ in range(rccl["ring"])]
         rccl["all"] = [torch.zeros(n_ * world, dtype=torch.uint8, device=cdev) for _ in range(rccl["ring"])]
+        torch.cuda.synchronize()      # the zero fills run on torch's stream: they must not land on top of flags a block's own stream wrote
     if world > 1:
         rccl_buffers(n)
     enq_boxes = []                  # box behind every block enqueued on this rank, in enqueue (= claim) order
@@ -1050,7 +1051,7 @@ def main():
 
         if args.config_boxes != 0 and keyset[0] is None:
             if world == 1:
-                k2, k5 = (48, 6) if args.config_boxes < 0 else (args.config_boxes, max(2, args.config_boxes // 8))
+                k2, k5 = (48, 12) if args.config_boxes < 0 else (args.config_boxes, max(2, args.config_boxes // 8))
                 only = os.environ.get("MPVSS_BENCH_CONFIGS", "c2,c5_slice").split(",")
                 result["configs"] = {}
                 if "c2" in only:
@@ -1061,9 +1062,9 @@ def main():
                                                                 "one GPU's slice of BASELINE config C5: positions 1..131072 of 1048576")
             elif world == 8 or os.environ.get("MPVSS_BENCH_C5") == "1":
                 # BASELINE config C5 itself: ONE box of world x 131072 participants, t = 1024, every rank its block
-                k5 = 6 if args.config_boxes < 0 else max(2, args.config_boxes)
+                k5 = 10 if args.config_boxes < 0 else max(2, args.config_boxes)
                 n5 = int(os.environ.get("MPVSS_BENCH_C5_N", "131072"))
-                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 4, rank * n5,
+                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 6, rank * n5,
                                            f"BASELINE config C5: {n5 * world} participants over {world} GPUs")
         # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
         if world == 1 and args.host_boxes > 0:
@@ -1189,6 +1190,7 @@ def main():
             # the block form: several batches in flight in ONE context (compute = enqueue only, absorb = wait + n verdict bytes)
             inflight, batches = 4, 12
             d_verd = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+            torch.cuda.synchronize()      # torch's zero fills must not land on top of verdicts the engine's streams write
 
             def wb_pipelined(count):
                 issued = done = 0

@@ -1,6 +1,7 @@
 exec < /dev/null
-mkdir -p gpurun_out/r03_hash
-rm -f gpurun_out/r03_hash/ab.txt
-for rep in 1 2 3; do
-timeout 600 tools/ab_bench.sh r03_hash/ab.txt -r 1 -- h6 MPVSS_BENCH_HASH_THREADS=6 -- h12 MPVSS_BENCH_HASH_THREADS=12 -- h12_d16 MPVSS_BENCH_HASH_THREADS=12 MPVSS_BENCH_DEPTH=16 -- h8_d10 MPVSS_BENCH_HASH_THREADS=8 MPVSS_BENCH_DEPTH=10
+mkdir -p gpurun_out/r03_c5
+rm -f gpurun_out/r03_c5/loop_*.txt
+for i in 1 2 3 4 5 6 7 8; do
+timeout 300 python -m pytest tests/test_gpu_bench_multirank.py -x -q -m gpu -k "c5 or four" 2>&1 | tail -80 | cut -c1-900 > gpurun_out/r03_c5/loop_$i.txt
+tail -1 gpurun_out/r03_c5/loop_$i.txt
 done

@@ -232,6 +232,7 @@ def test_ec_device_resident_positions_pick_the_path_on_the_device(engine, name):
         want = engine.ec_commit_eval(gid, cm, positions)
         d_pos = torch.tensor(positions, dtype=torch.int64, device=dev)
         d_out = torch.zeros(n * L, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()          # torch's fill runs on torch's stream, the engine's kernels on the engine's
         rc = engine.lib.mpvss_ec_commit_eval(engine.ctx, gid, capi.MPVSS_DEVICE, C.c_void_p(d_cm.data_ptr()), t,
                                              C.c_void_p(d_pos.data_ptr()), n, C.c_void_p(d_out.data_ptr()))
         engine._check(rc, "ec_commit_eval(device)")

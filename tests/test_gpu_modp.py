@@ -242,6 +242,7 @@ def test_verify_shares_block_api_keeps_batches_in_flight(engine):
         batches.append((cat(g, pks), cat(g, S), cat(g, Y), cat(g, c), cat(g, r)))
         want.append(bytes(0 if i == k else 1 for i in range(9)))
     dev = [torch.zeros(9, dtype=torch.uint8, device="cuda") for _ in batches]
+    torch.cuda.synchronize()              # torch's fills run on torch's stream, the engine's kernels on the engine's
     for b, d in zip(batches, dev):
         engine.verify_shares_compute(*b, verdicts_dev_ptr=d.data_ptr())
     with pytest.raises(capi.EngineError):          # the oldest block is a verify_share batch

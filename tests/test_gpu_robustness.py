@@ -46,6 +46,7 @@ def test_device_resident_buffers_match_host_buffers(engine):
     assert bytes(out.cpu().numpy().tobytes()) == host["X"]
     # negative position in a device array is reported, not silently computed
     d_bad = d_pos.clone(); d_bad[3] = -7
+    torch.cuda.synchronize()
     rc = engine.lib.mpvss_modp_commit_eval(engine.ctx, capi.MPVSS_DEVICE, vp(d_cm), t, vp(d_bad), n, vp(out))
     assert rc == -1
 
@@ -252,6 +253,7 @@ def test_block_wellformedness_bytes(engine):
 
     def run(pk, sh, rs):
         flags = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()      # torch's fill runs on torch's stream, the block's kernels on the slot's
         engine.verify_block_compute_flags(flat["commitments"], flat["positions"], pk, sh, rs, flat["challenge"], flags.data_ptr())
         st = engine.verify_block_absorb(capi.transcript_init())
         return list(flags.cpu().numpy()), capi.transcript_verdict(st, flat["challenge"])

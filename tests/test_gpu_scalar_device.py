@@ -25,6 +25,7 @@ def poly_eval_device(engine, coeffs, positions):
     n = len(positions)
     d_pos = torch.tensor(positions, dtype=torch.int64, device="cuda:0")
     out = torch.full((n * EB,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()          # torch's fill runs on torch's stream, the engine's kernels on the engine's
     engine.poly_eval_device(b"".join(map(fx, coeffs)), d_pos.data_ptr(), n, out.data_ptr())
     raw = bytes(out.cpu().numpy().tobytes())
     return [int.from_bytes(raw[i * EB:(i + 1) * EB], "big") for i in range(n)]
@@ -78,6 +79,7 @@ def test_dleq_responses_device_against_integers(engine):
     d_w, d_a = dev_u8(b"".join(map(fx, w))), dev_u8(b"".join(map(fx, a)))
     for c in (rng.randrange(1 << 256), rng.randrange(1 << 256) | 1, 0, 1, 2, QH, QH + 1, ORDER - 1, ORDER, 2**2048 - 1, rng.randrange(ORDER)):
         out = torch.full((n * EB,), 0x5A, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
         engine.dleq_responses_device(d_w.data_ptr(), d_a.data_ptr(), fx(c), n, out.data_ptr())
         raw = bytes(out.cpu().numpy().tobytes())
         got = [int.from_bytes(raw[i * EB:(i + 1) * EB], "big") for i in range(n)]
@@ -86,6 +88,7 @@ def test_dleq_responses_device_against_integers(engine):
             pass
     host = capi.dleq_responses(0, b"".join(map(fx, [x % ORDER for x in w])), b"".join(map(fx, a)), fx(12345))
     out = torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
     engine.dleq_responses_device(dev_u8(b"".join(map(fx, [x % ORDER for x in w]))).data_ptr(), d_a.data_ptr(), fx(12345), n, out.data_ptr())
     assert bytes(out.cpu().numpy().tobytes()) == host
 
@@ -104,6 +107,7 @@ def test_deal_compute_is_the_oracles_dealer(engine):
     d_pk, d_w = dev_u8(flat["publickeys"]), dev_u8(b"".join(map(fx, ws)))
     d_p = [torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
     cb = b"".join(map(fx, coeffs))
+    torch.cuda.synchronize()
     engine.deal_compute(cb, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[0].data_ptr())
     engine.deal_compute(cb, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[1].data_ptr())
     for k in range(2):
@@ -115,9 +119,11 @@ def test_deal_compute_is_the_oracles_dealer(engine):
         c = int.from_bytes(hashlib.sha256(digest).digest(), "big") % QH
         assert fx(c) == flat["challenge"]
         d_r = torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
         engine.dleq_responses_device(d_w.data_ptr(), d_p[k].data_ptr(), fx(c), n, d_r.data_ptr())
         assert bytes(d_r.cpu().numpy().tobytes()) == flat["responses"]
     bad = d_pos.clone(); bad[7] = -8
+    torch.cuda.synchronize()
     engine.deal_compute(cb, bad.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[0].data_ptr())
     with pytest.raises(EngineError):
         engine.distribute_absorb(capi.transcript_init(), n)
