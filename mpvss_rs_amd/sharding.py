@@ -91,6 +91,8 @@ class ShardedVerifier:
         enqueued = False
         n = len(positions)
         flags = torch.zeros(block, dtype=torch.uint8, device=self.dev) if block is not None else None
+        if flags is not None and self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)      # torch's zero fill runs on torch's stream, the engine writes on its own
         try:
             if ec_group:
                 eng.ec_verify_block_compute(ec_group, commitments, positions, pubkeys, shares, responses, challenge)
@@ -154,6 +156,8 @@ class ShardedVerifier:
         all-gathered: the per-share verdicts never visit the host before the collective."""
         n = len(r) // 32 if ec_group else len(pk) // EB
         t = torch.zeros(block, dtype=torch.uint8, device=self.dev)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)      # (as above: the fill must be done before the engine's stream writes verdicts)
         error: Optional[Exception] = None
         pre = (ec_group,) if ec_group else ()
         names = ("ec_verify_shares_compute", "ec_verify_shares_absorb", "ec_verify_shares") if ec_group else \
