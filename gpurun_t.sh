@@ -1,7 +1,10 @@
 exec < /dev/null
-mkdir -p gpurun_out/r03_c5
-rm -f gpurun_out/r03_c5/loop_*.txt
-for i in 1 2 3 4 5 6 7 8; do
-timeout 300 python -m pytest tests/test_gpu_bench_multirank.py -x -q -m gpu -k "c5 or four" 2>&1 | tail -80 | cut -c1-900 > gpurun_out/r03_c5/loop_$i.txt
-tail -1 gpurun_out/r03_c5/loop_$i.txt
-done
+mkdir -p gpurun_out/r03_final
+SECONDS=0; timeout 900 python3 bench.py > gpurun_out/r03_final/bench_default.json 2> gpurun_out/r03_final/bench_default_err.txt
+echo "bench wall seconds: $SECONDS"
+python3 -c "
+import json
+d=json.load(open('gpurun_out/r03_final/bench_default.json'))
+print(d['value'], d['steps'], d['warmup'], d['ms_per_step'], d.get('secondary_error'))
+print({k:round(v['value']) for k,v in d.get('configs',{}).items()}, round(d['host_buffers']['value']), round(d['distribute']['value']), round(d['distribute']['value_end_to_end']), round(d['extract_shares']['value']), {g:round(d['ec'][g]['value']) for g in d['ec']})
+"
