@@ -1058,13 +1058,13 @@ def main():
                     result["configs"]["c2"] = bench_shape(4096, 64, k2, int(os.environ.get("MPVSS_BENCH_C2_DEPTH", "14")), 0,
                                                           "BASELINE config C2")
                 if "c5_slice" in only:
-                    result["configs"]["c5_slice"] = bench_shape(131072, 1024, k5, 6, 0,
+                    result["configs"]["c5_slice"] = bench_shape(131072, 1024, k5, int(os.environ.get("MPVSS_BENCH_C5_DEPTH", "10")), 0,
                                                                 "one GPU's slice of BASELINE config C5: positions 1..131072 of 1048576")
             elif world == 8 or os.environ.get("MPVSS_BENCH_C5") == "1":
                 # BASELINE config C5 itself: ONE box of world x 131072 participants, t = 1024, every rank its block
                 k5 = 10 if args.config_boxes < 0 else max(2, args.config_boxes)
                 n5 = int(os.environ.get("MPVSS_BENCH_C5_N", "131072"))
-                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 6, rank * n5,
+                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 8, rank * n5,
                                            f"BASELINE config C5: {n5 * world} participants over {world} GPUs")
         # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
         if world == 1 and args.host_boxes > 0:
