@@ -1,11 +1,6 @@
 exec < /dev/null
-mkdir -p gpurun_out/r03_c5
-rm -f gpurun_out/r03_c5/depth.txt
-export MPVSS_BENCH_CONFIGS=c5_slice
-for d in 6 10 14; do
-MPVSS_BENCH_C5_DEPTH=$d timeout 400 python3 bench.py --gpus 1 --steps 2 --warmup 1 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --lone-boxes 0 --config-boxes 128 2>gpurun_out/r03_c5/err.txt | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-c = d['configs']['c5_slice']
-print('depth $d', round(c['value']), round(c['ms_per_box'], 1), c['boxes'], round(c['compute']['frac'], 3), c['host_ms_per_box'], d.get('secondary_error'))" | tee -a gpurun_out/r03_c5/depth.txt
+mkdir -p gpurun_out/r03_hash
+rm -f gpurun_out/r03_hash/ab3.txt
+for rep in 1 2 3; do
+timeout 900 tools/ab_bench.sh r03_hash/ab3.txt -r 1 -- h8_d10 MPVSS_BENCH_DEPTH=10 -- h8_d8 MPVSS_BENCH_DEPTH=8 -- h8_d6 MPVSS_BENCH_DEPTH=6 -- h8_d5 MPVSS_BENCH_DEPTH=5
 done
