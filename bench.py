@@ -664,6 +664,15 @@ def main():
             return seq, None
         return seq, capi.transcript_verdict(state, bx.challenge)
 
+    # Boxes in flight per rank when the blocks are driven from here (N > 1): a box stays in flight until its transcript is
+    # absorbed, and on rank g that waits for the g ranks before it (40 ms of SHA-256 each) on top of the GPU work -- with the
+    # N = 1 figure of 8 the later ranks of an eight-rank box would run dry (8 boxes per ~0.8 s of latency).  One more box per
+    # 58 ms of chain latency; an explicit MPVSS_BENCH_DEPTH is taken as it is.
+    if "MPVSS_BENCH_DEPTH" in os.environ:
+        RANK_DEPTH = min(PIPE_DEPTH, 8)
+    else:
+        RANK_DEPTH = min(8 + (7 * (world - 1) + 9) // 10 + (2 if world > 1 else 0), capi.BLOCK_SLOTS - max(HASH_THREADS, 1) - 4)
+
     def run_steps_many(seq_boxes, depth):
         """N = 1: complete verifications of the given boxes in ONE library call (mpvss_modp_verify_many): the calling thread
         enqueues the GPU work of up to `depth` boxes ahead, HASH_THREADS library threads absorb (wait for and hash)
@@ -691,7 +700,7 @@ def main():
             res = run_steps_many(seq_boxes, min(depth or PIPE_DEPTH, capi.BLOCK_SLOTS))
             return [(v, d, bx) for (v, d), bx in zip(res, seq_boxes)]
         # absorbing threads hold the oldest blocks, so leave them slack in the ring of block slots
-        depth = min(depth or min(PIPE_DEPTH, 8), capi.BLOCK_SLOTS - max(HASH_THREADS, 1))
+        depth = min(depth or RANK_DEPTH, capi.BLOCK_SLOTS - max(HASH_THREADS, 1))
         results = []
         issued = 0
         seq0 = len(enq_boxes)
@@ -741,7 +750,7 @@ def main():
     # and must not fall into the timed region when W is smaller than the number of boxes in flight.
     # (slots are reused most-recently-released first, so the pass enqueues as many boxes AT ONCE as the pipeline can
     # ever have in flight: boxes with GPU work pending + boxes being hashed + slack)
-    slot_init = min((PIPE_DEPTH if (world == 1 and USE_VERIFY_MANY) else min(PIPE_DEPTH, 8)) + max(HASH_THREADS, 1) + 4,
+    slot_init = min((PIPE_DEPTH if (world == 1 and USE_VERIFY_MANY) else RANK_DEPTH) + max(HASH_THREADS, 1) + 4,
                     capi.BLOCK_SLOTS - 1)
     gate(run_steps(slot_init, depth=slot_init), "slot initialisation")
     if args.warmup > 0:
@@ -873,7 +882,7 @@ def main():
                                 "sha256_transcript": pst["hash_ms"] / nb},
                  "hash_threads": max(HASH_THREADS, 1),
                  "boxes_in_flight": (min(PIPE_DEPTH, capi.BLOCK_SLOTS) if (world == 1 and USE_VERIFY_MANY)
-                                     else min(PIPE_DEPTH, 8, capi.BLOCK_SLOTS - max(HASH_THREADS, 1))),
+                                     else min(RANK_DEPTH, capi.BLOCK_SLOTS - max(HASH_THREADS, 1))),
                  "pipeline": ("mpvss_modp_verify_many (library threads; boxes_in_flight = boxes with GPU work pending)"
                               if (world == 1 and USE_VERIFY_MANY)
                               else "verify_block_compute / block_claim / absorb_claimed from a Python thread pool"
@@ -1064,7 +1073,7 @@ def main():
                 # BASELINE config C5 itself: ONE box of world x 131072 participants, t = 1024, every rank its block
                 k5 = 10 if args.config_boxes < 0 else max(2, args.config_boxes)
                 n5 = int(os.environ.get("MPVSS_BENCH_C5_N", "131072"))
-                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 8, rank * n5,
+                result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 12, rank * n5,
                                            f"BASELINE config C5: {n5 * world} participants over {world} GPUs")
         # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
         if world == 1 and args.host_boxes > 0:
