@@ -21,6 +21,9 @@
 // them; the rows of both constant matrices are ordered for that (tools/mfma_mont/model.py, which also proves every bound).
 // Exactness: model.py runs the same integer pipeline (signed digits, C-init corrections, v_k, guard, bias) with assertions.
 #pragma once
+#ifndef MM_REDUCE_PRIO
+#define MM_REDUCE_PRIO 1      // wave priority while a wave is in reduce(): measured +1-2 % in the headline pipeline (profiles/r03_pair_occupancy_ab.txt), inside the noise
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -149,6 +152,9 @@ __device__ __forceinline__ void phase_a(u64 (&T)[LP], const u32 (&a)[LP], u32* s
 
 __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* slot, const Tables* tb, const PairLane& pl) {
   __builtin_amdgcn_sched_barrier(0);
+#if MM_REDUCE_PRIO > 0
+  __builtin_amdgcn_s_setprio(MM_REDUCE_PRIO);          // the wave that is in its MFMA chains issues ahead of the one in its VALU rows
+#endif
   // ---------------- GEMM 1: m'' = T_lo * N' (mod R) --------------------------------------------------------------------
   // Software pipeline, one stage per row tile: the (dependent) MFMA chain of tile R runs on the matrix pipe while the VALU
   // does the epilogue of tile R-1; a scheduling barrier between the stages keeps the compiler from unrolling the whole GEMM
@@ -245,6 +251,9 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
   }
   epi2(7, acc[0]);
   __builtin_amdgcn_sched_barrier(0);
+#if MM_REDUCE_PRIO > 0
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // ---------------- final pass: carry-propagate inside the half, hand half 0's carry to half 1 -----------------------
   u64 c = 0;
 #pragma unroll
