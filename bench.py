@@ -354,7 +354,8 @@ def sliding_windows(c):
 QUAD_MUL_SLOTS, QUAD_SQ_SLOTS = (72 * 41 + 110) / 16.0, (72 * 32.5 + 110) / 16.0
 PAIR_MUL_SLOTS, PAIR_SQ_SLOTS = (3690 + 2 * 114) / 32.0, (2501 + 2 * 114) / 32.0
 PEAK_VALU_SLOTS_PER_S = 1024 / (MAD_NS_PER_SIMD * 1e-9)        # 256 CUs x 4 SIMDs, one wave-instruction per 2.07 ns per SIMD
-PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "17")) & (31 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 30)
+PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "49")) & (63 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 62)
+FD_PAIR_MIN_T = int(os.environ.get("MPVSS_FD_PAIR_MIN_T", "512"))     # from this many commitments the X path steps in the pair layout
 
 
 def modp_work(n, t, positions, cs):
@@ -382,12 +383,14 @@ def modp_work(n, t, positions, cs):
             seed_work = horner_modmuls(positions[chains * w0:chains * w0 + m0], t)
             seed_txt = f"{m0} Horner seeds"
         mm_x = seed_work + inv_tree_products(m0) + chains * t * (t - 1) + chains * t * steps + n
+        if (PAIR_MASK & 32) and t >= FD_PAIR_MIN_T:          # the stepping products (both levels) run in the pair layout
+            mul_n["x_pair"] = chains * t * steps + (t * (m0 - 1) if two_level else 0)
         x_path = (f"forward differences: {chains} strided chains stepping both ways from {m0} seeds in their middle "
                   f"(also outputs; {seed_txt}), inverses by simultaneous inversion, {steps} lock-step products per chain and level")
     else:
         mm_x = horner_modmuls(positions, t) + n
         x_path = "Horner in the exponent"
-    mul_n["x"] = mm_x                                          # (Horner's squarings are folded in at SQ_COST: a few % of the X path)
+    mul_n["x"] = mm_x - mul_n.get("x_pair", 0.0)               # (Horner's squarings are folded in at SQ_COST: a few % of the X path)
     comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
     gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
     w6 = os.environ.get("MPVSS_A2_W6", "1") != "0" and n >= 1024   # 6-bit windows for y^r (64-entry table) or 4-bit
@@ -413,7 +416,7 @@ def modp_work(n, t, positions, cs):
             d[key] /= k
     mm_total = sum(mul_n.values()) + SQ_COST * sum(sq_n.values())
     pair_bit = {"a2": 1, "tab": 2, "a1": 8}                     # MPVSS_PAIR bits (g^r, bit 2, is counted with a1)
-    slots = 0.0
+    slots = mul_n.get("x_pair", 0.0) * PAIR_MUL_SLOTS
     for key in ("x", "a1", "a2", "tab"):
         pair = bool(PAIR_MASK & pair_bit.get(key, 0)) and n >= 16
         slots += sq_n[key] * (PAIR_SQ_SLOTS if pair else QUAD_SQ_SLOTS) + mul_n[key] * (PAIR_MUL_SLOTS if pair else QUAD_MUL_SLOTS)

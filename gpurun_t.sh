@@ -1,10 +1,3 @@
 exec < /dev/null
-timeout 1500 bash tools/run_profiles.sh > gpurun_out/run_profiles.log 2>&1
-tail -2 gpurun_out/run_profiles.log | cut -c1-200
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_full_line.json 2> gpurun_out/prof/bench_full_err.txt
-python3 -c "
-import json
-d=json.load(open('gpurun_out/prof/bench_full_line.json'))
-print(d['value'], d['ms_per_step'], d.get('secondary_error'), d['roofline']['kernel_ms'], d['compute']['frac'])
-print({k:round(v['value']) for k,v in d.get('configs',{}).items()}, round(d['host_buffers']['value']), round(d['distribute']['value']), round(d['distribute']['value_end_to_end']), round(d['extract_shares']['value']), {g:round(d['ec'][g]['value']) for g in d['ec']}, round(d['verify_share']['value']), round(d['registered_keys']['value']))
-"
+mkdir -p gpurun_out/r03_fdpair
+timeout 1500 python -m pytest tests/test_gpu_fd.py -x -q -m gpu --durations=5 2>&1 | tail -14 | cut -c1-300

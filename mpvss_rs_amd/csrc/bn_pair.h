@@ -95,16 +95,19 @@ __device__ __forceinline__ void swap32(u32& a, u32& b) {
 //   a     : this lane's 36 limbs of the first operand
 //   slot  : LDS slot of THIS number holding the 72 limbs of b (SQ: a copy of a); it is overwritten with T_lo's operand words
 //   junk  : 72 LDS words any lane of half 1 may scribble on
+//   bsrc  : where b is read from -- the number's own slot, or (forward-difference stepping) the slot of the NEXT number of the
+//           wave: every lane reads b two 16-byte chunks ahead of the row whose retired limb it writes, and the lanes of a wave
+//           run in step, so a neighbour's slot is read before its owner overwrites it
 template <bool SQ>
-__device__ __forceinline__ void phase_a(u64 (&T)[LP], const u32 (&a)[LP], u32* slot, u32* junk, const PairLane& pl) {
+__device__ __forceinline__ void phase_a(u64 (&T)[LP], const u32 (&a)[LP], u32* slot, u32* junk, const PairLane& pl, const u32* bsrc) {
 #pragma unroll
   for (int k = 0; k < LP; ++k) T[k] = 0;
   u32* xs = pl.h ? junk : slot;           // where this lane's retired limb goes (only half 0 retires limbs of T_lo)
   // b is read four limbs at a time, two chunks (8 rows) ahead: the late rows of a squaring are short (a handful of mads),
   // a single-limb prefetch one row ahead would expose the LDS latency there
   v4i bq[3];
-  bq[0] = *reinterpret_cast<const v4i*>(slot);
-  bq[1] = *reinterpret_cast<const v4i*>(slot + 4);
+  bq[0] = *reinterpret_cast<const v4i*>(bsrc);
+  bq[1] = *reinterpret_cast<const v4i*>(bsrc + 4);
   // ---------------- phase A: T = a * b, one limb of b per row --------------------------------------------------------
   // Retiring a column is a chain of dependent instructions; it is written BETWEEN the products of the next row (all but
   // the one into the fresh column), so that the compiler can interleave the two: the late rows of a squaring have only a
@@ -131,7 +134,7 @@ __device__ __forceinline__ void phase_a(u64 (&T)[LP], const u32 (&a)[LP], u32* s
       const int i = o * LP + rr;
       if ((rr & 3) == 0) {
         const int nxt = i / 4 + 2;
-        bq[(rr / 4 + 2) % 3] = *reinterpret_cast<const v4i*>(slot + 4 * (nxt < L / 4 ? nxt : L / 4 - 1));
+        bq[(rr / 4 + 2) % 3] = *reinterpret_cast<const v4i*>(bsrc + 4 * (nxt < L / 4 ? nxt : L / 4 - 1));
       }
       const u32 bi = (u32)bq[(rr / 4) % 3][rr & 3];
       const u32 bi2 = bi << 1;
@@ -272,6 +275,10 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
   r[1] += (u32)(v0 >> W);
 }
 
+template <bool SQ>
+__device__ __forceinline__ void phase_a(u64 (&T)[LP], const u32 (&a)[LP], u32* slot, u32* junk, const PairLane& pl) {
+  phase_a<SQ>(T, a, slot, junk, pl, slot);
+}
 template <bool SQ>
 __device__ __forceinline__ void mont_pair(u32 (&r)[LP], const u32 (&a)[LP], u32* slot, u32* junk, const Tables* tb,
                                           const PairLane& pl) {

@@ -496,6 +496,127 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
 }
 
 // ---------------------------------------------------------------------------------------
+// Forward-difference stepping (k_modp_fd_step of modp_kernels.hip: D_k <- D_k * D_(k+1), output D_0) on the pair layout: a
+// pipeline stage is one wave = 32 consecutive levels of a chain, level k multiplies by level k + 1 -- the NEXT number of the
+// wave, whose LDS slot phase A reads directly (bn_pair.h) -- and the top level of a stage by the number the stage above hands
+// down through HBM (same self-validating words, tags and time-out as the quad kernel).  Same state arrays and outputs; the
+// stages of a chain are counted in 32s here (tpad = t rounded up to a power of two >= 32).  One wave per workgroup, as the
+// quad pipelines: a waiting stage only ever waits for workgroups dispatched before it.
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr u32 FD_VALID = 0x80000000u, FD_POISON = 0x40000000u;
+constexpr long long FD_TIMEOUT = 200000000LL;          // 2 s of the 100 MHz wall clock
+struct FdShared {
+  Tables tb;
+  __attribute__((aligned(16))) u32 slots[32 * SLOTW];
+  __attribute__((aligned(16))) u32 inslot[SLOTW];
+  __attribute__((aligned(16))) u32 oneslot[SLOTW];
+  u32 junk[L];
+};
+__device__ __forceinline__ void fd_publish(u32* __restrict__ dst, const u32 (&a)[LP], const PairLane& pl, u32 tag) {
+#pragma unroll
+  for (int i = 0; i < LP; ++i) __hip_atomic_store(dst + LP * pl.h + i, a[i] | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// number 31 of the wave (lanes 31 and 63) waits for one number from the stage above and puts it into `dst`; false
+// (wave-uniform) when the input was poisoned or the wait timed out
+__device__ __forceinline__ bool fd_receive(const u32* __restrict__ src, u32* dst, bool reader, const PairLane& pl) {
+  bool ok = true;
+  if (reader) {
+    u32 v[LP];
+    const long long t0 = wall_clock64();
+    while (true) {
+      u32 all = 0xffffffffu, any = 0;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        v[i] = __hip_atomic_load(src + LP * pl.h + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        all &= v[i];
+        any |= v[i];
+      }
+      const u32 st = (any & FD_POISON) ? FD_POISON : (all & FD_VALID);
+      const uint64_t both = (1ull << 31) | (1ull << 63);
+      const uint64_t good = __builtin_amdgcn_ballot_w64(st == FD_VALID) & both;
+      const uint64_t bad = __builtin_amdgcn_ballot_w64(st == FD_POISON) & both;
+      if (good == both) break;
+      if (bad != 0 || wall_clock64() - t0 > FD_TIMEOUT) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (int i = 0; i < LP; ++i) dst[LP * pl.h + i] = v[i] & 0x3fffffffu;
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(64) PAIR_OCC_ATTR
+k_modp_fd_step_pair(const u32* __restrict__ state, const u32* __restrict__ state_back, int chains, int t, int tpad, int w0,
+                    int chain_len, int count, u32* __restrict__ x_m, u32* __restrict__ hand, int* __restrict__ gate,
+                    int inject_fault, const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab, size_t box_state,
+                    size_t box_xm, size_t box_hand) {
+  __shared__ FdShared sh;
+  if (*gate != 1) return;
+  state += blockIdx.y * box_state;
+  state_back += blockIdx.y * box_state;
+  x_m += blockIdx.y * box_xm;
+  hand += blockIdx.y * box_hand;
+  const int stages = tpad / 32;
+  const int sidx = blockIdx.x / (2 * chains);                       // 0 = the top levels
+  const int dir = (blockIdx.x / chains) & 1;
+  const int chain = blockIdx.x % chains;
+  const int kbase = tpad - 32 * (sidx + 1);
+  if (kbase >= t || (dir == 1 && w0 == 0)) return;
+  tables_to_lds(&sh.tb, gtab);
+  __builtin_amdgcn_s_setprio(3);       // latency-critical and few: issue ahead of the wide kernels sharing the SIMD
+  const PairLane pl = make_pair_lane();
+  const int j = (int)(pl.lane & 31);
+  const int steps = dir == 0 ? chain_len - 1 - w0 : w0 + t - 1;
+  const int hand_len = chain_len + t;
+  const int k = kbase + j;
+  const bool has_up = kbase + 32 < t;
+  const bool has_down = kbase > 0;
+  u32* slot = sh.slots + j * SLOTW;
+  const bool reader = j == 31;
+  const u32* bsrc = (k + 1 < t) ? (reader ? sh.inslot : slot + SLOTW) : sh.oneslot;
+  const size_t lane_area = ((size_t)dir * chains + chain) * stages;
+  u32* mine = hand + (lane_area + sidx) * (size_t)hand_len * L;
+  const u32* up = hand + (lane_area + sidx - 1) * (size_t)hand_len * L;
+  const u32* st = (dir == 0 ? state : state_back) + (size_t)chain * t * L;
+  u32 D[LP];
+  if (k < t) load_pair_limbs(D, st + (size_t)k * L, pl); else load_pair_limbs(D, cs->one_m, pl);
+  if (j == 0) slot_fill_pair(sh.oneslot, cs->one_m, pl);
+  if (has_up && reader) slot_fill_pair(sh.inslot, st + (size_t)(kbase + 32) * L, pl);        // step 0 of the stage above
+  const bool writer = kbase == 0 && j == 0;
+  for (int step = 1; step <= steps; ++step) {
+    slot_store_pair(slot, D, pl);
+    const bool faulty = (inject_fault == 1 && !has_up && dir == 0 && chain == 0 && step == 5) ||
+                        (inject_fault == 2 && dir == 1 && chain == chains - 1 && sidx == (stages > 1 ? 1 : 0) && step == 40);
+    if (faulty) {
+      if (threadIdx.x == 0) *gate = 0;
+      if (has_down && j == 0) fd_publish(mine + (size_t)step * L, D, pl, FD_POISON);
+      return;
+    }
+    if (has_up && step > 1) {
+      if (!fd_receive(up + (size_t)(step - 1) * L, sh.inslot, reader, pl)) {
+        if (threadIdx.x == 0) *gate = 0;
+        if (has_down && j == 0) fd_publish(mine + (size_t)step * L, D, pl, FD_POISON);
+        return;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    u64 T[LP];
+    phase_a<false>(T, D, slot, sh.junk, pl, bsrc);
+    u32 r[LP];
+    reduce(r, T, slot, &sh.tb, pl);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < LP; ++i) D[i] = r[i];
+    if (has_down && j == 0) fd_publish(mine + (size_t)step * L, D, pl, FD_VALID);
+    const int jj = dir == 0 ? w0 + step : w0 + t - 1 - step;
+    const size_t idx = (size_t)chain + (size_t)chains * jj;
+    if (writer && step >= t && idx < (size_t)count) store_pair_limbs(x_m + idx * L, D, pl);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 extern "C" int modp_pair_tables_upload(void** dev_tables) {
   static_assert(sizeof(MM_GT1) == sizeof(Tables::gt1) && sizeof(MM_GT2) == sizeof(Tables::gt2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
                     sizeof(MM_C2) == sizeof(Tables::c2), "generated tables do not match bn_pair.h");
@@ -560,4 +681,20 @@ extern "C" int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* 
                      occupancy, curbuf, (const ModpConsts*)cs, (const Tables*)pair_tables);
   if (hipGetLastError() != hipSuccess) return 1;
   return modp_launch_bucket_combine(buckets, occupancy, count, out1, out2, cs, s);
+}
+
+extern "C" int modp_fd_tpad_pair(int t) {
+  int p = 32;
+  while (p < t) p <<= 1;
+  return p;
+}
+extern "C" int modp_launch_fd_step_pair_boxes(const uint32_t* state, const uint32_t* state_back, size_t box_state, int chains, int t,
+                                              int w0, int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand,
+                                              size_t box_hand, int boxes, int* gate, int inject_fault, const void* cs,
+                                              const void* pair_tables, hipStream_t s) {
+  const int tpad = modp_fd_tpad_pair(t);
+  hipLaunchKernelGGL(k_modp_fd_step_pair, dim3(2 * chains * (tpad / 32), boxes), dim3(64), 0, s, state, state_back, chains, t, tpad, w0,
+                     chain_len, count, x_m, hand, gate, inject_fault, (const ModpConsts*)cs, (const Tables*)pair_tables, box_state,
+                     box_xm, box_hand);
+  return (int)hipGetLastError();
 }

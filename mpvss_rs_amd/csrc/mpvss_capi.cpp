@@ -867,9 +867,24 @@ bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
 
 // boxes > 1: a GROUP of same-shaped boxes in one set of launches -- box b has its commitments at w.cm + b * t rows, its `cnt`
 // positions at dpos + b * box_positions (0: the boxes share one array) and its X at dX + b * cnt rows; one flag for the group.
+int pair_mask();     // which kernels take the pair layout (below)
 int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX, size_t boxes = 1,
            size_t box_positions = 0) {
   const int B = (int)boxes;
+  // The stepping kernels on the pair layout (MPVSS_PAIR bit 5) from MPVSS_FD_PAIR_MIN_T commitments: stages of 32 levels, 122
+  // instead of 191 issue slots per product, but half as many waves with longer steps.  Measured (profiles/r03_fd_pair_ab.txt):
+  // one GPU's slice of C5 (131072, 1024), where the stepping is a third of the work, 0.60 -> 0.69 M share verifications/s;
+  // the headline shape (t = 256) within noise, if anything slower (1.08 against 1.11 M): its X path is latency, not issue.
+  static const size_t pair_min_t = (size_t)fd_env("MPVSS_FD_PAIR_MIN_T", 512);
+  const bool step_pair = (pair_mask() & 32) != 0 && t >= pair_min_t;
+  auto launch_step = [&](const uint32_t* sf, const uint32_t* sb, size_t bx_st, int chains, int tt, int w0_, int clen, int cnt_, uint32_t* xm_,
+                         size_t bx_xm_, uint32_t* hand_, size_t bx_hand_, int fault) -> int {
+    if (step_pair)
+      return modp_launch_fd_step_pair_boxes(sf, sb, bx_st, chains, tt, w0_, clen, cnt_, xm_, bx_xm_, hand_, bx_hand_, B, (int*)ctx->w->fd_flag.p,
+                                            fault, ctx->consts, ctx->pair_tables, ctx->stream);
+    return modp_launch_fd_step_boxes(sf, sb, bx_st, chains, tt, w0_, clen, cnt_, xm_, bx_xm_, hand_, bx_hand_, B, (int*)ctx->w->fd_flag.p, fault,
+                                     ctx->consts, ctx->stream);
+  };
   static const int fd_chains_env = fd_env("MPVSS_FD_CHAINS", 0);
   const bool fd = fd_applies(t, hpos, cnt);
   if (!fd) {
@@ -1025,9 +1040,8 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
     LAUNCHCHK(ctx, modp_launch_fd_table_boxes(xseed, bx_xm, (const uint32_t*)w.fd_xinv.p, t * MODP_L, 1, (int)t, state_fwd, state_bwd,
                                               bx_state, (uint32_t*)((uint8_t*)w.fd_hand_t.p + hand_t), bx_hand_t, B, flag, 0,
                                               ctx->consts, ctx->stream));
-    LAUNCHCHK(ctx, modp_launch_fd_step_boxes(state_fwd, state_bwd, bx_state, 1, (int)t, 0, m0, m0, xseed, bx_xm,
-                                             (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), bx_hand_s, B, flag,
-                                             inject_fault == 3 ? 1 : 0, ctx->consts, ctx->stream));
+    LAUNCHCHK(ctx, launch_step(state_fwd, state_bwd, bx_state, 1, (int)t, 0, m0, m0, xseed, bx_xm,
+                               (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), bx_hand_s, inject_fault == 3 ? 1 : 0));
   } else {
     LAUNCHCHK(ctx, modp_launch_commit_eval_boxes((const uint32_t*)w.cm.p, (int)t, dpos + seed0, box_positions, m0, B, xseed, nullptr,
                                                  cnt, flag, 1, ctx->consts, ctx->stream));
@@ -1040,8 +1054,8 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   LAUNCHCHK(ctx, modp_launch_fd_table_boxes(xseed, bx_xm, (const uint32_t*)w.fd_xinv.p, (size_t)m0 * MODP_L, S, (int)t, state_fwd,
                                             state_bwd, bx_state, (uint32_t*)w.fd_hand_t.p, bx_hand_t, B, flag, inject_fault, ctx->consts,
                                             ctx->stream));
-  LAUNCHCHK(ctx, modp_launch_fd_step_boxes(state_fwd, state_bwd, bx_state, S, (int)t, w0, chain_len, (int)cnt, xm, bx_xm,
-                                           (uint32_t*)w.fd_hand_s.p, bx_hand_s, B, flag, inject_fault, ctx->consts, ctx->stream));
+  LAUNCHCHK(ctx, launch_step(state_fwd, state_bwd, bx_state, S, (int)t, w0, chain_len, (int)cnt, xm, bx_xm, (uint32_t*)w.fd_hand_s.p,
+                             bx_hand_s, inject_fault));
   LAUNCHCHK(ctx, modp_launch_from_mont(xm, B * (int)cnt, dX, flag, ctx->consts, ctx->stream));
   // fallback: plain Horner when the flag was cleared
   LAUNCHCHK(ctx, modp_launch_commit_eval_boxes((const uint32_t*)w.cm.p, (int)t, dpos, box_positions, (int)cnt, B, nullptr, dX, cnt, flag,
@@ -1085,13 +1099,14 @@ namespace {
 // MPVSS_PAIR: which kernels of the verifier's block path take the pair layout (bit 0: a2 = y^r Y^c, bit 1: the window tables,
 // bit 2: g^r through the wide comb, bit 3: a1 = g^r X^c, bit 4: the bucket phase of the dealer's / participant's twin
 // exponentiation -- 58.6 against 87.8 ms per 65536 shares alone on the chip, dealer 0.85 -> 0.92 M shares/s,
-// profiles/r03_dealer_ab.txt).  Default 17: a2 and the twin exponentiation.  A pair wave (230 VGPRs, two per SIMD at
+// profiles/r03_dealer_ab.txt; bit 5: the forward-difference stepping kernels of the X path when t >= MPVSS_FD_PAIR_MIN_T,
+// eval_x).  Default 49: a2, the twin exponentiation and the stepping of large thresholds.  A pair wave (230 VGPRs, two per SIMD at
 // most) leaves its SIMD idle while it waits for its MFMA chains and LDS reads; the quad kernels' waves (135 VGPRs) of the
 // other boxes in flight fill those gaps.  With every wide kernel in the pair layout there is nothing left to fill them:
 // measured on one box 1.063 M share verifications/s for a2 alone, 1.044 M with the tables, 1.022 M with all four,
 // 0.942 M with none (profiles/r03_pair_ab.txt).  MPVSS_A2_PAIR=0 clears bit 0 (older switch).
 int pair_mask() {
-  static const int m = fd_env("MPVSS_PAIR", 17) & (fd_env("MPVSS_A2_PAIR", 1) ? 31 : 30);
+  static const int m = fd_env("MPVSS_PAIR", 49) & (fd_env("MPVSS_A2_PAIR", 1) ? 63 : 62);
   return m;
 }
 int launch_table_odd(mpvss_ctx* ctx, const uint8_t* base_dev, size_t cnt, uint32_t* tab) {

@@ -50,23 +50,26 @@ def test_fd_equals_horner():
     a = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_MIN_SHARES": "2048", "CHECK_ORACLE": "1"})
     b = run(CASES, {"MPVSS_FD": "0"})
     c = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_L1": "0", "MPVSS_FD_MIN_SHARES": "2048"})
+    # the stepping kernels on the pair layout (stages of 32 levels; by default only from t = 512) for every case
+    d = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_MIN_SHARES": "2048", "MPVSS_FD_PAIR_MIN_T": "16"})
     assert len(a) == len(CASES) and all(len(h) == 64 for h in a)
-    for case, ha, hb, hc in zip(CASES, a, b, c):
-        assert ha == hb == hc, case
+    for case, ha, hb, hc, hd in zip(CASES, a, b, c, d):
+        assert ha == hb == hc == hd, case
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4", "1p", "2p", "3p"])
 def test_a_stage_that_gives_up_falls_back_to_horner(mode):
     """MPVSS_FD_TEST_FAULT makes one pipeline stage behave as if its wait had timed out (1: top stage of the first
     forward stepping chain, 2: a middle stage of the last backward chain, 3: a stage of the stride-1 seeding chain,
     4: the top stage of the table pipeline): it clears the device flag and poisons its output; the stages below must
     give up at once and the gated Horner launch must produce every X."""
     case = [(64, 8192, 1, "")]
+    pair = {"MPVSS_FD_PAIR_MIN_T": "16"} if mode.endswith("p") else {}      # "p": the pair-layout stepping kernel's stages
     t0 = time.time()
     b = run(case, {"MPVSS_FD": "0"})
     ref = time.time() - t0
     t0 = time.time()
-    a = run(case, {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_TEST_FAULT": mode})
+    a = run(case, dict({"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_TEST_FAULT": mode.rstrip("p")}, **pair))
     took = time.time() - t0
     assert a == b and len(a[0]) == 64
     # poisoned stages must give up at once, not wait for their 2 s timeouts one after the other (16 stages per chain)
