@@ -1063,7 +1063,7 @@ def main():
 
         if args.config_boxes != 0 and keyset[0] is None:
             if world == 1:
-                k2, k5 = (96, 12) if args.config_boxes < 0 else (args.config_boxes, max(2, args.config_boxes // 8))
+                k2, k5 = (192, 20) if args.config_boxes < 0 else (args.config_boxes, max(2, args.config_boxes // 8))
                 only = os.environ.get("MPVSS_BENCH_CONFIGS", "c2,c5_slice").split(",")
                 result["configs"] = {}
                 if "c2" in only:

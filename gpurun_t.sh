@@ -1,11 +1,11 @@
 exec < /dev/null
-mkdir -p gpurun_out/r03_fdpair
-rm -f gpurun_out/r03_fdpair/t512.txt
-for rep in 1 2; do
-for v in 512 100000; do
-MPVSS_FD_PAIR_MIN_T=$v timeout 400 python3 bench.py --gpus 1 --steps 12 --warmup 3 --threshold 512 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --lone-boxes 0 --config-boxes 0 2>gpurun_out/r03_fdpair/err.txt | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-print('t=512 pair_min_t $v', round(d['value']), round(d['ms_per_step'], 2), d.get('secondary_error'))" | tee -a gpurun_out/r03_fdpair/t512.txt
-done
-done
+mkdir -p gpurun_out/r03_final
+SECONDS=0
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_final/bench_full_line.json 2> gpurun_out/r03_final/bench_full_err.txt
+echo "wall $SECONDS s"
+python3 -c "
+import json
+d=json.load(open('gpurun_out/r03_final/bench_full_line.json'))
+print(d['value'], d['ms_per_step'], d.get('secondary_error'), d['roofline']['kernel_ms'], d['compute']['frac'])
+print({k:(round(v['value']), round(v['compute']['frac'],3), v['boxes']) for k,v in d.get('configs',{}).items()}, round(d['host_buffers']['value']), round(d['distribute']['value']), round(d['distribute']['value_end_to_end']), round(d['extract_shares']['value']), {g:round(d['ec'][g]['value']) for g in d['ec']}, round(d['verify_share']['value']), round(d['registered_keys']['value']))
+"
