@@ -130,6 +130,26 @@ def test_c2_boxes_grouped_into_one_block(engine):
     assert after[1] - before[1] == 2              # the group with the swapped box fell back (once per run), no other block did
 
 
+def test_grouped_boxes_with_a_large_threshold(engine):
+    """A group whose threshold is large enough for the pair-layout stepping kernel (t >= 512: k_modp_fd_step_pair with the
+    box as blockIdx.y): three (8192, 512) boxes of two dealers, one of them with a flipped commitment bit, against one
+    verify_distribution per box and the dealers' digests."""
+    b0, b1 = make_modp_box(engine, 8192, 512, 80), make_modp_box(engine, 8192, 512, 81)
+    as_box = lambda b, **kw: dict({"commitments": b["cm"], "positions": b["pos"], "pubkeys": b["pk"], "shares": b["Y"],
+                                   "responses": b["r"], "challenge": b["c"]}, **kw)
+    cm = bytearray(b1["cm"]); cm[300 * EB + 200] ^= 2
+    boxes = [as_box(b0), as_box(b1), as_box(b1, commitments=bytes(cm)), as_box(b0)]
+    one = lambda b: (lambda r: (r["verdict"], r["digest"]))(engine.verify_distribution(
+        b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
+    want = [one(b) for b in boxes[:3]] + [None]
+    want[3] = want[0]
+    assert want[0] == (True, b0["d"]["digest"]) and want[1] == (True, b1["d"]["digest"]) and want[2][0] is False
+    before = engine.fd_stats()
+    assert engine.verify_many(boxes, depth=4, hash_threads=2) == want
+    after = engine.fd_stats()
+    assert after[1] == before[1]                 # no fallback: the forward-difference pipelines held
+
+
 def test_grouped_boxes_in_device_memory_with_a_negative_position(engine):
     """Groups of boxes handed over in HBM (what bench.py's `configs.c2` times): positions are only looked at when the block
     is absorbed -- a negative one costs its own box (verdict False, zero digest; the reference would panic) and nothing
