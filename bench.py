@@ -1264,6 +1264,13 @@ def main():
             t_sync = time.perf_counter()
             eng.distribute(commitments, positions, pubkeys, pv_bytes, wit_bytes)
             deal_s = time.perf_counter() - t_sync
+            # the whole dealer in one call from host buffers (P(i), group work, digest, challenge, responses)
+            coeff_bytes0 = b"".join(fx(a) for a in coeffs)
+            eng.deal(coeff_bytes0, positions, pubkeys, wit_bytes)
+            t_one = time.perf_counter()
+            one = eng.deal(coeff_bytes0, positions, pubkeys, wit_bytes)
+            deal_one_s = time.perf_counter() - t_one
+            assert one["digest"] == dealer_digest and one["responses"] == responses and one["Y"] == shares, "mpvss_modp_deal differs"
             t_s = time.perf_counter()
             pv2 = capi.poly_eval(0, b"".join(fx(a) for a in coeffs), positions)
             rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)
@@ -1352,6 +1359,7 @@ def main():
             assert bytes(d_rs[0].cpu().numpy().tobytes()) == responses, "device scalar side differs from the Python integers"
             result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
                                     "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
+                                    "value_one_call_host_buffers_end_to_end": n / deal_one_s,
                                     "scalar_side_ms_per_box": scalar_s * 1e3, "scalar_side_on_device_ms_per_box": scalar_dev_s * 1e3,
                                     "value_end_to_end": n / e2e_s, "end_to_end_ms_per_box": e2e_s * 1e3,
                                     "value_end_to_end_host_scalars": n / e2e_host_s,
@@ -1359,7 +1367,8 @@ def main():
                                             "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
                                             "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
                                             "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
-                                            "PCIe included); scalar_side: P(i) and the responses for one box through "
+                                            "PCIe included); `value_one_call_host_buffers_end_to_end`: one mpvss_modp_deal call (P(i), group "
+                                            "work, digest, challenge, responses; host buffers, includes the ctypes marshalling of 64 MB); scalar_side: P(i) and the responses for one box through "
                                             "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`; `value_end_to_end`: "
                                             "every box with its own polynomial -- P(i) mod (q-1) and the responses on the device "
                                             "(mpvss_modp_poly_eval_device / _dleq_responses_device: residues mod (q-1)/2 in the Montgomery "

@@ -1,2 +1,2 @@
 exec < /dev/null
-timeout 800 python -m pytest tests/test_gpu_fd.py -x -q -m gpu -k "equals_horner" 2>&1 | tail -5 | cut -c1-300
+timeout 500 python -m pytest tests/test_gpu_scalar_device.py -x -q -m gpu 2>&1 | tail -12 | cut -c1-400

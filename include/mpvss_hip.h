@@ -253,6 +253,14 @@ int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_
  * mpvss_modp_dleq_responses_device) on the block's own stream and goes on as mpvss_modp_distribute_compute with
  * commitments == NULL: X_i = g^p_i, Y_i = y_i^p_i, a1_i = g^w_i, a2_i = y_i^w_i.  Absorbed by mpvss_modp_distribute_absorb (a
  * negative position fails the block there).  n <= 262144 shares per call. */
+/* ... and the whole of it in one call for HOST buffers: P(i), X_i, Y_i, a1_i, a2_i, the transcript digest, the challenge
+ * c = hash_to_scalar(digest) (participant.rs:251-252) and the responses r_i = w_i - P(i) c (:255-264), the 2048-bit scalar
+ * arithmetic on the device too.  What is left to the caller of participant.rs:160-286 is drawing the polynomial and the
+ * witnesses, the commitments C_j = g^a_j (mpvss_modp_batch_exp_fixed_base) and U.  x_out, a1_out, a2_out, digest32_out and
+ * challenge_out256 are optional; t <= n <= 262144. */
+int mpvss_modp_deal(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_host,
+                    const uint8_t* pubkeys_host, const uint8_t* witnesses_host, size_t n, uint8_t* x_out, uint8_t* y_out,
+                    uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out, uint8_t* challenge_out256, uint8_t* r_out);
 int mpvss_modp_deal_compute(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
                             const uint8_t* pubkeys_dev, const uint8_t* witnesses_dev, size_t n, uint8_t* p_dev_out,
                             uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out);

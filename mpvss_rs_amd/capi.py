@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
     "mpvss_modp_scalar_mul", "mpvss_modp_scalar_sub", "mpvss_ec_scalar_mul", "mpvss_ec_scalar_sub",
     "mpvss_modp_dleq_responses", "mpvss_ec_dleq_responses", "mpvss_modp_poly_eval", "mpvss_ec_poly_eval",
-    "mpvss_modp_poly_eval_device", "mpvss_modp_dleq_responses_device", "mpvss_modp_deal_compute",
+    "mpvss_modp_poly_eval_device", "mpvss_modp_dleq_responses_device", "mpvss_modp_deal_compute", "mpvss_modp_deal",
     "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
     "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
     "mpvss_modp_distribute_compute", "mpvss_modp_distribute_absorb",
@@ -169,6 +169,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_poly_eval_device.argtypes = [vp, u8p, sz, vp, sz, vp]
     lib.mpvss_modp_dleq_responses_device.argtypes = [vp, vp, vp, u8p, sz, vp]
     lib.mpvss_modp_deal_compute.argtypes = [vp, u8p, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.mpvss_modp_deal.argtypes = [vp, u8p, sz, i64p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_poly_eval.argtypes = [ci, u8p, sz, i64p, sz, u8p, ci]
     lib.mpvss_modp_reconstruct.argtypes = [vp, ci, i64p, u8p, sz, u8p, u8p]
     lib.mpvss_ec_reconstruct.argtypes = [vp, ci, ci, i64p, u8p, sz, u8p, u8p]
@@ -386,6 +387,19 @@ class Engine:
         kc, pc = _buf(coeffs)
         self._check(self.lib.mpvss_modp_deal_compute(self.ctx, pc, len(coeffs) // EB, positions_dev_ptr, pubkeys_dev_ptr,
                                                      witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None), "deal_compute")
+
+    def deal(self, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes) -> dict:
+        """the dealer's whole box from host buffers in one call: X, Y, a1, a2, digest, challenge, responses"""
+        n = len(positions)
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        k = [_buf(b) for b in (coeffs, pubkeys, witnesses)]
+        outs = [_out(n * EB) for _ in range(5)]
+        kd, pd = _out(32)
+        kc, pc = _out(EB)
+        self._check(self.lib.mpvss_modp_deal(self.ctx, k[0][1], len(coeffs) // EB, C.cast(pos, C.c_void_p), k[1][1], k[2][1], n,
+                                             outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd, pc, outs[4][1]), "deal")
+        X, Y, a1, a2, r = (bytes(o[0])[: n * EB] for o in outs)
+        return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32], "challenge": bytes(kc)[:EB], "responses": r}
 
     def dleq_responses_device(self, w_dev_ptr: int, alpha_dev_ptr: int, c: bytes, n: int, out_dev_ptr: int) -> None:
         """r[i] = w[i] - alpha[i] c mod (q-1), everything but the shared c in HBM"""

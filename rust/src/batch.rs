@@ -144,18 +144,21 @@ pub fn distribute_secret(group: &HipModpGroup, secret: &BigInt, publickeys: &[Bi
     let witnesses: Vec<BigInt> = (0..n).map(|_| group.generate_private_key()).collect();    // :223
     let pk: Vec<u8> = publickeys.iter().flat_map(|y| be256(y)).collect();
     let ws: Vec<u8> = witnesses.iter().flat_map(|w| be256(w)).collect();
-    let mut pv = vec![0u8; n * 256];
-    unsafe { ffi::mpvss_modp_poly_eval(coeffs.as_ptr(), t, positions.as_ptr(), n, pv.as_mut_ptr(), 0) };   // P(i) % order, :200-202
-    let (mut x, mut y, mut a1, mut a2) = (vec![0u8; n * 256], vec![0u8; n * 256], vec![0u8; n * 256], vec![0u8; n * 256]);
+    // P(i) % order (:200-202), X_i, Y_i, a1_i, a2_i (:207-249), the transcript digest and the challenge (:251-252) and the
+    // responses (:255-264) in one call: the 2048-bit scalar arithmetic runs on the device too (boxes of more than 262144
+    // participants go block by block through mpvss_modp_poly_eval / _distribute_compute / _dleq_responses instead)
+    let mut y = vec![0u8; n * 256];
+    let mut r = vec![0u8; n * 256];
     let mut digest = [0u8; 32];
+    let mut c256 = [0u8; 256];
     let rc = unsafe {
-        ffi::mpvss_modp_distribute(group.engine.raw(), ffi::MPVSS_HOST, cm.as_ptr(), t, positions.as_ptr(), pk.as_ptr(), pv.as_ptr(),
-                                   ws.as_ptr(), n, x.as_mut_ptr(), y.as_mut_ptr(), a1.as_mut_ptr(), a2.as_mut_ptr(), digest.as_mut_ptr())
+        ffi::mpvss_modp_deal(group.engine.raw(), coeffs.as_ptr(), t, positions.as_ptr(), pk.as_ptr(), ws.as_ptr(), n, std::ptr::null_mut(),
+                             y.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), digest.as_mut_ptr(), c256.as_mut_ptr(),
+                             r.as_mut_ptr())
     };
     group.engine.expect(rc, "distribute_secret");
-    let challenge = group.hash_to_scalar(&digest);                                     // :251-252
-    let mut r = vec![0u8; n * 256];
-    unsafe { ffi::mpvss_modp_dleq_responses(ws.as_ptr(), pv.as_ptr(), be256(&challenge).as_ptr(), 0, n, r.as_mut_ptr(), 0) };   // :255-264
+    let challenge = BigInt::from_bytes_be(Sign::Plus, &c256);
+    debug_assert_eq!(challenge, group.hash_to_scalar(&digest));
     let mut bx = DistributionSharesBox::new();
     let big = |b: &[u8]| BigInt::from_bytes_be(Sign::Plus, b);
     let mut pos_map = std::collections::HashMap::new();

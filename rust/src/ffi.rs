@@ -133,6 +133,9 @@ unsafe extern "C" {
                                          y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
     pub fn mpvss_modp_distribute_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, y_out_host: *mut u8, a1_out_host: *mut u8,
                                         a2_out_host: *mut u8) -> c_int;
+    pub fn mpvss_modp_deal(ctx: *mut mpvss_ctx, coeffs_host: *const u8, t: usize, positions_host: *const i64, pubkeys_host: *const u8,
+                           witnesses_host: *const u8, n: usize, x_out: *mut u8, y_out: *mut u8, a1_out: *mut u8, a2_out: *mut u8,
+                           digest32_out: *mut u8, challenge_out256: *mut u8, r_out: *mut u8) -> c_int;
     pub fn mpvss_modp_deal_compute(ctx: *mut mpvss_ctx, coeffs_host: *const u8, t: usize, positions_dev: *const i64, pubkeys_dev: *const u8,
                                    witnesses_dev: *const u8, n: usize, p_dev_out: *mut u8, x_dev_out: *mut u8, y_dev_out: *mut u8,
                                    a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;

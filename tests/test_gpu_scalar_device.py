@@ -128,3 +128,37 @@ def test_deal_compute_is_the_oracles_dealer(engine):
     with pytest.raises(EngineError):
         engine.distribute_absorb(capi.transcript_init(), n)
     assert "negative position" in engine.last_error() and engine.blocks_in_flight() == (0, 0)
+
+
+def test_deal_in_one_call_from_host_buffers(engine):
+    """mpvss_modp_deal == the oracle's distribute_secret for the same polynomial and witnesses (every output, the challenge and
+    the responses), and a 2100-share box dealt that way (twin-exponentiation path) verifies with the dealer's digest."""
+    import hashlib
+    import mpvss_oracle as O
+    from helpers import make_modp_instance
+    n, t = 23, 4
+    g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, 43)
+    flat = O.box_to_flat(g, box)
+    d = engine.deal(b"".join(map(fx, coeffs)), flat["positions"], flat["publickeys"], b"".join(map(fx, ws)))
+    assert d["digest"] == box["_digest"] and d["Y"] == flat["shares"]
+    assert d["challenge"] == flat["challenge"] and d["responses"] == flat["responses"]
+    ref = engine.verify_distribution(flat["commitments"], flat["positions"], flat["publickeys"], d["Y"], d["responses"], d["challenge"],
+                                     dump=True)
+    assert ref["verdict"] is True and (ref["X"], ref["a1"], ref["a2"]) == (d["X"], d["a1"], d["a2"])
+    rng = random.Random(9)
+    n, t = 2100, 7
+    coeffs = [rng.randrange(ORDER) for _ in range(t)]
+    keys = [rng.randrange(1, ORDER) for _ in range(n)]
+    wit = [rng.randrange(1, ORDER) for _ in range(n)]
+    pk = engine.batch_exp_fixed_base(fx(2), b"".join(map(fx, keys)))
+    cm = engine.batch_exp_fixed_base(fx(4), b"".join(map(fx, coeffs)))
+    pos = list(range(1, n + 1))
+    d = engine.deal(b"".join(map(fx, coeffs)), pos, pk, b"".join(map(fx, wit)))
+    assert d["challenge"] == fx(int.from_bytes(hashlib.sha256(d["digest"]).digest(), "big") % QH)
+    p = [sum(a * pow(i, j, ORDER) for j, a in enumerate(coeffs)) % ORDER for i in pos]
+    c = int.from_bytes(d["challenge"], "big")
+    assert d["responses"] == b"".join(fx((w - pi * c) % ORDER) for w, pi in zip(wit, p))
+    res = engine.verify_distribution(cm, pos, pk, d["Y"], d["responses"], d["challenge"])
+    assert res["verdict"] is True and res["digest"] == d["digest"]
+    with pytest.raises(EngineError):
+        engine.deal(b"".join(map(fx, coeffs)), [1, -2] + pos[2:], pk, b"".join(map(fx, wit)))
