@@ -311,30 +311,29 @@ class Participant {
     Bytes gbytes = be256(group->subgroup_generator());
     eng.check(mpvss_modp_batch_exp_fixed_base(eng.ctx(), MPVSS_HOST, gbytes.data(), coeffs.data(), threshold, cm.data()),
               "distribute_secret: commitments");
-    // per participant: position, P(i) mod order, witness              :196-248
+    // per participant: position and witness; P(i) mod order (:200-202), X_i, Y_i, a1_i, a2_i (:207-249), the transcript
+    // digest and the challenge (:251-252) and the responses r_i = w_i - P(i) c (:255-264) are ONE engine call
     DistributionSharesBox box;
     std::vector<int64_t> pos(n);
-    std::vector<BigUint> pvals(n), wits(n);
-    Bytes pk, pv, ws;
+    Bytes pk, ws;
     for (size_t i = 0; i < n; ++i) {
       pos[i] = (int64_t)i + 1;
-      pvals[i] = polynomial.get_value(BigUint((uint64_t)pos[i])) % order;
-      wits[i] = group->generate_private_key(rng);
-      append(pk, be256(publickeys[i])); append(pv, be256(pvals[i])); append(ws, be256(wits[i]));
+      append(pk, be256(publickeys[i]));
+      append(ws, be256(group->generate_private_key(rng)));
     }
-    Bytes X(n * MPVSS_MODP_BYTES), Y(X.size()), a1(X.size()), a2(X.size());
+    Bytes Y(n * MPVSS_MODP_BYTES), R(Y.size()), cbytes(MPVSS_MODP_BYTES);
     uint8_t digest[32];
-    eng.check(mpvss_modp_distribute(eng.ctx(), MPVSS_HOST, cm.data(), threshold, pos.data(), pk.data(), pv.data(), ws.data(), n,
-                                    X.data(), Y.data(), a1.data(), a2.data(), digest), "distribute_secret");
-    const BigUint challenge = group->hash_to_scalar(Bytes(digest, digest + 32));     // :251-252
+    eng.check(mpvss_modp_deal(eng.ctx(), coeffs.data(), threshold, pos.data(), pk.data(), ws.data(), n, nullptr, Y.data(), nullptr,
+                              nullptr, digest, cbytes.data(), R.data()), "distribute_secret");
+    const BigUint challenge = BigUint::from_bytes_be(cbytes.data(), MPVSS_MODP_BYTES);
+    if (!(challenge == group->hash_to_scalar(Bytes(digest, digest + 32)))) throw std::logic_error("distribute_secret: challenge");
     for (uint32_t j = 0; j < threshold; ++j)
       box.commitments.push_back(BigUint::from_bytes_be(cm.data() + j * MPVSS_MODP_BYTES, MPVSS_MODP_BYTES));
     for (size_t i = 0; i < n; ++i) {
       const Bytes key = group->element_to_bytes(publickeys[i]);
       box.positions[key] = pos[i];
       box.shares[key] = BigUint::from_bytes_be(Y.data() + i * MPVSS_MODP_BYTES, MPVSS_MODP_BYTES);
-      const BigUint alpha_c = group->scalar_mul(pvals[i], challenge) % order;         // :259-262
-      box.responses[key] = group->scalar_sub(wits[i], alpha_c) % order;
+      box.responses[key] = BigUint::from_bytes_be(R.data() + i * MPVSS_MODP_BYTES, MPVSS_MODP_BYTES);
     }
     box.publickeys = publickeys;
     box.challenge = challenge;
