@@ -1093,18 +1093,18 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
 namespace {
 // a = B1^r * B2^c with the 64-entry table of B1.  Two kernels compute it: the pair-layout one, whose Montgomery reduction
 // runs on the matrix cores (modp_pair_kernels.hip; default), and the VALU-only one (modp_kernels.hip; MPVSS_A2_PAIR=0).
-// Same tables, exponents and results; measured in the headline pipeline 1.03 against 0.92-0.98 M share verifications/s.
+// Same tables, exponents and results; measured in the headline pipeline 1.08-1.12 against 0.92-0.98 M share verifications/s.
 // c_sched: sliding-window schedule of ONE shared challenge (then c_dev is unused), else fixed 4-bit windows of c_dev
 // (stride c_stride; null: B1^r alone).
 // MPVSS_PAIR: which kernels of the verifier's block path take the pair layout (bit 0: a2 = y^r Y^c, bit 1: the window tables,
 // bit 2: g^r through the wide comb, bit 3: a1 = g^r X^c, bit 4: the bucket phase of the dealer's / participant's twin
 // exponentiation -- 58.6 against 87.8 ms per 65536 shares alone on the chip, dealer 0.85 -> 0.92 M shares/s,
 // profiles/r03_dealer_ab.txt; bit 5: the forward-difference stepping kernels of the X path when t >= MPVSS_FD_PAIR_MIN_T,
-// eval_x).  Default 49: a2, the twin exponentiation and the stepping of large thresholds.  A pair wave (230 VGPRs, two per SIMD at
-// most) leaves its SIMD idle while it waits for its MFMA chains and LDS reads; the quad kernels' waves (135 VGPRs) of the
-// other boxes in flight fill those gaps.  With every wide kernel in the pair layout there is nothing left to fill them:
-// measured on one box 1.063 M share verifications/s for a2 alone, 1.044 M with the tables, 1.022 M with all four,
-// 0.942 M with none (profiles/r03_pair_ab.txt).  MPVSS_A2_PAIR=0 clears bit 0 (older switch).
+// eval_x).  Default 49: a2, the twin exponentiation and the stepping of large thresholds.  With the a2 kernel's registers
+// allocated for two waves per SIMD (modp_pair_kernels.hip) the tables, g^r and a1 run as fast in either layout (MPVSS_PAIR 17 /
+// 21 / 25 / 29: 1.08-1.10 M share verifications/s, profiles/r03_pair_occupancy_ab.txt) and stay VALU-only; at one wave per
+// SIMD every further pair kernel cost throughput (1.063 M for a2 alone, 1.044 M with the tables, 1.022 M with all four, 0.942 M
+// with none: profiles/r03_pair_ab.txt).  MPVSS_A2_PAIR=0 clears bit 0 (older switch).
 int pair_mask() {
   static const int m = fd_env("MPVSS_PAIR", 49) & (fd_env("MPVSS_A2_PAIR", 1) ? 63 : 62);
   return m;
