@@ -606,6 +606,7 @@ k_modp_fd_step_pair(const u32* __restrict__ state, const u32* __restrict__ state
     phase_a<false>(T, D, slot, sh.junk, pl, bsrc);
     u32 r[LP];
     reduce(r, T, slot, &sh.tb, pl);
+    __builtin_amdgcn_s_setprio(3);       // (reduce() leaves the wave at priority 0)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < LP; ++i) D[i] = r[i];
