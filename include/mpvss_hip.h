@@ -257,7 +257,10 @@ int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_
  * c = hash_to_scalar(digest) (participant.rs:251-252) and the responses r_i = w_i - P(i) c (:255-264), the 2048-bit scalar
  * arithmetic on the device too.  What is left to the caller of participant.rs:160-286 is drawing the polynomial and the
  * witnesses, the commitments C_j = g^a_j (mpvss_modp_batch_exp_fixed_base) and U.  x_out, a1_out, a2_out, digest32_out and
- * challenge_out256 are optional; t <= n <= 262144. */
+ * challenge_out256 are optional; t <= n < 2^31: like the reference, the call has no size limit of its own -- a box of more than
+ * 262144 shares is cut into blocks internally (one transcript; the GPU works on one block while the host hashes the one before).
+ * The call keeps its inputs and intermediate secrets in buffers of its own, admits one deal at a time per context, and
+ * zeroes P(i), the witnesses and the staged coefficients (device and pinned host copies) before it returns. */
 int mpvss_modp_deal(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_host,
                     const uint8_t* pubkeys_host, const uint8_t* witnesses_host, size_t n, uint8_t* x_out, uint8_t* y_out,
                     uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out, uint8_t* challenge_out256, uint8_t* r_out);

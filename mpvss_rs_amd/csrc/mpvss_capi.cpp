@@ -77,7 +77,7 @@ struct mpvss_ctx {
   void* consts = nullptr;
   void* consts_q = nullptr;     // the same rows for q' = (q-1)/2 (scalar-ring kernels), uploaded on first use
   // staging of the stand-alone scalar-ring calls (capi_scalar.inc): their own stream, a ring of small pinned + device buffers
-  struct ScalarEntry { void* pin = nullptr; size_t cap = 0; DevBuf dev; hipEvent_t done = nullptr; };
+  struct ScalarEntry { void* pin = nullptr; size_t cap = 0; DevBuf dev; hipEvent_t done = nullptr; bool in_use = false; };
   static constexpr unsigned SCALAR_RING = 16;
   ScalarEntry scalar_ring[SCALAR_RING];
   unsigned scalar_seq = 0;
@@ -86,6 +86,11 @@ struct mpvss_ctx {
   std::string err;
   mutable std::mutex err_mu;     // guards `err` alone: mpvss_last_error may run beside calls of other threads
   std::mutex mu;
+  // mpvss_modp_deal: the one-call dealer's inputs and intermediate secrets (keys, P(i), witnesses, responses, positions, the
+  // staged polynomial) in buffers of their own -- the call releases `mu` while it waits for and hashes its blocks, and the
+  // shared workspace of the synchronous entry points is anybody's then.  deal_mu (taken BEFORE mu) admits one deal at a time.
+  struct DealBufs { DevBuf keys, p, w, r, pos, coef, c; void* pin = nullptr; size_t pin_cap = 0; } deal;
+  std::mutex deal_mu;
   // Device workspace of one call in flight (grow-only buffers, the stream pair and the events that order them).
   // work0 serves the ordinary entry points; every verify-block slot has its own, so that several boxes can be in
   // flight on the GPU at once (the serial phases of one box overlap the wide phases of the next).
@@ -638,6 +643,9 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   }
   if (ctx->scalar_stream) (void)hipStreamDestroy(ctx->scalar_stream);
   if (ctx->pair_tables) (void)hipFree(ctx->pair_tables);
+  for (DevBuf* b : {&ctx->deal.keys, &ctx->deal.p, &ctx->deal.w, &ctx->deal.r, &ctx->deal.pos, &ctx->deal.coef, &ctx->deal.c})
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->deal.pin) (void)hipHostFree(ctx->deal.pin);
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : ctx->slot) {
     if (sl.pin) (void)hipHostFree(sl.pin);
@@ -2454,10 +2462,13 @@ namespace {
 
 // the dealer's polynomial for a block whose P(i) is computed on the device, ahead of the group work and in the same stream
 struct DealPoly {
-  const uint8_t* coeffs_host;     // t x 256 bytes
+  const uint8_t* coeffs_host;     // t x 256 bytes (null when limbs_dev is given)
   size_t t;
   const int64_t* positions_dev;   // n positions (validated when the block is absorbed)
   uint8_t* p_dev_out;             // n x 256 bytes: P(i) mod (q-1), kept by the caller for the responses
+  // a box dealt in several blocks prepares its polynomial once: t x 72 limbs of a'_j in HBM and the two parities (modq_poly_limbs)
+  const uint32_t* limbs_dev = nullptr;
+  int par_even = 0, par_odd = 0;
 };
 void modq_poly_limbs(const uint8_t* coeffs_host, size_t t, uint32_t* limbs, int* par_even, int* par_odd);   // capi_scalar.inc
 int modq_consts(mpvss_ctx* ctx);
@@ -2467,8 +2478,8 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
                                     uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out,
                                     const DealPoly* poly = nullptr) {
   if (poly) {
-    if (space != MPVSS_DEVICE || commitments || !poly->coeffs_host || !poly->positions_dev || !poly->p_dev_out || poly->t == 0 ||
-        poly->t > 0x7fffffff || n > MAX_CHUNK)
+    if (space != MPVSS_DEVICE || commitments || (!poly->coeffs_host && !poly->limbs_dev) || !poly->positions_dev || !poly->p_dev_out ||
+        poly->t == 0 || poly->t > 0x7fffffff || n > MAX_CHUNK)
       return fail(ctx, MPVSS_E_INVALID, "deal: bad argument (device buffers, t >= 1, one chunk of shares)");
     p_values = poly->p_dev_out;
   }
@@ -2517,7 +2528,8 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   spans_reset(ctx);
   constexpr size_t FLAGS = 64;
   const size_t out_bytes = n * EB * 4 + n * 8 + FLAGS * 4;
-  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + (commitments ? t * EB : 0) : 0) + (poly ? poly->t * MODP_L * 4 : 0);
+  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + (commitments ? t * EB : 0) : 0) +
+                      (poly && !poly->limbs_dev ? poly->t * MODP_L * 4 : 0);
   if (need > sl.cap) {
     if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
     sl.pin = nullptr;
@@ -2535,13 +2547,22 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   if (poly) {
     // P(i) mod (q-1) first, on this block's own stream: the group work below reads it in stream order (k_modq_poly_eval)
     RET_IF(modq_consts(ctx));
-    uint32_t* hl = (uint32_t*)((uint8_t*)sl.pin + out_bytes);
-    int par_even, par_odd;
-    modq_poly_limbs(poly->coeffs_host, poly->t, hl, &par_even, &par_odd);
-    RET_IF(ensure(ctx, ctx->w->cm, poly->t * MODP_L * 4));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->w->cm.p, hl, poly->t * MODP_L * 4, hipMemcpyHostToDevice, ctx->stream));
-    LAUNCHCHK(ctx, modq_launch_poly_eval((const uint32_t*)ctx->w->cm.p, (int)poly->t, poly->positions_dev, (int)n, par_even, par_odd,
-                                         poly->p_dev_out, ctx->consts_q, ctx->stream));
+    if (poly->limbs_dev) {
+      LAUNCHCHK(ctx, modq_launch_poly_eval(poly->limbs_dev, (int)poly->t, poly->positions_dev, (int)n, poly->par_even, poly->par_odd,
+                                           poly->p_dev_out, ctx->consts_q, ctx->stream));
+    } else {
+      uint32_t* hl = (uint32_t*)((uint8_t*)sl.pin + out_bytes);
+      const size_t lb = poly->t * MODP_L * 4;
+      int par_even, par_odd;
+      modq_poly_limbs(poly->coeffs_host, poly->t, hl, &par_even, &par_odd);
+      RET_IF(ensure(ctx, ctx->w->cm, lb));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->w->cm.p, hl, lb, hipMemcpyHostToDevice, ctx->stream));
+      LAUNCHCHK(ctx, modq_launch_poly_eval((const uint32_t*)ctx->w->cm.p, (int)poly->t, poly->positions_dev, (int)n, par_even, par_odd,
+                                           poly->p_dev_out, ctx->consts_q, ctx->stream));
+      // the staged coefficients are the dealer's secret: zero the device copy and, in stream order, the pinned one with it
+      HIPCHK(ctx, hipMemsetAsync(ctx->w->cm.p, 0, lb, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(hl, ctx->w->cm.p, lb, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(ctx, hipMemcpyAsync(hpos, poly->positions_dev, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     sl.check_positions = true;          // a negative position fails the block when it is absorbed
   }

@@ -145,8 +145,8 @@ pub fn distribute_secret(group: &HipModpGroup, secret: &BigInt, publickeys: &[Bi
     let pk: Vec<u8> = publickeys.iter().flat_map(|y| be256(y)).collect();
     let ws: Vec<u8> = witnesses.iter().flat_map(|w| be256(w)).collect();
     // P(i) % order (:200-202), X_i, Y_i, a1_i, a2_i (:207-249), the transcript digest and the challenge (:251-252) and the
-    // responses (:255-264) in one call: the 2048-bit scalar arithmetic runs on the device too (boxes of more than 262144
-    // participants go block by block through mpvss_modp_poly_eval / _distribute_compute / _dleq_responses instead)
+    // responses (:255-264) in one call: the 2048-bit scalar arithmetic runs on the device too (any n: the library cuts a box
+    // of more than 262144 participants into blocks itself and keeps ONE transcript over them)
     let mut y = vec![0u8; n * 256];
     let mut r = vec![0u8; n * 256];
     let mut digest = [0u8; 32];

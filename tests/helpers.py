@@ -129,3 +129,10 @@ def modp_fast_share(args):
     a1 = pow(4, ri, q) * pow(x, ci, q) % q
     a2 = pow(yi, ri, q) * pow(Yi, ci, q) % q
     return tuple(v.to_bytes(256, "big") for v in (x, a1, a2))
+
+
+def modp_dual_pow_chunk(items):
+    """[(b1, e1, b2, e2), ..] -> [b1^e1 * b2^e2 mod q, ..] with CPython's pow (src/dleq.rs:66-84: two exp, one mul);
+    picklable for parallel_map."""
+    q = MODP_Q
+    return [pow(b1, e1, q) * pow(b2, e2, q) % q for b1, e1, b2, e2 in items]

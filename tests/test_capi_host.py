@@ -73,6 +73,129 @@ def test_rust_ffi_declares_the_exported_symbols():
     assert declared == set(EXPORTED_SYMBOLS), (sorted(declared - set(EXPORTED_SYMBOLS)), sorted(set(EXPORTED_SYMBOLS) - declared))
 
 
+def _c_decls(header_text):
+    """include/mpvss_hip.h -> ({function: (return type, [(parameter name, C type)])}, {struct: [(field, C type)]})"""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", header_text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*\w+\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            # "const uint8_t *a, *b" / "size_t a, b" / "double kernel_ms[4]"
+            base = re.match(r"((?:const\s+)?(?:unsigned\s+long\s+long|\w+))\s*(.*)", decl)
+            for item in base.group(2).split(","):
+                item = item.strip()
+                stars = item.count("*")
+                name = item.replace("*", "").strip()
+                arr = re.match(r"(\w+)\[(\d+)\]", name)
+                if arr:
+                    fields.append((arr.group(1), f"{base.group(1)}[{arr.group(2)}]"))
+                else:
+                    fields.append((name, base.group(1) + "*" * stars))
+        structs[m.group(1)] = fields
+    text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
+    funcs = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(mpvss_\w+)\s*\(([^()]*)\)\s*;", text):
+        ret = " ".join(m.group(1).replace("extern", "").split())
+        params = []
+        body = " ".join(m.group(3).split())
+        if body and body != "void":
+            for prm in body.split(","):
+                prm = prm.strip()
+                arr = re.match(r"(.*?)(\w+)\s*\[\d*\]$", prm)          # uint8_t out32[32] decays to a pointer
+                if arr:
+                    params.append((arr.group(2), " ".join(arr.group(1).split()) + "*"))
+                    continue
+                pm = re.match(r"(.*?)(\w+)$", prm)
+                params.append((pm.group(2), "".join(pm.group(1).split()).replace("const", "const ").replace("unsignedlonglong", "unsigned long long")))
+        funcs[m.group(2)] = (ret.replace(" *", "*"), params)
+    return funcs, structs
+
+
+_C2RUST = {"int": "c_int", "double": "c_double", "size_t": "usize", "unsigned long long": "c_ulonglong", "uint8_t": "u8",
+           "int64_t": "i64", "char": "c_char", "void": "c_void", "uint16_t": "u16", "uint32_t": "u32"}
+
+
+def _rust_type(ctype):
+    """the Rust FFI spelling of a C type of the header: `const uint8_t*` -> `*const u8`, `mpvss_ctx**` -> `*mut *mut mpvss_ctx`"""
+    import re
+    ctype = ctype.strip()
+    arr = re.match(r"(.*)\[(\d+)\]$", ctype)
+    if arr:
+        return f"[{_rust_type(arr.group(1))}; {arr.group(2)}]"
+    const = ctype.startswith("const ")
+    core = ctype[6:] if const else ctype
+    stars = core.count("*")
+    base = core.replace("*", "").strip()
+    rust = _C2RUST.get(base, base)
+    for k in range(stars):
+        rust = ("*const " if (const and k == 0) else "*mut ") + rust
+    return rust
+
+
+def _rust_decls(ffi_text):
+    import re
+    text = re.sub(r"//[^\n]*", " ", ffi_text)
+    funcs = {}
+    for m in re.finditer(r"pub fn (mpvss_\w+)\s*\(([^()]*)\)\s*(?:->\s*([^;]+?))?\s*;", text):
+        params = []
+        for prm in " ".join(m.group(2).split()).split(","):
+            prm = prm.strip()
+            if prm:
+                name, ty = prm.split(":", 1)
+                params.append((name.strip(), " ".join(ty.split())))
+        funcs[m.group(1)] = ((m.group(3) or "").strip(), params)
+    structs = {}
+    for m in re.finditer(r"pub struct (\w+)\s*\{(.*?)\}", text, flags=re.S):
+        fields = []
+        for f in m.group(2).split(","):
+            f = " ".join(f.split())
+            if f:
+                name, ty = f.split(":", 1)
+                fields.append((name.strip().removeprefix("pub ").strip() if hasattr(str, "removeprefix") else name.strip()[4:].strip(), ty.strip()))
+        structs[m.group(1)] = fields
+    return funcs, structs
+
+
+def test_rust_ffi_signatures_match_the_header():
+    """Names alone do not protect a binding that is never compiled here: an argument added to one side only is undefined
+    behaviour at the first call.  Every prototype of include/mpvss_hip.h and every `pub fn` of rust/src/ffi.rs is parsed
+    into (name, return type, [(parameter name, type)]) with the C types mapped to their Rust FFI spelling, and the `#[repr(C)]`
+    structs field by field; the two sides must agree exactly (src/group.rs:24-124 is what the crate implements on top)."""
+    cf, cs = _c_decls(open(os.path.join(ROOT, "include", "mpvss_hip.h")).read())
+    rf, rs = _rust_decls(open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read())
+    from mpvss_rs_amd import EXPORTED_SYMBOLS
+    assert set(cf) == set(EXPORTED_SYMBOLS) == set(rf), (sorted(set(cf) ^ set(EXPORTED_SYMBOLS)), sorted(set(rf) ^ set(cf)))
+    for name, (ret, params) in sorted(cf.items()):
+        want_ret = "" if ret == "void" else _rust_type(ret)
+        want = [(pn, _rust_type(pt)) for pn, pt in params]
+        assert rf[name][0] == want_ret, (name, rf[name][0], want_ret)
+        assert rf[name][1] == want, (name, [a for a, b in zip(rf[name][1], want) if a != b] or (len(rf[name][1]), len(want)))
+    for sname in ("mpvss_modp_box", "mpvss_ec_box", "mpvss_box_view", "mpvss_pipeline_stats"):
+        want = [(fn, _rust_type(ft)) for fn, ft in cs[sname]]
+        assert rs[sname] == want, (sname, rs[sname], want)
+
+
+def test_signature_parsers_notice_a_drifted_argument():
+    """the check above must fail for the drift it exists for: an extra argument, a reordered pair, a changed pointer kind"""
+    cf, _ = _c_decls("int mpvss_x(mpvss_ctx* ctx, const uint8_t* a, size_t n, uint8_t out32[32]);")
+    assert cf["mpvss_x"] == ("int", [("ctx", "mpvss_ctx*"), ("a", "const uint8_t*"), ("n", "size_t"), ("out32", "uint8_t*")])
+    want = [(pn, _rust_type(pt)) for pn, pt in cf["mpvss_x"][1]]
+    good, _ = _rust_decls("pub fn mpvss_x(ctx: *mut mpvss_ctx, a: *const u8, n: usize, out32: *mut u8) -> c_int;")
+    assert good["mpvss_x"] == ("c_int", want)
+    for bad in ("pub fn mpvss_x(ctx: *mut mpvss_ctx, a: *const u8, n: usize) -> c_int;",
+                "pub fn mpvss_x(ctx: *mut mpvss_ctx, n: usize, a: *const u8, out32: *mut u8) -> c_int;",
+                "pub fn mpvss_x(ctx: *mut mpvss_ctx, a: *mut u8, n: usize, out32: *mut u8) -> c_int;",
+                "pub fn mpvss_x(ctx: *mut mpvss_ctx, a: *const u8, n: usize, out32: *mut u8);"):
+        got, _ = _rust_decls(bad)
+        assert got["mpvss_x"] != ("c_int", want), bad
+
+
 def test_header_is_plain_c_and_cxx():
     """The boundary is a C ABI: include/mpvss_hip.h must compile on its own as C99 and as C++11 (what cgo / bindgen /
     a C++ host would feed it to), without warnings."""

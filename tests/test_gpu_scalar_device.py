@@ -162,3 +162,51 @@ def test_deal_in_one_call_from_host_buffers(engine):
     assert res["verdict"] is True and res["digest"] == d["digest"]
     with pytest.raises(EngineError):
         engine.deal(b"".join(map(fx, coeffs)), [1, -2] + pos[2:], pk, b"".join(map(fx, wit)))
+
+
+def test_deal_of_a_box_larger_than_one_block():
+    """src/participant.rs:160-286 has no size limit: mpvss_modp_deal cuts a box into blocks of MAX_CHUNK shares internally
+    (one transcript, the responses once the challenge is known).  Under MPVSS_MAX_CHUNK=16 (read once per process) a 75-share
+    box is five blocks: every output, the digest, the challenge and the responses must be the oracle's distribute_secret, a
+    second deal on the same context must not see anything of the first, and the C++ mirror of the crate API (whose
+    distribute_secret binds this call, as rust/src/batch.rs does) passes the reference's own tests the same way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import mpvss_oracle as O
+from helpers import make_modp_instance
+from mpvss_rs_amd import Engine
+fx = lambda v: v.to_bytes(256, "big")
+eng = Engine(0)
+for n, t, seed in ((75, 5, 61), (16, 16, 62), (33, 2, 63)):
+    g, privs, pks, coeffs, ws, box = make_modp_instance(n, t, seed)
+    flat = O.box_to_flat(g, box)
+    d = eng.deal(b"".join(map(fx, coeffs)), flat["positions"], flat["publickeys"], b"".join(map(fx, ws)))
+    assert d["digest"] == box["_digest"] and d["Y"] == flat["shares"], (n, t)
+    assert d["challenge"] == flat["challenge"] and d["responses"] == flat["responses"], (n, t)
+    assert [int.from_bytes(d["X"][i * 256:(i + 1) * 256], "big") for i in range(n)] == box["_X"]
+    assert [int.from_bytes(d["a1"][i * 256:(i + 1) * 256], "big") for i in range(n)] == box["_a1"]
+    assert [int.from_bytes(d["a2"][i * 256:(i + 1) * 256], "big") for i in range(n)] == box["_a2"]
+    res = eng.verify_distribution(flat["commitments"], flat["positions"], flat["publickeys"], d["Y"], d["responses"], d["challenge"])
+    assert res["verdict"] is True and res["digest"] == d["digest"]
+try:
+    eng.deal(b"".join(map(fx, coeffs)), [1, 2, -3] + flat["positions"][3:], flat["publickeys"], b"".join(map(fx, ws)))
+    raise SystemExit("a negative position was accepted")
+except Exception as e:
+    assert "negative position" in str(e) or "negative position" in eng.last_error(), e
+assert eng.blocks_in_flight() == (0, 0)
+print("chunked deal ok")
+""" % (root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
+    env = dict(os.environ, MPVSS_MAX_CHUNK="16")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "chunked deal ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    exe = os.path.join(root, "tests", "_build", "host_mirror_tests")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "mpvss_rs_amd", "csrc"), "examples", "-s"])
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "all passed" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
