@@ -138,6 +138,12 @@ def horner_modmuls(positions, t):
     return total
 
 
+EC_COUNTERS_FILE = os.path.join("profiles", "r04_ec_counters.json")      # PMC evidence taken on the headline shapes (committed files)
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+for _name in ("EC_COUNTERS_FILE", "TRAFFIC_FILE"):                          # (round 3's files until round 4's exist)
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), globals()[_name])):
+        globals()[_name] = globals()[_name].replace("r04_", "r03_")
+
 EC = {
     "secp256k1": {"gid": 1, "enc": 33, "be": True, "algo_bytes": 197,     # 33+33+32 in, 3 x 33 out
                   "order": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
@@ -231,6 +237,7 @@ def bench_ec(eng, name, args):
     pst = eng.pipeline_stats(reset=True)
     nb = max(pst["blocks"], 1)
     out = {"value": n / dt, "unit": "share verifications/s", "ms_per_box": dt * 1e3, "boxes": k,
+           "boxes_verified_in_this_process": 2 + init + k,      # (what a counter pass over this run divides by)
            "config": {"workload": f"{name} verify_distribution_shares n={n} t={t}, honest-dealer box, inputs resident in HBM, "
                                   f"{depth} boxes in flight in one context, {threads} hash threads ({cfg['ref']})"},
            "dtype": "u32 limbs (radix 2^26), u64 accumulators",
@@ -248,16 +255,23 @@ def bench_ec(eng, name, args):
     # passes of tools/run_profiles_ec.sh; profiles/r03_pmc_traffic.json: bytes per launch of the dominant kernel)
     try:
         if (n, t) == (65536, 256):
-            ecc = json.load(open(os.path.join(ROOT, "profiles", "r03_ec_counters.json")))[name]
+            cfile = EC_COUNTERS_FILE
+            ecc = json.load(open(os.path.join(ROOT, cfile)))[name]
             slots = ecc["valu_wave_insts_per_box"] / dt
-            out["compute"] = {"bound": "valu issue", "achieved": slots, "peak": PEAK_VALU_SLOTS_PER_S, "frac": slots / PEAK_VALU_SLOTS_PER_S,
+            out["compute"] = {"bound": "valu issue", "achieved": slots, "peak": PEAK_VALU_SLOTS_PER_S, "peak_is": PEAK_SOURCE,
+                              "frac": slots / PEAK_VALU_SLOTS_PER_S,
                               "unit": "VALU wave-instruction issue slots/s (SQ_INSTS_VALU per verified box x boxes/s)",
                               "valu_wave_insts_per_box": ecc["valu_wave_insts_per_box"],
-                              "hbm_bytes_per_box": ecc["hbm_bytes_per_box"], "hbm_gb_per_s": ecc["hbm_bytes_per_box"] / dt / 1e9}
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+                              "hbm_bytes_per_box": ecc["hbm_bytes_per_box"], "hbm_gb_per_s": ecc["hbm_bytes_per_box"] / dt / 1e9,
+                              "source": f"{cfile}: {ecc.get('how', 'rocprofv3 --pmc passes over the same call (mpvss_ec_verify_many, X paths batched), counters per verified box')}; "
+                                        "the box rate is this run's"}
+            tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"] + "_bytes_per_launch")
+            out["roofline"]["traffic_source"] = f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not measured in this run)"
     except (OSError, KeyError, ValueError):
         pass
+    if os.environ.get("MPVSS_BENCH_EC_VERIFY_ONLY") == "1":       # counter passes: nothing but verifications after the set-up
+        return out
     # dealer side in block form (mpvss_ec_distribute_compute / _absorb): inputs resident in HBM, X_i = P(i) G through the
     # comb, 8 blocks in flight, absorbed (validated + hashed) by a few host threads; the digest must be the dealer's
     import concurrent.futures
@@ -291,6 +305,57 @@ def bench_ec(eng, name, args):
     assert all(x == d["digest"] for x in dgs), f"dealer block API: transcript digest differs ({name})"
     out["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3, "boxes_in_flight": 8,
                          "value_synchronous_host_buffers": n / deal_s}
+    # ... and the dealer END TO END with the scalar side on the device as well: every box its own polynomial (t coefficients from
+    # the host), P(i) mod order by mpvss_ec_deal_compute on the block's stream, the group work, the transcript, the challenge
+    # c = hash_to_scalar(digest), the responses r_i = w_i - P(i) c by mpvss_ec_dleq_responses_device; only the coefficients, the
+    # digest and the challenge cross the bus (participant.rs:1134-1168, 1200-1230 / 1607-1631, 1662-1690)
+    e2e_boxes, e2e_depth = 16, 8
+    coeff_sets = []
+    for b in range(4):
+        rb = random.Random(SEED + 31 * gid + b)
+        coeff_sets.append(coeffs if b == 0 else [rb.randrange(order) for _ in range(t)])
+    coeff_bytes = [b"".join(map(sb, cs_)) for cs_ in coeff_sets]
+    ring_p = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(e2e_depth + 2)]
+    d_rr = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(e2e_depth + 2)]
+    torch.cuda.synchronize()
+
+    def e2e_post(b, d_pb):
+        st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+        eng._check(eng.lib.mpvss_ec_distribute_absorb(eng.ctx, st, None, None, None, None), "ec_distribute_absorb")
+        digest = capi.ec_transcript_verdict(gid, bytes(st), zero_c)[1]
+        cc = capi.ec_hash_to_scalar(gid, digest)
+        d_r = d_rr[b % len(d_rr)]
+        eng.ec_dleq_responses_device(gid, d_wt.data_ptr(), d_pb.data_ptr(), cc, n, d_r.data_ptr())
+        return digest, (bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None)
+
+    def deal_e2e(count):
+        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:       # blocks are absorbed in FIFO order
+            post = []
+            for b in range(count):
+                d_pb = ring_p[b % len(ring_p)]
+                while len(post) - sum(f.done() for f in post) >= e2e_depth:
+                    time.sleep(0.0002)
+                eng.ec_deal_compute(gid, coeff_bytes[b % len(coeff_bytes)], d_pos.data_ptr(), d_pk.data_ptr(), d_wt.data_ptr(), n, d_pb.data_ptr())
+                post.append(pool.submit(e2e_post, b, d_pb))
+            return [f.result() for f in post]
+
+    deal_e2e(4)
+    torch.cuda.synchronize()
+    t_e = time.perf_counter()
+    e2e = deal_e2e(e2e_boxes)
+    torch.cuda.synchronize()
+    e2e_s = (time.perf_counter() - t_e) / e2e_boxes
+    assert e2e[0][0] == d["digest"] and e2e[0][1] == responses, f"end-to-end dealer ({name}): box 0 differs from the dealer's"
+    t_one = time.perf_counter()
+    one = eng.ec_deal(gid, coeff_bytes[0], positions, pks, b"".join(map(sb, wits)))
+    one_s = time.perf_counter() - t_one
+    assert one["digest"] == d["digest"] and one["responses"] == responses and one["Y"] == d["Y"], f"mpvss_ec_deal differs ({name})"
+    out["distribute"].update({"value_end_to_end": n / e2e_s, "end_to_end_ms_per_box": e2e_s * 1e3, "end_to_end_boxes_in_flight": e2e_depth,
+                              "value_one_call_host_buffers_end_to_end": n / one_s,
+                              "note": "`value`: group work of the dealer's blocks with P(i) given (mpvss_ec_distribute_compute / _absorb); "
+                                      "`value_end_to_end`: every box from its own t coefficients -- P(i) mod order and the responses on the device "
+                                      "(mpvss_ec_deal_compute, mpvss_ec_dleq_responses_device), group work, transcript, challenge, boxes pipelined; "
+                                      "`value_one_call_host_buffers_end_to_end`: one mpvss_ec_deal call from host buffers"})
     if args.cpu_sample != 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from concurrent.futures import ThreadPoolExecutor
@@ -353,7 +418,14 @@ def sliding_windows(c):
 #                             (tools/mfma_mont/count_isa.py), + 114 MFMAs that each hold the SIMD's issue for 2 slots
 QUAD_MUL_SLOTS, QUAD_SQ_SLOTS = (72 * 41 + 110) / 16.0, (72 * 32.5 + 110) / 16.0
 PAIR_MUL_SLOTS, PAIR_SQ_SLOTS = (3690 + 2 * 114) / 32.0, (2501 + 2 * 114) / 32.0
-PEAK_VALU_SLOTS_PER_S = 1024 / (MAD_NS_PER_SIMD * 1e-9)        # 256 CUs x 4 SIMDs, one wave-instruction per 2.07 ns per SIMD
+# The peak of the issue-slot accounting is a physical one: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at the
+# nominal 2.4 GHz shader clock -- nothing can exceed it, so no `frac` of it can exceed 1.  What the chip SUSTAINS is lower (it
+# lowers its clock under load: about 2.0-2.1 GHz in these kernels, and a v_mad_u64_u32 issues in ~4.35 cycles): that figure is
+# measured live in every run by mpvss_issue_probe (`compute.sustained_probe`) and the achieved rate is also given relative to
+# it (`vs_sustained_mad64`, a ratio of two measurements of different instruction mixes: it is not called a fraction).
+NOMINAL_CLOCK_GHZ = 2.4
+PEAK_VALU_SLOTS_PER_S = 1024 * NOMINAL_CLOCK_GHZ * 1e9 / 4.0
+PEAK_SOURCE = "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: chip parameters, cycle constants)"
 PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "49")) & (63 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 62)
 FD_PAIR_MIN_T = int(os.environ.get("MPVSS_FD_PAIR_MIN_T", "512"))     # from this many commitments the X path steps in the pair layout
 
@@ -450,6 +522,8 @@ def main():
     ap.add_argument("--lone-boxes", type=int, default=2, help="boxes verified one at a time after the timed region "
                                                               "(isolated kernel durations for the roofline; 0: skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="shares timed on the all-core CPU port (-1: 1 per core, 0: skip all CPU legs)")
+    ap.add_argument("--steady-steps", type=int, default=100, help="boxes of the `value_steady_state` figure at N=1, after the timed "
+                    "region (0: skip)")
     ap.add_argument("--config-boxes", type=int, default=-1, help="boxes timed for the other BASELINE shapes in `configs` "
                     "(C2 n=4096 t=64, one GPU's slice of C5 n=131072 t=1024; -1: 48 / 6, 0: skip)")
     args = ap.parse_args()
@@ -807,6 +881,28 @@ def main():
         assert bytes(o2.cpu().numpy().tobytes()) == dres["a2"] and bytes(o1.cpu().numpy().tobytes()) == dres["a1"], \
             "verifier commitments differ from the dealer's"
         del d_X, o1, o2
+    # steady state: the same pipeline over many more boxes (the K-step region ends with the boxes in flight finishing together
+    # and their hashes running with nothing beside them; over 100 boxes that tail no longer shows)
+    steady = None
+    if world == 1 and args.steady_steps > 0:
+        barrier()
+        ts0 = time.perf_counter()
+        res_ss = run_steps(args.steady_steps)
+        barrier()
+        ss_s = time.perf_counter() - ts0
+        gate(res_ss, "steady-state steps")
+        steady = {"value": n * args.steady_steps / ss_s, "steps": args.steady_steps, "ms_per_step": ss_s / args.steady_steps * 1e3}
+        eng.pipeline_stats(reset=True)
+    # what this device sustains of the kernels' basic instructions right now (4 waves per SIMD issuing back to back for ~40 ms)
+    probe = None
+    if world == 1:
+        p0, p1 = eng.issue_probe(0, 40.0), eng.issue_probe(1, 40.0)
+        probe = {"mad64_insts_per_s": p0["insts_per_s"], "mad64_shader_clock_ghz": p0["shader_clock_ghz"],
+                 "mad64_cycles_per_inst": 1024 * p0["shader_clock_ghz"] * 1e9 / p0["insts_per_s"] if p0["insts_per_s"] else None,
+                 "alu32_insts_per_s": p1["insts_per_s"], "alu32_shader_clock_ghz": p1["shader_clock_ghz"],
+                 "how": "mpvss_issue_probe, live in this run after the timed region: 4 waves per SIMD on every CU issue v_mad_u64_u32 "
+                        "(mad64) / v_add3_u32, v_and_b32, v_lshl_add_u32 (alu32) back to back for ~40 ms; the clock is s_memtime "
+                        "against s_memrealtime inside the kernel"}
     a2_launch_ms_overlapped = a2_ms / a2_n
     a2_one_box_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else None
     a2_launch_ms = alone_ms if alone_ms else (a2_one_box_ms if a2_one_box_ms else a2_launch_ms_overlapped)
@@ -820,6 +916,8 @@ def main():
     result = {
         "metric": "DLEQ share verifications/sec, 2048-bit MODP, n=65536 t=256",
         "value": value,
+        "value_steady_state": steady["value"] if steady else None,
+        "steady_state": steady,
         "unit": "share verifications/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -857,10 +955,16 @@ def main():
         },
         "compute": {
             "bound": "valu issue",
-            "achieved": wk["slots"] / (ms_per_step * 1e-3), "peak": PEAK_VALU_SLOTS_PER_S,
+            "achieved": wk["slots"] / (ms_per_step * 1e-3), "peak": PEAK_VALU_SLOTS_PER_S, "peak_is": PEAK_SOURCE,
             "unit": "VALU wave-instruction issue slots/s (all kernels / step wall time; one slot = one wave64 VALU instruction on one "
-                    "SIMD, 2.07 ns measured; an MFMA holds the issue for two slots)",
+                    "SIMD; an MFMA holds the issue for two slots)",
             "frac": wk["slots"] / (ms_per_step * 1e-3) / PEAK_VALU_SLOTS_PER_S,
+            "sustained_probe": probe,
+            "vs_sustained_mad64": (wk["slots"] / (ms_per_step * 1e-3) / probe["mad64_insts_per_s"]) if probe and probe["mad64_insts_per_s"] else None,
+            "vs_sustained_mad64_is": "achieved slots/s over the v_mad_u64_u32 rate the probe sustained in this run (a ratio of two "
+                                     "measurements: a kernel whose mix is lighter than pure 64-bit mads can exceed 1)",
+            "slots_source": "instruction counts per Montgomery operation from the ISA (tools/mfma_mont/count_isa.py for the pair layout, "
+                            "bn_quad.h row counts for the quad layout) x the operations the kernels execute for this run's challenges",
             "valu_slots_per_share": wk["slots"] / n,
             "slots_per_operation": {"quad_product": QUAD_MUL_SLOTS, "quad_squaring": QUAD_SQ_SLOTS, "pair_product": PAIR_MUL_SLOTS,
                                     "pair_squaring": PAIR_SQ_SLOTS,
@@ -868,12 +972,14 @@ def main():
                                             "matrix cores); MPVSS_PAIR bit mask in use: %d" % PAIR_MASK},
             "operations_per_share": wk["ops"],
             "modmul_per_share": mm_total / n,
-            "modmul_equivalents": {"achieved": achieved_modmul, "peak_valu_only": peak_modmul, "frac_of_valu_only_peak": achieved_modmul / peak_modmul,
-                                   "note": "rounds 1-2 accounting: product equivalents per second (a squaring 0.764) against what the VALU-only "
-                                           "product can reach (3.05 G/s); with the reduction on the matrix cores this ratio may exceed the old ceiling 0.88"},
+            "modmul_equivalents": {"achieved": achieved_modmul, "peak_valu_only": peak_modmul, "ratio_to_valu_only_product_rate": achieved_modmul / peak_modmul,
+                                   "note": "rounds 1-2 accounting: product equivalents per second (a squaring 0.764) relative to what the VALU-only "
+                                           "product reached in round 1's microbenchmark (3.05 G/s) -- a ratio to another formulation's rate, not a "
+                                           "fraction of a peak: with the reduction on the matrix cores it may exceed 1"},
             "x_path": wk["x_path"],
             "a2_kernel_alone": ({"ms": alone_ms, "valu_slots_per_s": wk["a2_slots"] / (alone_ms * 1e-3),
                                  "frac": wk["a2_slots"] / (alone_ms * 1e-3) / PEAK_VALU_SLOTS_PER_S,
+                                 "vs_sustained_mad64": (wk["a2_slots"] / (alone_ms * 1e-3) / probe["mad64_insts_per_s"]) if probe else None,
                                  "products_per_share": a2_products} if alone_ms else None),
             "kernel_ms_sums": {"x_path": x_ms, "a1_comb_dual_exp": a1_ms, "a2_dual_exp": a2_ms, "tables": tb_ms,
                                "note": "per-kind sums of launch durations per step in the timed region; boxes and kinds "
@@ -902,10 +1008,12 @@ def main():
                           "mpvss_modp_verify_block_compute_flags), one per box and rank, asynchronous, inside the timed region; "
                           "every byte of every rank checked == 1",
             "also": "barrier and max-reduction of the timing over the same group; the 128-byte hash state per box and hop over gloo"}
-    traffic_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    traffic_file = os.path.join(ROOT, TRAFFIC_FILE)
     if os.path.exists(traffic_file) and (n, t) == (65536, 256):     # the PMC run was taken on the headline shape
         try:
             result["roofline"]["traffic"] = json.load(open(traffic_file)).get(a2_kernel + "_bytes_per_launch")
+            result["roofline"]["traffic_source"] = (f"{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
+                                                    "(tools/run_profiles.sh), a committed file -- not measured in this run")
         except Exception:
             pass
 
@@ -1052,7 +1160,8 @@ def main():
                         "boxes_in_flight": depth, "distinct_boxes": len(cur.boxes),
                         "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n_} t={t_} per GPU ({what}), "
                                                f"honest-dealer boxes, inputs resident in HBM"},
-                        "compute": {"bound": "valu issue", "achieved": rate, "peak": PEAK_VALU_SLOTS_PER_S, "frac": rate / PEAK_VALU_SLOTS_PER_S,
+                        "compute": {"bound": "valu issue", "achieved": rate, "peak": PEAK_VALU_SLOTS_PER_S, "peak_is": PEAK_SOURCE,
+                                    "frac": rate / PEAK_VALU_SLOTS_PER_S,
                                     "unit": "VALU wave-instruction issue slots/s", "valu_slots_per_share": wk_["slots"] / n_,
                                     "modmul_per_share": wk_["mm_total"] / n_, "x_path": wk_["x_path"]}}
             finally:
@@ -1136,7 +1245,7 @@ def main():
                 result["registered_keys"] = {
                     "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
                     "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
-                    "compute_frac": mm_k / (el_k / args.steps) / PEAK_MODMUL_PER_S,
+                    "modmul_equivalents_per_s": mm_k / (el_k / args.steps),
                     "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)) in HBM, built once per key set, "
                             "a2 = y^r Y^c in 571 products instead of 2620; same verdict and transcript digest; not the headline"}
             except capi.EngineError as err:

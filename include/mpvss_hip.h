@@ -349,6 +349,26 @@ int mpvss_ec_distribute_compute(mpvss_ctx* ctx, int group, int space, const uint
                                 uint8_t* a1_dev_out, uint8_t* a2_dev_out);
 int mpvss_ec_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,
                                uint8_t* a1_out_host, uint8_t* a2_out_host);
+/* The curve groups' dealer with the SCALAR side on the device as well (src/participant.rs:1134-1168, 1200-1230 secp256k1;
+ * 1607-1631, 1662-1690 ristretto255) -- the counterparts of mpvss_modp_poly_eval_device / _dleq_responses_device / _deal_compute /
+ * _deal.  Scalars are 32 bytes in the group's byte order; positions enter as `position as u64`, as in the reference.
+ *   poly_eval_device     out_dev[i] = P(positions_dev[i]) mod order (t coefficients from the host, Horner's rule, one share per lane)
+ *   dleq_responses_device r_dev_out[i] = w_dev[i] - alpha_dev[i] c mod order (one shared challenge from the host)
+ *   deal_compute         one dealer's block with P(i) evaluated on the block's own stream into p_dev_out (kept for the responses),
+ *                        then as mpvss_ec_distribute_compute with commitments == NULL; absorbed by mpvss_ec_distribute_absorb
+ *   deal                 the whole box in one call from HOST buffers: P(i), X_i, Y_i, a1_i, a2_i, digest, challenge, responses;
+ *                        x_out, a1_out, a2_out, digest32_out, challenge_out32 are optional; t <= n.  One deal at a time per context;
+ *                        P(i), the witnesses and the coefficients are zeroed on the device before it returns. */
+int mpvss_ec_poly_eval_device(mpvss_ctx* ctx, int group, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
+                              size_t n, uint8_t* out_dev);
+int mpvss_ec_dleq_responses_device(mpvss_ctx* ctx, int group, const uint8_t* w_dev, const uint8_t* alpha_dev,
+                                   const uint8_t* c_host32, size_t n, uint8_t* r_dev_out);
+int mpvss_ec_deal_compute(mpvss_ctx* ctx, int group, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
+                          const uint8_t* pubkeys_dev, const uint8_t* witnesses_dev, size_t n, uint8_t* p_dev_out,
+                          uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out);
+int mpvss_ec_deal(mpvss_ctx* ctx, int group, const uint8_t* coeffs_host, size_t t, const int64_t* positions_host,
+                  const uint8_t* pubkeys_host, const uint8_t* witnesses_host, size_t n, uint8_t* x_out, uint8_t* y_out,
+                  uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out, uint8_t* challenge_out32, uint8_t* r_out);
 /* Group::hash_to_scalar(data), host only; out32 in the group's scalar byte order */
 int mpvss_ec_hash_to_scalar(int group, const uint8_t* data, size_t len, uint8_t out32[32]);
 
@@ -477,6 +497,12 @@ int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* out, int rese
 int mpvss_blocks_in_flight(mpvss_ctx* ctx, int* in_flight_out, int* gpu_pending_out);
 /* 1 when the transcript hash uses the CPU's SHA extensions (about 1.7 GB/s per thread), 0 for the portable code */
 int mpvss_sha256_uses_shani(void);
+/* Measurement aid (no reference counterpart): what this device sustains, now, of the instruction the kernels are made of -- four
+ * waves per SIMD on every CU issue it back to back for about target_ms.  kind 0: v_mad_u64_u32 (the limb product of all three
+ * groups), kind 1: 32-bit integer work.  Wave-instructions per second over the whole chip, the shader clock the waves saw
+ * (s_memtime against the 100 MHz s_memrealtime) and the duration; the last two are optional. */
+int mpvss_issue_probe(mpvss_ctx* ctx, int kind, double target_ms, double* insts_per_s_out, double* shader_clock_ghz_out,
+                      double* ms_out);
 
 #ifdef __cplusplus
 }

@@ -30,10 +30,11 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_distribute_compute", "mpvss_ec_distribute_absorb", "mpvss_ec_hash_to_scalar",
+    "mpvss_ec_poly_eval_device", "mpvss_ec_dleq_responses_device", "mpvss_ec_deal_compute", "mpvss_ec_deal",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
-    "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani",
+    "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani", "mpvss_issue_probe",
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
     "mpvss_ec_batch_exp_generator", "mpvss_ec_verify_block_compute", "mpvss_ec_verify_block_absorb",
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
@@ -152,6 +153,10 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_distribute_compute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_distribute_absorb.argtypes = [vp, u8p, u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_poly_eval_device.argtypes = [vp, ci, u8p, sz, vp, sz, vp]
+    lib.mpvss_ec_dleq_responses_device.argtypes = [vp, ci, vp, vp, u8p, sz, vp]
+    lib.mpvss_ec_deal_compute.argtypes = [vp, ci, u8p, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.mpvss_ec_deal.argtypes = [vp, ci, u8p, sz, i64p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_hash_to_scalar.argtypes = [ci, u8p, sz, u8p]
     lib.mpvss_ec_batch_exp_generator.argtypes = [vp, ci, ci, u8p, sz, u8p]
     lib.mpvss_box_wire_size.argtypes = [ci, sz, sz, sz]
@@ -182,6 +187,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_pipeline_stats_get.argtypes = [vp, C.POINTER(PipelineStats), ci]
     lib.mpvss_blocks_in_flight.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.mpvss_sha256_uses_shani.restype = ci
+    lib.mpvss_issue_probe.argtypes = [vp, ci, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mpvss_modp_extract_shares.argtypes = [vp, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
     lib.mpvss_ec_extract_shares.argtypes = [vp, ci, ci, u8p, u8p, u8p, u8p, sz, u8p, u8p]
     return lib
@@ -245,6 +251,12 @@ class Engine:
                                                                    C.cast(pos, C.c_void_p), bufs[1][1], bufs[2][1], bufs[3][1], n,
                                                                    bufs[4][1], C.c_void_p(wellformed_dev_ptr)),
                     "verify_block_compute_flags")
+
+    def issue_probe(self, kind: int, target_ms: float = 40.0) -> dict:
+        """what the device sustains of the kernels' basic instruction (0: v_mad_u64_u32, 1: 32-bit integer work), 4 waves per SIMD"""
+        rate, clk, ms = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._check(self.lib.mpvss_issue_probe(self.ctx, kind, float(target_ms), C.byref(rate), C.byref(clk), C.byref(ms)), "issue_probe")
+        return {"insts_per_s": rate.value, "shader_clock_ghz": clk.value, "ms": ms.value}
 
     def kernel_ms(self, kernel_id: int) -> float:
         return self.lib.mpvss_last_kernel_ms(self.ctx, kernel_id)
@@ -610,6 +622,38 @@ class Engine:
         self._check(self.lib.mpvss_ec_distribute_compute(self.ctx, group, MPVSS_HOST, pc, t, C.cast(pos, C.c_void_p), py, pp, pw,
                                                          n, None, None, None, None), "ec_distribute_compute")
         return n
+
+    def ec_poly_eval_device(self, group: int, coeffs: bytes, positions_dev_ptr: int, n: int, out_dev_ptr: int) -> None:
+        kc, pc = _buf(coeffs)
+        self._check(self.lib.mpvss_ec_poly_eval_device(self.ctx, group, pc, len(coeffs) // 32, positions_dev_ptr, n, out_dev_ptr),
+                    "ec_poly_eval_device")
+
+    def ec_dleq_responses_device(self, group: int, w_dev_ptr: int, alpha_dev_ptr: int, c: bytes, n: int, out_dev_ptr: int) -> None:
+        kc, pc = _buf(c)
+        self._check(self.lib.mpvss_ec_dleq_responses_device(self.ctx, group, w_dev_ptr, alpha_dev_ptr, pc, n, out_dev_ptr),
+                    "ec_dleq_responses_device")
+
+    def ec_deal_compute(self, group: int, coeffs: bytes, positions_dev_ptr: int, pubkeys_dev_ptr: int, witnesses_dev_ptr: int, n: int,
+                        p_dev_out_ptr: int) -> None:
+        """one curve-group dealer's block, P(i) included, enqueued (absorb with ec_distribute_absorb)"""
+        kc, pc = _buf(coeffs)
+        self._check(self.lib.mpvss_ec_deal_compute(self.ctx, group, pc, len(coeffs) // 32, positions_dev_ptr, pubkeys_dev_ptr,
+                                                   witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None), "ec_deal_compute")
+
+    def ec_deal(self, group: int, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes) -> dict:
+        """a curve group's whole box from host buffers in one call: X, Y, a1, a2, digest, challenge, responses"""
+        n = len(positions)
+        L = 33 if group == GROUP_SECP256K1 else 32
+        pos = (C.c_int64 * max(n, 1))(*positions)
+        k = [_buf(b) for b in (coeffs, pubkeys, witnesses)]
+        outs = [_out(n * L) for _ in range(4)]
+        kr, pr = _out(n * 32)
+        kd, pd = _out(32)
+        kc, pc = _out(32)
+        self._check(self.lib.mpvss_ec_deal(self.ctx, group, k[0][1], len(coeffs) // 32, pos, k[1][1], k[2][1], n,
+                                           outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd, pc, pr), "ec_deal")
+        X, Y, a1, a2 = (bytes(o[0])[: n * L] for o in outs)
+        return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32], "challenge": bytes(kc)[:32], "responses": bytes(kr)[: n * 32]}
 
     def ec_distribute_absorb(self, group: int, state: bytes, n: int):
         """(state, X, Y, a1, a2) of the oldest dealer block"""

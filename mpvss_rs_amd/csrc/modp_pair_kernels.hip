@@ -155,6 +155,41 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
 // box has ONE challenge) against the table of Y -- on the pair layout.  tab1 [count][64][72], tab2 [count][16][72] in
 // Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
 // ---------------------------------------------------------------------------------------
+#ifndef PAIR_PREFETCH
+#define PAIR_PREFETCH 1         // the operand of the NEXT product comes in by LDS-DMA while the current operation reduces (0: fetched when needed)
+#endif
+
+namespace {
+// The next product's operands of the wave's 32 numbers, HBM -> LDS slots, without registers (global_load_lds_dwordx4).  One
+// DMA instruction moves 64 x 16 bytes to CONSECUTIVE LDS addresses, and the wave's 32 slots of SLOTW = 76 words are 608
+// consecutive 16-byte pieces (19 per number: 18 of data, one of padding), so lane l of instruction i fetches piece 64 i + l:
+// piece q = (64 i + l) % 19 of number n = (64 i + l) / 19, whose table entry it learns from lane n by a shuffle.
+//   src of number n = base + (x0 + n, clamped to count - 1) * num_stride + entry_n * 72 words;   entry: this lane's OWN number's
+__device__ __forceinline__ void slots_prefetch_pair(u32* wave_slots, const u32* __restrict__ base, size_t num_stride, int x0, int count,
+                                                    u32 entry, const PairLane& pl) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    int p = (int)pl.lane + 64 * i;
+    asm volatile("" : "+v"(p));          // (recomputed per call: hoisted out of the main loop these addresses would be 20 registers, i.e. spills)
+    const bool valid = p < 32 * (SLOTW / 4);
+    const int n = valid ? (int)(((u32)p * 3450u) >> 16) : 31;        // p / 19 for p < 608
+    const int q = p - 19 * n;
+    const u32 e = (u32)__shfl((int)entry, n);
+    const int xj = (x0 + n < count) ? x0 + n : count - 1;
+    const u32* src = base + (size_t)xj * num_stride + (size_t)e * L + (q < 18 ? q : 17) * 4;
+    if (valid)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)src,
+                                       (__attribute__((address_space(3))) void*)(uintptr_t)(wave_slots + i * 256), 16, 0, 0);
+  }
+}
+// where the operand of a kernel's NEXT product lives: number n of the wave reads base + (x0 + n) * stride + ent_n * 72 words
+struct PairNext {
+  const u32* base = nullptr;     // null: the next operation takes nothing from HBM (a squaring, a register operand)
+  size_t stride = 0;
+  u32 ent = 0;
+};
+}  // namespace
+
 extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
 k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
                         const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
@@ -163,72 +198,106 @@ k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ ta
   __shared__ PairShared sh;
   tables_to_lds(&sh.tb, gtab);
   const PairLane pl = make_pair_lane();
-  const int wave = threadIdx.x >> 6;
-  const int xi = (blockIdx.x * PAIR_WAVES + wave) * 32 + (int)(pl.lane & 31);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform values stay in scalar registers)
+  const int x0 = (blockIdx.x * PAIR_WAVES + wave) * 32;
+  const int xi = x0 + (int)(pl.lane & 31);
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
-  u32* slot = &sh.slots[wave][(pl.lane & 31) * SLOTW];
+  u32* wslots = sh.slots[wave];
+  u32* slot = &wslots[(pl.lane & 31) * SLOTW];
   u32* junk = sh.junk[wave];
   const Tables* tb = &sh.tb;
   u32 acc[LP];
-  const u32* t1 = tab1 + (size_t)x * 64 * L;
-  const u32* t2 = tab2 + (size_t)x * 16 * L;
-  const uint8_t* e1 = e1_be + (size_t)x * 256;
-  const uint8_t* c_be = c_all + (size_t)x * c_stride;
+  // (per-number pointers are formed from x where they are used: the product keeps 230 registers live, and every 64-bit
+  // pointer carried across it is two more)
   auto digit6 = [&](int w) -> u32 {
+    const uint8_t* e1 = e1_be + (size_t)x * 256;
     const int o = 6 * w, k = o >> 3;
     const u32 lo = e1[255 - k];
     const u32 hi = (k + 1 < 256) ? e1[254 - k] : 0u;
     return ((lo | (hi << 8)) >> (o & 7)) & 63u;
   };
-  load_pair_limbs(acc, t1 + (size_t)digit6(341) * L, pl);
-  int cur = 2046;
-  int s = 0;                       // 0: square, 1: product with tab1, 2: product with tab2, 3: leave the Montgomery domain
-  int si = 0;
+  load_pair_limbs(acc, tab1 + ((size_t)x * 64 + digit6(341)) * L, pl);
+  // The schedule: from weight cur = 2046 down, per bit one squaring, then (cur % 6 == 0) the product with y^digit from tab1, then
+  // the product with Y^digit from tab2 where the schedule of c (or its fixed 4-bit windows) has one; at the end the product with
+  // plain 1 that leaves the Montgomery domain.  next_op() steps that state machine to the next operation that is not skipped:
+  //   kind 0 squaring; 1 product with entry `ent` of tab1; 2 with entry `ent` of tab2; 3 the closing product with cs->one
+  int cur = 2046, s = 0, si = 0;
   const int sn = c_sched ? (int)c_sched[0] : 0;
-  while (true) {
-    const u32* fill = nullptr;
-    bool skip = false;
-    if (s == 0) {
-      --cur;
-    } else if (s == 1) {
-      if (cur % 6 == 0) fill = t1 + (size_t)digit6(cur / 6) * L; else skip = true;
-    } else if (s == 2) {
-      if (c_sched != nullptr) {
-        if (si < sn && cur == (int)c_sched[1 + 2 * si]) {
-          fill = t2 + (size_t)c_sched[2 + 2 * si] * L;
-          ++si;
-        } else {
-          skip = true;
-        }
-      } else if ((cur & 3) == 0 && cur < 256 && c_all != nullptr) {
-        const u32 byte = c_be[255 - (cur >> 3)];
-        fill = t2 + (size_t)((cur & 4) ? (byte >> 4) : (byte & 15)) * L;
-      } else {
-        skip = true;
-      }
-    } else {
-      fill = cs->one;
-    }
-    if (!skip) {
-      u64 T[LP];
+  struct Op { int kind; u32 ent; };
+  auto next_op = [&]() -> Op {
+    while (true) {
+      Op op{-1, 0u};
       if (s == 0) {
-        slot_store_pair(slot, acc, pl);
-        __builtin_amdgcn_wave_barrier();
-        phase_a<true>(T, acc, slot, junk, pl);
+        --cur;
+        op.kind = 0;
+      } else if (s == 1) {
+        if (cur % 6 == 0) { op.kind = 1; op.ent = digit6(cur / 6); }
+      } else if (s == 2) {
+        if (c_sched != nullptr) {
+          if (si < sn && cur == (int)c_sched[1 + 2 * si]) {
+            op.kind = 2;
+            op.ent = c_sched[2 + 2 * si];
+            ++si;
+          }
+        } else if ((cur & 3) == 0 && cur < 256 && c_all != nullptr) {
+          const u32 byte = c_all[(size_t)x * c_stride + 255 - (cur >> 3)];
+          op.kind = 2;
+          op.ent = (cur & 4) ? (byte >> 4) : (byte & 15);
+        }
       } else {
-        slot_fill_pair(slot, fill, pl);
-        __builtin_amdgcn_wave_barrier();
-        phase_a<false>(T, acc, slot, junk, pl);
+        op.kind = 3;
       }
-      u32 r[LP];
-      reduce(r, T, slot, tb, pl);                 // ONE copy of the reduction in the kernel
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < LP; ++k) acc[k] = r[k];
+      if (s != 3) s = (s == 2) ? (cur == 0 ? 3 : 0) : s + 1;
+      if (op.kind >= 0) return op;
     }
-    if (s == 3) break;
-    s = (s == 2) ? (cur == 0 ? 3 : 0) : s + 1;
+  };
+  auto source = [&](const Op& op, const u32*& base, size_t& stride) {       // table of a product: base of number 0, words per number
+    if (op.kind == 1) { base = tab1; stride = (size_t)64 * L; }
+    else if (op.kind == 2) { base = tab2; stride = (size_t)16 * L; }
+    else { base = cs->one; stride = 0; }
+  };
+  Op op = next_op();
+  bool fetched = false;              // the operand of `op` is already on its way into the slots
+  while (true) {
+    Op nx{-1, 0u};
+    if (op.kind != 3) nx = next_op();
+    u64 T[LP];
+    if (op.kind == 0) {
+      slot_store_pair(slot, acc, pl);
+      __builtin_amdgcn_wave_barrier();
+      phase_a<true>(T, acc, slot, junk, pl);
+    } else {
+      const u32* base;
+      size_t stride;
+      source(op, base, stride);
+      if (fetched) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        slot_fill_pair(slot, base + (size_t)x * stride + (size_t)op.ent * L, pl);
+      }
+      __builtin_amdgcn_wave_barrier();
+      phase_a<false>(T, acc, slot, junk, pl);
+    }
+    u32 r[LP];
+#if PAIR_PREFETCH
+    fetched = nx.kind > 0;
+    reduce(r, T, slot, tb, pl, [&]() {          // ONE copy of the reduction in the kernel
+      if (nx.kind > 0) {
+        const u32* base;
+        size_t stride;
+        source(nx, base, stride);
+        slots_prefetch_pair(wslots, base, stride, x0, count, nx.ent, pl);
+      }
+    });
+#else
+    reduce(r, T, slot, tb, pl);
+#endif
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < LP; ++k) acc[k] = r[k];
+    if (op.kind == 3) break;
+    op = nx;
   }
   store_canonical_pair(out_be + (size_t)x * 256, acc, slot, cs, pl, live);
 }
@@ -260,6 +329,35 @@ __device__ __forceinline__ void pair_step(u32 (&acc)[LP], bool sq, const u32* fi
   for (int k = 0; k < LP; ++k) acc[k] = r[k];
 }
 
+// The same for kernels whose products take their second operand from HBM: `fetched` says that this operation's operand is
+// already on its way into the slots (an LDS-DMA started under the previous reduction), `nx` names the next one's, whose DMA
+// starts as soon as this reduction has the slot's contents in registers.  A squaring (sq) needs neither.
+template <bool HAS_SQ>
+__device__ __forceinline__ void pair_step_pf(u32 (&acc)[LP], bool sq, const u32* fill, bool fetched, const PairNext& nx, u32* wslots,
+                                             int x0, int count, u32* slot, u32* junk, const Tables* tb, const PairLane& pl) {
+  u64 T[LP];
+  if (HAS_SQ && sq) {
+    slot_store_pair(slot, acc, pl);
+    __builtin_amdgcn_wave_barrier();
+    phase_a<true>(T, acc, slot, junk, pl);
+  } else {
+    if (fetched) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else slot_fill_pair(slot, fill, pl);
+    __builtin_amdgcn_wave_barrier();
+    phase_a<false>(T, acc, slot, junk, pl);
+  }
+  u32 r[LP];
+#if PAIR_PREFETCH
+  reduce(r, T, slot, tb, pl, [&]() {
+    if (nx.base != nullptr) slots_prefetch_pair(wslots, nx.base, nx.stride, x0, count, nx.ent, pl);
+  });
+#else
+  reduce(r, T, slot, tb, pl);
+#endif
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < LP; ++k) acc[k] = r[k];
+}
+
 // limb j (W bits at bit offset W j) of a 256-byte big-endian integer (as be256_limb of modp_kernels.hip)
 __device__ __forceinline__ u32 be256_limb_pair(const uint8_t* __restrict__ be, int j) {
   const int o = W * j;
@@ -286,9 +384,10 @@ __device__ __forceinline__ void store_pair_limbs(u32* __restrict__ g, const u32 
 
 struct PairCtx {          // what every pair kernel sets up the same way
   PairLane pl;
-  int x;
+  int x, x0;              // this lane's number (clamped to count - 1), the first number of its wave
   bool live;
   u32* slot;
+  u32* wslots;            // the wave's 32 slots
   u32* junk;
   const Tables* tb;
 };
@@ -300,11 +399,13 @@ struct PairCtx {          // what every pair kernel sets up the same way
   PairCtx pc;                                                                              \
   pc.pl = make_pair_lane();                                                                \
   {                                                                                        \
-    const int wave_ = threadIdx.x >> 6;                                                    \
-    const int xi_ = (blockIdx.x * PAIR_WAVES + wave_) * 32 + (int)(pc.pl.lane & 31);       \
+    const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                    \
+    pc.x0 = (blockIdx.x * PAIR_WAVES + wave_) * 32;                                        \
+    const int xi_ = pc.x0 + (int)(pc.pl.lane & 31);                                        \
     pc.live = xi_ < (count);                                                               \
     pc.x = pc.live ? xi_ : (count)-1;                                                      \
-    pc.slot = &sh.slots[wave_][(pc.pl.lane & 31) * SLOTW];                                 \
+    pc.wslots = sh.slots[wave_];                                                           \
+    pc.slot = &pc.wslots[(pc.pl.lane & 31) * SLOTW];                                       \
     pc.junk = sh.junk[wave_];                                                              \
     pc.tb = &sh.tb;                                                                        \
   }
@@ -361,13 +462,21 @@ k_modp_comb16_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict
                        const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
   PAIR_KERNEL_PROLOGUE(gtab, count)
   const PairLane& pl = pc.pl;
-  const uint8_t* e1 = e1_be + (size_t)pc.x * 256;
-  auto entry = [&](int k) { return comb16 + ((size_t)k * 65536 + (((u32)e1[254 - 2 * k] << 8) | e1[255 - 2 * k])) * L; };
-  u32 acc[LP], dummy[LP];
-  load_pair_limbs(acc, entry(0), pl);
-#pragma unroll
-  for (int k = 0; k < LP; ++k) dummy[k] = 0;
-  for (int k = 1; k < 128; ++k) pair_step<false>(acc, false, entry(k), dummy, pc.slot, pc.junk, pc.tb, pl);
+  auto digit16 = [&](int k) -> u32 {
+    const uint8_t* e1 = e1_be + (size_t)pc.x * 256;
+    return ((u32)e1[254 - 2 * k] << 8) | e1[255 - 2 * k];
+  };
+  auto row = [&](int k) { return comb16 + (size_t)k * 65536 * L; };      // row k of the comb: the same for every number
+  u32 acc[LP];
+  load_pair_limbs(acc, row(0) + (size_t)digit16(0) * L, pl);
+  // every operation is a product with an entry of the next row: its DMA runs under the reduction before it
+  u32 d = digit16(1);
+  for (int k = 1; k < 128; ++k) {
+    PairNext nx;
+    if (k + 1 < 128) { nx.base = row(k + 1); nx.ent = digit16(k + 1); }
+    pair_step_pf<false>(acc, false, row(k) + (size_t)d * L, PAIR_PREFETCH && k > 1, nx, pc.wslots, pc.x0, count, pc.slot, pc.junk, pc.tb, pl);
+    d = nx.ent;
+  }
   if (pc.live) store_pair_limbs(p_m + (size_t)pc.x * L, acc, pl);
 }
 
@@ -381,33 +490,48 @@ k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, cons
                           const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
   PAIR_KERNEL_PROLOGUE(gtab, count)
   const PairLane& pl = pc.pl;
-  const u32* t2 = tab2 + (size_t)pc.x * tab2_stride;
   const int sn = (int)c_sched[0];
-  u32 acc[LP], dummy[LP];
-#pragma unroll
-  for (int k = 0; k < LP; ++k) dummy[k] = 0;
-  load_pair_limbs(acc, t2 + (size_t)c_sched[2] * L, pl);     // top window: load instead of multiply
-  int cur = (int)c_sched[1], si = 1;
-  int stage = 0;          // 0: square down one bit (or go on to the last two products at weight 0), 1: window product
-  int tail = 0;           // 1: times the stored g^r, 2: leave the Montgomery domain
-  while (true) {
-    bool sq = false;
-    const u32* fill = nullptr;
-    if (tail == 0) {
+  u32 acc[LP];
+  load_pair_limbs(acc, tab2 + (size_t)pc.x * tab2_stride + (size_t)c_sched[2] * L, pl);     // top window: load instead of multiply
+  // operations from the top window's weight down: a squaring per bit, a product with X^digit where the schedule has a window,
+  // at weight 0 the product with the stored g^r and the one with plain 1 that leaves the Montgomery domain.
+  //   kind 0 squaring; 1 product with entry `ent` of tab2; 2 with p_m; 3 with cs->one (the last)
+  int cur = (int)c_sched[1], si = 1, stage = 0, tail = 0;
+  struct Op { int kind; u32 ent; };
+  auto next_op = [&]() -> Op {
+    while (true) {
+      if (tail == 1) { tail = 2; return Op{3, 0u}; }
       if (stage == 0) {
-        if (cur == 0) { tail = 1; fill = p_m + (size_t)pc.x * L; }
-        else { sq = true; --cur; stage = 1; }
-      } else {
-        stage = 0;
-        if (si < sn && cur == (int)c_sched[1 + 2 * si]) { fill = t2 + (size_t)c_sched[2 + 2 * si] * L; ++si; }
-        else continue;
+        if (cur == 0) { tail = 1; return Op{2, 0u}; }
+        --cur;
+        stage = 1;
+        return Op{0, 0u};
       }
-    } else {
-      fill = cs->one;
-      tail = 2;
+      stage = 0;
+      if (si < sn && cur == (int)c_sched[1 + 2 * si]) {
+        const u32 e = c_sched[2 + 2 * si];
+        ++si;
+        return Op{1, e};
+      }
     }
-    pair_step<true>(acc, sq, fill, dummy, pc.slot, pc.junk, pc.tb, pl);
-    if (tail == 2) break;
+  };
+  auto source = [&](const Op& op, PairNext& nx) {
+    if (op.kind == 1) { nx.base = tab2; nx.stride = tab2_stride; nx.ent = op.ent; }
+    else if (op.kind == 2) { nx.base = p_m; nx.stride = L; nx.ent = 0; }
+    else if (op.kind == 3) { nx.base = cs->one; nx.stride = 0; nx.ent = 0; }
+  };
+  Op op = next_op();
+  bool fetched = false;
+  while (true) {
+    PairNext me, nx;
+    source(op, me);
+    Op nop{-1, 0u};
+    if (op.kind != 3) { nop = next_op(); source(nop, nx); }
+    const u32* fill = me.base ? me.base + (size_t)pc.x * me.stride + (size_t)me.ent * L : nullptr;
+    pair_step_pf<true>(acc, op.kind == 0, fill, fetched, nx, pc.wslots, pc.x0, count, pc.slot, pc.junk, pc.tb, pl);
+    fetched = PAIR_PREFETCH && nx.base != nullptr;
+    if (op.kind == 3) break;
+    op = nop;
   }
   store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);
 }

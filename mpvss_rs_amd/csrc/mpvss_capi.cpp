@@ -2280,6 +2280,51 @@ extern "C" int mpvss_pipeline_stats_get(mpvss_ctx* ctx, mpvss_pipeline_stats* ou
 
 extern "C" int mpvss_sha256_uses_shani(void) { return mpvss::sha256_uses_shani() ? 1 : 0; }
 
+// What this device sustains of the kernels' basic instruction right now (bench.py holds its issue-slot accounting against it):
+// 4 waves per SIMD on every CU issue the instruction back to back for about target_ms.
+extern "C" int mpvss_issue_probe(mpvss_ctx* ctx, int kind, double target_ms, double* insts_per_s_out, double* shader_clock_ghz_out,
+                                 double* ms_out) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if ((kind != 0 && kind != 1) || !insts_per_s_out || target_ms <= 0 || target_ms > 2000)
+    return fail(ctx, MPVSS_E_INVALID, "issue_probe: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipDeviceProp_t prop;
+  HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  const int blocks = prop.multiProcessorCount * 4;           // 256-thread blocks: one wave per SIMD each
+  const size_t waves = (size_t)blocks * 4;
+  DevBuf out, st;
+  RET_IF(ensure(ctx, out, (size_t)blocks * 256 * 4));
+  int rc = ensure(ctx, st, waves * 16);
+  if (rc != 0) { (void)hipFree(out.p); return rc; }
+  struct Free { DevBuf &a, &b; ~Free() { (void)hipFree(a.p); (void)hipFree(b.p); } } fr{out, st};
+  hipEvent_t e0, e1;
+  HIPCHK(ctx, hipEventCreate(&e0));
+  HIPCHK(ctx, hipEventCreate(&e1));
+  struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } ev{e0, e1};
+  float ms = 0;
+  int iters = 2000;
+  for (int pass = 0; pass < 2; ++pass) {                      // a short calibration launch, then the measurement
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    LAUNCHCHK(ctx, issue_probe_launch((uint32_t*)out.p, (unsigned long long*)st.p, blocks, iters, kind, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    if (pass == 0) {
+      const double scale = target_ms / (ms > 0.01f ? ms : 0.01f);
+      iters = (int)std::min(50000000.0, std::max(2000.0, iters * scale));
+    }
+  }
+  std::vector<unsigned long long> hs(waves * 2);
+  HIPCHK(ctx, hipMemcpy(hs.data(), st.p, hs.size() * 8, hipMemcpyDeviceToHost));
+  double cyc = 0, wall = 0;
+  for (size_t w = 0; w < waves; ++w) { cyc += (double)hs[2 * w]; wall += (double)hs[2 * w + 1]; }
+  *insts_per_s_out = (double)waves * iters * 64.0 / (ms * 1e-3);
+  if (shader_clock_ghz_out) *shader_clock_ghz_out = wall > 0 ? cyc / wall * 0.1 : 0.0;
+  if (ms_out) *ms_out = ms;
+  return MPVSS_OK;
+}
+
 // ---- verify_share, batched ----------------------------------------------------------------------------
 // n independent share-box proofs (participant.rs:361-386 -> dleq.rs:275-302).  Everything runs on the device: the two
 // double exponentiations, then K7 (verdict_kernels.hip): one lane per share hashes the four framed elements, applies

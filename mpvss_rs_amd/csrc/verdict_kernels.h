@@ -22,6 +22,16 @@ int verdict_launch_ec(int group, const uint8_t* h1, const uint8_t* h2, const uin
                       const uint8_t* c, const uint8_t* r, int count, uint8_t* verdict, uint8_t* ok, hipStream_t s);
 /* *first_bad = min(*first_bad, index of the first scalar >= the group order); scalars [count][32] */
 int verdict_launch_check_scalars(int group, const uint8_t* scalars, int count, int* first_bad, hipStream_t s);
+/* the curve groups' scalar ring on the device: out[i] = P(positions[i]) mod order for the t coefficients at coeffs_dev (32 bytes
+ * each, the group's byte order); coef_m_scratch: t x 8 words of device scratch.  r[i] = w[i] - alpha[i] c mod order (c_stride 0:
+ * one shared c) */
+int ec_scalar_launch_poly_eval(int group, const uint8_t* coeffs_dev, int t, const int64_t* positions, int count,
+                               uint32_t* coef_m_scratch, uint8_t* out, hipStream_t s);
+int ec_scalar_launch_responses(int group, const uint8_t* w, const uint8_t* alpha, const uint8_t* c, size_t c_stride, int count,
+                               uint8_t* out, hipStream_t s);
+/* measurement aid: `blocks` x 4 waves, each issuing iters x 64 VALU instructions of `kind` (0: v_mad_u64_u32, 1: 32-bit integer
+ * work); stamps[2 w] / [2 w + 1] = shader-clock / 100 MHz wall ticks of wave w; out: blocks x 256 words */
+int issue_probe_launch(uint32_t* out, unsigned long long* stamps, int blocks, int iters, int kind, hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

@@ -458,3 +458,222 @@ extern "C" int verdict_launch_check_scalars(int group, const uint8_t* scalars, i
   else hipLaunchKernelGGL(k_rist_check_scalars, dim3((count + 255) / 256), dim3(256), 0, s, scalars, count, first_bad);
   return (int)hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Measurement aid (mpvss_issue_probe, bench.py): what one SIMD sustains of the instruction the engine's kernels are made of,
+// on THIS device, now -- every wave issues `iters` x 64 independent-enough VALU instructions (8 accumulator chains) and stamps
+// its shader-clock and wall-clock (100 MHz) time; 4 waves per SIMD.  kind 0: v_mad_u64_u32 (the limb product of all three
+// groups' kernels); kind 1: 32-bit integer work (v_add3_u32 / v_and_b32 / v_lshl_add_u32).
+// ---------------------------------------------------------------------------------------------------------------------
+#define PROBE_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define PROBE_REP64(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
+extern "C" __global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, unsigned long long* stamps, int iters, int kind, uint32_t seed) {
+  uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+  uint64_t p[8];
+  uint32_t q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { p[k] = a + k; q[k] = b + k; }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  if (kind == 0) {
+    for (int it = 0; it < iters; ++it) {
+#define X(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p[k]) : "v"(a), "v"(b) : "vcc");
+      PROBE_REP64(X)
+#undef X
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#define X(k) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(a), "v"(b));
+      PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
+#undef X
+#define X(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(q[k]) : "v"(b));
+      PROBE_REP8(X) PROBE_REP8(X)
+#undef X
+#define X(k) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(q[k]) : "v"(a));
+      PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
+#undef X
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc ^= p[k] ^ q[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(acc ^ (acc >> 32));
+  if ((threadIdx.x & 63) == 0) {
+    const size_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    stamps[2 * w] = t1 - t0;
+    stamps[2 * w + 1] = r1 - r0;
+  }
+}
+
+extern "C" int issue_probe_launch(uint32_t* out, unsigned long long* stamps, int blocks, int iters, int kind, hipStream_t s) {
+  hipLaunchKernelGGL(k_issue_probe, dim3(blocks), dim3(256), 0, s, out, stamps, iters, kind, 12345u);
+  return (int)hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The curve groups' scalar side of the dealer on the device (one share per lane, 8 x 32-bit Montgomery arithmetic mod the
+// group order, ec_scalar.h):
+//   P(i) mod n     Polynomial::get_value src/polynomial.rs:50-58 followed by the caller's reduction (`% n`
+//                  src/participant.rs:1155-1157, Scalar arithmetic :1619-1621): Horner's rule, the position as `position as u64`
+//   r_i = w_i - P(i) c mod n     src/dleq.rs:42-50 through Group::scalar_mul / scalar_sub (secp256k1.rs:173-181, ristretto255.rs:244-252)
+// Scalars cross as 32 bytes in the group's byte order (secp256k1 big-endian, ristretto255 little-endian); any 256-bit input is
+// reduced, as the host functions of the same ABI do (mpvss_ec_poly_eval, mpvss_ec_dleq_responses).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+template <bool BE>
+__device__ __forceinline__ void sc_load(ec::Sc& a, const uint8_t* __restrict__ b) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint8_t* q = BE ? b + 28 - 4 * i : b + 4 * i;
+    a.v[i] = BE ? (((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | q[3])
+                : (((u32)q[3] << 24) | ((u32)q[2] << 16) | ((u32)q[1] << 8) | q[0]);
+  }
+}
+template <bool BE>
+__device__ __forceinline__ void sc_store(uint8_t* __restrict__ b, const ec::Sc& a) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint8_t* q = BE ? b + 28 - 4 * i : b + 4 * i;
+    const u32 v = a.v[i];
+    if (BE) { q[0] = (uint8_t)(v >> 24); q[1] = (uint8_t)(v >> 16); q[2] = (uint8_t)(v >> 8); q[3] = (uint8_t)v; }
+    else { q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); q[3] = (uint8_t)(v >> 24); }
+  }
+}
+// r = a + b mod n for reduced a, b
+template <class O>
+__device__ __forceinline__ void sc_add(ec::Sc& r, const ec::Sc& a, const ec::Sc& b) {
+  u32 t[8];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (u64)a.v[i] + b.v[i];
+    t[i] = (u32)c;
+    c >>= 32;
+  }
+  bool ge = c != 0;
+  if (!ge) {
+    ge = true;
+    bool decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; --i)
+      if (!decided && t[i] != O::n(i)) { ge = t[i] > O::n(i); decided = true; }
+  }
+  const u32 mask = ge ? 0xffffffffu : 0u;
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 d = (u64)t[i] - (O::n(i) & mask) - borrow;
+    r.v[i] = (u32)d;
+    borrow = (d >> 63) & 1;
+  }
+}
+// r = a - b mod n for reduced a, b
+template <class O>
+__device__ __forceinline__ void sc_sub(ec::Sc& r, const ec::Sc& a, const ec::Sc& b) {
+  u32 t[8];
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 d = (u64)a.v[i] - b.v[i] - borrow;
+    t[i] = (u32)d;
+    borrow = (d >> 63) & 1;
+  }
+  const u32 mask = borrow ? 0xffffffffu : 0u;
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (u64)t[i] + (O::n(i) & mask);
+    r.v[i] = (u32)c;
+    c >>= 32;
+  }
+}
+template <class O>
+__device__ __forceinline__ void sc_consts(ec::Sc& r2, ec::Sc& one) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { r2.v[i] = O::r2(i); one.v[i] = i == 0 ? 1u : 0u; }
+}
+
+// coef_m[j] = coeffs[j] * R mod n (reduced): t lanes
+template <class O, bool BE>
+__global__ void k_ec_coeffs_to_mont(const uint8_t* __restrict__ coeffs, int t, u32* __restrict__ coef_m) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t) return;
+  ec::Sc a, r2, one;
+  sc_consts<O>(r2, one);
+  sc_load<BE>(a, coeffs + (size_t)j * 32);
+  ec::ScalarField<O>::mont_mul(a, a, r2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) coef_m[(size_t)j * 8 + i] = a.v[i];
+}
+
+template <class O, bool BE>
+__global__ void __launch_bounds__(64) k_ec_poly_eval(const u32* __restrict__ coef_m, int t, const int64_t* __restrict__ positions,
+                                                    int count, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  typedef ec::ScalarField<O> F;
+  ec::Sc x, acc, c, r2, one;
+  sc_consts<O>(r2, one);
+  const uint64_t pos = (uint64_t)positions[i];          // `position as u64` (participant.rs:1419, 1862)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x.v[k] = 0;
+  x.v[0] = (u32)pos;
+  x.v[1] = (u32)(pos >> 32);
+  F::mont_mul(x, x, r2);                                // x R
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc.v[k] = coef_m[(size_t)(t - 1) * 8 + k];
+  for (int j = t - 2; j >= 0; --j) {
+    F::mont_mul(acc, acc, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.v[k] = coef_m[(size_t)j * 8 + k];
+    sc_add<O>(acc, acc, c);
+  }
+  F::mont_mul(acc, acc, one);                           // out of the Montgomery domain, reduced
+  sc_store<BE>(out + (size_t)i * 32, acc);
+}
+
+template <class O, bool BE>
+__global__ void __launch_bounds__(64) k_ec_responses(const uint8_t* __restrict__ w, const uint8_t* __restrict__ alpha,
+                                                    const uint8_t* __restrict__ c, size_t c_stride, int count, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  typedef ec::ScalarField<O> F;
+  ec::Sc ww, aa, cc, r2, one, prod;
+  sc_consts<O>(r2, one);
+  sc_load<BE>(ww, w + (size_t)i * 32);
+  sc_load<BE>(aa, alpha + (size_t)i * 32);
+  sc_load<BE>(cc, c + (size_t)i * c_stride);
+  F::mont_mul(aa, aa, r2);                              // alpha R
+  F::mont_mul(prod, aa, cc);                            // alpha c mod n
+  F::mont_mul(ww, ww, r2);
+  F::mont_mul(ww, ww, one);                             // w mod n
+  sc_sub<O>(ww, ww, prod);
+  sc_store<BE>(out + (size_t)i * 32, ww);
+}
+}  // namespace
+
+extern "C" int ec_scalar_launch_poly_eval(int group, const uint8_t* coeffs_dev, int t, const int64_t* positions, int count,
+                                          uint32_t* coef_m_scratch, uint8_t* out, hipStream_t s) {
+  if (count <= 0 || t <= 0) return 0;
+  const dim3 gt((t + 63) / 64), gn((count + 63) / 64), b(64);
+  if (group == 1) {
+    hipLaunchKernelGGL((k_ec_coeffs_to_mont<ec::OrderSecp, true>), gt, b, 0, s, coeffs_dev, t, coef_m_scratch);
+    hipLaunchKernelGGL((k_ec_poly_eval<ec::OrderSecp, true>), gn, b, 0, s, coef_m_scratch, t, positions, count, out);
+  } else {
+    hipLaunchKernelGGL((k_ec_coeffs_to_mont<ec::OrderEd, false>), gt, b, 0, s, coeffs_dev, t, coef_m_scratch);
+    hipLaunchKernelGGL((k_ec_poly_eval<ec::OrderEd, false>), gn, b, 0, s, coef_m_scratch, t, positions, count, out);
+  }
+  return (int)hipGetLastError();
+}
+extern "C" int ec_scalar_launch_responses(int group, const uint8_t* w, const uint8_t* alpha, const uint8_t* c, size_t c_stride,
+                                          int count, uint8_t* out, hipStream_t s) {
+  if (count <= 0) return 0;
+  const dim3 gn((count + 63) / 64), b(64);
+  if (group == 1)
+    hipLaunchKernelGGL((k_ec_responses<ec::OrderSecp, true>), gn, b, 0, s, w, alpha, c, c_stride, count, out);
+  else
+    hipLaunchKernelGGL((k_ec_responses<ec::OrderEd, false>), gn, b, 0, s, w, alpha, c, c_stride, count, out);
+  return (int)hipGetLastError();
+}

@@ -171,6 +171,16 @@ unsafe extern "C" {
         x_dev_out: *mut u8, y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
     pub fn mpvss_ec_distribute_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, y_out_host: *mut u8,
         a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
+    pub fn mpvss_ec_poly_eval_device(ctx: *mut mpvss_ctx, group: c_int, coeffs_host: *const u8, t: usize, positions_dev: *const i64,
+                                     n: usize, out_dev: *mut u8) -> c_int;
+    pub fn mpvss_ec_dleq_responses_device(ctx: *mut mpvss_ctx, group: c_int, w_dev: *const u8, alpha_dev: *const u8,
+                                          c_host32: *const u8, n: usize, r_dev_out: *mut u8) -> c_int;
+    pub fn mpvss_ec_deal_compute(ctx: *mut mpvss_ctx, group: c_int, coeffs_host: *const u8, t: usize, positions_dev: *const i64,
+                                 pubkeys_dev: *const u8, witnesses_dev: *const u8, n: usize, p_dev_out: *mut u8,
+                                 x_dev_out: *mut u8, y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
+    pub fn mpvss_ec_deal(ctx: *mut mpvss_ctx, group: c_int, coeffs_host: *const u8, t: usize, positions_host: *const i64,
+                         pubkeys_host: *const u8, witnesses_host: *const u8, n: usize, x_out: *mut u8, y_out: *mut u8,
+                         a1_out: *mut u8, a2_out: *mut u8, digest32_out: *mut u8, challenge_out32: *mut u8, r_out: *mut u8) -> c_int;
     pub fn mpvss_ec_hash_to_scalar(group: c_int, data: *const u8, len: usize, out32: *mut u8) -> c_int;
     // ---- extract_secret_share, batched
     pub fn mpvss_modp_extract_shares(ctx: *mut mpvss_ctx, space: c_int, pk: *const u8, y: *const u8, xinv: *const u8, w: *const u8, n: usize,
@@ -213,4 +223,6 @@ unsafe extern "C" {
     pub fn mpvss_pipeline_stats_get(ctx: *mut mpvss_ctx, out: *mut mpvss_pipeline_stats, reset: c_int) -> c_int;
     pub fn mpvss_blocks_in_flight(ctx: *mut mpvss_ctx, in_flight_out: *mut c_int, gpu_pending_out: *mut c_int) -> c_int;
     pub fn mpvss_sha256_uses_shani() -> c_int;
+    pub fn mpvss_issue_probe(ctx: *mut mpvss_ctx, kind: c_int, target_ms: c_double, insts_per_s_out: *mut c_double,
+                             shader_clock_ghz_out: *mut c_double, ms_out: *mut c_double) -> c_int;
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds ONE curve-group box of the headline shape (n=65536, t=256) exactly as bench.py's bench_ec does and verifies it K times
-through mpvss_ec_verify_many -- the program the PMC passes of tools/run_profiles_ec.sh run twice per group (K = 0 and K = 8): the
-difference of the summed counters is what K verifications cost, free of the set-up kernels.
+through mpvss_ec_verify_many with bench.py's own depth and hash threads (MPVSS_BENCH_EC_DEPTH = 16 boxes in flight, X paths of 16
+boxes per launch, 6 hash threads: the call bench.py times) -- the program the PMC passes of tools/run_profiles_ec.sh run twice per
+group (K = 0 and K = 32): the difference of the summed counters is what K verifications cost, free of the set-up kernels.
   python3 tools/ec_box_for_pmc.py <secp256k1|ristretto255> <K>"""
 import ctypes as C
 import os
@@ -44,7 +45,8 @@ if K > 0:
     arr = (capi.EcBox * K)(*([box] * K))
     verdicts = (C.c_int * K)()
     digests = (C.c_uint8 * (32 * K))()
-    eng._check(eng.lib.mpvss_ec_verify_many(eng.ctx, gid, capi.MPVSS_DEVICE, arr, K, 8, 4, verdicts, C.cast(digests, C.c_void_p)), "ec_verify_many")
+    depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "16")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "6"))
+    eng._check(eng.lib.mpvss_ec_verify_many(eng.ctx, gid, capi.MPVSS_DEVICE, arr, K, depth, threads, verdicts, C.cast(digests, C.c_void_p)), "ec_verify_many")
     assert all(verdicts[i] == 1 for i in range(K)) and bytes(digests)[:32] == d["digest"]
 print(name, "verified", K)
 eng.close()

@@ -21,7 +21,7 @@ M29 = (1 << W) - 1
 with open(os.path.join(out_dir, "in.bin"), "wb") as f:
     for x in xs:
         f.write(struct.pack("<72I", *[(x >> (W * k)) & M29 for k in range(L)]))
-exe = os.path.join(HERE, "ubench")
+exe = os.environ.get("UBENCH", os.path.join(HERE, "ubench"))
 res = subprocess.run([exe, os.path.join(out_dir, "in.bin"), os.path.join(out_dir, "out"), str(n), str(S), "3"],
                      capture_output=True, text=True)
 print(res.stdout, res.stderr)

@@ -28,9 +28,15 @@ constexpr int WAVES = UB_WAVES;   // waves per workgroup of the pair kernel (one
 #ifndef UB_WPE
 #define UB_WPE 2
 #endif
+#ifndef UB_STAGGER
+#define UB_STAGGER 0     // odd waves of a workgroup start this many s_sleep units late (the two waves of a SIMD run the same program)
+#endif
+// UB_STAMPS: a diagnostic build -- every wave adds up the shader-clock cycles it spends in phase A and in the reduction
+// (s_memtime around each) and notes the wall clock (s_memrealtime, 100 MHz) around its loop; the sums go to a buffer of their
+// own that nothing else reads: stamps[wave][4] = {cycles in phase A, cycles in reduce, loop cycles, loop wall ticks}
 template <bool MUL>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(UB_WPE, UB_WPE))) k_chain_pair(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
-                                                          int S, const mm::Tables* __restrict__ gt) {
+                                                          int S, const mm::Tables* __restrict__ gt, unsigned long long* __restrict__ stamps) {
   __shared__ mm::Tables tb;
   __shared__ __attribute__((aligned(16))) uint32_t slots[WAVES][32 * mm::SLOTW];
   __shared__ uint32_t junk[WAVES][mm::L];
@@ -52,9 +58,42 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     a[k] = in[(size_t)num * mm::L + mm::LP * pl.h + k];
     slot[mm::LP * pl.h + k] = a[k];
   }
+#if UB_STAGGER > 0
+  if (wave & 1) __builtin_amdgcn_s_sleep(UB_STAGGER);
+#endif
+#ifdef UB_STAMPS
+  unsigned long long cyc_a = 0, cyc_r = 0;
+  const unsigned long long loop_c0 = __builtin_amdgcn_s_memtime(), loop_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma nounroll
   for (int s = 0; s < S; ++s) {
     uint32_t r[mm::LP];
+#ifdef UB_STAMPS
+    {
+      if (MUL) {
+        const uint4* g4 = reinterpret_cast<const uint4*>(in + (size_t)num * mm::L + mm::LP * pl.h);
+        uint4* s4 = reinterpret_cast<uint4*>(slot + mm::LP * pl.h);
+#pragma unroll
+        for (int c = 0; c < mm::LP / 4; ++c) s4[c] = g4[c];
+        __builtin_amdgcn_wave_barrier();
+      }
+      uint64_t T[mm::LP];
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      mm::phase_a<!MUL>(T, a, slot, junk[wave], pl);
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      mm::reduce(r, T, slot, &tb, pl);
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      cyc_a += t1 - t0;
+      cyc_r += t2 - t1;
+#pragma unroll
+      for (int k = 0; k < mm::LP; ++k) {
+        a[k] = r[k];
+        if (!MUL) slot[mm::LP * pl.h + k] = r[k];
+      }
+      asm volatile("" ::: "memory");
+      continue;
+    }
+#endif
     if (MUL) {
       const uint4* g4 = reinterpret_cast<const uint4*>(in + (size_t)num * mm::L + mm::LP * pl.h);
       uint4* s4 = reinterpret_cast<uint4*>(slot + mm::LP * pl.h);
@@ -74,6 +113,15 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     }
     asm volatile("" ::: "memory");
   }
+#ifdef UB_STAMPS
+  if (pl.lane == 0) {
+    unsigned long long* st = stamps + (size_t)(blockIdx.x * WAVES + wave) * 4;
+    st[0] = cyc_a;
+    st[1] = cyc_r;
+    st[2] = __builtin_amdgcn_s_memtime() - loop_c0;
+    st[3] = __builtin_amdgcn_s_memrealtime() - loop_w0;
+  }
+#endif
   if (live)
 #pragma unroll
     for (int k = 0; k < mm::LP; ++k) out[(size_t)num * mm::L + mm::LP * pl.h + k] = a[k];
@@ -176,6 +224,10 @@ int main(int argc, char** argv) {
     hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_chain_pair<false>, 64 * WAVES, 0);
     printf("pair kernel: %d waves per workgroup, occupancy API: %d workgroups per CU (%s)\n", WAVES, nb, hipGetErrorString(oe));
   }
+  const int nwaves = ((n + 32 * WAVES - 1) / (32 * WAVES)) * WAVES;
+  unsigned long long* dstamps;
+  CHECK(hipMalloc(&dstamps, (size_t)nwaves * 4 * 8));
+  CHECK(hipMemset(dstamps, 0, (size_t)nwaves * 4 * 8));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -186,9 +238,9 @@ int main(int argc, char** argv) {
       CHECK(hipMemset(dout, 0, hin.size() * 4));
       CHECK(hipEventRecord(e0, 0));
       if (which == 0)
-        hipLaunchKernelGGL(k_chain_pair<false>, dim3((n + 32 * WAVES - 1) / (32 * WAVES)), dim3(64 * WAVES), 0, 0, din, dout, n, S, dt);
+        hipLaunchKernelGGL(k_chain_pair<false>, dim3((n + 32 * WAVES - 1) / (32 * WAVES)), dim3(64 * WAVES), 0, 0, din, dout, n, S, dt, dstamps);
       else if (which == 2)
-        hipLaunchKernelGGL(k_chain_pair<true>, dim3((n + 32 * WAVES - 1) / (32 * WAVES)), dim3(64 * WAVES), 0, 0, din, dout, n, S, dt);
+        hipLaunchKernelGGL(k_chain_pair<true>, dim3((n + 32 * WAVES - 1) / (32 * WAVES)), dim3(64 * WAVES), 0, 0, din, dout, n, S, dt, dstamps);
       else
         hipLaunchKernelGGL(k_chain_quad, dim3((n + 15) / 16), dim3(64), 0, 0, din, dout, n, S, dn);
       CHECK(hipGetLastError());
@@ -207,6 +259,16 @@ int main(int argc, char** argv) {
     printf("%s: n=%d S=%d best of %d: %.3f ms -> %.3f G %s/s\n",
            which == 0 ? "pair (MFMA reduction)" : (which == 1 ? "quad (VALU only)   " : "pair, products       "), n, S, reps, best,
            (double)n * S / (best * 1e-3) / 1e9, which == 2 ? "products" : "squarings");
+#ifdef UB_STAMPS
+    if (which != 1) {
+      std::vector<unsigned long long> hs((size_t)nwaves * 4);
+      CHECK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));
+      double a = 0, r = 0, c = 0, w = 0;
+      for (int i = 0; i < nwaves; ++i) { a += hs[4 * i]; r += hs[4 * i + 1]; c += hs[4 * i + 2]; w += hs[4 * i + 3]; }
+      printf("  stamps (mean over %d waves, per operation): phase A %.0f cycles, reduce %.0f cycles, whole iteration %.0f cycles; "
+             "shader clock %.3f GHz\n", nwaves, a / nwaves / S, r / nwaves / S, c / nwaves / S, c / w * 0.1);
+    }
+#endif
   }
   return 0;
 }
