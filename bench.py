@@ -315,29 +315,34 @@ def bench_ec(eng, name, args):
         rb = random.Random(SEED + 31 * gid + b)
         coeff_sets.append(coeffs if b == 0 else [rb.randrange(order) for _ in range(t)])
     coeff_bytes = [b"".join(map(sb, cs_)) for cs_ in coeff_sets]
-    ring_p = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(e2e_depth + 2)]
-    d_rr = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(e2e_depth + 2)]
+    ring_p = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(e2e_depth + 6)]     # P(i) of a box lives until its responses are out
+    d_rr = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(e2e_depth + 6)]
     torch.cuda.synchronize()
 
-    def e2e_post(b, d_pb):
-        st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
-        eng._check(eng.lib.mpvss_ec_distribute_absorb(eng.ctx, st, None, None, None, None), "ec_distribute_absorb")
-        digest = capi.ec_transcript_verdict(gid, bytes(st), zero_c)[1]
+    def e2e_resp(b, d_pb, digest):
         cc = capi.ec_hash_to_scalar(gid, digest)
         d_r = d_rr[b % len(d_rr)]
         eng.ec_dleq_responses_device(gid, d_wt.data_ptr(), d_pb.data_ptr(), cc, n, d_r.data_ptr())
-        return digest, (bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None)
+        return bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None
 
     def deal_e2e(count):
-        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:       # blocks are absorbed in FIFO order
+        # the block of every box is claimed as soon as it is enqueued (mpvss_block_claim: the ticket says which block a thread
+        # holds), three threads wait for and hash blocks side by side, the challenge and the responses of a box are another pool's
+        with concurrent.futures.ThreadPoolExecutor(max_workers=3) as absorb_pool, concurrent.futures.ThreadPoolExecutor(max_workers=3) as resp_pool:
+            def e2e_post(b, d_pb, ticket):
+                st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+                eng._check(eng.lib.mpvss_ec_block_absorb_claimed(eng.ctx, ticket, st, None, None, None, None), "ec_block_absorb_claimed")
+                digest = capi.ec_transcript_verdict(gid, bytes(st), zero_c)[1]
+                return digest, resp_pool.submit(e2e_resp, b, d_pb, digest)
             post = []
             for b in range(count):
                 d_pb = ring_p[b % len(ring_p)]
                 while len(post) - sum(f.done() for f in post) >= e2e_depth:
                     time.sleep(0.0002)
                 eng.ec_deal_compute(gid, coeff_bytes[b % len(coeff_bytes)], d_pos.data_ptr(), d_pk.data_ptr(), d_wt.data_ptr(), n, d_pb.data_ptr())
-                post.append(pool.submit(e2e_post, b, d_pb))
-            return [f.result() for f in post]
+                post.append(absorb_pool.submit(e2e_post, b, d_pb, eng.block_claim()))
+            outs = [f.result() for f in post]
+            return [(dg_, fut.result()) for dg_, fut in outs]
 
     deal_e2e(4)
     torch.cuda.synchronize()
@@ -766,16 +771,98 @@ def main():
         raw = bytes(digests)
         return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(k)]
 
+    CHAINED = os.environ.get("MPVSS_BENCH_CHAINED", "1")      # 0: blocks driven from Python threads (round 3); 2: the chained call at N = 1 too
+
+    def run_steps_chained(seq_boxes, depth):
+        """N > 1: the SAME library pipeline as N = 1 (mpvss_modp_verify_many_chained: the calling thread enqueues, library threads
+        absorb), with the 128-byte running state of every box travelling rank to rank through two callbacks the library makes
+        around each box's absorb: state_in receives this rank's starting state of the box from the rank before (gloo, tag = box
+        number), state_out sends it on.  One more thread issues the per-box all-gather of the well-formedness bytes in box order."""
+        import queue
+        k = len(seq_boxes)
+        seq0 = len(enq_boxes)
+        enq_boxes.extend(seq_boxes)
+        arr = (capi.ModpBox * k)(*[capi.ModpBox(bx.d_cm.data_ptr(), bx.t, cur.d_pos.data_ptr(), cur.d_pk.data_ptr(), bx.d_sh.data_ptr(),
+                                                bx.d_rs.data_ptr(), bx.n, C.cast(bx.ch_buf, C.c_void_p), None, 0) for bx in seq_boxes])
+        wf = None
+        if world > 1:
+            wf = (C.c_void_p * k)(*[rccl["mine"][(seq0 + i) % rccl["ring"]].data_ptr() for i in range(k)])
+        verdicts = (C.c_int * k)()
+        digests = (C.c_uint8 * (32 * k))()
+        done_q, errors = queue.Queue(), []
+        SB = capi.TRANSCRIPT_STATE_BYTES
+
+        def cb_in(user, box, state, ok):
+            try:
+                buf = torch.empty(SB + 1, dtype=torch.uint8, device=commdev)
+                dist.recv(buf, src=rank - 1, group=chain, tag=seq0 + box)
+                raw = bytes(buf.cpu().numpy().tobytes())
+                C.memmove(state, raw[1:], SB)
+                return 0 if raw[0] else 1
+            except Exception as exc:      # noqa: BLE001 - reported after the call
+                errors.append(exc)
+                return 1
+
+        def cb_out(user, box, state, ok):
+            try:
+                if world > 1 and rank + 1 < world:
+                    msg = bytes([1 if ok else 0]) + C.string_at(state, SB)
+                    dist.send(torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(commdev), dst=rank + 1, group=chain, tag=seq0 + box)
+            except Exception as exc:      # noqa: BLE001
+                errors.append(exc)
+            done_q.put(seq0 + box)        # this rank's flags of the box are final
+            return 0
+
+        def gatherer():
+            torch.cuda.set_device(dev)
+            pend, nxt = set(), seq0
+            while nxt < seq0 + k:
+                pend.add(done_q.get())
+                while nxt in pend:
+                    pend.discard(nxt)
+                    if world > 1:
+                        rccl_gather_flags(nxt)
+                    nxt += 1
+
+        gt = threading.Thread(target=gatherer)
+        gt.start()
+        c_in = capi.CHAIN_CB(cb_in) if (world > 1 and rank > 0) else capi.CHAIN_CB()
+        c_out = capi.CHAIN_CB(cb_out)
+        threads = min(32, max(HASH_THREADS, 1) + (min(world - 1, 8) if world > 1 else 0))
+        rc = lib.mpvss_modp_verify_many_chained(ctx, capi.MPVSS_DEVICE, arr, k, depth, threads, wf, c_in, c_out, None, verdicts,
+                                                C.cast(digests, C.c_void_p))
+        gt.join()
+        eng._check(rc, "verify_many_chained")
+        if errors:
+            raise errors[0]
+        raw = bytes(digests)
+        return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(k)]
+
     def run_steps(k, depth=None, first=0):
         """k complete verifications -- step s verifies box (first + s) mod (number of distinct boxes) -- software-pipelined:
         up to `depth` boxes have their GPU work enqueued while host threads hash the oldest ones.  On one GPU the whole
         pipeline runs inside the library (run_steps_many); with several ranks the running hash state of every box travels
-        rank to rank, so the blocks are driven from here (compute / claim / absorb_claimed) with HASH_THREADS boxes
-        being absorbed at a time.  Returns [(verdict, digest, box)]."""
+        rank to rank: the same library pipeline with two callbacks around every box's absorb (run_steps_chained; with
+        MPVSS_BENCH_CHAINED=0 the blocks are driven from Python threads instead: compute / claim / absorb_claimed).
+        Returns [(verdict, digest, box)]."""
         seq_boxes = [cur.boxes[(first + s) % len(cur.boxes)] for s in range(k)]
-        if world == 1 and USE_VERIFY_MANY and k > 0:
+        if world == 1 and USE_VERIFY_MANY and k > 0 and (CHAINED != "2" or keyset[0] is not None):
             res = run_steps_many(seq_boxes, min(depth or PIPE_DEPTH, capi.BLOCK_SLOTS))
             return [(v, d, bx) for (v, d), bx in zip(res, seq_boxes)]
+        if k > 0 and keyset[0] is None and ((world > 1 and CHAINED != "0") or CHAINED == "2"):
+            results = run_steps_chained(seq_boxes, min(depth or (PIPE_DEPTH if world == 1 else RANK_DEPTH), capi.BLOCK_SLOTS - 8))
+            if world > 1:
+                rccl_reap(0)
+                assert rccl["bad"] == 0, "a share of an honest box was reported as not well-formed"
+                if rank == world - 1:
+                    flat = b"".join(bytes([int(v)]) + d for v, d in results)
+                    out = torch.frombuffer(bytearray(flat), dtype=torch.uint8).to(commdev)
+                else:
+                    out = torch.zeros(33 * k, dtype=torch.uint8, device=commdev)
+                dist.broadcast(out, src=world - 1, group=chain)
+                raw = bytes(out.cpu().numpy().tobytes())
+                results = [(bool(raw[33 * i]), raw[33 * i + 1:33 * i + 33]) for i in range(k)]
+            return [(v, d, bx) for (v, d), bx in zip(results, seq_boxes)]
         # absorbing threads hold the oldest blocks, so leave them slack in the ring of block slots
         depth = min(depth or RANK_DEPTH, capi.BLOCK_SLOTS - max(HASH_THREADS, 1))
         results = []
@@ -993,10 +1080,17 @@ def main():
                  "boxes_in_flight": (min(PIPE_DEPTH, capi.BLOCK_SLOTS) if (world == 1 and USE_VERIFY_MANY)
                                      else min(RANK_DEPTH, capi.BLOCK_SLOTS - max(HASH_THREADS, 1))),
                  "pipeline": ("mpvss_modp_verify_many (library threads; boxes_in_flight = boxes with GPU work pending)"
-                              if (world == 1 and USE_VERIFY_MANY)
+                              if (world == 1 and USE_VERIFY_MANY and CHAINED != "2")
+                              else "mpvss_modp_verify_many_chained (the same library pipeline; the 128-byte hash state of every box travels "
+                                   "rank to rank through the state_in / state_out callbacks: gloo, tag = box)"
+                              if ((world > 1 and CHAINED != "0") or CHAINED == "2")
                               else "verify_block_compute / block_claim / absorb_claimed from a Python thread pool"
                                    + ("; the hash state of every box travels rank to rank (gloo, tag = box)" if world > 1 else "")),
                  "slot_init_boxes": slot_init,
+                 "hbm": (lambda fr_tot: {"bytes_in_use_on_this_rank": fr_tot[1] - fr_tot[0], "bytes_total": fr_tot[1],
+                                         "note": "device memory in use on rank 0's GPU after the timed region (torch.cuda.mem_get_info): "
+                                                 "block-slot workspaces of the boxes in flight, the wide combs (2.4 GB per generator), "
+                                                 "inputs of the distinct boxes, torch's own pool"})(torch.cuda.mem_get_info(dev)),
                  "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                  "setup_s": setup_s},
     }

@@ -153,8 +153,8 @@ int mpvss_modp_verify_block_compute_flags(mpvss_ctx* ctx, int space, const uint8
                                           const uint8_t* responses, size_t n, const uint8_t* challenge_host,
                                           uint8_t* wellformed_dev_out);
 /* The same in two steps, for callers whose transcript state arrives from elsewhere (one rank of a sharded verification:
- * the state of box b comes from the previous rank): mpvss_block_claim takes the oldest block in flight (MODP
- * distribution blocks only) and returns its ticket -- tickets count the blocks of this context in enqueue order --,
+ * the state of box b comes from the previous rank): mpvss_block_claim takes the oldest block in flight (a verifier's or
+ * dealer's distribution block of any of the three groups) and returns its ticket -- tickets count the blocks of this context in enqueue order --,
  * mpvss_modp_verify_block_absorb_claimed waits for and hashes exactly that block.  Several threads may hold claimed
  * blocks at once; every claimed block must be absorbed. */
 int mpvss_block_claim(mpvss_ctx* ctx, unsigned long long* ticket_out);
@@ -183,6 +183,21 @@ typedef struct mpvss_modp_box {
 } mpvss_modp_box;
 int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
                            int hash_threads, int* verdicts, uint8_t* digests32);
+
+/* The same pipeline for ONE box held by SEVERAL engines (one per GPU, src/participant.rs:399-455 with the participants
+ * sharded): this engine verifies its contiguous block of every box; a box's transcript is one ordered hash, so the 128-byte
+ * running state travels engine to engine through two callbacks the library calls on its own threads, several boxes at a time,
+ * each box exactly once:
+ *   state_in(user, box, state, 1)   fill in the state this engine's block of `box` starts from (may block until the engine before
+ *                                   has sent it); return non-zero when an earlier engine failed on the box.  NULL: first engine.
+ *   state_out(user, box, state, ok) hand the state on after the block has been absorbed (ok = 0: this or an earlier engine failed
+ *                                   on the box, the state is zero).  NULL: last engine.
+ * verdicts / digests32 come from this engine's final state: meaningful on the last engine.  wellformed_dev_out: NULL or `count`
+ * device buffers of n bytes each that receive the shares' well-formedness flags (mpvss_modp_verify_block_compute_flags). */
+typedef int (*mpvss_chain_cb)(void* user, size_t box, uint8_t* state, int ok);
+int mpvss_modp_verify_many_chained(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
+                                   int hash_threads, uint8_t* const* wellformed_dev_out, mpvss_chain_cb state_in,
+                                   mpvss_chain_cb state_out, void* user, int* verdicts, uint8_t* digests32);
 
 /* ---- registered public keys (opt-in) ---------------------------------------------------- */
 
@@ -359,6 +374,9 @@ int mpvss_ec_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_ho
  *   deal                 the whole box in one call from HOST buffers: P(i), X_i, Y_i, a1_i, a2_i, digest, challenge, responses;
  *                        x_out, a1_out, a2_out, digest32_out, challenge_out32 are optional; t <= n.  One deal at a time per context;
  *                        P(i), the witnesses and the coefficients are zeroed on the device before it returns. */
+/* a curve-group block taken by mpvss_block_claim: waits for and hashes exactly that block (cf. mpvss_modp_verify_block_absorb_claimed) */
+int mpvss_ec_block_absorb_claimed(mpvss_ctx* ctx, unsigned long long ticket, uint8_t* state, uint8_t* x_out_host,
+                                  uint8_t* y_out_host, uint8_t* a1_out_host, uint8_t* a2_out_host);
 int mpvss_ec_poly_eval_device(mpvss_ctx* ctx, int group, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
                               size_t n, uint8_t* out_dev);
 int mpvss_ec_dleq_responses_device(mpvss_ctx* ctx, int group, const uint8_t* w_dev, const uint8_t* alpha_dev,

@@ -30,11 +30,11 @@ EXPORTED_SYMBOLS = (
     "mpvss_modp_transcript_verdict", "mpvss_modp_transcript_absorb",
     "mpvss_ec_batch_exp", "mpvss_ec_batch_mul", "mpvss_ec_commit_eval", "mpvss_ec_dleq_commitments",
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_distribute_compute", "mpvss_ec_distribute_absorb", "mpvss_ec_hash_to_scalar",
-    "mpvss_ec_poly_eval_device", "mpvss_ec_dleq_responses_device", "mpvss_ec_deal_compute", "mpvss_ec_deal",
+    "mpvss_ec_block_absorb_claimed", "mpvss_ec_poly_eval_device", "mpvss_ec_dleq_responses_device", "mpvss_ec_deal_compute", "mpvss_ec_deal",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
     "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
-    "mpvss_modp_verify_many", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani", "mpvss_issue_probe",
+    "mpvss_modp_verify_many", "mpvss_modp_verify_many_chained", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani", "mpvss_issue_probe",
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
     "mpvss_ec_batch_exp_generator", "mpvss_ec_verify_block_compute", "mpvss_ec_verify_block_absorb",
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
@@ -85,6 +85,10 @@ class PipelineStats(C.Structure):
     """struct mpvss_pipeline_stats"""
     _fields_ = [("enqueue_ms", C.c_double), ("wait_ms", C.c_double), ("hash_ms", C.c_double),
                 ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_ulonglong * 4), ("blocks", C.c_ulonglong)]
+
+
+# state_in / state_out of mpvss_modp_verify_many_chained: int cb(void* user, size_t box, uint8_t* state, int ok)
+CHAIN_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8), C.c_int)
 
 
 def load_library() -> C.CDLL:
@@ -153,6 +157,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_distribute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_distribute_compute.argtypes = [vp, ci, ci, u8p, sz, i64p, u8p, u8p, u8p, sz, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_distribute_absorb.argtypes = [vp, u8p, u8p, u8p, u8p, u8p]
+    lib.mpvss_ec_block_absorb_claimed.argtypes = [vp, C.c_ulonglong, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_poly_eval_device.argtypes = [vp, ci, u8p, sz, vp, sz, vp]
     lib.mpvss_ec_dleq_responses_device.argtypes = [vp, ci, vp, vp, u8p, sz, vp]
     lib.mpvss_ec_deal_compute.argtypes = [vp, ci, u8p, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp]
@@ -184,6 +189,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_ec_transcript_verdict.argtypes = [ci, u8p, u8p, C.POINTER(ci), u8p]
     lib.mpvss_ec_verify_many.argtypes = [vp, ci, ci, C.POINTER(EcBox), sz, ci, ci, C.POINTER(ci), u8p]
     lib.mpvss_modp_verify_many.argtypes = [vp, ci, C.POINTER(ModpBox), sz, ci, ci, C.POINTER(ci), u8p]
+    lib.mpvss_modp_verify_many_chained.argtypes = [vp, ci, C.POINTER(ModpBox), sz, ci, ci, C.POINTER(vp), CHAIN_CB, CHAIN_CB, vp,
+                                                   C.POINTER(ci), u8p]
     lib.mpvss_pipeline_stats_get.argtypes = [vp, C.POINTER(PipelineStats), ci]
     lib.mpvss_blocks_in_flight.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.mpvss_sha256_uses_shani.restype = ci

@@ -8,6 +8,7 @@
 
 #include "ec_curves.h"
 #include "ec_scalar.h"
+#include "ec_glv.h"
 #include "ec_kernels.h"
 
 using namespace ec;
@@ -337,11 +338,113 @@ __device__ __forceinline__ void comb_build_body(u32* __restrict__ comb) {
   }
 }
 
+#ifndef EC_GLV
+#define EC_GLV 1          // secp256k1: table-based scalars are split by the GLV endomorphism (ec_glv.h): 128 doublings instead of 256
+#endif
+[[maybe_unused]] constexpr int DW_K_ROWS = 20;      // LDS rows of recoded scalars per lane: 9 (65 windows, the comb's scalar) + 10 (two GLV halves), or 2 x 10
+
+// secp256k1 with the endomorphism: every scalar that multiplies a per-share table is split k = k1 + k2 lambda, |k1|, |k2| < 2^128,
+// and the loop runs 33 signed 4-bit windows over up to four (table, half) pairs -- the entry of phi(P) is P's with X times beta.
+// The generator's scalar (comb != null) keeps its 65 windows: the comb has no doublings to save.
+__device__ __forceinline__ void dual_win_glv_body(const u32* __restrict__ comb, const u32* __restrict__ tab1,
+                                                  const uint8_t* __restrict__ k1, size_t k1_stride, const u32* __restrict__ tab2,
+                                                  const uint8_t* __restrict__ k2, size_t k2_stride, int count,
+                                                  u32* __restrict__ out_pts, u32* lds) {
+  typedef Secp C;
+  constexpr int AW = C::AFFINE_PACKED_WORDS;
+  u32* lds_comb = lds;
+  u32* lds_k = lds + (comb != nullptr ? 65 * 8 * AW : 0);        // [DW_K_ROWS][DW_THREADS]
+  const int xi = blockIdx.x * DW_THREADS + threadIdx.x;
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  if (comb != nullptr) {
+    for (int i = threadIdx.x; i < 65 * 8 * AW; i += DW_THREADS) lds_comb[i] = comb[i];
+  }
+  // tables and their scalars: with a comb for the first scalar the (single) table belongs to the SECOND scalar
+  const u32* t1 = tab1 != nullptr ? tab1 + (size_t)x * 8 * C::CACHED_WORDS : nullptr;
+  const u32* t2 = tab2 != nullptr ? tab2 + (size_t)x * 8 * C::CACHED_WORDS : nullptr;
+  const u32* tabs[2] = {t1 != nullptr ? t1 : t2, t2};
+  const uint8_t* tks[2] = {t1 != nullptr ? k1 + (size_t)x * k1_stride : k2 + (size_t)x * k2_stride, k2 + (size_t)x * k2_stride};
+  const int ntab = (t1 != nullptr && t2 != nullptr) ? 2 : ((t1 != nullptr || t2 != nullptr) ? 1 : 0);
+  const int glv_row0 = comb != nullptr ? 9 : 0;
+  {
+    if (comb != nullptr) {
+      u32 kp[9];
+      recode_signed4<C>(kp, k1 + (size_t)x * k1_stride);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) lds_k[j * DW_THREADS + threadIdx.x] = kp[j];
+    }
+#pragma unroll 1
+    for (int b = 0; b < ntab; ++b) {
+      u32 kw[8];
+      scalar_words<C>(kw, tks[b]);
+      GlvHalf h[2];
+      secp_glv_split(h, kw);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          lds_k[(glv_row0 + 10 * b + 5 * j + i) * DW_THREADS + threadIdx.x] = h[j].kp[i] | ((i == 4 && h[j].neg) ? 0x80000000u : 0u);
+      }
+    }
+  }
+  __syncthreads();
+  typename C::Point acc;
+  C::identity(acc);
+  if (ntab > 0) {
+    u32 words[4] = {0, 0, 0, 0};
+    u32 negs = 0;                      // bit s: half s = 2 b + j is negative
+    for (int s = 0; s < 2 * ntab; ++s)
+      negs |= (lds_k[(glv_row0 + 5 * s + 4) * DW_THREADS + threadIdx.x] >> 31) << s;
+    for (int w = 32; w >= 0; --w) {
+      if ((w & 7) == 7 || w == 32) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (s < 2 * ntab) words[s] = lds_k[(glv_row0 + 5 * s + (w >> 3)) * DW_THREADS + threadIdx.x];
+      }
+      if (w != 32) {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) C::dbl(acc, acc);
+      }
+      // ONE addition site for the (up to) four table halves: the loop body has to stay inside the instruction cache
+#pragma unroll 1
+      for (int s = 0; s < 2 * ntab; ++s) {
+        const u32* tb = tabs[s >> 1];
+        const int nib = (int)((words[s] >> (4 * (w & 7))) & 15u);
+        int d = w == 32 ? nib : nib - 8;
+        if ((negs >> s) & 1u) d = -d;
+        add_signed_digit<C>(acc, d, [&](typename C::Cached& e, int i) {
+          load_cached<C>(e, tb + i * C::CACHED_WORDS);
+          if (s & 1) secp_phi_cached(e);
+        });
+      }
+    }
+  }
+  if (comb != nullptr) {     // k1 * G from the comb in LDS: one mixed addition per window, no doublings
+    typename C::Point g;
+    C::identity(g);
+    u32 w1 = 0;
+    for (int w = 0; w < 65; ++w) {
+      if ((w & 7) == 0) w1 = lds_k[(w >> 3) * DW_THREADS + threadIdx.x];
+      add_signed_digit_affine<C>(g, signed_digit4(w1, w),
+                                 [&](typename C::Affine& e, int i) { C::unpack_affine(e, lds_comb + (w * 8 + i) * AW); });
+    }
+    C::add(acc, acc, g);
+  }
+  if (live) store_point_aos<C>(out_pts + (size_t)x * C::POINT_WORDS, acc);
+}
+
 template <class C>
 __device__ __forceinline__ void dual_win_body(const u32* __restrict__ comb, const u32* __restrict__ tab1,
                                               const uint8_t* __restrict__ k1, size_t k1_stride, const u32* __restrict__ tab2,
                                               const uint8_t* __restrict__ k2, size_t k2_stride, int count,
                                               u32* __restrict__ out_pts, u32* lds) {
+#if EC_GLV
+  if constexpr (C::SCALAR_BIG_ENDIAN) {                          // (secp256k1)
+    dual_win_glv_body(comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts, lds);
+    return;
+  }
+#endif
   constexpr int AW = C::AFFINE_PACKED_WORDS;
   u32* lds_comb = lds;                                           // [65 * 8 * AW]        (only when comb != null)
   u32* lds_k = lds + (comb != nullptr ? 65 * 8 * AW : 0);        // [2][9][DW_THREADS]   recoded scalars
@@ -669,7 +772,7 @@ extern "C" int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_
                                   const uint32_t* tab2, const uint8_t* k2, size_t k2_stride, int count, uint32_t* out_pts,
                                   hipStream_t s) {
   if (count <= 0) return 0;
-  const size_t lds = ((comb != nullptr ? (size_t)ec_comb_words(group) : 0) + (size_t)2 * 9 * DW_THREADS) * 4;
+  const size_t lds = ((comb != nullptr ? (size_t)ec_comb_words(group) : 0) + (size_t)DW_K_ROWS * DW_THREADS) * 4;
   const dim3 grid((count + DW_THREADS - 1) / DW_THREADS);
   if (group == 1)
     hipLaunchKernelGGL(k_secp_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);

@@ -1972,7 +1972,7 @@ extern "C" int mpvss_block_claim(mpvss_ctx* ctx, unsigned long long* ticket_out)
   if (!ticket_out) return fail(ctx, MPVSS_E_INVALID, "claim: null ticket");
   mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
   if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "claim: no block in flight");
-  if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "claim: the oldest block in flight is not a MODP distribution block");
+  if (sl.kind != 0 && sl.kind != 2) return fail(ctx, MPVSS_E_INVALID, "claim: the oldest block in flight is not a distribution block");
   sl.absorbing = true;
   sl.claimed = true;
   sl.ticket = ctx->tail;
@@ -2014,15 +2014,21 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
 namespace {
 
 int ec_verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
-                                  uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out);     // capi_ec.inc
+                                  uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out, const unsigned long long* ticket = nullptr);     // capi_ec.inc
 
 // issue(b): enqueue box b (called with the context lock held); finish(idx, state): verdict of box idx from its state
 // issue(b, &parts): enqueue box b as `parts` consecutive blocks (called with the context lock held; a box in several parts
 // has its transcript absorbed part by part, in order, by ONE worker); finish(idx, state): verdict of box idx from its state
-template <class Issue, class Finish>
-int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, Issue issue, Finish finish) {
+// begin(idx, state) (optional): the state box idx's transcript starts from -- the initial one by default; a chained run (several
+// engines, one box: mpvss_modp_verify_many_chained) takes it from the engine before, false = that engine failed;
+// give_up(idx) (optional): box idx will not reach finish() (malformed here, or failed upstream): a chained run passes that on
+struct PipeInitState { bool operator()(size_t, uint8_t* state) const { mpvss_transcript_init(state); return true; } };
+struct PipeNoGiveUp { void operator()(size_t) const {} };
+template <class Issue, class Finish, class Begin = PipeInitState, class GiveUp = PipeNoGiveUp>
+int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, Issue issue, Finish finish, Begin begin = Begin(),
+                     GiveUp give_up = GiveUp(), int max_threads = 16) {
   if (hash_threads < 1) hash_threads = 1;
-  if (hash_threads > 16) hash_threads = 16;
+  if (hash_threads > max_threads) hash_threads = max_threads;
   if (depth < 1) depth = 1;
   if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
   struct Hint {
@@ -2094,9 +2100,12 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
         continue;
       }
       uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
-      mpvss_transcript_init(state);
       bool malformed = ent.bad;
       size_t box = ent.box;
+      if (!begin(ent.box, state)) {              // (may wait: a chained run receives the state from the engine before)
+        mpvss_transcript_init(state);
+        malformed = true;
+      }
       for (unsigned p = 0; p < ent.parts; ++p) {
         size_t seq = seq0 + p;
         int prc;
@@ -2128,6 +2137,7 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
         else if (prc != MPVSS_OK && rc == MPVSS_OK) rc = prc;
       }
       if (rc == MPVSS_OK && !malformed && box < count) rc = finish(box, state);
+      else if (box < count) give_up(box);
       if (rc != MPVSS_OK) {
         std::lock_guard<std::mutex> l(sh.m);
         if (sh.rc == MPVSS_OK) sh.rc = rc;
@@ -2245,6 +2255,63 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
         return mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],
                                              digests32 ? digests32 + 32 * idx : nullptr);
       });
+}
+
+// One box over SEVERAL engines (one per GPU: participants sharded): this engine holds one contiguous block of every
+// box; the transcript of a box is one ordered hash, so its 128-byte running state travels engine to engine.  The same pipeline
+// as mpvss_modp_verify_many -- the calling thread enqueues, library threads absorb -- with two callbacks around every box's
+// absorb: state_in(user, box, state, 1) fills in the state this engine's block starts from (it may wait for the engine before;
+// null: the initial state, i.e. the first engine of the chain; a non-zero return means an earlier engine failed: the box gets
+// verdict 0 here and the failure is passed on), state_out(user, box, state, ok) hands the state on once the block is absorbed
+// (ok = 0: this or an earlier engine failed on the box; null: the last engine).  Callbacks run on library threads, several
+// boxes at a time, each box exactly once.  verdicts / digests32 are this engine's view of the final state: meaningful on the
+// last engine of the chain.  wellformed_dev_out (optional): per box a device buffer of n bytes that receives the shares'
+// well-formedness flags (mpvss_modp_verify_block_compute_flags) -- what the engines of a box all-gather.
+extern "C" int mpvss_modp_verify_many_chained(mpvss_ctx* ctx, int space, const mpvss_modp_box* boxes, size_t count, int depth,
+                                              int hash_threads, uint8_t* const* wellformed_dev_out, mpvss_chain_cb state_in,
+                                              mpvss_chain_cb state_out, void* user, int* verdicts, uint8_t* digests32) {
+  if (!ctx) return MPVSS_E_INVALID;
+  if (count == 0) return MPVSS_OK;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!boxes || !verdicts) return fail(ctx, MPVSS_E_INVALID, "verify_many_chained: bad argument");
+    if (ctx->head != ctx->tail)
+      return fail(ctx, MPVSS_E_INVALID, "verify_many_chained: blocks of the block API are in flight, absorb them first");
+  }
+  for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
+  if (digests32) memset(digests32, 0, 32 * count);
+  return run_box_pipeline(
+      ctx, count, depth, hash_threads,
+      [&](size_t b, unsigned* parts, unsigned* nbox) {
+        const mpvss_modp_box& bx = boxes[b];
+        *nbox = 1;
+        const int rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
+                                                   bx.n, bx.challenge_host, bx.keyset, bx.key_offset,
+                                                   wellformed_dev_out ? wellformed_dev_out[b] : nullptr);
+        if (rc != MPVSS_OK) return rc;
+        *parts = 1;
+        return (int)MPVSS_OK;
+      },
+      [&](size_t idx, const uint8_t* state) {
+        if (state_out) {
+          uint8_t copy[MPVSS_TRANSCRIPT_STATE_BYTES];
+          memcpy(copy, state, sizeof(copy));
+          (void)state_out(user, idx, copy, 1);
+        }
+        return mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx], digests32 ? digests32 + 32 * idx : nullptr);
+      },
+      [&](size_t idx, uint8_t* state) {
+        if (!state_in) { mpvss_transcript_init(state); return true; }
+        return state_in(user, idx, state, 1) == 0;
+      },
+      [&](size_t idx) {
+        if (state_out) {
+          uint8_t zero[MPVSS_TRANSCRIPT_STATE_BYTES];
+          memset(zero, 0, sizeof(zero));
+          (void)state_out(user, idx, zero, 0);
+        }
+      },
+      32);
 }
 
 extern "C" int mpvss_blocks_in_flight(mpvss_ctx* ctx, int* in_flight_out, int* gpu_pending_out) {

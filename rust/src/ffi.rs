@@ -75,6 +75,9 @@ pub struct mpvss_box_view {
     pub u_be: *const u8,
 }
 
+/// `state_in` / `state_out` of mpvss_modp_verify_many_chained (None = NULL)
+pub type mpvss_chain_cb = Option<unsafe extern "C" fn(user: *mut c_void, box_index: usize, state: *mut u8, ok: c_int) -> c_int>;
+
 #[link(name = "mpvss_hip")]
 unsafe extern "C" {
     // ---- context
@@ -111,6 +114,9 @@ unsafe extern "C" {
     pub fn mpvss_modp_transcript_verdict(state: *const u8, challenge_host: *const u8, verdict: *mut c_int, digest32_out: *mut u8) -> c_int;
     pub fn mpvss_modp_verify_many(ctx: *mut mpvss_ctx, space: c_int, boxes: *const mpvss_modp_box, count: usize, depth: c_int, hash_threads: c_int,
                                   verdicts: *mut c_int, digests32: *mut u8) -> c_int;
+    pub fn mpvss_modp_verify_many_chained(ctx: *mut mpvss_ctx, space: c_int, boxes: *const mpvss_modp_box, count: usize, depth: c_int,
+                                          hash_threads: c_int, wellformed_dev_out: *const *mut u8, state_in: mpvss_chain_cb,
+                                          state_out: mpvss_chain_cb, user: *mut c_void, verdicts: *mut c_int, digests32: *mut u8) -> c_int;
     // ---- registered public keys
     pub fn mpvss_modp_keyset_create(ctx: *mut mpvss_ctx, space: c_int, pubkeys: *const u8, n: usize, out: *mut *mut mpvss_keyset) -> c_int;
     pub fn mpvss_modp_keyset_destroy(ctx: *mut mpvss_ctx, keyset: *mut mpvss_keyset);
@@ -171,6 +177,8 @@ unsafe extern "C" {
         x_dev_out: *mut u8, y_dev_out: *mut u8, a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
     pub fn mpvss_ec_distribute_absorb(ctx: *mut mpvss_ctx, state: *mut u8, x_out_host: *mut u8, y_out_host: *mut u8,
         a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
+    pub fn mpvss_ec_block_absorb_claimed(ctx: *mut mpvss_ctx, ticket: c_ulonglong, state: *mut u8, x_out_host: *mut u8,
+                                         y_out_host: *mut u8, a1_out_host: *mut u8, a2_out_host: *mut u8) -> c_int;
     pub fn mpvss_ec_poly_eval_device(ctx: *mut mpvss_ctx, group: c_int, coeffs_host: *const u8, t: usize, positions_dev: *const i64,
                                      n: usize, out_dev: *mut u8) -> c_int;
     pub fn mpvss_ec_dleq_responses_device(ctx: *mut mpvss_ctx, group: c_int, w_dev: *const u8, alpha_dev: *const u8,

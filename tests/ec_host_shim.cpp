@@ -1,6 +1,7 @@
 // Host build of the kernels' EC arithmetic (mpvss_rs_amd/csrc/ec_curves.h) for CPU unit tests.
 // Test infrastructure: compiled by tests/test_ec_host.py with g++, never shipped.
 #include "../mpvss_rs_amd/csrc/ec_curves.h"
+#include "../mpvss_rs_amd/csrc/ec_glv.h"
 
 using namespace ec;
 
@@ -93,7 +94,55 @@ static int t_comb(const uint8_t* k, uint8_t* out) {
   return 0;
 }
 
+// secp256k1 with the GLV endomorphism (ec_glv.h, what k_secp_dual_win runs): every scalar split into two 128-bit halves, 33 signed
+// windows, the table of phi(P) made from P's on the fly
+static int t_dual_win_glv(const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, uint8_t* out) {
+  Secp::Point a, b, r;
+  if (!Secp::decode(a, p1)) return -1;
+  if (p2) { if (!Secp::decode(b, p2)) return -2; } else Secp::identity(b);
+  Secp::Cached tabs[2][8];
+  build_cached_table<Secp>(tabs[0], a);
+  build_cached_table<Secp>(tabs[1], b);
+  GlvHalf h[2][2];
+  u32 kw[8];
+  scalar_words<Secp>(kw, k1);
+  secp_glv_split(h[0], kw);
+  if (p2) { scalar_words<Secp>(kw, k2); secp_glv_split(h[1], kw); }
+  Secp::identity(r);
+  for (int w = 32; w >= 0; --w) {
+    if (w != 32) for (int i = 0; i < 4; ++i) Secp::dbl(r, r);
+    for (int t = 0; t < (p2 ? 2 : 1); ++t)
+      for (int j = 0; j < 2; ++j)
+        add_signed_digit<Secp>(r, glv_digit(h[t][j], w), [&](Secp::Cached& e, int i) { e = tabs[t][i]; if (j) secp_phi_cached(e); });
+  }
+  Secp::encode(out, r);
+  return 0;
+}
+
 extern "C" {
+int ec_dual_win_glv(const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, uint8_t* out) {
+  return t_dual_win_glv(p1, k1, p2, k2, out);
+}
+// the split alone: out = |k1| (17 bytes LE) | sign | |k2| (17 bytes LE) | sign  (magnitudes from the recoded words)
+int secp_glv_split_bytes(const uint8_t* k_be32, uint8_t* out36) {
+  u32 kw[8];
+  scalar_words<Secp>(kw, k_be32);
+  GlvHalf h[2];
+  secp_glv_split(h, kw);
+  for (int j = 0; j < 2; ++j) {
+    // undo the + 0x88..8 of the recoding: magnitude = kp - sum 8 * 16^w
+    uint64_t borrow = 0;
+    u32 m[5];
+    for (int i = 0; i < 5; ++i) {
+      const uint64_t d = (uint64_t)h[j].kp[i] - (i < 4 ? 0x88888888u : 0u) - borrow;
+      m[i] = (u32)d;
+      borrow = (d >> 63) & 1;
+    }
+    for (int i = 0; i < 17; ++i) out36[18 * j + i] = (uint8_t)(m[i / 4] >> (8 * (i % 4)));
+    out36[18 * j + 17] = h[j].neg ? 1 : 0;
+  }
+  return 0;
+}
 int ec_dual_win(int curve, const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, const uint8_t* k2, uint8_t* out) {
   return curve == 0 ? t_dual_win<Secp>(p1, k1, p2, k2, out) : t_dual_win<Ristretto>(p1, k1, p2, k2, out);
 }

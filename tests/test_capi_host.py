@@ -112,7 +112,10 @@ def _c_decls(header_text):
                     params.append((arr.group(2), " ".join(arr.group(1).split()) + "*"))
                     continue
                 pm = re.match(r"(.*?)(\w+)$", prm)
-                params.append((pm.group(2), "".join(pm.group(1).split()).replace("const", "const ").replace("unsignedlonglong", "unsigned long long")))
+                ty = "".join(pm.group(1).split())
+                if not ty.endswith("*const*"):
+                    ty = ty.replace("const", "const ")
+                params.append((pm.group(2), ty.replace("unsignedlonglong", "unsigned long long")))
         funcs[m.group(2)] = (ret.replace(" *", "*"), params)
     return funcs, structs
 
@@ -125,6 +128,8 @@ def _rust_type(ctype):
     """the Rust FFI spelling of a C type of the header: `const uint8_t*` -> `*const u8`, `mpvss_ctx**` -> `*mut *mut mpvss_ctx`"""
     import re
     ctype = ctype.strip()
+    if ctype.replace(" ", "").endswith("*const*"):            # T* const*: a read-only array of pointers
+        return "*const " + _rust_type(ctype.replace(" ", "")[:-len("const*")])
     arr = re.match(r"(.*)\[(\d+)\]$", ctype)
     if arr:
         return f"[{_rust_type(arr.group(1))}; {arr.group(2)}]"

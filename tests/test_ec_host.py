@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "_build", "libec_host.so")
 def shim():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     src = os.path.join(HERE, "ec_host_shim.cpp")
-    deps = [src] + [os.path.join(HERE, "..", "mpvss_rs_amd", "csrc", f) for f in ("ec_field.h", "ec_curves.h", "ec_consts.h")]
+    deps = [src] + [os.path.join(HERE, "..", "mpvss_rs_amd", "csrc", f) for f in ("ec_field.h", "ec_curves.h", "ec_consts.h", "ec_glv.h", "ec_scalar.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", LIB])
     return C.CDLL(LIB)
@@ -140,3 +140,39 @@ def test_windowed_paths(shim, curve, name):
         out4 = (C.c_uint8 * (4 * 33))()
         assert shim.secp_encode_batch4(buf(b"".join(e(x) for x in pts)), out4) == 0
         assert bytes(out4) == b"".join(e(G.exp(x, 3)) for x in pts)
+
+
+def test_secp256k1_glv_split_and_windowed_multiplication(shim):
+    """ec_glv.h: k = k1 + k2 lambda (mod n) with |k1|, |k2| < 2^128 for every k -- 0, 1, n - 1, lambda, n - lambda, values around
+    n / 2 and 2^128, unreduced inputs (n, 2^256 - 1), 3000 random ones -- and the 33-window double multiplication built on it
+    (phi(P) = (beta x, y) made from P's table) equals the oracle's k1 P + k2 Q, incl. the identity as a base and P, -P."""
+    G = O.GROUPS["secp256k1"]()
+    n = G.group_order_int()
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    assert pow(lam, 3, n) == 1
+    rng = random.Random(0x61F)
+    ks = [0, 1, 2, n - 1, n - 2, lam, n - lam, lam + 1, (n - 1) // 2, (n + 1) // 2, 1 << 128, (1 << 128) - 1, (1 << 128) + 1, 1 << 255,
+          n - (1 << 128), n, (1 << 256) - 1, int("8" * 64, 16), int("7" * 64, 16)] + [rng.randrange(n) for _ in range(3000)]
+    out = (C.c_uint8 * 36)()
+    for k in ks:
+        assert shim.secp_glv_split_bytes(buf(k.to_bytes(32, "big")), out) == 0
+        raw = bytes(out)
+        m1, s1, m2, s2 = int.from_bytes(raw[0:17], "little"), raw[17], int.from_bytes(raw[18:35], "little"), raw[35]
+        assert m1 < (1 << 128) and m2 < (1 << 128), hex(k)
+        assert ((-m1 if s1 else m1) + (-m2 if s2 else m2) * lam - k) % n == 0, hex(k)
+    e, s = G.element_to_bytes, G.scalar_to_bytes
+    B = G.generator()
+    P, Q = G.exp(B, rng.randrange(1, n)), G.exp(B, rng.randrange(1, n))
+    outp = (C.c_uint8 * 33)()
+    sample = ks[:17] + ks[19:40]                       # (canonical scalars: the group API rejects the others before any kernel runs)
+    for k1, k2 in zip(sample, reversed(sample)):
+        assert shim.ec_dual_win_glv(buf(e(P)), buf(s(k1)), buf(e(Q)), buf(s(k2)), outp) == 0
+        assert bytes(outp) == e(G.mul(G.exp(P, k1), G.exp(Q, k2))), (hex(k1), hex(k2))
+        assert shim.ec_dual_win_glv(buf(e(P)), buf(s(k1)), None, None, outp) == 0
+        assert bytes(outp) == e(G.exp(P, k1)), hex(k1)
+    ident = G.identity()
+    k1, k2 = rng.randrange(n), rng.randrange(n)
+    assert shim.ec_dual_win_glv(buf(e(ident)), buf(s(k1)), buf(e(Q)), buf(s(k2)), outp) == 0
+    assert bytes(outp) == e(G.exp(Q, k2))
+    assert shim.ec_dual_win_glv(buf(e(P)), buf(s(k1)), buf(e(G.element_inverse(P))), buf(s(k1)), outp) == 0
+    assert bytes(outp) == e(ident)

@@ -20,7 +20,11 @@ def _free_port():
 
 
 def _run(ranks, steps, n, depth, timeout=900, extra_env=None, config_boxes="0"):
-    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MPVSS_BENCH_DEPTH=str(depth), MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    if depth is not None:                  # None: the boxes in flight per rank follow bench.py's own formula for that world size
+        env["MPVSS_BENCH_DEPTH"] = str(depth)
+    else:
+        env.pop("MPVSS_BENCH_DEPTH", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps",
            str(steps), "--warmup", "1", "--participants", str(n), "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0",
@@ -47,7 +51,7 @@ def test_the_drivers_own_command_starts_its_ranks():
     assert res["config"]["n_per_gpu"] == 65536 and "131072 participants in the box" in res["config"]["workload"]
     assert res["config"]["distinct_boxes"] == 3
     assert res["value"] > 0 and res["compute"]["fd_fallbacks"] == 0
-    assert res["host"]["pipeline"].startswith("verify_block_compute / block_claim / absorb_claimed")
+    assert res["host"]["pipeline"].startswith("mpvss_modp_verify_many_chained")      # N > 1 runs the library's own pipeline
     # one data collective per box over a group of two ranks: slot initialisation + warm-up + timed boxes at least
     assert res["rccl"]["rccl_world_size"] == 2 and res["rccl"]["per_box"] == 1 and res["rccl"]["data_collectives"] >= 3 + 1
     assert res["rccl"]["bytes_per_rank_per_box"] == 65536
@@ -78,3 +82,34 @@ def test_the_c5_object_of_an_eight_gpu_run_in_small():
     c5 = res["c5"]
     assert c5["boxes"] == 3 and c5["value"] > 0 and "32768 participants over 2 GPUs" in c5["config"]["workload"]
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["rccl"]["data_collectives"] >= 3 + 3
+
+
+def test_eight_ranks_at_the_real_world_size():
+    """The first real `--gpus 8` is the driver's: everything that depends on the WORLD SIZE rather than on the GPU count runs
+    here with eight ranks on the one GPU of the test box (gloo) -- the boxes in flight per rank from bench.py's own formula
+    (no MPVSS_BENCH_DEPTH), eight hash threads per rank receiving the running state by box tag from the rank before and sending
+    it on, the per-box all-gather of eight ranks' flag bytes reaped in order, the verdict broadcast from the last rank, and the
+    `c5` object that only an eight-rank line carries (forced small: 8 x 4096 participants, t = 64).  A clean exit with the line
+    IS the parity check (bench.py aborts unless every box verifies with the dealer's digest on every rank)."""
+    out = _run(8, 6, 2048, None, timeout=600, extra_env={"MPVSS_BENCH_C5_N": "4096", "MPVSS_BENCH_C5_T": "64", "OMP_NUM_THREADS": "2"},
+               config_boxes="3")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+    assert "secondary_error" not in res
+    assert res["n_gpus"] == 8 and res["steps"] == 6 and "16384 participants in the box" in res["config"]["workload"]
+    assert res["rccl"]["rccl_world_size"] == 8 and res["rccl"]["data_collectives"] >= 6
+    assert res["host"]["boxes_in_flight"] >= 8 + 5            # 8 + one more box per 58 ms of chain latency at eight ranks + 2
+    assert res["host"]["hbm"]["bytes_in_use_on_this_rank"] > 0 and res["host"]["hbm"]["bytes_total"] > 2 ** 37
+    c5 = res["c5"]
+    assert c5["boxes"] == 3 and c5["value"] > 0 and "32768 participants over 8 GPUs" in c5["config"]["workload"]
+    assert res["compute"]["fd_fallbacks"] == 0
+
+
+def test_the_python_driven_blocks_still_agree_with_the_chained_pipeline():
+    """MPVSS_BENCH_CHAINED=0 keeps round 3's N > 1 flow (blocks driven from a Python thread pool: compute / claim /
+    absorb_claimed) beside the library's chained pipeline; both must verify the same boxes with the dealers' digests."""
+    for mode, name in (("0", "verify_block_compute / block_claim / absorb_claimed"), ("1", "mpvss_modp_verify_many_chained")):
+        out = _run(2, 5, 4096, 4, timeout=420, extra_env={"MPVSS_BENCH_CHAINED": mode})
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+        assert res["host"]["pipeline"].startswith(name) and res["rccl"]["data_collectives"] >= 5 and res["value"] > 0

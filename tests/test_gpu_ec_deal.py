@@ -38,7 +38,7 @@ def test_ec_deal_reproduces_the_golden_boxes(engine, name, shape):
     d = engine.ec_deal(gid, coeffs, b["positions"], cat(b["publickeys"]), wits)
     assert d["X"] == cat(fx["expected"]["X"]) and d["a1"] == cat(fx["expected"]["a1"]) and d["a2"] == cat(fx["expected"]["a2"])
     assert d["Y"] == cat(b["shares"]) and d["digest"] == bytes.fromhex(fx["expected"]["transcript_digest"])
-    assert d["challenge"] == sb(int(b["challenge"], 16)) and d["responses"] == b"".join(sb(int(r, 16)) for r in b["responses"])
+    assert d["challenge"] == bytes.fromhex(b["challenge"]) and d["responses"] == cat(b["responses"])     # (encoded scalars in the fixture)
 
 
 @pytest.mark.parametrize("name", ["secp256k1", "ristretto255"])
@@ -121,6 +121,19 @@ def test_ec_deal_compute_blocks_and_one_call_deal_of_a_larger_box(engine, name):
         torch.cuda.synchronize()
         engine.ec_dleq_responses_device(gid, d_w.data_ptr(), d_p[k].data_ptr(), c, n, d_r.data_ptr())
         assert dbytes(d_r) == d["responses"]
+    # claimed blocks (mpvss_block_claim + mpvss_ec_block_absorb_claimed): two dealers' blocks, absorbed in the REVERSE order
+    import ctypes as C
+    cb2 = b"".join(map(sb, [rng.randrange(order) for _ in range(t)]))
+    engine.ec_deal_compute(gid, cb, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[0].data_ptr())
+    t0 = engine.block_claim()
+    engine.ec_deal_compute(gid, cb2, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[1].data_ptr())
+    t1 = engine.block_claim()
+    digests = {}
+    for tk in (t1, t0):
+        st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+        engine._check(engine.lib.mpvss_ec_block_absorb_claimed(engine.ctx, tk, st, None, None, None, None), "ec_block_absorb_claimed")
+        digests[tk] = capi.ec_transcript_verdict(gid, bytes(st), bytes(32))[1]
+    assert digests[t0] == want["digest"] and digests[t1] != want["digest"] and engine.blocks_in_flight() == (0, 0)
     # one share through the oracle in the reference order
     i = 1234
     cmx = [G.element_from_fixed(cm[k:k + L]) for k in range(0, len(cm), L)]

@@ -285,9 +285,15 @@ def test_dealer_shared_squarings_bucket_path(engine):
     args = (b"".join(map(fx, ys)), b"".join(map(fx, ps)), b"".join(map(fx, ws)))
     engine.distribute_compute(None, None, *args)
     st, X, Y, a1, a2 = engine.distribute_absorb(capi.transcript_init(), n)
-    assert split(Y) == [pow(y, e, Q) for y, e in zip(ys, ps)]
-    assert split(a2) == [pow(y, e, Q) for y, e in zip(ys, ws)]
-    assert split(X) == [pow(4, e, Q) for e in ps] and split(a1) == [pow(4, e, Q) for e in ws]     # g = 4, modp.rs:65-66
+    from helpers import modp_dual_pow_chunk, parallel_map
+
+    def pows(bases, exps):                 # base^exp mod q for every pair, on oracle-only worker processes
+        items = [(b, e, 1, 0) for b, e in zip(bases, exps)]
+        step = max(1, len(items) // 32)
+        return [v for part in parallel_map(modp_dual_pow_chunk, [items[k:k + step] for k in range(0, len(items), step)]) for v in part]
+    assert split(Y) == pows(ys, ps)
+    assert split(a2) == pows(ys, ws)
+    assert split(X) == pows([4] * n, ps) and split(a1) == pows([4] * n, ws)     # g = 4, modp.rs:65-66
     # below 1024 shares: left-to-right windows, same results
     m = 200
     engine.distribute_compute(None, None, *(a[-m * EB:] for a in args))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One A/B line of the headline pipeline per variant (replaces the per-experiment scripts of earlier rounds):
-#   tools/ab_bench.sh OUTFILE [-k STEPS] [-r REPS] -- NAME1 ENV=VAL ... -- NAME2 ENV=VAL ... 
+#   tools/ab_bench.sh OUTFILE [-k STEPS] [-r REPS] [-s STEADY_STEPS] -- NAME1 ENV=VAL ... -- NAME2 ENV=VAL ... 
 # Every variant runs `bench.py --gpus 1 --steps STEPS --warmup 5` with the secondary figures switched off, REPS times, under
 # the given environment, and appends "NAME value ms_per_step a2_alone_ms kernel_ms_sums" to gpurun_out/OUTFILE.
 # Variant libraries (e.g. a kernel built with other -D flags): make -C mpvss_rs_amd/csrc PAIR_EXTRA=... and pass
@@ -12,9 +12,9 @@ set -u
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/$1; shift
 mkdir -p "$(dirname "$OUT")"
-STEPS=20; REPS=1
+STEPS=20; REPS=1; STEADY=0
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do
-  case "$1" in -k) STEPS=$2; shift 2;; -r) REPS=$2; shift 2;; *) echo "bad option $1"; exit 2;; esac
+  case "$1" in -k) STEPS=$2; shift 2;; -r) REPS=$2; shift 2;; -s) STEADY=$2; shift 2;; *) echo "bad option $1"; exit 2;; esac
 done
 while [ $# -gt 0 ]; do
   shift                      # the "--"
@@ -23,10 +23,10 @@ while [ $# -gt 0 ]; do
   while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
   for rep in $(seq $REPS); do
     env "${ENVS[@]}" python3 bench.py --gpus 1 --steps $STEPS --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 \
-        --host-boxes 0 --config-boxes 0 --lone-boxes 1 2>/dev/null | python3 -c "
+        --host-boxes 0 --config-boxes 0 --lone-boxes 1 --steady-steps $STEADY 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('$NAME', round(d['value']), round(d['ms_per_step'], 2), round(d['roofline']['kernel_ms'], 1),
+print('$NAME', round(d['value']), round(d['ms_per_step'], 2), round(d['roofline']['kernel_ms'], 1), 'steady', round(d['value_steady_state'] or 0),
       {k: round(v) for k, v in d['compute']['kernel_ms_sums'].items() if k != 'note'})" | tee -a "$OUT"
   done
 done
