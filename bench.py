@@ -361,6 +361,40 @@ def bench_ec(eng, name, args):
                                       "`value_end_to_end`: every box from its own t coefficients -- P(i) mod order and the responses on the device "
                                       "(mpvss_ec_deal_compute, mpvss_ec_dleq_responses_device), group work, transcript, challenge, boxes pipelined; "
                                       "`value_one_call_host_buffers_end_to_end`: one mpvss_ec_deal call from host buffers"})
+    # W_B for the curve group (participant.rs:1346-1371 / 1789-1814): a batch of decrypted-share proofs -- a1 = r G + c pk, a2 = r S + c Y
+    # and the per-share hash verdict (K7) on the device --, inputs resident in HBM, several batches in flight in one context
+    m = min(n, 16384)
+    xinv = b"".join(sb(pow(x_, -1, order)) for x_ in privs[:m])
+    rng_w = random.Random(SEED + 97 * gid)
+    wit_b = [rng_w.randrange(1, order) for _ in range(m)]
+    S_, cb_ = eng.ec_extract_shares(gid, pks[:m * L], d["Y"][:m * L], xinv, b"".join(map(sb, wit_b)))
+    from_b = (lambda b_: int.from_bytes(b_, "big")) if cfg["be"] else (lambda b_: int.from_bytes(b_, "little"))
+    rb_ = b"".join(sb((w_ - x_ * from_b(cb_[i * 32:(i + 1) * 32])) % order) for i, (w_, x_) in enumerate(zip(wit_b, privs[:m])))   # dleq.rs:42-50
+    d_S, d_cb, d_rb = dbuf(S_), dbuf(cb_), dbuf(rb_)
+    verd = (C.c_uint8 * m)()
+    inflight, batches = 4, 12
+    torch.cuda.synchronize()
+
+    def wb_pipelined(count):
+        issued = done = 0
+        while done < count:
+            while issued < count and issued - done < inflight:
+                eng._check(eng.lib.mpvss_ec_verify_shares_compute(eng.ctx, gid, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_Y), vp(d_cb), vp(d_rb),
+                                                                  m, None), "ec_verify_shares_compute")
+                issued += 1
+            eng._check(eng.lib.mpvss_ec_verify_shares_absorb(eng.ctx, verd), "ec_verify_shares_absorb")
+            assert bytes(verd) == b"\x01" * m, f"verify_share verdicts ({name})"
+            done += 1
+
+    wb_pipelined(inflight)
+    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    wb_pipelined(batches)
+    torch.cuda.synchronize()
+    wb_s = (time.perf_counter() - t_w) / batches
+    out["verify_share"] = {"value": m / wb_s, "unit": "share-box verifications/s", "batch": m, "batches_in_flight": inflight,
+                           "note": "W_B for the curve group: a1 = r G + c pk, a2 = r S + c Y and the per-share hash verdict on the device "
+                                   "(mpvss_ec_verify_shares_compute / _absorb), share boxes made by mpvss_ec_extract_shares, inputs resident in HBM"}
     if args.cpu_sample != 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from concurrent.futures import ThreadPoolExecutor
@@ -388,6 +422,34 @@ def bench_ec(eng, name, args):
                       f"scalar multiplications with full-width exponents, t+2 additions, an affine conversion each for secp256k1) in "
                       f"oracle/ec_ref.c (textbook double-and-add; the reference's k256 / curve25519-dalek are about 3-4x faster per "
                       f"multiplication) on {cores} threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal"}
+        if gid == 1:      # the strong-CPU line: the same sequence with libcrypto's EC_POINT_mul (oracle/openssl_ref.py; no ristretto255 there)
+            try:
+                import openssl_ref
+                if openssl_ref.ec_available():
+                    tls = threading.local()
+
+                    def work_ssl(i):
+                        if not hasattr(tls, "ref"):
+                            tls.ref = openssl_ref.OpenSslSecpRef()
+                        return tls.ref.share_work(cm, positions[i], pks[i * L:(i + 1) * L], d["Y"][i * L:(i + 1) * L],
+                                                  responses[i * 32:(i + 1) * 32], cbytes)
+                    t1 = time.perf_counter(); work_ssl(idx[0]); one = time.perf_counter() - t1
+                    ks_ = max(cores, min(16 * cores, int(4.0 * cores / max(one, 1e-3))))
+                    idx_s = sorted({int((j + 0.5) * n / ks_) for j in range(ks_)})
+                    tc = time.perf_counter()
+                    with ThreadPoolExecutor(max_workers=cores) as ex:
+                        outs = list(ex.map(work_ssl, idx_s))
+                    ssl_s = time.perf_counter() - tc
+                    for i, (x, a1, a2) in zip(idx_s, outs):
+                        s_ = slice(i * L, (i + 1) * L)
+                        assert (x, a1, a2) == (Xb[s_], A1b[s_], A2b[s_]), f"GPU/OpenSSL mismatch at {name} share {i}"
+                    out["cpu_baseline"]["openssl"] = {
+                        "value": len(idx_s) / ssl_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
+                        "library": openssl_ref.version(),
+                        "sample": f"{len(idx_s)} shares, the same operation sequence with libcrypto's EC_POINT_mul / EC_POINT_add on {cores} "
+                                  f"threads, {ssl_s:.1f}s; one share on one thread {one * 1e3:.0f} ms; GPU X/a1/a2 of those shares checked equal"}
+            except Exception as exc:      # noqa: BLE001 - optional line
+                out["cpu_baseline"]["openssl"] = {"value": None, "note": f"skipped: {exc}"}
     return out
 
 

@@ -156,7 +156,12 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
 // Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
 // ---------------------------------------------------------------------------------------
 #ifndef PAIR_PREFETCH
-#define PAIR_PREFETCH 1         // the operand of the NEXT product comes in by LDS-DMA while the current operation reduces (0: fetched when needed)
+#define PAIR_PREFETCH 0         // 1: the operand of the NEXT product comes in by LDS-DMA (global_load_lds_dwordx4 into the number's slot, which is free
+                                // once the reduction holds T_lo in registers) while the current operation reduces; 0: fetched when needed.
+                                // Built, bit-exact (the whole GPU suite ran with it) and measured: the a2 launch alone 37.5 +- 0.3 ms either way
+                                // (profiles/r04_a2_alone_variants.txt), the pipeline within its run-to-run noise (profiles/r04_pair_variants_ab.txt),
+                                // for 4 % more VALU instructions (80 address instructions per product): two waves per SIMD already hide a product's
+                                // nine scattered 16-byte reads.  Off.
 #endif
 
 namespace {

@@ -1340,9 +1340,19 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   int* hflags = (int*)((uint8_t*)sl.pin + n * EB * 4 + n * 8);
   if (space == MPVSS_HOST) {
     uint8_t* in = (uint8_t*)sl.pin + out_bytes;
-    if (!ks) memcpy(in, pubkeys, n * EB);
-    memcpy(in + n * EB, shares, n * EB);
-    memcpy(in + 2 * n * EB, responses, n * EB);
+    // three arrays of n x 256 bytes (48 MB at the headline shape) into pinned memory: this thread holds the context lock, so the
+    // copies run side by side on helper threads (4-5 ms -> 1.5 ms per box; round 3's host_buffers figure trailed the HBM one by 5 %)
+    if (n * EB >= ((size_t)4 << 20)) {
+      std::thread t1([&] { memcpy(in + n * EB, shares, n * EB); });
+      std::thread t2([&] { memcpy(in + 2 * n * EB, responses, n * EB); });
+      if (!ks) memcpy(in, pubkeys, n * EB);
+      t1.join();
+      t2.join();
+    } else {
+      if (!ks) memcpy(in, pubkeys, n * EB);
+      memcpy(in + n * EB, shares, n * EB);
+      memcpy(in + 2 * n * EB, responses, n * EB);
+    }
     memcpy(in + 3 * n * EB, commitments, t * EB);
     memcpy(hpos, positions, n * 8);
     if (!ks) pubkeys = in;

@@ -108,3 +108,107 @@ class OpenSslRef:
         for b in (four, bn_y, bn_Y, bn_r, bn_c):
             lib.BN_free(b)
         return out
+
+
+# ---- secp256k1 through libcrypto's EC_POINT_mul: the curve groups' "strong CPU" line -----------------------
+# The reference's per-share sequence (src/participant.rs:1404-1430 -> src/dleq.rs:66-84 with Secp256k1Group::exp / ::mul,
+# src/groups/secp256k1.rs:91-107): t scalar multiplications with the running exponent i^j mod n and t additions for X_i, then
+# two multiplications and an addition for each of a1 and a2.  oracle/ec_ref.c does the same with a textbook double-and-add;
+# this class with OpenSSL's EC_POINT_mul.  (libcrypto has no ristretto255.)
+NID_SECP256K1 = 714
+SECP_N_HEX = "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141"
+_ec_ready = False
+
+
+def _load_ec():
+    global _ec_ready
+    lib = _load()
+    if _ec_ready:
+        return lib
+    vp = C.c_void_p
+    for fn, res, args in (
+        ("EC_GROUP_new_by_curve_name", vp, [C.c_int]), ("EC_GROUP_free", None, [vp]),
+        ("EC_POINT_new", vp, [vp]), ("EC_POINT_free", None, [vp]),
+        ("EC_POINT_oct2point", C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+        ("EC_POINT_point2oct", C.c_size_t, [vp, vp, C.c_int, vp, C.c_size_t, vp]),
+        ("EC_POINT_mul", C.c_int, [vp, vp, vp, vp, vp, vp]), ("EC_POINT_add", C.c_int, [vp, vp, vp, vp, vp]),
+        ("EC_POINT_set_to_infinity", C.c_int, [vp, vp]), ("EC_POINT_is_at_infinity", C.c_int, [vp, vp]),
+    ):
+        f = getattr(lib, fn)
+        f.restype = res
+        f.argtypes = args
+    _ec_ready = True
+    return lib
+
+
+def ec_available() -> bool:
+    try:
+        lib = _load_ec()
+        g = lib.EC_GROUP_new_by_curve_name(NID_SECP256K1)
+        if not g:
+            return False
+        lib.EC_GROUP_free(g)
+        return True
+    except Exception:
+        return False
+
+
+class OpenSslSecpRef:
+    """One instance per thread.  Elements are 33-byte SEC1 compressed encodings, the identity 33 zero bytes (k256's GroupEncoding);
+    scalars 32 bytes big-endian."""
+
+    def __init__(self):
+        self.lib = lib = _load_ec()
+        self.ctx = lib.BN_CTX_new()
+        self.group = lib.EC_GROUP_new_by_curve_name(NID_SECP256K1)
+        if not self.group:
+            raise OSError("libcrypto has no secp256k1")
+        nb = bytes.fromhex(SECP_N_HEX)
+        self.n = lib.BN_bin2bn(nb, len(nb), None)
+        self.pts = [lib.EC_POINT_new(self.group) for _ in range(6)]
+        self.bns = [lib.BN_new() for _ in range(3)]
+
+    def _point(self, pt, enc: bytes):
+        if enc == bytes(33):
+            assert self.lib.EC_POINT_set_to_infinity(self.group, pt) == 1
+        elif self.lib.EC_POINT_oct2point(self.group, pt, enc, len(enc), self.ctx) != 1:
+            raise ValueError("invalid encoding")
+
+    def _enc(self, pt) -> bytes:
+        if self.lib.EC_POINT_is_at_infinity(self.group, pt):
+            return bytes(33)
+        buf = (C.c_uint8 * 33)()
+        assert self.lib.EC_POINT_point2oct(self.group, pt, 2, buf, 33, self.ctx) == 33      # POINT_CONVERSION_COMPRESSED
+        return bytes(buf)
+
+    def share_work(self, commitments: bytes, position: int, y: bytes, Y: bytes, r: bytes, c: bytes):
+        """X_i, a1_i, a2_i of one share, reference operation order (participant.rs:1404-1430)."""
+        lib, ctx, grp = self.lib, self.ctx, self.group
+        x, cj, pw, p1, p2, acc = self.pts
+        e, i_bn, tmp = self.bns
+        t = len(commitments) // 33
+        assert lib.EC_POINT_set_to_infinity(grp, x) == 1
+        lib.BN_set_word(e, 1)
+        lib.BN_set_word(i_bn, position % (1 << 64))
+        for j in range(t):
+            self._point(cj, commitments[33 * j:33 * j + 33])
+            lib.EC_POINT_mul(grp, pw, None, cj, e, ctx)            # exp(C_j, exponent)          :1409-1411
+            lib.EC_POINT_add(grp, x, x, pw, ctx)                   # mul(x, ...)                 :1412
+            lib.BN_mod_mul(e, e, i_bn, self.n, ctx)                # exponent * i                :1413-1416
+        bn_r = lib.BN_bin2bn(r, 32, None)
+        bn_c = lib.BN_bin2bn(c, 32, None)
+        outs = [self._enc(x)]
+        for base in (None, y):                                     # a1 = r G + c X, a2 = r y + c Y   dleq.rs:75-81
+            if base is None:
+                lib.EC_POINT_mul(grp, p1, bn_r, None, None, ctx)
+                lib.EC_POINT_mul(grp, p2, None, x, bn_c, ctx)
+            else:
+                self._point(cj, base)
+                lib.EC_POINT_mul(grp, p1, None, cj, bn_r, ctx)
+                self._point(cj, Y)
+                lib.EC_POINT_mul(grp, p2, None, cj, bn_c, ctx)
+            lib.EC_POINT_add(grp, acc, p1, p2, ctx)
+            outs.append(self._enc(acc))
+        lib.BN_free(bn_r)
+        lib.BN_free(bn_c)
+        return tuple(outs)

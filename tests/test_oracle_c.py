@@ -93,3 +93,30 @@ def test_c_curve_share_work_matches_python_oracle(name):
         assert R.share_work(gid, cmb, pos, yy, YY, r, c) == ec_reference_share((name, cmb, pos, yy, YY, r, c)), (pos,)
     with pytest.raises(ValueError):
         R.share_work(gid, enc, 1, bytes([5]) + bytes(L - 1), Y, Gc.scalar_to_fixed(1), Gc.scalar_to_fixed(1))
+
+
+def test_openssl_secp256k1_baseline_follows_the_reference_sequence():
+    """oracle/openssl_ref.py::OpenSslSecpRef (bench.py's strong-CPU line for secp256k1: libcrypto's EC_POINT_mul in the place of
+    k256) against the Python oracle in the reference order, incl. the identity as a commitment and position 0."""
+    import random
+    import mpvss_oracle as O
+    import openssl_ref
+    if not openssl_ref.ec_available():
+        pytest.skip("libcrypto without secp256k1")
+    G = O.GROUPS["secp256k1"]()
+    n = G.group_order_int()
+    rng = random.Random(31)
+    B = G.generator()
+    e, s = G.element_to_bytes, G.scalar_to_bytes
+    ref = openssl_ref.OpenSslSecpRef()
+    for t in (1, 4):
+        cm = [G.exp(B, rng.randrange(n)) for _ in range(t)]
+        if t == 4:
+            cm[2] = G.identity()
+        y, Y = G.exp(B, rng.randrange(1, n)), G.exp(B, rng.randrange(1, n))
+        r, c = rng.randrange(n), rng.randrange(n)
+        for pos in (0, 1, 9, 65536):
+            X = O.commitment_eval(G, cm, pos)
+            a1, a2 = O.dleq_verifier_commitments(G, G.subgroup_generator(), X, y, Y, r, c)
+            got = ref.share_work(b"".join(map(e, cm)), pos, e(y), e(Y), s(r), s(c))
+            assert got == (e(X), e(a1), e(a2)), (t, pos)

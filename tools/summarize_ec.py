@@ -6,14 +6,16 @@ usage: summarize_ec.py <gpurun_out/prof_ec> <out.json>"""
 import csv
 import glob
 import json
+import os
 import sys
 
 src, out = sys.argv[1], sys.argv[2]
 
 
 def total(pattern, counter):
-    files = glob.glob(f"{src}/{pattern}/*/*counter_collection.csv")
+    files = sorted(glob.glob(f"{src}/{pattern}/*/*counter_collection.csv"), key=os.path.getmtime)      # (the newest pass: gpurun merges runs)
     assert files, pattern
+    files = files[-1:]
     return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == counter)
 
 
