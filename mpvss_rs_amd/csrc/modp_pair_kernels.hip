@@ -155,6 +155,12 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
 // box has ONE challenge) against the table of Y -- on the pair layout.  tab1 [count][64][72], tab2 [count][16][72] in
 // Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
 // ---------------------------------------------------------------------------------------
+#ifndef TWIN_PREFETCH
+#define TWIN_PREFETCH 0         // the same for the bucket products of k_modp_twin_exp_buckets_pair (the dealer's and the participant's kernel): built,
+                                // bit-exact (dealer / extract / scalar tests), measured over three interleaved pairs of pipelined dealer runs
+                                // (tools/bench_dealer.py, profiles/r04_twin_prefetch_ab.txt): 1.10 / 1.08 / 1.11 M shares/s without, 1.09 / 1.07 /
+                                // 1.10 M with -- the prefetch loses 1 %.  Off.
+#endif
 #ifndef PAIR_PREFETCH
 #define PAIR_PREFETCH 0         // 1: the operand of the NEXT product comes in by LDS-DMA (global_load_lds_dwordx4 into the number's slot, which is free
                                 // once the reduction holds T_lo in registers) while the current operation reduces; 0: fetched when needed.
@@ -170,8 +176,10 @@ namespace {
 // consecutive 16-byte pieces (19 per number: 18 of data, one of padding), so lane l of instruction i fetches piece 64 i + l:
 // piece q = (64 i + l) % 19 of number n = (64 i + l) / 19, whose table entry it learns from lane n by a shuffle.
 //   src of number n = base + (x0 + n, clamped to count - 1) * num_stride + entry_n * 72 words;   entry: this lane's OWN number's
+//   entry == PREFETCH_ALT: that number takes the 72 words at `alt` instead (a constant operand: the same for every number)
+constexpr u32 PREFETCH_ALT = 0xffffffffu;
 __device__ __forceinline__ void slots_prefetch_pair(u32* wave_slots, const u32* __restrict__ base, size_t num_stride, int x0, int count,
-                                                    u32 entry, const PairLane& pl) {
+                                                    u32 entry, const PairLane& pl, const u32* __restrict__ alt = nullptr) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     int p = (int)pl.lane + 64 * i;
@@ -182,6 +190,7 @@ __device__ __forceinline__ void slots_prefetch_pair(u32* wave_slots, const u32* 
     const u32 e = (u32)__shfl((int)entry, n);
     const int xj = (x0 + n < count) ? x0 + n : count - 1;
     const u32* src = base + (size_t)xj * num_stride + (size_t)e * L + (q < 18 ? q : 17) * 4;
+    if (alt != nullptr && e == PREFETCH_ALT) src = alt + (q < 18 ? q : 17) * 4;
     if (valid)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)src,
                                        (__attribute__((address_space(3))) void*)(uintptr_t)(wave_slots + i * 256), 16, 0, 0);
@@ -577,7 +586,12 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
   u32 occ[2] = {0, 0};
   // op 0: the base into Montgomery form; per window k: ops 1, 2 = the bucket products of the two exponents, ops 3 .. 2+BW the
   // squarings.  ONE product site, one squaring site and one reduction in the loop (instruction cache).
+  // TWIN_PREFETCH: the bucket (or the harmless operand) of the NEXT bucket product comes in by LDS-DMA while the operation
+  // before it reduces -- the last squaring of a window fetches for op 1 of the next, op 1 for op 2 --, as the VALU-only kernel
+  // does (modp_kernels.hip::bucket_prefetch).  A bucket is only ever written by its own number's earlier operations, which
+  // the s_waitcnt vmcnt(0) in front of the prefetch has seen complete.
   int k = 0, op = 0;
+  bool fetched = false;
   while (true) {
     const bool sq = op >= 3;
     const u32* fill = cs->r2;
@@ -600,12 +614,28 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
       __builtin_amdgcn_wave_barrier();
       phase_a<true>(T, acc, pc.slot, pc.junk, pl);
     } else {
-      slot_fill_pair(pc.slot, fill, pl);
+      if (fetched) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else slot_fill_pair(pc.slot, fill, pl);
       __builtin_amdgcn_wave_barrier();
       phase_a<false>(T, acc, pc.slot, pc.junk, pl);
     }
     u32 r[LP];
+#if TWIN_PREFETCH
+    // which bucket product follows this operation, if any: (exponent e', window k')
+    const int ne = op == 1 ? 1 : (op == 2 + BW ? 0 : -1);
+    const int nk = op == 1 ? k : k + 1;
+    fetched = ne >= 0 && nk < BWIN;
+    reduce(r, T, pc.slot, pc.tb, pl, [&]() {
+      if (fetched) {
+        const u32 nd = digit(ex[ne], nk);
+        const bool nhas = (occ[ne] >> nd) & 1u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        slots_prefetch_pair(pc.wslots, buckets + (size_t)ne * BENT * L, (size_t)2 * BENT * L, pc.x0, count,
+                            (nd != 0 && nhas) ? nd - 1 : PREFETCH_ALT, pl, cs->one_m);
+      }
+    });
+#else
     reduce(r, T, pc.slot, pc.tb, pl);
+#endif
     __builtin_amdgcn_wave_barrier();
     if (sq || op == 0) {
 #pragma unroll

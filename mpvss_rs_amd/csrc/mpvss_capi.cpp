@@ -1341,7 +1341,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   if (space == MPVSS_HOST) {
     uint8_t* in = (uint8_t*)sl.pin + out_bytes;
     // three arrays of n x 256 bytes (48 MB at the headline shape) into pinned memory: this thread holds the context lock, so the
-    // copies run side by side on helper threads (4-5 ms -> 1.5 ms per box; round 3's host_buffers figure trailed the HBM one by 5 %)
+    // copies run side by side on helper threads (4-5 ms -> 1.5 ms of lock-held time per box).  (The host_buffers figure of the bench
+    // did not move with it -- 1.05 beside 1.11 M from HBM, as before: the 5 % are not this copy.)
     if (n * EB >= ((size_t)4 << 20)) {
       std::thread t1([&] { memcpy(in + n * EB, shares, n * EB); });
       std::thread t2([&] { memcpy(in + 2 * n * EB, responses, n * EB); });

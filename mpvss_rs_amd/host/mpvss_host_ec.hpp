@@ -169,7 +169,7 @@ class EcParticipant {
     eng.check(mpvss_ec_batch_exp_generator(eng.ctx(), T::GROUP, MPVSS_HOST, coeffs.data(), threshold, cm.data()),
               "distribute_secret: commitments");                                   // C_j = a_j G
     std::vector<int64_t> pos(n);
-    Bytes pk, ws, pv(n * 32), r(n * 32);
+    Bytes pk, ws, r(n * 32);
     std::vector<BigUint> wits(n);
     for (size_t i = 0; i < n; ++i) {
       pos[i] = (int64_t)i + 1;
@@ -177,15 +177,14 @@ class EcParticipant {
       append(pk, publickeys[i]);
       append(ws, group->scalar_bytes(wits[i]));
     }
-    // P(i) mod order for all participants (polynomial.rs:50-58 + `% order`), scalar-field work behind the C ABI
-    eng.check(mpvss_ec_poly_eval(T::GROUP, coeffs.data(), threshold, pos.data(), n, pv.data(), 0), "distribute_secret: P(i)");
-    Bytes X(n * L), Y(n * L), a1(n * L), a2(n * L);
+    // P(i) mod order (polynomial.rs:50-58 + `% order`), X_i, Y_i, a1_i, a2_i, the transcript digest, the challenge
+    // c = hash_to_scalar(digest) and the responses r_i = w_i - P(i) c in ONE call, the scalar side on the device too
+    Bytes Y(n * L), cb(32);
     uint8_t digest[32];
-    eng.check(mpvss_ec_distribute(eng.ctx(), T::GROUP, MPVSS_HOST, cm.data(), threshold, pos.data(), pk.data(), pv.data(), ws.data(),
-                                  n, X.data(), Y.data(), a1.data(), a2.data(), digest), "distribute_secret");
+    eng.check(mpvss_ec_deal(eng.ctx(), T::GROUP, coeffs.data(), threshold, pos.data(), pk.data(), ws.data(), n, nullptr, Y.data(), nullptr,
+                            nullptr, digest, cb.data(), r.data()), "distribute_secret");
     const BigUint challenge = group->hash_to_scalar(Bytes(digest, digest + 32));
-    const Bytes cb = group->scalar_bytes(challenge);
-    eng.check(mpvss_ec_dleq_responses(T::GROUP, ws.data(), pv.data(), cb.data(), 0, n, r.data(), 0), "distribute_secret: responses");
+    if (!(group->scalar_bytes(challenge) == cb)) throw std::logic_error("distribute_secret: challenge");
     EcDistributionSharesBox box;
     for (uint32_t j = 0; j < threshold; ++j) box.commitments.emplace_back(cm.begin() + j * L, cm.begin() + (j + 1) * L);
     for (size_t i = 0; i < n; ++i) {

@@ -265,3 +265,27 @@ pub fn ec_verify_distribution_shares<G: Group>(engine: &crate::Engine, group_id:
     };
     rc == ffi::MPVSS_OK && verdict == 1
 }
+
+/// The dealer's whole box for a curve group in one call (`mpvss_ec_deal`): the body of `distribute_secret`
+/// (participant.rs:1094-1274 secp256k1, 1573-1717 ristretto255) between "draw the polynomial and the witnesses" and "put the maps
+/// together" -- P(i) mod order (:1155-1157 / :1619-1621), X_i, Y_i, a1_i, a2_i, the transcript digest, the challenge
+/// c = hash_to_scalar(digest) (:1200-1210 / :1662-1672) and the responses r_i = w_i - P(i) c -- everything on the device.
+/// `coeffs` / `witnesses`: 32-byte scalars in the boundary's byte order, `pubkeys`: encoded elements; returns
+/// (Y encodings, digest, challenge bytes, response bytes) or the library's error code.
+pub fn ec_deal(engine: &crate::Engine, group_id: i32, enc_len: usize, coeffs: &[u8], pubkeys: &[u8], witnesses: &[u8])
+               -> Result<(Vec<u8>, [u8; 32], [u8; 32], Vec<u8>), i32> {
+    let (t, n) = (coeffs.len() / 32, witnesses.len() / 32);
+    let positions: Vec<i64> = (1..=n as i64).collect();                                 // :1139,1151,1198
+    let mut y = vec![0u8; n * enc_len];
+    let mut r = vec![0u8; n * 32];
+    let (mut digest, mut challenge) = ([0u8; 32], [0u8; 32]);
+    let rc = unsafe {
+        ffi::mpvss_ec_deal(engine.raw(), group_id, coeffs.as_ptr(), t, positions.as_ptr(), pubkeys.as_ptr(), witnesses.as_ptr(), n,
+                           std::ptr::null_mut(), y.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), digest.as_mut_ptr(),
+                           challenge.as_mut_ptr(), r.as_mut_ptr())
+    };
+    if rc != ffi::MPVSS_OK {
+        return Err(rc);
+    }
+    Ok((y, digest, challenge, r))
+}
