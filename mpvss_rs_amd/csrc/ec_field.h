@@ -165,6 +165,22 @@ struct F {
     reduce_columns(r, c);
   }
 
+  // r = a * b + c * d with one reduction (limbs up to 2^28.5: 20 products of 2^57 fit a 64-bit column with room for the folds)
+  static EC_HD void mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c2, const Fe& d) {
+    u64 c[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+      for (int j = 0; j < 10; ++j) c[i + j] += (u64)a.v[i] * b.v[j];
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+      for (int j = 0; j < 10; ++j) c[i + j] += (u64)c2.v[i] * d.v[j];
+    reduce_columns(r, c);
+  }
+
   static EC_HD void sqr(Fe& r, const Fe& a) {
     u64 c[20];
 #pragma unroll

@@ -24,6 +24,24 @@ int ec_launch_fd_boxes(int group, const uint32_t* cm, int t, const int64_t* posi
                        int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
                        uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride, size_t pos_stride,
                        size_t pts_stride, size_t state_stride, size_t enc_stride, hipStream_t s);
+/* the same with the stepping launches as pipelines of quad-lane stages (quad != null): for boxes that have the chip to
+   themselves.  hand: ec_fd_quad_hand_words() words per box (zeroed by the launcher), gate: the boxes' writable gate
+   (a stage that gives up clears it: the gated Horner launch must follow), fault: test hook (1 = one stage gives up) */
+typedef struct EcQuadStepping {
+  uint32_t* hand;
+  size_t hand_box_words;
+  int* gate;
+  int fault;
+  uint32_t* wtab;          /* scratch window tables of the seed kernel: ec_fd_seed_tab_words() words per box, or null (8 lanes per seed, bit by bit) */
+  size_t wtab_box_words;
+  int table;               /* the difference tables by the same pipeline (1) or one workgroup per chain (0) */
+} EcQuadStepping;
+size_t ec_fd_quad_hand_words(int t, int chains, int w0, int chain_len);
+size_t ec_fd_seed_tab_words(int group, int seeds);
+int ec_launch_fd_boxes_q(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                         int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                         uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride, size_t pos_stride,
+                         size_t pts_stride, size_t state_stride, size_t enc_stride, const EcQuadStepping* quad, hipStream_t s);
 int ec_launch_commit_eval_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count, uint8_t* x_enc,
                                 const int* gate, int want, int boxes, size_t cm_stride, size_t pos_stride, size_t enc_stride,
                                 hipStream_t s);

@@ -6,9 +6,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "ec_curves.h"
 #include "ec_scalar.h"
 #include "ec_glv.h"
+#include "ec_quad.h"
 #include "ec_kernels.h"
 
 using namespace ec;
@@ -263,6 +266,235 @@ __device__ __forceinline__ void fd_step_body(const u32* __restrict__ fwd, const 
   }
 }
 
+// ---- stepping by a pipeline of single-wave stages, four lanes per level (the lone box's latency) ---------------------
+// fd_step_body above is one workgroup per chain with one lane per level: every step is one complete addition in
+// EVERY lane -- 12 (9) field products one after the other -- between two workgroup barriers, 6-7 us per step, and a
+// lone box waits for 2 x 2300 of them.  Here a level is a QUAD of lanes (ec_quad.h: the independent products of the
+// addition side by side), a wave holds 16 consecutive levels, and the t levels of a chain are a pipeline of t/16
+// single-wave workgroups on different SIMDs, exactly as modp_kernels.hip's stepping kernels are: level k needs level
+// k+1 of the previous step only, so a stage needs one point per step from the stage above and nothing from below.
+// The point travels through HBM as self-validating words (bit 31 set on every limb word of a buffer zeroed before the
+// launch; limbs are < 2^29), written and polled with agent-scope relaxed atomics; the entry of the next step is
+// requested before this step's addition and checked after it.  Stages take their place in the chain from a ticket
+// (the top stage first), so a stage only ever waits for a workgroup that has started.  A stage whose wait times out
+// (or that is told to fail by the test hook) clears the box's gate -- the gated Horner launch then recomputes every
+// X -- and poisons its output so that the stages below give up at once.
+constexpr u32 EC_HAND_VALID = 0x80000000u;
+constexpr u32 EC_HAND_POISON = 0x40000000u;
+constexpr u32 EC_HAND_LIMB = 0x3fffffffu;
+constexpr long long EC_FD_TIMEOUT_TICKS = 200000000LL;      // 2 s of the 100 MHz wall clock
+constexpr int EC_QUAD_LEVELS = 16;                          // levels per wave
+constexpr int EC_HAND_ENTRY = 40;                           // words per handed point: 4 lanes x 10
+
+__device__ __forceinline__ void ec_hand_publish(u32* __restrict__ dst, const Fe& a, u32 tag) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) __hip_atomic_store(dst + i, a.v[i] | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ec_hand_load(u32 (&v)[10], const u32* __restrict__ src) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) v[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32 ec_hand_state(const u32 (&v)[10]) {
+  u32 all = 0xffffffffu, any = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    all &= v[i];
+    any |= v[i];
+  }
+  return (any & EC_HAND_POISON) ? EC_HAND_POISON : (all & EC_HAND_VALID);
+}
+// lanes 60..63 (`reader`) hold the words requested earlier in v; waits until all four have valid words.  Wave-uniform result.
+__device__ __forceinline__ bool ec_hand_wait(u32 (&v)[10], const u32* __restrict__ src, bool reader) {
+  bool ok = true;
+  if (reader) {
+    const long long t0 = wall_clock64();
+    while (true) {
+      const u32 st = ec_hand_state(v);
+      const uint64_t good = __builtin_amdgcn_ballot_w64(st == EC_HAND_VALID) >> 60;
+      const uint64_t bad = __builtin_amdgcn_ballot_w64(st == EC_HAND_POISON) >> 60;
+      if (good == 0xf) break;
+      if (bad != 0 || wall_clock64() - t0 > EC_FD_TIMEOUT_TICKS) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+      ec_hand_load(v, src);
+    }
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
+
+// words of handoff space one box needs for a stepping launch (tickets first)
+__host__ __device__ inline size_t ec_quad_hand_words(int t, int chains, int max_steps) {
+  const size_t nst = (size_t)(t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+  const size_t tickets = ((size_t)2 * chains + 63) / 64 * 64;
+  return tickets + (size_t)2 * chains * nst * (size_t)(max_steps + 1) * EC_HAND_ENTRY;
+}
+
+template <class Q>
+__device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, const u32* __restrict__ bwd, int chains, int t,
+                                                  int w0, int chain_len, int count, u32* __restrict__ pts, u32* __restrict__ hand,
+                                                  int max_steps, int* __restrict__ gate, int inject_fault) {
+  typedef typename Q::C C;
+  extern __shared__ u32 lds[];
+  constexpr int PW = C::POINT_WORDS;
+  const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+  const int cd = blockIdx.x / nst;
+  const int dir = cd / chains, chain = cd % chains;
+  if (dir == 1 && w0 == 0) return;
+  int* tickets = reinterpret_cast<int*>(hand);
+  u32* entries = hand + ((size_t)2 * chains + 63) / 64 * 64;
+  int ticket = 0;
+  if (threadIdx.x == 0) ticket = atomicAdd(tickets + cd, 1);
+  const int sidx = __builtin_amdgcn_readfirstlane(ticket);           // 0 = the top levels
+  const int kbase = (nst - 1 - sidx) * EC_QUAD_LEVELS;
+  const int lane = threadIdx.x, quad = lane >> 2, role = lane & 3;
+  const int k = kbase + quad;
+  const bool has_up = sidx > 0, has_down = kbase > 0;
+  const bool reader = quad == EC_QUAD_LEVELS - 1;
+  const int steps = dir == 0 ? chain_len - 1 - w0 : w0 + t - 1;
+  const u32* st = (dir == 0 ? fwd : bwd) + (size_t)chain * t * PW;
+  const size_t stage_words = (size_t)(max_steps + 1) * EC_HAND_ENTRY;
+  u32* mine = entries + ((size_t)cd * nst + sidx) * stage_words + role * 10;
+  const u32* up = entries + ((size_t)cd * nst + (has_up ? sidx - 1 : 0)) * stage_words + role * 10;
+  typename Q::St D, top;
+  if (k < t) Q::load(D, st + (size_t)k * PW, role); else Q::identity(D, role);
+  // the level above this wave's: its initial value comes from the table, the later ones from the stage above
+  if (has_up && kbase + EC_QUAD_LEVELS < t) Q::load(top, st + (size_t)(kbase + EC_QUAD_LEVELS) * PW, role); else Q::identity(top, role);
+  u32 pre[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) pre[i] = 0;
+  if (has_up && reader && steps >= 2) ec_hand_load(pre, up + (size_t)1 * EC_HAND_ENTRY);
+  for (int step = 1; step <= steps; ++step) {
+    typename Q::St nb;
+    Fe prim;
+    if (has_up && step >= 2) {                                       // entry step-1 of the stage above
+      bool ok = ec_hand_wait(pre, up + (size_t)(step - 1) * EC_HAND_ENTRY, reader);
+      if (inject_fault == 1 && cd == 0 && sidx == 1 && step == 3) ok = false;
+      if (!ok) {
+        if (threadIdx.x == 0) __hip_atomic_store(gate + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (has_down && quad == 0) {
+          Fe z;
+          Secp::Fp::zero(z);
+          ec_hand_publish(mine + (size_t)step * EC_HAND_ENTRY, z, EC_HAND_POISON);
+        }
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) prim.v[i] = pre[i] & EC_HAND_LIMB;
+      Q::nb_from_primary(top, prim, role);
+      if (reader && step < steps) ec_hand_load(pre, up + (size_t)step * EC_HAND_ENTRY);     // for the next step, under this one's addition
+    }
+    fe_from_next_quad(prim, Q::primary(D));
+    Q::nb_from_primary(nb, prim, role);
+    Q::select(nb, top, reader);
+    Q::add(D, nb, role, lds);
+    if (has_down) {
+      if (quad == 0) ec_hand_publish(mine + (size_t)step * EC_HAND_ENTRY, Q::primary(D), EC_HAND_VALID);
+    } else if (step >= t) {
+      const int j = dir == 0 ? w0 + step : w0 + t - 1 - step;
+      const size_t idx = (size_t)chain + (size_t)chains * j;
+      Fe o;
+      Q::out_words(o, D, role);
+      if (quad == 0 && Q::out_lane(role) && idx < (size_t)count) {
+        u32* dst = pts + idx * PW + Q::out_offset(role);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) dst[i] = o.v[i];
+      }
+    }
+  }
+}
+
+// The difference tables by the same pipeline: E_l[k] = E_{l-1}[k+1] - E_{l-1}[k] has the neighbour structure of the
+// stepping recurrence (element k needs element k+1 of the previous level), so a stage of 16 elements needs one point
+// per level from the stage above while its top element is still in the triangle (k <= t-1-l).  fwd[l] = E_l[0] leaves
+// from the bottom stage, bwd[l] = (-1)^l E_l[t-1-l] from whichever stage holds element t-1-l.
+template <class Q>
+__device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds, int chains, int t, u32* __restrict__ fwd,
+                                                   u32* __restrict__ bwd, u32* __restrict__ hand, int* __restrict__ gate,
+                                                   int inject_fault) {
+  typedef typename Q::C C;
+  extern __shared__ u32 lds[];
+  constexpr int PW = C::POINT_WORDS;
+  const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+  const int chain = blockIdx.x / nst;
+  int* tickets = reinterpret_cast<int*>(hand);
+  u32* entries = hand + ((size_t)2 * chains + 63) / 64 * 64;
+  int ticket = 0;
+  if (threadIdx.x == 0) ticket = atomicAdd(tickets + chain, 1);
+  const int sidx = __builtin_amdgcn_readfirstlane(ticket);           // 0 = the top elements
+  const int kbase = (nst - 1 - sidx) * EC_QUAD_LEVELS;
+  const int lane = threadIdx.x, quad = lane >> 2, role = lane & 3;
+  const int k = kbase + quad;
+  const bool has_up = sidx > 0, has_down = kbase > 0;
+  const bool reader = quad == EC_QUAD_LEVELS - 1;
+  const size_t stage_words = (size_t)(t + 1) * EC_HAND_ENTRY;
+  u32* mine = entries + ((size_t)chain * nst + sidx) * stage_words + role * 10;
+  const u32* up = entries + ((size_t)chain * nst + (has_up ? sidx - 1 : 0)) * stage_words + role * 10;
+  u32* f = fwd + (size_t)chain * t * PW;
+  u32* b = bwd + (size_t)chain * t * PW;
+  typename Q::St E, top;
+  if (k < t) Q::load(E, seeds + ((size_t)chain + (size_t)chains * k) * PW, role); else Q::identity(E, role);
+  if (has_up && kbase + EC_QUAD_LEVELS < t) Q::load(top, seeds + ((size_t)chain + (size_t)chains * (kbase + EC_QUAD_LEVELS)) * PW, role);
+  else Q::identity(top, role);
+  auto emit = [&](int lvl) {                                          // level lvl is in E
+    const int kb = t - 1 - lvl;                                       // the element that leaves backward
+    if (kbase == 0 || (kb >= kbase && kb < kbase + EC_QUAD_LEVELS)) {
+      Fe o;
+      Q::out_words(o, E, role);
+      if (kbase == 0 && quad == 0 && Q::out_lane(role)) {
+        u32* dst = f + (size_t)lvl * PW + Q::out_offset(role);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) dst[i] = o.v[i];
+      }
+      if (lvl & 1) {
+        typename Q::St n = E;
+        Q::neg(n, role);
+        Q::out_words(o, n, role);
+      }
+      if (k == kb && Q::out_lane(role)) {
+        u32* dst = b + (size_t)lvl * PW + Q::out_offset(role);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) dst[i] = o.v[i];
+      }
+    }
+  };
+  emit(0);
+  const int last_lvl = t - 1 - kbase;                                 // element k is in level l while k <= t-1-l
+  u32 pre[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) pre[i] = 0;
+  const auto need_up = [&](int lvl) { return has_up && lvl >= 2 && kbase + EC_QUAD_LEVELS - 1 <= t - 1 - lvl; };
+  if (reader && need_up(2)) ec_hand_load(pre, up + (size_t)1 * EC_HAND_ENTRY);
+  for (int lvl = 1; lvl <= last_lvl; ++lvl) {
+    typename Q::St nb, neg;
+    Fe prim;
+    if (need_up(lvl)) {                                               // level lvl-1 of the first element of the stage above
+      bool ok = ec_hand_wait(pre, up + (size_t)(lvl - 1) * EC_HAND_ENTRY, reader);
+      if (inject_fault == 2 && chain == 0 && sidx == 1 && lvl == 3) ok = false;
+      if (!ok) {
+        if (threadIdx.x == 0) __hip_atomic_store(gate + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (has_down && quad == 0) {
+          Fe z;
+          Secp::Fp::zero(z);
+          ec_hand_publish(mine + (size_t)lvl * EC_HAND_ENTRY, z, EC_HAND_POISON);
+        }
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) prim.v[i] = pre[i] & EC_HAND_LIMB;
+      Q::nb_from_primary(top, prim, role);
+      if (reader && need_up(lvl + 1)) ec_hand_load(pre, up + (size_t)lvl * EC_HAND_ENTRY);
+    }
+    fe_from_next_quad(prim, Q::primary(E));
+    Q::nb_from_primary(nb, prim, role);
+    Q::select(nb, top, reader);
+    neg = E;
+    Q::neg(neg, role);
+    Q::add(neg, nb, role, lds);                                       // E_{l-1}[k+1] - E_{l-1}[k]
+    Q::select(E, neg, k <= t - 1 - lvl);
+    if (has_down && quad == 0) ec_hand_publish(mine + (size_t)lvl * EC_HAND_ENTRY, Q::primary(E), EC_HAND_VALID);
+    emit(lvl);
+  }
+}
+
 template <class C>
 __device__ __forceinline__ void encode_body(const u32* __restrict__ pts, int count, uint8_t* __restrict__ enc) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,6 +741,116 @@ __device__ __forceinline__ void dual_win_body(const u32* __restrict__ comb, cons
   if (live) store_point_aos<C>(out_pts + (size_t)x * C::POINT_WORDS, acc);
 }
 
+// ---- seeds for a box that has the chip to itself --------------------------------------------------------------------
+// seeds_split_body with the piece's factor x^lo applied through signed 4-bit windows (and secp256k1's endomorphism)
+// instead of 256 doublings and 256 additions: the lane's table P .. 8P goes to its own 8 entries of `wtab` (HBM, read
+// back through L2: 65 or 2 x 33 look-ups against 128 / 256 doublings), the recoded scalar to LDS.  With PARTS = 16 the
+// sequential depth of a seed is t/16 Horner steps + one windowed multiplication: about 0.45 of seeds_split_body's.
+[[maybe_unused]] constexpr int SEEDS_WIN_K_ROWS = 10;
+template <class C, class O, int PARTS>
+__device__ __forceinline__ void seeds_win_body(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions,
+                                               int count, u32* __restrict__ pts, u32* __restrict__ wtab) {
+  extern __shared__ u32 lds[];
+  constexpr int CW = C::CACHED_WORDS;
+  u32* lds_k = lds + 64 * C::POINT_WORDS;                  // [SEEDS_WIN_K_ROWS][64]
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int xi = gi / PARTS, part = gi % PARTS;
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  const uint64_t pos = (uint64_t)positions[x];
+  const int nb = (pos == 0) ? 0 : 64 - __builtin_clzll(pos);
+  const int len = (t + PARTS - 1) / PARTS;
+  const int lo = part * len;
+  const int hi = (lo + len < t) ? lo + len : t;
+  typename C::Point acc, cj, r;
+  C::identity(acc);
+  for (int j = hi - 1; j >= lo; --j) {
+    small_scalar_mul<C>(r, acc, pos, nb);
+    load_point_aos<C>(cj, cm + (size_t)j * C::POINT_WORDS);
+    C::add(acc, r, cj);
+  }
+  {                                                        // times x^lo (1 for the first piece: the same code, a few wasted additions of the identity)
+    Sc sc;
+    ScalarField<O>::pow_u64(sc, pos, (u32)lo);
+    u32* mine = wtab + (size_t)gi * 8 * CW;
+    typename C::Cached e;
+    cj = acc;
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i) {
+      C::to_cached(e, cj);
+      store_cached<C>(mine + i * CW, e);
+      if (i < 7) C::add(cj, cj, acc);
+    }
+    __threadfence_block();
+    const int k = threadIdx.x;
+    C::identity(r);
+#if EC_GLV
+    if constexpr (C::SCALAR_BIG_ENDIAN) {
+      GlvHalf h[2];
+      secp_glv_split(h, sc.v);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) lds_k[(5 * j + i) * 64 + k] = h[j].kp[i];
+      u32 words[2] = {0, 0};
+      const u32 negs = (h[0].neg ? 1u : 0u) | (h[1].neg ? 2u : 0u);
+      for (int w = 32; w >= 0; --w) {
+        if ((w & 7) == 7 || w == 32) {
+          words[0] = lds_k[(w >> 3) * 64 + k];
+          words[1] = lds_k[(5 + (w >> 3)) * 64 + k];
+        }
+        if (w != 32) {
+#pragma unroll 1
+          for (int i = 0; i < 4; ++i) C::dbl(r, r);
+        }
+#pragma unroll 1
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int nib = (int)(((s2 ? words[1] : words[0]) >> (4 * (w & 7))) & 15u);
+          int d = w == 32 ? nib : nib - 8;
+          if ((negs >> s2) & 1u) d = -d;
+          add_signed_digit<C>(r, d, [&](typename C::Cached& ce, int i) {
+            load_cached<C>(ce, mine + i * CW);
+            if (s2 & 1) secp_phi_cached(ce);
+          });
+        }
+      }
+    } else
+#endif
+    {
+      u64 carry = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        carry += (u64)sc.v[i] + 0x88888888u;
+        lds_k[i * 64 + k] = (u32)carry;
+        carry >>= 32;
+      }
+      lds_k[8 * 64 + k] = (u32)carry;
+      u32 word = 0;
+      for (int w = 64; w >= 0; --w) {
+        if ((w & 7) == 7 || w == 64) word = lds_k[(w >> 3) * 64 + k];
+        if (w != 64) {
+#pragma unroll 1
+          for (int i = 0; i < 4; ++i) C::dbl(r, r);
+        }
+        add_signed_digit<C>(r, signed_digit4(word, w), [&](typename C::Cached& ce, int i) { load_cached<C>(ce, mine + i * CW); });
+      }
+    }
+    acc = r;
+  }
+  // sum of the PARTS pieces: tree through LDS (pieces of one seed sit in adjacent lanes)
+  const int k = threadIdx.x;
+  for (int d = PARTS / 2; d >= 1; d >>= 1) {
+    lds_put_raw<C>(lds, k, acc);
+    __syncthreads();
+    if (part < d) {
+      lds_get_raw<C>(cj, lds, k + d);
+      C::add(acc, acc, cj);
+    }
+    __syncthreads();
+  }
+  if (live && part == 0) store_point_aos<C>(pts + (size_t)x * C::POINT_WORDS, acc);
+}
+
 // out = sum of m points (internal coordinates): the fold of reconstruct's Lagrange factors (participant.rs:1489-1492).
 // One workgroup: every lane adds up a strided subset, then a tree through LDS.
 template <class C>
@@ -555,7 +897,7 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
 #endif
 #define EC_DEF(...) { __VA_ARGS__ }
 #define EC_DECL(...) ;
-#define EC_KERNELS(NAME, CURVE, ORDER, BODY)                                                                           \
+#define EC_KERNELS(NAME, CURVE, ORDER, QUAD, BODY)                                                                     \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_decode(const uint8_t* enc, int count, u32* pts,          \
                                                                      uint8_t* ok)                                      \
       BODY(decode_body<CURVE>(enc, count, pts, ok);)                                                                   \
@@ -583,6 +925,13 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
       BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
            seeds_split_body<CURVE, ORDER, 8>(cm + blockIdx.y * bs.cm, t, pos + blockIdx.y * bs.pos, count,             \
                                              pts + blockIdx.y * bs.pts);)                                              \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_seeds_win(const u32* cm, int t, const int64_t* pos,   \
+                                                                           int count, u32* pts, u32* wtab,             \
+                                                                           size_t wtab_box, const int* gate,           \
+                                                                           BoxStride bs)                               \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           seeds_win_body<CURVE, ORDER, 16>(cm + blockIdx.y * bs.cm, t, pos + blockIdx.y * bs.pos, count,              \
+                                            pts + blockIdx.y * bs.pts, wtab + blockIdx.y * wtab_box);)                 \
   extern "C" __global__ void __launch_bounds__(512) k_##NAME##_fd_table(const u32* seeds, int chains, int t, u32* fwd, \
                                                                         u32* bwd, const int* gate, BoxStride bs)       \
       BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
@@ -594,6 +943,20 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
       BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
            fd_step_body<CURVE>(fwd + blockIdx.y * bs.state, bwd + blockIdx.y * bs.state, chains, t, w0, chain_len,     \
                                count, pts + blockIdx.y * bs.pts);)                                                     \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_step_quad(                                            \
+      const u32* fwd, const u32* bwd, int chains, int t, int w0, int chain_len, int count, u32* pts, u32* hand,        \
+      size_t hand_box, int max_steps, int* gate, int inject_fault, BoxStride bs)                                       \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           fd_quad_step_body<QUAD>(fwd + blockIdx.y * bs.state, bwd + blockIdx.y * bs.state, chains, t, w0, chain_len, \
+                                   count, pts + blockIdx.y * bs.pts, hand + blockIdx.y * hand_box, max_steps, gate,    \
+                                   inject_fault);)                                                                     \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_fd_table_quad(const u32* seeds, int chains, int t,       \
+                                                                            u32* fwd, u32* bwd, u32* hand,             \
+                                                                            size_t hand_box, int* gate,                \
+                                                                            int inject_fault, BoxStride bs)            \
+      BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
+           fd_quad_table_body<QUAD>(seeds + blockIdx.y * bs.pts, chains, t, fwd + blockIdx.y * bs.state,               \
+                                    bwd + blockIdx.y * bs.state, hand + blockIdx.y * hand_box, gate, inject_fault);)   \
   extern "C" __global__ void __launch_bounds__(64) k_##NAME##_encode(const u32* pts, int count, uint8_t* enc,          \
                                                                      const int* gate, BoxStride bs)                    \
       BODY(EC_BOX_GATE_CHECK(gate, 1);                                                                                 \
@@ -613,7 +976,7 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
       BODY(extern __shared__ u32 lds[]; sum_points_body<CURVE>(pts, m, out, lds);)
 
 #if EC_PART != 2
-EC_KERNELS(secp, Secp, OrderSecp, EC_DEF)
+EC_KERNELS(secp, Secp, OrderSecp, QuadSecp, EC_DEF)
 EC_WIN_KERNELS(secp, Secp, EC_DEF)
 extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate,
                                                                      BoxStride bs) {
@@ -622,10 +985,10 @@ extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* 
 }
 #endif
 #if EC_PART == 1
-EC_KERNELS(rist, Ristretto, OrderEd, EC_DECL)
+EC_KERNELS(rist, Ristretto, OrderEd, QuadRist, EC_DECL)
 EC_WIN_KERNELS(rist, Ristretto, EC_DECL)
 #else
-EC_KERNELS(rist, Ristretto, OrderEd, EC_DEF)
+EC_KERNELS(rist, Ristretto, OrderEd, QuadRist, EC_DEF)
 EC_WIN_KERNELS(rist, Ristretto, EC_DEF)
 #endif
 
@@ -688,10 +1051,22 @@ extern "C" int ec_launch_encode_boxes(int group, const uint32_t* pts, int count,
 // boxes > 1: `boxes` boxes of the same shape in every launch.  Per box: cm_stride words of commitments, pos_stride
 // positions, pts_stride words of points, enc_stride bytes of encodings, state_stride words of difference tables
 // (state_fwd, state_bwd and state_l1 all advance by it), gate[b].
-extern "C" int ec_launch_fd_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
-                                  int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
-                                  uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride,
-                                  size_t pos_stride, size_t pts_stride, size_t state_stride, size_t enc_stride, hipStream_t s) {
+// quad != null: the stepping launches are pipelines of quad-lane stages (fd_quad_step_body) -- for boxes that have the
+// chip to themselves; quad->hand holds ec_fd_quad_hand_words() words per box and is zeroed here before each launch,
+// quad->gate is the boxes' (writable) gate.
+extern "C" size_t ec_fd_quad_hand_words(int t, int chains, int w0, int chain_len) {
+  const int m0 = chains * t, w1 = (m0 - t) / 2;
+  const int steps_l1 = std::max(m0 - 1 - w1, w1 + t - 1), steps = std::max(chain_len - 1 - w0, w0 + t - 1);
+  return std::max(std::max(ec_quad_hand_words(t, 1, steps_l1), ec_quad_hand_words(t, chains, steps)), ec_quad_hand_words(t, chains, t));
+}
+extern "C" size_t ec_fd_seed_tab_words(int group, int seeds) {
+  return (size_t)blocks_for(16 * seeds) * 64 * 8 * (size_t)(group == 1 ? Secp::CACHED_WORDS : Ristretto::CACHED_WORDS);
+}
+extern "C" int ec_launch_fd_boxes_q(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                                    int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                                    uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride,
+                                    size_t pos_stride, size_t pts_stride, size_t state_stride, size_t enc_stride,
+                                    const EcQuadStepping* quad, hipStream_t s) {
   const int m0 = chains * t;
   const size_t seed0 = (size_t)chains * w0;
   const int pw = ec_point_words(group);
@@ -709,36 +1084,91 @@ extern "C" int ec_launch_fd_boxes(int group, const uint32_t* cm, int t, const in
   uint32_t* l1_bwd = two_level ? state_l1 + (size_t)t * pw : nullptr;
   const BoxStride bs{cm_stride, pos_stride, pts_stride, state_stride, enc_stride};
   const unsigned B = (unsigned)boxes;
+  auto step_quad = [&](uint32_t* fwd, uint32_t* bwd, int nchains, int first, int len, int cnt, uint32_t* out) -> int {
+    const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+    const int max_steps = std::max(len - 1 - first, first + t - 1);
+    if (ec_quad_hand_words(t, nchains, max_steps) > quad->hand_box_words) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(quad->hand, 0, (size_t)boxes * quad->hand_box_words * 4, s);
+    if (e != hipSuccess) return (int)e;
+    if (group == 1)
+      hipLaunchKernelGGL(k_secp_fd_step_quad, dim3(2 * nchains * nst, B), dim3(64), QuadSecp::LDS_WORDS * 4, s, fwd, bwd, nchains, t,
+                         first, len, cnt, out, quad->hand, quad->hand_box_words, max_steps, quad->gate, quad->fault, bs);
+    else
+      hipLaunchKernelGGL(k_rist_fd_step_quad, dim3(2 * nchains * nst, B), dim3(64), QuadRist::LDS_WORDS * 4, s, fwd, bwd, nchains, t,
+                         first, len, cnt, out, quad->hand, quad->hand_box_words, max_steps, quad->gate, quad->fault, bs);
+    return 0;
+  };
+  const bool win = split && quad != nullptr && quad->wtab != nullptr;     // 16 lanes per seed, windowed x^lo
+  const size_t lds_win = ((size_t)64 * pw + SEEDS_WIN_K_ROWS * 64) * 4;
+  if (win) {
+    if (group == 1)
+      hipLaunchKernelGGL(k_secp_fd_seeds_win, dim3(blocks_for(16 * horner), B), dim3(64), lds_win, s, cm, t, hpos, horner, hseeds,
+                         quad->wtab, quad->wtab_box_words, gate, bs);
+    else
+      hipLaunchKernelGGL(k_rist_fd_seeds_win, dim3(blocks_for(16 * horner), B), dim3(64), lds_win, s, cm, t, hpos, horner, hseeds,
+                         quad->wtab, quad->wtab_box_words, gate, bs);
+  }
+  auto table_quad = [&](const uint32_t* sd, int nchains, uint32_t* fw, uint32_t* bw) -> int {
+    const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+    if (ec_quad_hand_words(t, nchains, t) > quad->hand_box_words) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(quad->hand, 0, (size_t)boxes * quad->hand_box_words * 4, s);
+    if (e != hipSuccess) return (int)e;
+    if (group == 1)
+      hipLaunchKernelGGL(k_secp_fd_table_quad, dim3(nchains * nst, B), dim3(64), QuadSecp::LDS_WORDS * 4, s, sd, nchains, t, fw, bw,
+                         quad->hand, quad->hand_box_words, quad->gate, quad->fault, bs);
+    else
+      hipLaunchKernelGGL(k_rist_fd_table_quad, dim3(nchains * nst, B), dim3(64), QuadRist::LDS_WORDS * 4, s, sd, nchains, t, fw, bw,
+                         quad->hand, quad->hand_box_words, quad->gate, quad->fault, bs);
+    return 0;
+  };
+  const bool qtab = quad != nullptr && quad->table;
   if (group == 1) {
-    if (split)
+    if (win) {}
+    else if (split)
       hipLaunchKernelGGL(k_secp_fd_seeds_split, dim3(blocks_for(8 * horner), B), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate, bs);
     else
       hipLaunchKernelGGL(k_secp_fd_seeds, dim3(blocks_for(horner), B), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate, bs);
     if (two_level) {
-      hipLaunchKernelGGL(k_secp_fd_table, dim3(1, B), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate, bs);
-      hipLaunchKernelGGL(k_secp_fd_step, dim3(2, B), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate, bs);
+      if (qtab) { if (int rc = table_quad(hseeds, 1, l1_fwd, l1_bwd)) return rc; }
+      else hipLaunchKernelGGL(k_secp_fd_table, dim3(1, B), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate, bs);
+      if (quad) { if (int rc = step_quad(l1_fwd, l1_bwd, 1, w1, m0, m0, seeds)) return rc; }
+      else hipLaunchKernelGGL(k_secp_fd_step, dim3(2, B), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate, bs);
     }
-    hipLaunchKernelGGL(k_secp_fd_table, dim3(chains, B), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate, bs);
-    hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains, B), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
-                       count, pts, gate, bs);
+    if (qtab) { if (int rc = table_quad(seeds, chains, state_fwd, state_bwd)) return rc; }
+    else hipLaunchKernelGGL(k_secp_fd_table, dim3(chains, B), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate, bs);
+    if (quad) { if (int rc = step_quad(state_fwd, state_bwd, chains, w0, chain_len, count, pts)) return rc; }
+    else hipLaunchKernelGGL(k_secp_fd_step, dim3(2 * chains, B), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
+                            count, pts, gate, bs);
   } else {
-    if (split)
+    if (win) {}
+    else if (split)
       hipLaunchKernelGGL(k_rist_fd_seeds_split, dim3(blocks_for(8 * horner), B), dim3(64), lds_seed, s, cm, t, hpos, horner, hseeds, gate, bs);
     else
       hipLaunchKernelGGL(k_rist_fd_seeds, dim3(blocks_for(horner), B), dim3(64), 0, s, cm, t, hpos, horner, hseeds, gate, bs);
     if (two_level) {
-      hipLaunchKernelGGL(k_rist_fd_table, dim3(1, B), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate, bs);
-      hipLaunchKernelGGL(k_rist_fd_step, dim3(2, B), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate, bs);
+      if (qtab) { if (int rc = table_quad(hseeds, 1, l1_fwd, l1_bwd)) return rc; }
+      else hipLaunchKernelGGL(k_rist_fd_table, dim3(1, B), dim3(lanes), lds, s, hseeds, 1, t, l1_fwd, l1_bwd, gate, bs);
+      if (quad) { if (int rc = step_quad(l1_fwd, l1_bwd, 1, w1, m0, m0, seeds)) return rc; }
+      else hipLaunchKernelGGL(k_rist_fd_step, dim3(2, B), dim3(lanes), lds, s, l1_fwd, l1_bwd, 1, t, w1, m0, m0, seeds, gate, bs);
     }
-    hipLaunchKernelGGL(k_rist_fd_table, dim3(chains, B), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate, bs);
-    hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains, B), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
-                       count, pts, gate, bs);
+    if (qtab) { if (int rc = table_quad(seeds, chains, state_fwd, state_bwd)) return rc; }
+    else hipLaunchKernelGGL(k_rist_fd_table, dim3(chains, B), dim3(lanes), lds, s, seeds, chains, t, state_fwd, state_bwd, gate, bs);
+    if (quad) { if (int rc = step_quad(state_fwd, state_bwd, chains, w0, chain_len, count, pts)) return rc; }
+    else hipLaunchKernelGGL(k_rist_fd_step, dim3(2 * chains, B), dim3(lanes), lds, s, state_fwd, state_bwd, chains, t, w0, chain_len,
+                            count, pts, gate, bs);
   }
   if (x_enc != nullptr) {
     const int rc = ec_launch_encode_boxes(group, pts, count, x_enc, gate, boxes, pts_stride, enc_stride, s);
     if (rc != 0) return rc;
   }
   return (int)hipGetLastError();
+}
+extern "C" int ec_launch_fd_boxes(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
+                                  int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,
+                                  uint8_t* x_enc, int split_seeds, const int* gate, int boxes, size_t cm_stride,
+                                  size_t pos_stride, size_t pts_stride, size_t state_stride, size_t enc_stride, hipStream_t s) {
+  return ec_launch_fd_boxes_q(group, cm, t, positions, count, chains, w0, chain_len, pts, state_fwd, state_bwd, state_l1, x_enc,
+                              split_seeds, gate, boxes, cm_stride, pos_stride, pts_stride, state_stride, enc_stride, nullptr, s);
 }
 extern "C" int ec_launch_fd(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
                             int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,

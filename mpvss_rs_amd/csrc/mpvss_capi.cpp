@@ -58,9 +58,10 @@ struct EcWork {   // device workspace of the elliptic-curve entry points (one pe
   DevBuf tab1, tab2, tab3;       // window tables of per-share bases: [n][8][cached words]
   DevBuf p1, p2;                 // results of the double-scalar multiplications in internal coordinates
   DevBuf flags;                  // ints: [0] forward-difference gate, [1] first bad response, [2] first bad challenge
+  DevBuf hand, wtab;             // hand-over space of the quad-lane stepping pipeline, window tables of its seed kernel (a box that has the chip to itself)
   std::vector<DevBuf*> all() {
     return {&a, &b, &c, &d, &e, &pos, &cm, &cmenc, &x, &o1, &o2, &ok, &gen, &chal, &pts, &fdst, &tab1, &tab2, &tab3, &p1, &p2,
-            &flags};
+            &flags, &hand, &wtab};
   }
 };
 
@@ -211,12 +212,12 @@ struct mpvss_ctx {
   }
   // Curve groups: X paths of several boxes of one mpvss_ec_verify_many call computed by the same launches (capi_ec.inc)
   struct XBatch {
-    DevBuf cmenc, cm, okcm, pos, pts, xenc, state, flags;
+    DevBuf cmenc, cm, okcm, pos, pts, xenc, state, flags, hand, wtab;
     hipStream_t s = nullptr;
     hipEvent_t done = nullptr;
     void* pin = nullptr;
     size_t pin_cap = 0;
-    std::vector<DevBuf*> all() { return {&cmenc, &cm, &okcm, &pos, &pts, &xenc, &state, &flags}; }
+    std::vector<DevBuf*> all() { return {&cmenc, &cm, &okcm, &pos, &pts, &xenc, &state, &flags, &hand, &wtab}; }
   };
   std::vector<XBatch*> ec_xb;
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
