@@ -206,10 +206,19 @@ def bench_ec(eng, name, args):
     verify(dump=True)                                   # warm-up + the outputs for the CPU comparison
     # isolated launches: one synchronous box, nothing else on the GPU
     eng.pipeline_stats(reset=True)
+    torch.cuda.synchronize()
+    t_l0 = time.perf_counter()
     verify()
+    lone_wall = (time.perf_counter() - t_l0) * 1e3
     lst = eng.pipeline_stats(reset=True)
     lone = {"x_path": lst["kernel_ms"][0], "dual_win": lst["kernel_ms"][1], "tables": lst["kernel_ms"][2],
-            "encode": lst["kernel_ms"][3], "dual_win_launches": lst["kernel_launches"][1]}
+            "encode": lst["kernel_ms"][3], "dual_win_launches": lst["kernel_launches"][1],
+            # the whole synchronous call (a2 runs beside the X path, so the GPU part is shorter than the sum of the launches above):
+            # enqueue + wait = the box on the GPU, then its transcript on one host thread
+            "call_wall_ms": lone_wall, "enqueue_ms": lst["enqueue_ms"], "wait_for_gpu_ms": lst["wait_ms"],
+            "sha256_transcript_ms": lst["hash_ms"],
+            "x_path_is": "seed kernel with windowed x^lo, difference tables and stepping as pipelines of quad-lane stages (ec_quad.h): "
+                         "what a box that has the chip to itself takes; batched boxes keep one workgroup per chain"}
     dual_ms = lone["dual_win"] / max(lone["dual_win_launches"], 1)
     # timed: K boxes through the library's pipeline (mpvss_ec_verify_many): EC_DEPTH boxes in flight in ONE context
     k = args.ec_boxes

@@ -279,6 +279,9 @@ __device__ __forceinline__ void fd_step_body(const u32* __restrict__ fwd, const 
 // (the top stage first), so a stage only ever waits for a workgroup that has started.  A stage whose wait times out
 // (or that is told to fail by the test hook) clears the box's gate -- the gated Horner launch then recomputes every
 // X -- and poisons its output so that the stages below give up at once.
+#ifndef EC_LONE_SETPRIO
+#define EC_LONE_SETPRIO 3       // wave priority of the lone box's latency-bound launches (seeds, table and stepping pipelines)
+#endif
 constexpr u32 EC_HAND_VALID = 0x80000000u;
 constexpr u32 EC_HAND_POISON = 0x40000000u;
 constexpr u32 EC_HAND_LIMB = 0x3fffffffu;
@@ -335,6 +338,7 @@ __device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, c
   typedef typename Q::C C;
   extern __shared__ u32 lds[];
   constexpr int PW = C::POINT_WORDS;
+  __builtin_amdgcn_s_setprio(EC_LONE_SETPRIO);    // latency-critical and few: issue ahead of the wide kernels sharing the SIMD (a2's)
   const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
   const int cd = blockIdx.x / nst;
   const int dir = cd / chains, chain = cd % chains;
@@ -413,6 +417,7 @@ __device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds
   typedef typename Q::C C;
   extern __shared__ u32 lds[];
   constexpr int PW = C::POINT_WORDS;
+  __builtin_amdgcn_s_setprio(EC_LONE_SETPRIO);
   const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
   const int chain = blockIdx.x / nst;
   int* tickets = reinterpret_cast<int*>(hand);
@@ -752,6 +757,7 @@ __device__ __forceinline__ void seeds_win_body(const u32* __restrict__ cm, int t
                                                int count, u32* __restrict__ pts, u32* __restrict__ wtab) {
   extern __shared__ u32 lds[];
   constexpr int CW = C::CACHED_WORDS;
+  __builtin_amdgcn_s_setprio(EC_LONE_SETPRIO);
   u32* lds_k = lds + 64 * C::POINT_WORDS;                  // [SEEDS_WIN_K_ROWS][64]
   const int gi = blockIdx.x * blockDim.x + threadIdx.x;
   const int xi = gi / PARTS, part = gi % PARTS;

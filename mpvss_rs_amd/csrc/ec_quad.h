@@ -177,7 +177,8 @@ struct QuadSecp {
     fe_quad_perm<1, 2, 0, 1>(mn, m);
     Fp::add(zz, m, mn);
     Fp::sub(mm, m, mn);
-    Fp::neg(ncrk, crk);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) ncrk.v[i] = PrimeConsts<PrimeSecp>::subpad(i) - crk.v[i];      // (no carry: a factor of mul2, limbs < 2^30)
     fe_select(s1, mm, m, c == 1);
     fe_select(s1, ncrk, s1, c == 2);
     // publish S0 = crk, S1, S2 = zz; fetch A, B, C, D by (lane of the quad, slot)

@@ -1,2 +1,2 @@
-timeout 1500 python -m pytest tests/test_gpu_ec_fd.py -x -q -m gpu > gpurun_out/r04_ecq_tests.log 2>&1; tail -15 gpurun_out/r04_ecq_tests.log
-python3 tools/ec_x_latency.py > gpurun_out/r04_ec_x_latency.txt 2>&1; grep -v amdgpu.ids gpurun_out/r04_ec_x_latency.txt
+timeout 1500 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/r04_suite_quad.log 2>&1; tail -25 gpurun_out/r04_suite_quad.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_quad.json 2> gpurun_out/r04_bench_quad.err; tail -c 600 gpurun_out/r04_bench_quad.json; tail -3 gpurun_out/r04_bench_quad.err

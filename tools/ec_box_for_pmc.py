@@ -46,7 +46,8 @@ if K > 0:
     verdicts = (C.c_int * K)()
     digests = (C.c_uint8 * (32 * K))()
     depth, threads = int(os.environ.get("MPVSS_BENCH_EC_DEPTH", "16")), int(os.environ.get("MPVSS_BENCH_EC_HASH_THREADS", "6"))
-    eng._check(eng.lib.mpvss_ec_verify_many(eng.ctx, gid, capi.MPVSS_DEVICE, arr, K, depth, threads, verdicts, C.cast(digests, C.c_void_p)), "ec_verify_many")
+    for _ in range(int(os.environ.get("MPVSS_BOX_REPEAT", "1"))):      # (tools/ec_lone_box_trace.sh: the same K boxes again, warm)
+        eng._check(eng.lib.mpvss_ec_verify_many(eng.ctx, gid, capi.MPVSS_DEVICE, arr, K, depth, threads, verdicts, C.cast(digests, C.c_void_p)), "ec_verify_many")
     assert all(verdicts[i] == 1 for i in range(K)) and bytes(digests)[:32] == d["digest"]
 print(name, "verified", K)
 eng.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wall time of ONE curve-group X path (n = 65536, t = 256, consecutive positions) through the synchronous call
 mpvss_ec_commit_eval -- the chip to itself -- for the stepping variants: MPVSS_EC_FD_QUAD=0/2, MPVSS_EC_FD_L1=0/2.
-  python3 tools/ec_x_latency.py            (spawns one child per variant: the switches are read once per process)"""
+  python3 tools/ec_x_latency.py            (ENV=VALUE arguments go to every child; VARIANTS=quad:l1,... picks the variants; one child per variant: the switches are read once per process)"""
 import hashlib
 import os
 import random
@@ -31,10 +31,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             h = hashlib.sha256(out).hexdigest()[:16]
         print(f"{name:13} {best * 1e3:7.2f} ms  {h}  x_path kernel_ms {eng.kernel_ms(0):.2f}")
     sys.exit(0)
-for quad in ("0", "2"):
-    for l1 in ("0", "2"):
-        env = dict(os.environ, MPVSS_EC_FD_QUAD=quad, MPVSS_EC_FD_L1=l1)
-        for k, v in [a.split("=") for a in sys.argv[1:]]:
-            env[k] = v
-        print(f"== MPVSS_EC_FD_QUAD={quad} MPVSS_EC_FD_L1={l1}", flush=True)
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env)
+variants = [v.split(":") for v in os.environ.get("VARIANTS", "0:0,0:2,2:0,2:2").split(",")]      # quad:l1
+for quad, l1 in variants:
+    env = dict(os.environ, MPVSS_EC_FD_QUAD=quad, MPVSS_EC_FD_L1=l1)
+    extra = [a.split("=") for a in sys.argv[1:]]
+    for k, v in extra:
+        env[k] = v
+    print(f"== MPVSS_EC_FD_QUAD={quad} MPVSS_EC_FD_L1={l1} " + " ".join(f"{k}={v}" for k, v in extra), flush=True)
+    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env)
