@@ -114,6 +114,8 @@ struct mpvss_ctx {
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
     hipEvent_t ev_fork = nullptr, ev_gr = nullptr;
     hipEvent_t ev_a2 = nullptr;
+    hipStream_t sx = nullptr;                // MPVSS_X_CUS > 0: the X path's own stream, confined to the first CUs (sa, sb: to the others)
+    hipEvent_t ev_x = nullptr;
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
@@ -561,8 +563,20 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
     // a block slot's stream carries the latency-bound chain of its box: highest priority, so that it never queues
     // behind (or shares a hardware queue with) the wide launches, which go to the slot's low-priority second stream
     static const int use_prio = fd_env("MPVSS_STREAM_PRIO", 1);
-    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, use_prio ? ctx->prio_high : 0));
-    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, use_prio ? ctx->prio_low : 0));
+    // MPVSS_X_CUS = K > 0 (experiment, profiles/r04_cu_partition_ab.txt): the latency-bound X path on K CUs of its own, the
+    // wide launches on the other 256 - K (hipExtStreamCreateWithCUMask: contiguous bit ranges map to K/8 CUs of every XCD)
+    static const int x_cus = fd_env("MPVSS_X_CUS", 0);
+    if (x_cus > 0 && x_cus < 256) {
+      uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < 256; ++b) (b < x_cus ? lo : hi)[b >> 5] |= 1u << (b & 31);
+      HIPCHK(ctx, hipExtStreamCreateWithCUMask(&w.sx, 8, lo));
+      HIPCHK(ctx, hipExtStreamCreateWithCUMask(&w.sa, 8, hi));
+      HIPCHK(ctx, hipExtStreamCreateWithCUMask(&w.sb, 8, hi));
+      HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_x, hipEventDisableTiming));
+    } else {
+      HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, use_prio ? ctx->prio_high : 0));
+      HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, use_prio ? ctx->prio_low : 0));
+    }
   }
   for (hipEvent_t* e : {&w.ev_fork, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -580,6 +594,8 @@ void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
   for (hipEvent_t e : {w.ev_fork, w.ev_gr})
     if (e) (void)hipEventDestroy(e);
   if (w.ev_a2) (void)hipEventDestroy(w.ev_a2);
+  if (w.ev_x) (void)hipEventDestroy(w.ev_x);
+  if (w.sx) { (void)hipStreamSynchronize(w.sx); (void)hipStreamDestroy(w.sx); }
   if (w.root) (void)hipHostFree(w.root);
   if (w.sb) (void)hipStreamDestroy(w.sb);
   if (w.sa && owns_sa) (void)hipStreamDestroy(w.sa);
@@ -1715,7 +1731,17 @@ int verify_group_compute_locked(mpvss_ctx* ctx, int space, const mpvss_modp_box*
                                                            comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     HIPCHK(ctx, hipEventRecord(w.ev_gr, ctx->stream));
   }
-  RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
+  if (w.sx) {          // the X path on its own CUs; the block's stream takes over when X is there
+    HIPCHK(ctx, hipStreamWaitEvent(w.sx, w.ev_fork, 0));
+    {
+      Swap sw(ctx, w.sx);
+      RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
+      HIPCHK(ctx, hipEventRecord(w.ev_x, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, w.ev_x, 0));
+  } else {
+    RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
+  }
   {
     const uint32_t* tx;
     RET_IF(number_tables(ctx, dX, N, w.tab3, &tx));
