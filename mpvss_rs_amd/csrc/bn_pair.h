@@ -187,12 +187,13 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // slot_free(): called once the reduction holds T_lo in registers, i.e. from the moment the number's LDS slot is free again --
 // a kernel that knows its NEXT operand starts the LDS-DMA of it there, under the two GEMMs (modp_pair_kernels.hip)
-template <class Hook = NoHook>
+// PRIO_IN / PRIO_OUT: wave priority inside the two GEMMs / afterwards (the latency-bound stepping waves keep theirs throughout)
+template <class Hook = NoHook, int PRIO_IN = MM_REDUCE_PRIO, int PRIO_OUT = 0>
 __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* slot, const Tables* tb, const PairLane& pl,
                                        Hook&& slot_free = NoHook()) {
   __builtin_amdgcn_sched_barrier(0);
 #if MM_REDUCE_PRIO > 0
-  __builtin_amdgcn_s_setprio(MM_REDUCE_PRIO);          // the wave that is in its MFMA chains issues ahead of the one in its VALU rows
+  __builtin_amdgcn_s_setprio(PRIO_IN);          // the wave that is in its MFMA chains issues ahead of the one in its VALU rows
 #endif
   // ---------------- GEMM 1: m'' = T_lo * N' (mod R) --------------------------------------------------------------------
   // Software pipeline, one stage per row tile: the (dependent) MFMA chain of tile R runs on the matrix pipe while the VALU
@@ -366,7 +367,7 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
   epi2(7, acc[0]);
   __builtin_amdgcn_sched_barrier(0);
 #if MM_REDUCE_PRIO > 0
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(PRIO_OUT);
 #endif
   // ---------------- final pass: carry-propagate inside the half, hand half 0's carry to half 1 -----------------------
   u64 c = 0;

@@ -155,6 +155,9 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
 // box has ONE challenge) against the table of Y -- on the pair layout.  tab1 [count][64][72], tab2 [count][16][72] in
 // Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
 // ---------------------------------------------------------------------------------------
+#ifndef FD_STEP_KEEP_PRIO
+#define FD_STEP_KEEP_PRIO 0    // stepping waves at priority 3 inside reduce() too (1) or at reduce()'s own priority there (0)
+#endif
 #ifndef TWIN_PREFETCH
 #define TWIN_PREFETCH 0         // the same for the bucket products of k_modp_twin_exp_buckets_pair (the dealer's and the participant's kernel): built,
                                 // bit-exact (dealer / extract / scalar tests), measured over three interleaved pairs of pipelined dealer runs
@@ -764,8 +767,12 @@ k_modp_fd_step_pair(const u32* __restrict__ state, const u32* __restrict__ state
     u64 T[LP];
     phase_a<false>(T, D, slot, sh.junk, pl, bsrc);
     u32 r[LP];
+#if FD_STEP_KEEP_PRIO
+    reduce<NoHook, 3, 3>(r, T, slot, &sh.tb, pl);
+#else
     reduce(r, T, slot, &sh.tb, pl);
     __builtin_amdgcn_s_setprio(3);       // (reduce() leaves the wave at priority 0)
+#endif
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < LP; ++i) D[i] = r[i];
