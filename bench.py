@@ -1187,6 +1187,239 @@ def main():
     # reported in `secondary_error` and the process exits non-zero after printing.
     secondary_error = None
     try:
+        # (Order: the Python-driven secondary legs of the MODP group first -- W_B, extract, the dealer --, then the CPU baselines, the
+        # other shapes, host buffers, registered keys and the curve groups.  With the CPU legs and the large shapes ahead of them the
+        # Python-driven legs read 15-20 % lower in the same process (0.92 against 1.10 M for verify_share; profiles/r04_wb_order.txt):
+        # an artefact of the process's state, not of the library.)
+        # ---------------- W_B: decrypted-share verifications (participant.rs:361-386), SURVEY 8(d) ----------------
+        # Secondary figure, rank 0 at N=1 only, outside the timed region above: a bounded batch of share boxes
+        # (built with the engine's own extract_shares), inputs resident in HBM, verdicts checked.
+        if rank == 0 and world == 1 and args.wb_shares != 0:
+            m = min(n, args.wb_shares if args.wb_shares > 0 else 16384)
+            sl = slice(0, m * EB)
+            rng_w = random.Random(SEED + 7)
+            wit_b = [keygen(rng_w) for _ in range(m)]
+            xinv = b"".join(fx(pow(x, -1, ORDER)) for x in privs[:m])
+            wit_bytes_b = b"".join(map(fx, wit_b))
+            S, cb = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)            # also warms the path up
+            t_x = time.perf_counter()
+            S2, cb2 = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
+            extract_s = time.perf_counter() - t_x
+            assert (S2, cb2) == (S, cb)
+            # block form: several batches in flight (compute forms e2 = w / x on host threads and enqueues; the challenge hash runs
+            # on the device); 4 in flight, 10 timed
+            def extract_pipelined(count, inflight=4):
+                issued = done = 0
+                last = None
+                while done < count:
+                    while issued < count and issued - done < inflight:
+                        eng.extract_shares_compute(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
+                        issued += 1
+                    last = eng.extract_shares_absorb(m)
+                    done += 1
+                return last
+            assert extract_pipelined(4) == (S, cb), "extract_shares block form differs from the synchronous call"
+            torch.cuda.synchronize()
+            t_x = time.perf_counter()
+            extract_pipelined(10)
+            extract_blk_s = (time.perf_counter() - t_x) / 10
+            result["extract_shares"] = {"value": m / extract_blk_s, "unit": "shares decrypted and proven/s", "batch": m,
+                                        "batches_in_flight": 4, "value_synchronous_call": m / extract_s,
+                                        "note": "extract_secret_share for `batch` participants per call, host buffers (participant.rs:294-353): "
+                                                "S_i = Y_i^(1/x_i), a1 = G^w_i, a2 = S_i^w_i (S and a2 from one chain of squarings) and the "
+                                                "per-share challenge hash; `value`: mpvss_modp_extract_shares_compute/_absorb, several batches "
+                                                "in flight, challenge hash on the device (K7); `value_synchronous_call`: one "
+                                                "mpvss_modp_extract_shares call, hash on the host"}
+            rb = b"".join(fx((w - x * int.from_bytes(cb[i * EB:(i + 1) * EB], "big")) % ORDER)
+                          for i, (w, x) in enumerate(zip(wit_b, privs[:m])))                      # dleq.rs:42-50
+            d_S, d_cb, d_rb = dev_u8(S), dev_u8(cb), dev_u8(rb)
+            verd = (C.c_uint8 * m)()
+            torch.cuda.synchronize()
+            reps = 3
+            for it in range(reps + 1):
+                if it == 1:
+                    tw = time.perf_counter()
+                eng._check(lib.mpvss_modp_verify_shares(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb), vp(d_rb),
+                                                        m, verd), "verify_shares")
+            wb_s = (time.perf_counter() - tw) / reps
+            assert bytes(verd) == b"\x01" * m, "verify_share verdicts"
+            # the block form: several batches in flight in ONE context (compute = enqueue only, absorb = wait + n verdict bytes)
+            inflight, batches = 4, 12
+            d_verd = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+            torch.cuda.synchronize()      # torch's zero fills must not land on top of verdicts the engine's streams write
+
+            def wb_pipelined(count):
+                issued = done = 0
+                while done < count:
+                    while issued < count and issued - done < inflight:
+                        eng._check(lib.mpvss_modp_verify_shares_compute(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb),
+                                                                        vp(d_rb), m, vp(d_verd[issued % inflight])), "verify_shares_compute")
+                        issued += 1
+                    eng._check(lib.mpvss_modp_verify_shares_absorb(ctx, verd), "verify_shares_absorb")
+                    assert bytes(verd) == b"\x01" * m, "verify_share verdicts (block API)"
+                    done += 1
+
+            wb_pipelined(inflight)                                # slot workspaces
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            wb_pipelined(batches)
+            torch.cuda.synchronize()
+            wbp_s = (time.perf_counter() - tw) / batches
+            assert all(bool((dv == 1).all()) for dv in d_verd), "device verdict tensors"
+            result["verify_share"] = {"value": m / wbp_s, "unit": "share-box verifications/s", "batch": m,
+                                      "batches_in_flight": inflight, "value_synchronous_calls": m / wb_s,
+                                      "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c and the per-share SHA-256 verdict (K7) on the device; "
+                                              "inputs resident in HBM; `value`: mpvss_modp_verify_shares_compute/_absorb with "
+                                              f"{inflight} batches in flight in one context, verdict bytes also left in device tensors; "
+                                              "`value_synchronous_calls`: one mpvss_modp_verify_shares call at a time"}
+        if world == 1:
+            # dealer side in block form: inputs resident in HBM, DEAL_DEPTH boxes in flight, X_i = g^P(i) through the comb,
+            # host hashing of the oldest box beside the GPU work of the next ones; plus the scalar side of one box
+            # (P(i), responses) behind the C ABI, timed separately
+            d_pv, d_wt = dev_u8(pv_bytes), dev_u8(wit_bytes)
+            deal_depth, deal_boxes = 8, 12
+
+            def deal_absorb():
+                st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
+                eng._check(lib.mpvss_modp_distribute_absorb(ctx, st, None, None, None, None), "distribute_absorb")
+                return capi.transcript_verdict(bytes(st), bytes(EB))[1]
+
+            def deal_pipelined(count):
+                issued = 0
+                pend, digests = collections.deque(), []
+                while issued < count or pend:
+                    if issued < count and len(pend) < deal_depth:
+                        eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pv), vp(d_wt), n,
+                                                                     None, None, None, None), "distribute_compute")
+                        issued += 1
+                        pend.append(hash_pool.submit(deal_absorb))        # absorbs take the blocks in FIFO order
+                    else:
+                        digests.append(pend.popleft().result())
+                return digests
+
+            deal_pipelined(16)                 # every slot's workspace grows to the dealer's size here
+            torch.cuda.synchronize()
+            t_d = time.perf_counter()
+            dg = deal_pipelined(deal_boxes)
+            torch.cuda.synchronize()
+            deal_blk_s = (time.perf_counter() - t_d) / deal_boxes
+            if world == 1 and rank == 0:
+                assert all(x == dealer_digest for x in dg), "dealer block API: transcript digest differs"
+            t_sync = time.perf_counter()
+            eng.distribute(commitments, positions, pubkeys, pv_bytes, wit_bytes)
+            deal_s = time.perf_counter() - t_sync
+            # the whole dealer in one call from host buffers (P(i), group work, digest, challenge, responses)
+            coeff_bytes0 = b"".join(fx(a) for a in coeffs)
+            eng.deal(coeff_bytes0, positions, pubkeys, wit_bytes)
+            t_one = time.perf_counter()
+            one = eng.deal(coeff_bytes0, positions, pubkeys, wit_bytes)
+            deal_one_s = time.perf_counter() - t_one
+            assert one["digest"] == dealer_digest and one["responses"] == responses and one["Y"] == shares, "mpvss_modp_deal differs"
+            t_s = time.perf_counter()
+            pv2 = capi.poly_eval(0, b"".join(fx(a) for a in coeffs), positions)
+            rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)
+            scalar_s = time.perf_counter() - t_s
+            assert pv2 == pv_bytes and rs2 == responses, "scalar side (C ABI) differs from the Python integers"
+            # ... and the dealer END TO END: per box the scalar side before (P(i) for the box's own polynomial: forward
+            # differences in Z/(q-1) on host threads, H2D of the values) and after the group work (challenge from the
+            # transcript digest, responses r_i = w_i - P(i) c), pipelined over the boxes on host threads beside the GPU
+            e2e_boxes = 16
+            coeff_sets = [b"".join(fx(a) for a in boxes[b % len(boxes)].coeffs) for b in range(e2e_boxes)]
+            scalar_pool = concurrent.futures.ThreadPoolExecutor(max_workers=3)
+            absorb_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)      # blocks are absorbed in FIFO order
+
+            def e2e_post(pv):
+                digest = deal_absorb()
+                cc = fx(int.from_bytes(hashlib.sha256(digest).digest(), "big") % ((Q - 1) // 2))
+                return digest, scalar_pool.submit(capi.dleq_responses, 0, wit_bytes, pv, cc)
+
+            def deal_e2e(count):
+                pre = [scalar_pool.submit(capi.poly_eval, 0, coeff_sets[b], positions) for b in range(count)]
+                post, keep = [], collections.deque()
+                for b in range(count):
+                    pv = pre[b].result()
+                    d_pvb = dev_u8(pv)
+                    keep.append(d_pvb)
+                    while len(post) - sum(f.done() for f in post) >= deal_depth:      # at most deal_depth boxes in flight
+                        time.sleep(0.0005)
+                    eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pvb), vp(d_wt), n,
+                                                                 None, None, None, None), "distribute_compute")
+                    post.append(absorb_pool.submit(e2e_post, pv))
+                outs = [f.result() for f in post]
+                return [(dgst, fut.result()) for dgst, fut in outs]
+
+            deal_e2e(3)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            e2e = deal_e2e(e2e_boxes)
+            torch.cuda.synchronize()
+            e2e_host_s = (time.perf_counter() - t_e) / e2e_boxes
+            assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer: box 0 differs"
+            scalar_pool.shutdown()
+
+            # ... and with the scalar side on the device as well: P(i) mod (q-1) by mpvss_modp_poly_eval_device into HBM, the
+            # group work on those values, the challenge from the transcript digest, r_i by mpvss_modp_dleq_responses_device --
+            # nothing of a box but its t coefficients, its digest and its challenge crosses the bus
+            ring = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]     # P(i) of a box lives until its responses are out
+
+            resp_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+            d_rs = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]
+
+            def e2e_resp(b, d_pvb, cc):
+                d_r = d_rs[b % len(d_rs)]
+                eng.dleq_responses_device(d_wt.data_ptr(), d_pvb.data_ptr(), cc, n, d_r.data_ptr())
+                return bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None
+
+            def e2e_post_dev(b, d_pvb, ticket):
+                st = eng.verify_block_absorb_claimed(ticket, capi.transcript_init())       # dealer blocks are absorbed like verifier blocks
+                digest = capi.transcript_verdict(st, bytes(EB))[1]
+                cc = fx(int.from_bytes(hashlib.sha256(digest).digest(), "big") % ((Q - 1) // 2))
+                return digest, resp_pool.submit(e2e_resp, b, d_pvb, cc)      # the responses wait for wave slots, not the next absorb
+
+            def deal_e2e_dev(count):
+                post = []
+                for b in range(count):
+                    d_pvb = ring[b % len(ring)]
+                    while len(post) - sum(f.done() for f in post) >= deal_depth:      # at most deal_depth boxes in flight
+                        time.sleep(0.0005)
+                    eng.deal_compute(coeff_sets[b], cur.d_pos.data_ptr(), d_pk.data_ptr(), d_wt.data_ptr(), n, d_pvb.data_ptr())
+                    post.append(hash_pool.submit(e2e_post_dev, b, d_pvb, eng.block_claim()))     # several boxes are hashed at a time
+                outs = [f.result() for f in post]
+                return [(dgst, fut.result()) for dgst, fut in outs]
+
+            deal_e2e_dev(3)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            e2e = deal_e2e_dev(e2e_boxes)
+            torch.cuda.synchronize()
+            e2e_s = (time.perf_counter() - t_e) / e2e_boxes
+            assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer (device scalars): box 0 differs"
+            absorb_pool.shutdown()
+            resp_pool.shutdown()
+            t_s = time.perf_counter()
+            eng.poly_eval_device(coeff_sets[0], cur.d_pos.data_ptr(), n, ring[0].data_ptr())
+            eng.dleq_responses_device(d_wt.data_ptr(), ring[0].data_ptr(), challenge, n, d_rs[0].data_ptr())
+            scalar_dev_s = time.perf_counter() - t_s
+            assert bytes(d_rs[0].cpu().numpy().tobytes()) == responses, "device scalar side differs from the Python integers"
+            result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
+                                    "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
+                                    "value_one_call_host_buffers_end_to_end": n / deal_one_s,
+                                    "scalar_side_ms_per_box": scalar_s * 1e3, "scalar_side_on_device_ms_per_box": scalar_dev_s * 1e3,
+                                    "value_end_to_end": n / e2e_s, "end_to_end_ms_per_box": e2e_s * 1e3,
+                                    "value_end_to_end_host_scalars": n / e2e_host_s,
+                                    "note": "dealer side of distribute_secret (participant.rs:160-286): X_i = g^P(i), Y_i = y_i^P(i), "
+                                            "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
+                                            "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
+                                            "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
+                                            "PCIe included); `value_one_call_host_buffers_end_to_end`: one mpvss_modp_deal call (P(i), group "
+                                            "work, digest, challenge, responses; host buffers, includes the ctypes marshalling of 64 MB); scalar_side: P(i) and the responses for one box through "
+                                            "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`; `value_end_to_end`: "
+                                            "every box with its own polynomial -- P(i) mod (q-1) and the responses on the device "
+                                            "(mpvss_modp_poly_eval_device / _dleq_responses_device: residues mod (q-1)/2 in the Montgomery "
+                                            "kernels, parity beside), the group work, the transcript hash and the challenge, boxes pipelined; "
+                                            "`value_end_to_end_host_scalars`: the same with P(i) (forward differences in Z/(q-1)) and the "
+                                            "responses on host threads and the values uploaded"}
+
         # ---------------- CPU baselines (rank 0, N == 1 only), SURVEY 8(d) ----------------
         # (i) the C port of the reference's operation sequence on ONE thread -- how src/participant.rs:408 runs (no rayon
         # on this path); (ii) the same on every free core (`cpu_baseline.value`); (iii) the same sequence with OpenSSL's
@@ -1421,234 +1654,6 @@ def main():
         if rank == 0 and world == 1 and args.ec_boxes > 0:
             result["ec"] = {name: bench_ec(eng, name, args) for name in ("secp256k1", "ristretto255")}
 
-        # ---------------- W_B: decrypted-share verifications (participant.rs:361-386), SURVEY 8(d) ----------------
-        # Secondary figure, rank 0 at N=1 only, outside the timed region above: a bounded batch of share boxes
-        # (built with the engine's own extract_shares), inputs resident in HBM, verdicts checked.
-        if rank == 0 and world == 1 and args.wb_shares != 0:
-            m = min(n, args.wb_shares if args.wb_shares > 0 else 16384)
-            sl = slice(0, m * EB)
-            rng_w = random.Random(SEED + 7)
-            wit_b = [keygen(rng_w) for _ in range(m)]
-            xinv = b"".join(fx(pow(x, -1, ORDER)) for x in privs[:m])
-            wit_bytes_b = b"".join(map(fx, wit_b))
-            S, cb = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)            # also warms the path up
-            t_x = time.perf_counter()
-            S2, cb2 = eng.extract_shares(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
-            extract_s = time.perf_counter() - t_x
-            assert (S2, cb2) == (S, cb)
-            # block form: several batches in flight (compute forms e2 = w / x on host threads and enqueues; the challenge hash runs
-            # on the device); 4 in flight, 10 timed
-            def extract_pipelined(count, inflight=4):
-                issued = done = 0
-                last = None
-                while done < count:
-                    while issued < count and issued - done < inflight:
-                        eng.extract_shares_compute(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
-                        issued += 1
-                    last = eng.extract_shares_absorb(m)
-                    done += 1
-                return last
-            assert extract_pipelined(4) == (S, cb), "extract_shares block form differs from the synchronous call"
-            torch.cuda.synchronize()
-            t_x = time.perf_counter()
-            extract_pipelined(10)
-            extract_blk_s = (time.perf_counter() - t_x) / 10
-            result["extract_shares"] = {"value": m / extract_blk_s, "unit": "shares decrypted and proven/s", "batch": m,
-                                        "batches_in_flight": 4, "value_synchronous_call": m / extract_s,
-                                        "note": "extract_secret_share for `batch` participants per call, host buffers (participant.rs:294-353): "
-                                                "S_i = Y_i^(1/x_i), a1 = G^w_i, a2 = S_i^w_i (S and a2 from one chain of squarings) and the "
-                                                "per-share challenge hash; `value`: mpvss_modp_extract_shares_compute/_absorb, several batches "
-                                                "in flight, challenge hash on the device (K7); `value_synchronous_call`: one "
-                                                "mpvss_modp_extract_shares call, hash on the host"}
-            rb = b"".join(fx((w - x * int.from_bytes(cb[i * EB:(i + 1) * EB], "big")) % ORDER)
-                          for i, (w, x) in enumerate(zip(wit_b, privs[:m])))                      # dleq.rs:42-50
-            d_S, d_cb, d_rb = dev_u8(S), dev_u8(cb), dev_u8(rb)
-            verd = (C.c_uint8 * m)()
-            torch.cuda.synchronize()
-            reps = 3
-            for it in range(reps + 1):
-                if it == 1:
-                    tw = time.perf_counter()
-                eng._check(lib.mpvss_modp_verify_shares(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb), vp(d_rb),
-                                                        m, verd), "verify_shares")
-            wb_s = (time.perf_counter() - tw) / reps
-            assert bytes(verd) == b"\x01" * m, "verify_share verdicts"
-            # the block form: several batches in flight in ONE context (compute = enqueue only, absorb = wait + n verdict bytes)
-            inflight, batches = 4, 12
-            d_verd = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(inflight)]
-            torch.cuda.synchronize()      # torch's zero fills must not land on top of verdicts the engine's streams write
-
-            def wb_pipelined(count):
-                issued = done = 0
-                while done < count:
-                    while issued < count and issued - done < inflight:
-                        eng._check(lib.mpvss_modp_verify_shares_compute(ctx, capi.MPVSS_DEVICE, vp(d_pk), vp(d_S), vp(d_sh), vp(d_cb),
-                                                                        vp(d_rb), m, vp(d_verd[issued % inflight])), "verify_shares_compute")
-                        issued += 1
-                    eng._check(lib.mpvss_modp_verify_shares_absorb(ctx, verd), "verify_shares_absorb")
-                    assert bytes(verd) == b"\x01" * m, "verify_share verdicts (block API)"
-                    done += 1
-
-            wb_pipelined(inflight)                                # slot workspaces
-            torch.cuda.synchronize()
-            tw = time.perf_counter()
-            wb_pipelined(batches)
-            torch.cuda.synchronize()
-            wbp_s = (time.perf_counter() - tw) / batches
-            assert all(bool((dv == 1).all()) for dv in d_verd), "device verdict tensors"
-            result["verify_share"] = {"value": m / wbp_s, "unit": "share-box verifications/s", "batch": m,
-                                      "batches_in_flight": inflight, "value_synchronous_calls": m / wb_s,
-                                      "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c and the per-share SHA-256 verdict (K7) on the device; "
-                                              "inputs resident in HBM; `value`: mpvss_modp_verify_shares_compute/_absorb with "
-                                              f"{inflight} batches in flight in one context, verdict bytes also left in device tensors; "
-                                              "`value_synchronous_calls`: one mpvss_modp_verify_shares call at a time"}
-        if world == 1:
-            # dealer side in block form: inputs resident in HBM, DEAL_DEPTH boxes in flight, X_i = g^P(i) through the comb,
-            # host hashing of the oldest box beside the GPU work of the next ones; plus the scalar side of one box
-            # (P(i), responses) behind the C ABI, timed separately
-            d_pv, d_wt = dev_u8(pv_bytes), dev_u8(wit_bytes)
-            deal_depth, deal_boxes = 8, 12
-
-            def deal_absorb():
-                st = (C.c_uint8 * capi.TRANSCRIPT_STATE_BYTES).from_buffer_copy(capi.transcript_init())
-                eng._check(lib.mpvss_modp_distribute_absorb(ctx, st, None, None, None, None), "distribute_absorb")
-                return capi.transcript_verdict(bytes(st), bytes(EB))[1]
-
-            def deal_pipelined(count):
-                issued = 0
-                pend, digests = collections.deque(), []
-                while issued < count or pend:
-                    if issued < count and len(pend) < deal_depth:
-                        eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pv), vp(d_wt), n,
-                                                                     None, None, None, None), "distribute_compute")
-                        issued += 1
-                        pend.append(hash_pool.submit(deal_absorb))        # absorbs take the blocks in FIFO order
-                    else:
-                        digests.append(pend.popleft().result())
-                return digests
-
-            deal_pipelined(16)                 # every slot's workspace grows to the dealer's size here
-            torch.cuda.synchronize()
-            t_d = time.perf_counter()
-            dg = deal_pipelined(deal_boxes)
-            torch.cuda.synchronize()
-            deal_blk_s = (time.perf_counter() - t_d) / deal_boxes
-            if world == 1 and rank == 0:
-                assert all(x == dealer_digest for x in dg), "dealer block API: transcript digest differs"
-            t_sync = time.perf_counter()
-            eng.distribute(commitments, positions, pubkeys, pv_bytes, wit_bytes)
-            deal_s = time.perf_counter() - t_sync
-            # the whole dealer in one call from host buffers (P(i), group work, digest, challenge, responses)
-            coeff_bytes0 = b"".join(fx(a) for a in coeffs)
-            eng.deal(coeff_bytes0, positions, pubkeys, wit_bytes)
-            t_one = time.perf_counter()
-            one = eng.deal(coeff_bytes0, positions, pubkeys, wit_bytes)
-            deal_one_s = time.perf_counter() - t_one
-            assert one["digest"] == dealer_digest and one["responses"] == responses and one["Y"] == shares, "mpvss_modp_deal differs"
-            t_s = time.perf_counter()
-            pv2 = capi.poly_eval(0, b"".join(fx(a) for a in coeffs), positions)
-            rs2 = capi.dleq_responses(0, wit_bytes, pv2, challenge)
-            scalar_s = time.perf_counter() - t_s
-            assert pv2 == pv_bytes and rs2 == responses, "scalar side (C ABI) differs from the Python integers"
-            # ... and the dealer END TO END: per box the scalar side before (P(i) for the box's own polynomial: forward
-            # differences in Z/(q-1) on host threads, H2D of the values) and after the group work (challenge from the
-            # transcript digest, responses r_i = w_i - P(i) c), pipelined over the boxes on host threads beside the GPU
-            e2e_boxes = 16
-            coeff_sets = [b"".join(fx(a) for a in boxes[b % len(boxes)].coeffs) for b in range(e2e_boxes)]
-            scalar_pool = concurrent.futures.ThreadPoolExecutor(max_workers=3)
-            absorb_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)      # blocks are absorbed in FIFO order
-
-            def e2e_post(pv):
-                digest = deal_absorb()
-                cc = fx(int.from_bytes(hashlib.sha256(digest).digest(), "big") % ((Q - 1) // 2))
-                return digest, scalar_pool.submit(capi.dleq_responses, 0, wit_bytes, pv, cc)
-
-            def deal_e2e(count):
-                pre = [scalar_pool.submit(capi.poly_eval, 0, coeff_sets[b], positions) for b in range(count)]
-                post, keep = [], collections.deque()
-                for b in range(count):
-                    pv = pre[b].result()
-                    d_pvb = dev_u8(pv)
-                    keep.append(d_pvb)
-                    while len(post) - sum(f.done() for f in post) >= deal_depth:      # at most deal_depth boxes in flight
-                        time.sleep(0.0005)
-                    eng._check(lib.mpvss_modp_distribute_compute(ctx, capi.MPVSS_DEVICE, None, 0, None, vp(d_pk), vp(d_pvb), vp(d_wt), n,
-                                                                 None, None, None, None), "distribute_compute")
-                    post.append(absorb_pool.submit(e2e_post, pv))
-                outs = [f.result() for f in post]
-                return [(dgst, fut.result()) for dgst, fut in outs]
-
-            deal_e2e(3)
-            torch.cuda.synchronize()
-            t_e = time.perf_counter()
-            e2e = deal_e2e(e2e_boxes)
-            torch.cuda.synchronize()
-            e2e_host_s = (time.perf_counter() - t_e) / e2e_boxes
-            assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer: box 0 differs"
-            scalar_pool.shutdown()
-
-            # ... and with the scalar side on the device as well: P(i) mod (q-1) by mpvss_modp_poly_eval_device into HBM, the
-            # group work on those values, the challenge from the transcript digest, r_i by mpvss_modp_dleq_responses_device --
-            # nothing of a box but its t coefficients, its digest and its challenge crosses the bus
-            ring = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]     # P(i) of a box lives until its responses are out
-
-            resp_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
-            d_rs = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]
-
-            def e2e_resp(b, d_pvb, cc):
-                d_r = d_rs[b % len(d_rs)]
-                eng.dleq_responses_device(d_wt.data_ptr(), d_pvb.data_ptr(), cc, n, d_r.data_ptr())
-                return bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None
-
-            def e2e_post_dev(b, d_pvb, ticket):
-                st = eng.verify_block_absorb_claimed(ticket, capi.transcript_init())       # dealer blocks are absorbed like verifier blocks
-                digest = capi.transcript_verdict(st, bytes(EB))[1]
-                cc = fx(int.from_bytes(hashlib.sha256(digest).digest(), "big") % ((Q - 1) // 2))
-                return digest, resp_pool.submit(e2e_resp, b, d_pvb, cc)      # the responses wait for wave slots, not the next absorb
-
-            def deal_e2e_dev(count):
-                post = []
-                for b in range(count):
-                    d_pvb = ring[b % len(ring)]
-                    while len(post) - sum(f.done() for f in post) >= deal_depth:      # at most deal_depth boxes in flight
-                        time.sleep(0.0005)
-                    eng.deal_compute(coeff_sets[b], cur.d_pos.data_ptr(), d_pk.data_ptr(), d_wt.data_ptr(), n, d_pvb.data_ptr())
-                    post.append(hash_pool.submit(e2e_post_dev, b, d_pvb, eng.block_claim()))     # several boxes are hashed at a time
-                outs = [f.result() for f in post]
-                return [(dgst, fut.result()) for dgst, fut in outs]
-
-            deal_e2e_dev(3)
-            torch.cuda.synchronize()
-            t_e = time.perf_counter()
-            e2e = deal_e2e_dev(e2e_boxes)
-            torch.cuda.synchronize()
-            e2e_s = (time.perf_counter() - t_e) / e2e_boxes
-            assert e2e[0][0] == dealer_digest and e2e[0][1] == responses, "end-to-end dealer (device scalars): box 0 differs"
-            absorb_pool.shutdown()
-            resp_pool.shutdown()
-            t_s = time.perf_counter()
-            eng.poly_eval_device(coeff_sets[0], cur.d_pos.data_ptr(), n, ring[0].data_ptr())
-            eng.dleq_responses_device(d_wt.data_ptr(), ring[0].data_ptr(), challenge, n, d_rs[0].data_ptr())
-            scalar_dev_s = time.perf_counter() - t_s
-            assert bytes(d_rs[0].cpu().numpy().tobytes()) == responses, "device scalar side differs from the Python integers"
-            result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
-                                    "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
-                                    "value_one_call_host_buffers_end_to_end": n / deal_one_s,
-                                    "scalar_side_ms_per_box": scalar_s * 1e3, "scalar_side_on_device_ms_per_box": scalar_dev_s * 1e3,
-                                    "value_end_to_end": n / e2e_s, "end_to_end_ms_per_box": e2e_s * 1e3,
-                                    "value_end_to_end_host_scalars": n / e2e_host_s,
-                                    "note": "dealer side of distribute_secret (participant.rs:160-286): X_i = g^P(i), Y_i = y_i^P(i), "
-                                            "a1 = g^w_i, a2 = y_i^w_i and the ordered transcript hash; `value`: "
-                                            "mpvss_modp_distribute_compute/_absorb, inputs resident in HBM, several boxes in flight; "
-                                            "`value_synchronous_host_buffers`: one mpvss_modp_distribute call (X from the commitments, "
-                                            "PCIe included); `value_one_call_host_buffers_end_to_end`: one mpvss_modp_deal call (P(i), group "
-                                            "work, digest, challenge, responses; host buffers, includes the ctypes marshalling of 64 MB); scalar_side: P(i) and the responses for one box through "
-                                            "mpvss_modp_poly_eval / mpvss_modp_dleq_responses (host threads), not in `value`; `value_end_to_end`: "
-                                            "every box with its own polynomial -- P(i) mod (q-1) and the responses on the device "
-                                            "(mpvss_modp_poly_eval_device / _dleq_responses_device: residues mod (q-1)/2 in the Montgomery "
-                                            "kernels, parity beside), the group work, the transcript hash and the challenge, boxes pipelined; "
-                                            "`value_end_to_end_host_scalars`: the same with P(i) (forward differences in Z/(q-1)) and the "
-                                            "responses on host threads and the values uploaded"}
     except Exception as exc:      # noqa: BLE001 - reported in the line and through the exit code
         import traceback
         secondary_error = "".join(traceback.format_exception_only(type(exc), exc)).strip()

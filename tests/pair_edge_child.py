@@ -80,12 +80,15 @@ def fd():
     rng = random.Random(0xFD51)
     t, n, p0 = 512, 9000, 40000
     pos = list(range(p0, p0 + n))
-    spread = sorted(set([0, 1, 32, 511, 512, n // 2, n - 1] + [rng.randrange(n) for _ in range(2)]))
+    spread = sorted(set([0, 1, 511, 512, n - 1] + [rng.randrange(n) for _ in range(1)]))
+    # random commitments g^a from the engine's fixed-base comb (oracle-checked elsewhere): 1500 Python modpows otherwise
+    raw = eng.batch_exp_fixed_base(fx(4), b"".join(fx(rng.randrange(Q - 1)) for _ in range(3 * t)))
+    rnd = [int.from_bytes(raw[k * EB:(k + 1) * EB], "big") for k in range(3 * t)]
     cases = {
         "+-1 only": [1 if rng.random() < 0.5 else Q - 1 for _ in range(t)],
-        "random with 1, Q-1, Q+1": [pow(4, rng.randrange(Q - 1), Q) for _ in range(t)],
-        "a zero commitment": [pow(4, rng.randrange(Q - 1), Q) for _ in range(t)],
-        "C_0 = Q": [pow(4, rng.randrange(Q - 1), Q) for _ in range(t)],
+        "random with 1, Q-1, Q+1": rnd[:t],
+        "a zero commitment": rnd[t:2 * t],
+        "C_0 = Q": rnd[2 * t:],
     }
     cases["random with 1, Q-1, Q+1"][3] = 1
     cases["random with 1, Q-1, Q+1"][7] = Q - 1
@@ -103,7 +106,7 @@ def fd():
         want = parallel_map(modp_reference_x, [([v % Q for v in cm], pos[i]) for i in spread])    # reference order
         assert got == want, what
         # the fast form (Horner in the exponent) on a spread 2 % of the box
-        more = sorted(rng.sample(range(n), 120))
+        more = sorted(rng.sample(range(n), 72))
         cmb = b"".join(map(fx, cm))
         fast = parallel_map(modp_fast_share, [(cmb, pos[i], fx(1), fx(1), fx(0), fx(0)) for i in more])
         for i, (x, _, _) in zip(more, fast):

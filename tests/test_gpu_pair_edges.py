@@ -156,6 +156,6 @@ def test_table_comb_and_a1_pair_kernels_on_hostile_operands():
 def test_fd_step_pair_kernel_with_edge_commitments():
     """k_modp_fd_step_pair at t = 512 (MPVSS_FD_PAIR_MIN_T=16 also sends the stride-1 seeding chain through it): commitments
     in {1, q-1} only, random ones with 1 / q-1 / q+1 among them, and boxes whose X is 0 (a zero or unreduced-q commitment:
-    no inverse, the device flag must send them down Horner's rule) -- against O.commitment_eval in the reference order on 9
-    positions per box (36 in all) and the fast form on 120 more each."""
+    no inverse, the device flag must send them down Horner's rule) -- against O.commitment_eval in the reference order on 6
+    positions per box (24 in all) and the fast form on 72 more each."""
     _child("fd", {"MPVSS_FD_PAIR_MIN_T": "16", "MPVSS_FD_L1": "2"})
