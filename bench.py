@@ -1363,10 +1363,10 @@ def main():
             ring = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]     # P(i) of a box lives until its responses are out
 
             resp_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
-            d_rs = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]
+            d_rs_e2e = [torch.empty(n * EB, dtype=torch.uint8, device=dev) for _ in range(e2e_boxes)]
 
             def e2e_resp(b, d_pvb, cc):
-                d_r = d_rs[b % len(d_rs)]
+                d_r = d_rs_e2e[b % len(d_rs_e2e)]
                 eng.dleq_responses_device(d_wt.data_ptr(), d_pvb.data_ptr(), cc, n, d_r.data_ptr())
                 return bytes(d_r.cpu().numpy().tobytes()) if b == 0 else None
 
@@ -1398,9 +1398,9 @@ def main():
             resp_pool.shutdown()
             t_s = time.perf_counter()
             eng.poly_eval_device(coeff_sets[0], cur.d_pos.data_ptr(), n, ring[0].data_ptr())
-            eng.dleq_responses_device(d_wt.data_ptr(), ring[0].data_ptr(), challenge, n, d_rs[0].data_ptr())
+            eng.dleq_responses_device(d_wt.data_ptr(), ring[0].data_ptr(), challenge, n, d_rs_e2e[0].data_ptr())
             scalar_dev_s = time.perf_counter() - t_s
-            assert bytes(d_rs[0].cpu().numpy().tobytes()) == responses, "device scalar side differs from the Python integers"
+            assert bytes(d_rs_e2e[0].cpu().numpy().tobytes()) == responses, "device scalar side differs from the Python integers"
             result["distribute"] = {"value": n / deal_blk_s, "unit": "shares dealt/s", "ms_per_box": deal_blk_s * 1e3,
                                     "boxes_in_flight": deal_depth, "value_synchronous_host_buffers": n / deal_s,
                                     "value_one_call_host_buffers_end_to_end": n / deal_one_s,

@@ -306,22 +306,17 @@ __device__ __forceinline__ u32 ec_hand_state(const u32 (&v)[10]) {
   }
   return (any & EC_HAND_POISON) ? EC_HAND_POISON : (all & EC_HAND_VALID);
 }
-// lanes 60..63 (`reader`) hold the words requested earlier in v; waits until all four have valid words.  Wave-uniform result.
-__device__ __forceinline__ bool ec_hand_wait(u32 (&v)[10], const u32* __restrict__ src, bool reader) {
-  bool ok = true;
-  if (reader) {
-    const long long t0 = wall_clock64();
-    while (true) {
-      const u32 st = ec_hand_state(v);
-      const uint64_t good = __builtin_amdgcn_ballot_w64(st == EC_HAND_VALID) >> 60;
-      const uint64_t bad = __builtin_amdgcn_ballot_w64(st == EC_HAND_POISON) >> 60;
-      if (good == 0xf) break;
-      if (bad != 0 || wall_clock64() - t0 > EC_FD_TIMEOUT_TICKS) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(2);
-      ec_hand_load(v, src);
-    }
+// Every quad of the wave asks for the same entry (lane role i: words 10 i .. 10 i + 9) -- no lane-dependent control flow
+// around the DPP moves that follow (ec_quad.h); waits until every lane holds valid words.  Wave-uniform result.
+__device__ __forceinline__ bool ec_hand_wait(u32 (&v)[10], const u32* __restrict__ src) {
+  const long long t0 = wall_clock64();
+  while (true) {
+    const u32 st = ec_hand_state(v);
+    if (__builtin_amdgcn_ballot_w64(st == EC_HAND_VALID) == ~0ull) return true;
+    if (__builtin_amdgcn_ballot_w64(st == EC_HAND_POISON) != 0 || wall_clock64() - t0 > EC_FD_TIMEOUT_TICKS) return false;
+    __builtin_amdgcn_s_sleep(2);
+    ec_hand_load(v, src);
   }
-  return __builtin_amdgcn_ballot_w64(!ok) == 0;
 }
 
 // words of handoff space one box needs for a stepping launch (tickets first)
@@ -365,12 +360,12 @@ __device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, c
   u32 pre[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) pre[i] = 0;
-  if (has_up && reader && steps >= 2) ec_hand_load(pre, up + (size_t)1 * EC_HAND_ENTRY);
+  if (has_up && steps >= 2) ec_hand_load(pre, up + (size_t)1 * EC_HAND_ENTRY);
   for (int step = 1; step <= steps; ++step) {
     typename Q::St nb;
     Fe prim;
     if (has_up && step >= 2) {                                       // entry step-1 of the stage above
-      bool ok = ec_hand_wait(pre, up + (size_t)(step - 1) * EC_HAND_ENTRY, reader);
+      bool ok = ec_hand_wait(pre, up + (size_t)(step - 1) * EC_HAND_ENTRY);
       if (inject_fault == 1 && cd == 0 && sidx == 1 && step == 3) ok = false;
       if (!ok) {
         if (threadIdx.x == 0) __hip_atomic_store(gate + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -384,7 +379,7 @@ __device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, c
 #pragma unroll
       for (int i = 0; i < 10; ++i) prim.v[i] = pre[i] & EC_HAND_LIMB;
       Q::nb_from_primary(top, prim, role);
-      if (reader && step < steps) ec_hand_load(pre, up + (size_t)step * EC_HAND_ENTRY);     // for the next step, under this one's addition
+      if (step < steps) ec_hand_load(pre, up + (size_t)step * EC_HAND_ENTRY);     // for the next step, under this one's addition
     }
     fe_from_next_quad(prim, Q::primary(D));
     Q::nb_from_primary(nb, prim, role);
@@ -467,12 +462,12 @@ __device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds
 #pragma unroll
   for (int i = 0; i < 10; ++i) pre[i] = 0;
   const auto need_up = [&](int lvl) { return has_up && lvl >= 2 && kbase + EC_QUAD_LEVELS - 1 <= t - 1 - lvl; };
-  if (reader && need_up(2)) ec_hand_load(pre, up + (size_t)1 * EC_HAND_ENTRY);
+  if (need_up(2)) ec_hand_load(pre, up + (size_t)1 * EC_HAND_ENTRY);
   for (int lvl = 1; lvl <= last_lvl; ++lvl) {
     typename Q::St nb, neg;
     Fe prim;
     if (need_up(lvl)) {                                               // level lvl-1 of the first element of the stage above
-      bool ok = ec_hand_wait(pre, up + (size_t)(lvl - 1) * EC_HAND_ENTRY, reader);
+      bool ok = ec_hand_wait(pre, up + (size_t)(lvl - 1) * EC_HAND_ENTRY);
       if (inject_fault == 2 && chain == 0 && sidx == 1 && lvl == 3) ok = false;
       if (!ok) {
         if (threadIdx.x == 0) __hip_atomic_store(gate + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -486,7 +481,7 @@ __device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds
 #pragma unroll
       for (int i = 0; i < 10; ++i) prim.v[i] = pre[i] & EC_HAND_LIMB;
       Q::nb_from_primary(top, prim, role);
-      if (reader && need_up(lvl + 1)) ec_hand_load(pre, up + (size_t)lvl * EC_HAND_ENTRY);
+      if (need_up(lvl + 1)) ec_hand_load(pre, up + (size_t)lvl * EC_HAND_ENTRY);
     }
     fe_from_next_quad(prim, Q::primary(E));
     Q::nb_from_primary(nb, prim, role);

@@ -1,9 +1,10 @@
-run() { name=$1; shift
-  python3 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-sample 0 --host-boxes 0 --config-boxes 0 --registered-keys 0 --steady-steps 0 "$@" 2>gpurun_out/_err.txt | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-print('$name', 'verify_share', round(d['verify_share']['value']), 'extract', round(d['extract_shares']['value']), 'distribute', round(d['distribute']['value']), 'e2e', round(d['distribute']['value_end_to_end']))" || tail -3 gpurun_out/_err.txt
-}
-run no_ec --ec-boxes 0
-run with_ec --ec-boxes 64
-run no_ec --ec-boxes 0
+timeout 900 python -m pytest tests/test_gpu_ec_fd.py tests/test_gpu_host_mirror.py tests/test_gpu_ec.py -x -q -m gpu --durations=5 > gpurun_out/r04_ecq_tests.log 2>&1; tail -12 gpurun_out/r04_ecq_tests.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_quad.json 2> gpurun_out/r04_bench_quad.err; python3 - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r04_bench_quad.json").read().strip().splitlines()[-1])
+print("value",round(d["value"]),"steady",round(d["value_steady_state"]), "verify_share", round(d["verify_share"]["value"]), "extract", round(d["extract_shares"]["value"]), "dist", round(d["distribute"]["value"]), round(d["distribute"]["value_end_to_end"]), "reg", round(d["registered_keys"]["value"]), "host", round(d["host_buffers"]["value"]), {k: round(v["value"]) for k,v in d["configs"].items()})
+for g in ("secp256k1","ristretto255"):
+    e=d["ec"][g]; print(g, round(e["value"]), round(e["distribute"]["value"]), round(e["distribute"]["value_end_to_end"]), round(e["verify_share"]["value"]), {k: (round(v,2) if isinstance(v,float) else v) for k,v in e["kernel_ms_isolated"].items() if k!="x_path_is"})
+print(d.get("secondary_error"))
+PY
+tail -3 gpurun_out/r04_bench_quad.err
