@@ -659,6 +659,26 @@ EC_HD void small_scalar_mul(typename C::Point& r, const typename C::Point& p, ui
   }
 }
 
+// the same through the non-adjacent form of k (k < 2^62): a third of the digits are non-zero instead of half, negation is free.
+// NAF digit i = bit i+1 of 3k minus bit i+1 of k.  One addition site (the operand is selected).
+template <class C>
+EC_HD void small_scalar_mul_naf(typename C::Point& r, const typename C::Point& p, uint64_t k) {
+  const uint64_t x3 = 3 * k;
+  const uint64_t plus = (x3 & ~k) >> 1, minus = (k & ~x3) >> 1, any = plus | minus;
+  const int nbits = any == 0 ? 0 : 64 - __builtin_clzll(any);
+  typename C::Point np, sel;
+  C::neg(np, p);
+  C::identity(r);
+  for (int i = nbits - 1; i >= 0; --i) {
+    C::dbl(r, r);
+    if ((any >> i) & 1) {
+      sel = p;
+      C::cmov(sel, np, (minus >> i) & 1);
+      C::add(r, r, sel);
+    }
+  }
+}
+
 // r = k1 * p1 + k2 * p2 (Group::exp twice + Group::mul, dleq.rs:75-81), interleaved bit by bit with
 // the joint table {p1, p2, p1 + p2}; k2 may be null (plain Group::exp).
 template <class C>

@@ -759,14 +759,13 @@ __device__ __forceinline__ void seeds_win_body(const u32* __restrict__ cm, int t
   const bool live = xi < count;
   const int x = live ? xi : count - 1;
   const uint64_t pos = (uint64_t)positions[x];
-  const int nb = (pos == 0) ? 0 : 64 - __builtin_clzll(pos);
   const int len = (t + PARTS - 1) / PARTS;
   const int lo = part * len;
   const int hi = (lo + len < t) ? lo + len : t;
   typename C::Point acc, cj, r;
   C::identity(acc);
   for (int j = hi - 1; j >= lo; --j) {
-    small_scalar_mul<C>(r, acc, pos, nb);
+    small_scalar_mul_naf<C>(r, acc, pos);
     load_point_aos<C>(cj, cm + (size_t)j * C::POINT_WORDS);
     C::add(acc, r, cj);
   }

@@ -22,9 +22,12 @@
 //                                      lane 1: Y3 = S1[1] S2[1] + S0[2] S1[0]
 //                                      lane 2: Z3 = S2[1] S0[1] + S1[0] S0[0]
 //   two products and a double product deep instead of twelve products.
-// EVERYTHING HERE IS BRANCH-FREE ON PURPOSE: lane-dependent choices are selects, never `if (lane ...) x = y`.  A divergent
-// assignment ahead of the DPP moves let the compiler sink them into the divergent region -- the moves then read inactive
-// lanes as 0 (bound_ctrl) and the negation came out wrong for secp256k1 (tests/ec_quad_unit.hip caught it).
+// CROSS-LANE MOVES AND THE OPTIMISER.  hipcc treats __builtin_amdgcn_mov_dpp as if it were lane-local: with a lane-dependent
+// `if (lane ...) x = y` ahead of it the moves were sunk into the divergent region (inactive lanes read as 0), and with a
+// lane-dependent select feeding it the move was distributed over the select's arms (each lane then picks by ITS OWN condition
+// what another lane computed) -- both came out as points off the curve in tests/ec_quad_unit.hip, the second only when two
+// additions were inlined one after the other.  So (a) everything here is branch-free, lane-dependent choices are selects, and
+// (b) the operand of every cross-lane move passes through an empty `asm volatile` first, which makes it opaque.
 // tests: tests/ec_quad_unit.hip through tests/test_gpu_ec_fd.py (addition, negation + addition against the one-lane formulas:
 // doublings, P + (-P), the identity on either side); the stepping and table pipelines against Horner's rule and the oracle.
 #pragma once
@@ -36,8 +39,11 @@ namespace ec {
 template <int P0, int P1, int P2, int P3>
 __device__ __forceinline__ void fe_quad_perm(Fe& r, const Fe& a) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i)
-    r.v[i] = (u32)__builtin_amdgcn_mov_dpp((int)a.v[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+  for (int i = 0; i < 10; ++i) {
+    u32 x = a.v[i];
+    asm volatile("" : "+v"(x));        // opaque to the optimiser: see the note on lane-dependent selects above
+    r.v[i] = (u32)__builtin_amdgcn_mov_dpp((int)x, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+  }
 }
 __device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool take_a) {
 #pragma unroll
@@ -46,7 +52,11 @@ __device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool 
 // the same word of the lane four places up (the quad of the next level); lanes 60..63 get their own
 __device__ __forceinline__ void fe_from_next_quad(Fe& r, const Fe& a) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) r.v[i] = (u32)__shfl_down((int)a.v[i], 4);
+  for (int i = 0; i < 10; ++i) {
+    u32 x = a.v[i];
+    asm volatile("" : "+v"(x));
+    r.v[i] = (u32)__shfl_down((int)x, 4);
+  }
 }
 
 struct QuadRist {
@@ -156,11 +166,10 @@ struct QuadSecp {
   }
   __device__ static void neg(St& s, int role) {            // (X, -Y, Z)
     const int c = coord(role);
-    Fe y, n;
-    fe_select(y, s.a, s.b, c == 1);
-    Fp::neg(n, y);
+    Fe n;
+    Fp::neg(n, s.a);
     fe_select(s.a, n, s.a, c == 1);
-    fe_select(s.b, n, s.b, c == 0);
+    fe_quad_perm<1, 2, 0, 1>(s.b, s.a);
   }
   __device__ static void add(St& s, const Nb& q, int role, u32* lds) {
     const int c = coord(role), lane = threadIdx.x & 63;
@@ -171,12 +180,14 @@ struct QuadSecp {
     Fp::mul(sm, sp, sq);
     fe_quad_perm<1, 2, 0, 1>(tn, t);
     Fp::add(u, t, tn);
-    Fp::sub(cr, sm, u);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) cr.v[i] = sm.v[i] + PrimeConsts<PrimeSecp>::subpad(i) - u.v[i];    // (carried by mul_small below; < 2^30)
     Fp::mul_small(m, t, c == 0 ? 3u : c == 1 ? 1u : 21u);
     Fp::mul_small(crk, cr, c == 2 ? 21u : 1u);
     fe_quad_perm<1, 2, 0, 1>(mn, m);
     Fp::add(zz, m, mn);
-    Fp::sub(mm, m, mn);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) mm.v[i] = m.v[i] + PrimeConsts<PrimeSecp>::subpad(i) - mn.v[i];     // (a factor of mul2: no carry, < 2^30)
 #pragma unroll
     for (int i = 0; i < 10; ++i) ncrk.v[i] = PrimeConsts<PrimeSecp>::subpad(i) - crk.v[i];      // (no carry: a factor of mul2, limbs < 2^30)
     fe_select(s1, mm, m, c == 1);

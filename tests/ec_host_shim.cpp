@@ -34,6 +34,14 @@ static int t_small(const uint8_t* p, uint64_t k, uint8_t* out) {
   return 0;
 }
 template <class C>
+static int t_small_naf(const uint8_t* p, uint64_t k, uint8_t* out) {
+  typename C::Point a, r;
+  if (!C::decode(a, p)) return -1;
+  small_scalar_mul_naf<C>(r, a, k);
+  C::encode(out, r);
+  return 0;
+}
+template <class C>
 static int t_gen(uint8_t* out) {
   typename C::Point g;
   C::generator(g);
@@ -165,6 +173,9 @@ int ec_dual(int curve, const uint8_t* p1, const uint8_t* k1, const uint8_t* p2, 
 }
 int ec_add(int curve, const uint8_t* p1, const uint8_t* p2, uint8_t* out, int use_dbl) {
   return curve == 0 ? t_add<Secp>(p1, p2, out, use_dbl) : t_add<Ristretto>(p1, p2, out, use_dbl);
+}
+int ec_small_naf(int curve, const uint8_t* p, uint64_t k, uint8_t* out) {
+  return curve == 0 ? t_small_naf<Secp>(p, k, out) : t_small_naf<Ristretto>(p, k, out);
 }
 int ec_small(int curve, const uint8_t* p, uint64_t k, uint8_t* out) {
   return curve == 0 ? t_small<Secp>(p, k, out) : t_small<Ristretto>(p, k, out);

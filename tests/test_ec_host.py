@@ -99,6 +99,13 @@ def test_group_law_and_encodings(shim, curve, name):
     for k in [0, 1, 5, 65536, 65535, (1 << 40) + 77]:
         shim.ec_small(curve, buf(e(pts[0])), C.c_uint64(k), out)
         assert bytes(out) == e(G.exp(pts[0], k))
+    # the same through the non-adjacent form (the seed kernel of a lone box): runs of ones, alternating bits, the largest position
+    for k in [0, 1, 2, 3, 5, 7, 0x5555, 0xAAAA, 65535, 65536, 65537, (1 << 40) + 77, (1 << 61) - 1, (1 << 61) - 2] + \
+            [rng.getrandbits(rng.randrange(1, 62)) for _ in range(12)]:
+        shim.ec_small_naf(curve, buf(e(pts[0])), C.c_uint64(k), out)
+        assert bytes(out) == e(G.exp(pts[0], k)), k
+    shim.ec_small_naf(curve, buf(e(ident)), C.c_uint64(12345), out)
+    assert bytes(out) == e(ident)
     # invalid encodings are rejected
     bad = [b"\x05" + bytes(32), b"\x02" + (O.SECP_P).to_bytes(32, "big")] if curve == 0 else \
           [bytes.fromhex("01" + "00" * 31), bytes.fromhex("ed" + "ff" * 30 + "7f")]
