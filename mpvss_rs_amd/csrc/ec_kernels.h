@@ -35,8 +35,9 @@ typedef struct EcQuadStepping {
   uint32_t* wtab;          /* scratch window tables of the seed kernel: ec_fd_seed_tab_words() words per box, or null (8 lanes per seed, bit by bit) */
   size_t wtab_box_words;
   int table;               /* the difference tables by the same pipeline (1) or one workgroup per chain (0) */
+  int oct;                 /* secp256k1: eight lanes per point, six products side by side (1) or four lanes (0) */
 } EcQuadStepping;
-size_t ec_fd_quad_hand_words(int t, int chains, int w0, int chain_len);
+size_t ec_fd_quad_hand_words(int group, int oct, int t, int chains, int w0, int chain_len);
 size_t ec_fd_seed_tab_words(int group, int seeds);
 int ec_launch_fd_boxes_q(int group, const uint32_t* cm, int t, const int64_t* positions, int count, int chains, int w0,
                          int chain_len, uint32_t* pts, uint32_t* state_fwd, uint32_t* state_bwd, uint32_t* state_l1,

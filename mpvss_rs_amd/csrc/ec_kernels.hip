@@ -286,8 +286,7 @@ constexpr u32 EC_HAND_VALID = 0x80000000u;
 constexpr u32 EC_HAND_POISON = 0x40000000u;
 constexpr u32 EC_HAND_LIMB = 0x3fffffffu;
 constexpr long long EC_FD_TIMEOUT_TICKS = 200000000LL;      // 2 s of the 100 MHz wall clock
-constexpr int EC_QUAD_LEVELS = 16;                          // levels per wave
-constexpr int EC_HAND_ENTRY = 40;                           // words per handed point: 4 lanes x 10
+// levels per wave and words per handed point come from the lane layout: Q::LEVELS = 64 / Q::LANES, 10 words per lane
 
 __device__ __forceinline__ void ec_hand_publish(u32* __restrict__ dst, const Fe& a, u32 tag) {
 #pragma unroll
@@ -320,10 +319,11 @@ __device__ __forceinline__ bool ec_hand_wait(u32 (&v)[10], const u32* __restrict
 }
 
 // words of handoff space one box needs for a stepping launch (tickets first)
-__host__ __device__ inline size_t ec_quad_hand_words(int t, int chains, int max_steps) {
-  const size_t nst = (size_t)(t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+__host__ __device__ inline size_t ec_quad_hand_words(int t, int chains, int max_steps, int lanes) {
+  const int levels = 64 / lanes;
+  const size_t nst = (size_t)(t + levels - 1) / levels;
   const size_t tickets = ((size_t)2 * chains + 63) / 64 * 64;
-  return tickets + (size_t)2 * chains * nst * (size_t)(max_steps + 1) * EC_HAND_ENTRY;
+  return tickets + (size_t)2 * chains * nst * (size_t)(max_steps + 1) * (size_t)(lanes * 10);
 }
 
 template <class Q>
@@ -334,6 +334,7 @@ __device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, c
   extern __shared__ u32 lds[];
   constexpr int PW = C::POINT_WORDS;
   __builtin_amdgcn_s_setprio(EC_LONE_SETPRIO);    // latency-critical and few: issue ahead of the wide kernels sharing the SIMD (a2's)
+  constexpr int EC_QUAD_LEVELS = Q::LEVELS, EC_HAND_ENTRY = Q::LANES * 10;
   const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
   const int cd = blockIdx.x / nst;
   const int dir = cd / chains, chain = cd % chains;
@@ -344,7 +345,7 @@ __device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, c
   if (threadIdx.x == 0) ticket = atomicAdd(tickets + cd, 1);
   const int sidx = __builtin_amdgcn_readfirstlane(ticket);           // 0 = the top levels
   const int kbase = (nst - 1 - sidx) * EC_QUAD_LEVELS;
-  const int lane = threadIdx.x, quad = lane >> 2, role = lane & 3;
+  const int lane = threadIdx.x, quad = lane / Q::LANES, role = lane % Q::LANES;
   const int k = kbase + quad;
   const bool has_up = sidx > 0, has_down = kbase > 0;
   const bool reader = quad == EC_QUAD_LEVELS - 1;
@@ -381,7 +382,7 @@ __device__ __forceinline__ void fd_quad_step_body(const u32* __restrict__ fwd, c
       Q::nb_from_primary(top, prim, role);
       if (step < steps) ec_hand_load(pre, up + (size_t)step * EC_HAND_ENTRY);     // for the next step, under this one's addition
     }
-    fe_from_next_quad(prim, Q::primary(D));
+    fe_from_next_group<Q::LANES>(prim, Q::primary(D));
     Q::nb_from_primary(nb, prim, role);
     Q::select(nb, top, reader);
     Q::add(D, nb, role, lds);
@@ -413,6 +414,7 @@ __device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds
   extern __shared__ u32 lds[];
   constexpr int PW = C::POINT_WORDS;
   __builtin_amdgcn_s_setprio(EC_LONE_SETPRIO);
+  constexpr int EC_QUAD_LEVELS = Q::LEVELS, EC_HAND_ENTRY = Q::LANES * 10;
   const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
   const int chain = blockIdx.x / nst;
   int* tickets = reinterpret_cast<int*>(hand);
@@ -421,7 +423,7 @@ __device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds
   if (threadIdx.x == 0) ticket = atomicAdd(tickets + chain, 1);
   const int sidx = __builtin_amdgcn_readfirstlane(ticket);           // 0 = the top elements
   const int kbase = (nst - 1 - sidx) * EC_QUAD_LEVELS;
-  const int lane = threadIdx.x, quad = lane >> 2, role = lane & 3;
+  const int lane = threadIdx.x, quad = lane / Q::LANES, role = lane % Q::LANES;
   const int k = kbase + quad;
   const bool has_up = sidx > 0, has_down = kbase > 0;
   const bool reader = quad == EC_QUAD_LEVELS - 1;
@@ -483,7 +485,7 @@ __device__ __forceinline__ void fd_quad_table_body(const u32* __restrict__ seeds
       Q::nb_from_primary(top, prim, role);
       if (need_up(lvl + 1)) ec_hand_load(pre, up + (size_t)lvl * EC_HAND_ENTRY);
     }
-    fe_from_next_quad(prim, Q::primary(E));
+    fe_from_next_group<Q::LANES>(prim, Q::primary(E));
     Q::nb_from_primary(nb, prim, role);
     Q::select(nb, top, reader);
     neg = E;
@@ -978,6 +980,19 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
 #if EC_PART != 2
 EC_KERNELS(secp, Secp, OrderSecp, QuadSecp, EC_DEF)
 EC_WIN_KERNELS(secp, Secp, EC_DEF)
+extern "C" __global__ void __launch_bounds__(64) k_secp_fd_step_oct(const u32* fwd, const u32* bwd, int chains, int t, int w0, int chain_len,
+                                                                    int count, u32* pts, u32* hand, size_t hand_box, int max_steps,
+                                                                    int* gate, int inject_fault, BoxStride bs) {
+  EC_BOX_GATE_CHECK(gate, 1);
+  fd_quad_step_body<OctSecp>(fwd + blockIdx.y * bs.state, bwd + blockIdx.y * bs.state, chains, t, w0, chain_len, count,
+                             pts + blockIdx.y * bs.pts, hand + blockIdx.y * hand_box, max_steps, gate, inject_fault);
+}
+extern "C" __global__ void __launch_bounds__(64) k_secp_fd_table_oct(const u32* seeds, int chains, int t, u32* fwd, u32* bwd, u32* hand,
+                                                                     size_t hand_box, int* gate, int inject_fault, BoxStride bs) {
+  EC_BOX_GATE_CHECK(gate, 1);
+  fd_quad_table_body<OctSecp>(seeds + blockIdx.y * bs.pts, chains, t, fwd + blockIdx.y * bs.state, bwd + blockIdx.y * bs.state,
+                              hand + blockIdx.y * hand_box, gate, inject_fault);
+}
 extern "C" __global__ void __launch_bounds__(64) k_secp_encode_batch(const u32* pts, int count, uint8_t* enc, const int* gate,
                                                                      BoxStride bs) {
   EC_BOX_GATE_CHECK(gate, 1);
@@ -1054,10 +1069,13 @@ extern "C" int ec_launch_encode_boxes(int group, const uint32_t* pts, int count,
 // quad != null: the stepping launches are pipelines of quad-lane stages (fd_quad_step_body) -- for boxes that have the
 // chip to themselves; quad->hand holds ec_fd_quad_hand_words() words per box and is zeroed here before each launch,
 // quad->gate is the boxes' (writable) gate.
-extern "C" size_t ec_fd_quad_hand_words(int t, int chains, int w0, int chain_len) {
-  const int m0 = chains * t, w1 = (m0 - t) / 2;
+// lanes per point of the stepping / table pipelines: secp256k1 8 (OctSecp; 4 = QuadSecp with quad->oct == 0), ristretto255 4
+static inline int ec_quad_lanes(int group, int oct) { return group == 1 && oct ? 8 : 4; }
+extern "C" size_t ec_fd_quad_hand_words(int group, int oct, int t, int chains, int w0, int chain_len) {
+  const int m0 = chains * t, w1 = (m0 - t) / 2, lanes = ec_quad_lanes(group, oct);
   const int steps_l1 = std::max(m0 - 1 - w1, w1 + t - 1), steps = std::max(chain_len - 1 - w0, w0 + t - 1);
-  return std::max(std::max(ec_quad_hand_words(t, 1, steps_l1), ec_quad_hand_words(t, chains, steps)), ec_quad_hand_words(t, chains, t));
+  return std::max(std::max(ec_quad_hand_words(t, 1, steps_l1, lanes), ec_quad_hand_words(t, chains, steps, lanes)),
+                  ec_quad_hand_words(t, chains, t, lanes));
 }
 extern "C" size_t ec_fd_seed_tab_words(int group, int seeds) {
   return (size_t)blocks_for(16 * seeds) * 64 * 8 * (size_t)(group == 1 ? Secp::CACHED_WORDS : Ristretto::CACHED_WORDS);
@@ -1085,12 +1103,20 @@ extern "C" int ec_launch_fd_boxes_q(int group, const uint32_t* cm, int t, const 
   const BoxStride bs{cm_stride, pos_stride, pts_stride, state_stride, enc_stride};
   const unsigned B = (unsigned)boxes;
   auto step_quad = [&](uint32_t* fwd, uint32_t* bwd, int nchains, int first, int len, int cnt, uint32_t* out) -> int {
-    const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
+    const int lanes_q = ec_quad_lanes(group, quad->oct), levels = 64 / lanes_q;
+    const int nst = (t + levels - 1) / levels;
     const int max_steps = std::max(len - 1 - first, first + t - 1);
-    if (ec_quad_hand_words(t, nchains, max_steps) > quad->hand_box_words) return (int)hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(quad->hand, 0, (size_t)boxes * quad->hand_box_words * 4, s);
-    if (e != hipSuccess) return (int)e;
-    if (group == 1)
+    const size_t need = ec_quad_hand_words(t, nchains, max_steps, lanes_q);
+    if (need > quad->hand_box_words) return (int)hipErrorInvalidValue;
+    // (only what this launch uses is zeroed: the space is sized for the largest launch of the box)
+    for (int b = 0; b < boxes; ++b) {
+      hipError_t e = hipMemsetAsync(quad->hand + (size_t)b * quad->hand_box_words, 0, need * 4, s);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (group == 1 && quad->oct)
+      hipLaunchKernelGGL(k_secp_fd_step_oct, dim3(2 * nchains * nst, B), dim3(64), OctSecp::LDS_WORDS * 4, s, fwd, bwd, nchains, t,
+                         first, len, cnt, out, quad->hand, quad->hand_box_words, max_steps, quad->gate, quad->fault, bs);
+    else if (group == 1)
       hipLaunchKernelGGL(k_secp_fd_step_quad, dim3(2 * nchains * nst, B), dim3(64), QuadSecp::LDS_WORDS * 4, s, fwd, bwd, nchains, t,
                          first, len, cnt, out, quad->hand, quad->hand_box_words, max_steps, quad->gate, quad->fault, bs);
     else
@@ -1109,11 +1135,18 @@ extern "C" int ec_launch_fd_boxes_q(int group, const uint32_t* cm, int t, const 
                          quad->wtab, quad->wtab_box_words, gate, bs);
   }
   auto table_quad = [&](const uint32_t* sd, int nchains, uint32_t* fw, uint32_t* bw) -> int {
-    const int nst = (t + EC_QUAD_LEVELS - 1) / EC_QUAD_LEVELS;
-    if (ec_quad_hand_words(t, nchains, t) > quad->hand_box_words) return (int)hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(quad->hand, 0, (size_t)boxes * quad->hand_box_words * 4, s);
-    if (e != hipSuccess) return (int)e;
-    if (group == 1)
+    const int lanes_q = ec_quad_lanes(group, quad->oct), levels = 64 / lanes_q;
+    const int nst = (t + levels - 1) / levels;
+    const size_t need = ec_quad_hand_words(t, nchains, t, lanes_q);
+    if (need > quad->hand_box_words) return (int)hipErrorInvalidValue;
+    for (int b = 0; b < boxes; ++b) {
+      hipError_t e = hipMemsetAsync(quad->hand + (size_t)b * quad->hand_box_words, 0, need * 4, s);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (group == 1 && quad->oct)
+      hipLaunchKernelGGL(k_secp_fd_table_oct, dim3(nchains * nst, B), dim3(64), OctSecp::LDS_WORDS * 4, s, sd, nchains, t, fw, bw,
+                         quad->hand, quad->hand_box_words, quad->gate, quad->fault, bs);
+    else if (group == 1)
       hipLaunchKernelGGL(k_secp_fd_table_quad, dim3(nchains * nst, B), dim3(64), QuadSecp::LDS_WORDS * 4, s, sd, nchains, t, fw, bw,
                          quad->hand, quad->hand_box_words, quad->gate, quad->fault, bs);
     else

@@ -41,27 +41,29 @@ __device__ __forceinline__ void fe_quad_perm(Fe& r, const Fe& a) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     u32 x = a.v[i];
-    asm volatile("" : "+v"(x));        // opaque to the optimiser: see the note on lane-dependent selects above
+    asm("" : "+v"(x));                 // opaque to the optimiser: see the note on lane-dependent selects above
     r.v[i] = (u32)__builtin_amdgcn_mov_dpp((int)x, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
   }
 }
 __device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool take_a) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) r.v[i] = take_a ? a.v[i] : b.v[i];
+  for (int i = 0; i < 10; ++i) r.v[i] = take_a ? a.v[i] : b.v[i];      // (v_cndmask_b32; the same through v_bfi_b32 and a VGPR mask measured 6 % slower)
 }
-// the same word of the lane four places up (the quad of the next level); lanes 60..63 get their own
-__device__ __forceinline__ void fe_from_next_quad(Fe& r, const Fe& a) {
+// the same word of the lane LANES places up (the lanes of the next level); the last group gets its own
+template <int LANES>
+__device__ __forceinline__ void fe_from_next_group(Fe& r, const Fe& a) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     u32 x = a.v[i];
-    asm volatile("" : "+v"(x));
-    r.v[i] = (u32)__shfl_down((int)x, 4);
+    asm("" : "+v"(x));
+    r.v[i] = (u32)__shfl_down((int)x, LANES);
   }
 }
 
 struct QuadRist {
   typedef Ristretto C;
   typedef Ristretto::Fp Fp;
+  static constexpr int LANES = 4, LEVELS = 16;             // lanes per point, points (levels) per wave
   static constexpr int LDS_WORDS = 0;
   struct St {
     Fe u;
@@ -134,6 +136,7 @@ struct QuadRist {
 struct QuadSecp {
   typedef Secp C;
   typedef Secp::Fp Fp;
+  static constexpr int LANES = 4, LEVELS = 16;
   static constexpr int LDS_WORDS = 3 * 10 * 64;             // [slot][word][lane]
   struct St {
     Fe a, b;
@@ -223,6 +226,147 @@ struct QuadSecp {
   __device__ static int out_offset(int role) { return role * 10; }
   __device__ static bool out_lane(int role) { return role < 3; }
   __device__ static void out_words(Fe& o, const St& s, int) { o = s.a; }
+};
+
+// secp256k1 with EIGHT lanes per point, six of them at work: every product of the complete addition in a lane of its own --
+// ONE product and one more deep instead of two and a double one (QuadSecp), at twice the waves per chain; what a lone wave
+// can issue is what bounds a step, so the products per lane are the step time.
+//   lane m keeps the form u_m of its point:  u = (X, Y, Z, X + Y, Y + Z, X + Z)        (lanes 6, 7 mirror lanes 0, 1)
+//   t_m = u_m(P) u_m(Q)                                                  -> X1X2, Y1Y2, Z1Z2 and the three Karatsuba products
+//   mid_m = K (t_A -+ kB t_B - t_C) from LDS:  t3', t4', y3 = 21 t5', t1' = t1 - 21 t2, z3 = t1 + 21 t2, t0' = 3 t0
+//   p_m = mid_a mid_b:  t4' y3, t3' t1', y3 t0', t1' z3, t0' t3', z3 t4'
+//   u'_m = signed sums of the p:  X3 = p1 - p0, Y3 = p3 + p2, Z3 = p5 + p4 and their pairwise sums
+// Checked in integers first (doublings, P + (-P), the identity); tests/ec_quad_unit.hip runs it beside QuadSecp.
+struct OctSecp {
+  typedef Secp C;
+  typedef Secp::Fp Fp;
+  static constexpr int LANES = 8, LEVELS = 8;
+  static constexpr int LDS_WORDS = 3 * 10 * 64;             // three rounds x [word][lane]
+  struct St {
+    Fe u;
+  };
+  typedef St Nb;
+  __device__ static int form(int role) { return role >= 6 ? role - 6 : role; }
+  // u_m = cx X + cy Y + cz Z with coefficients 0 / 1; sy: Y enters negated
+  __device__ static void from_xyz(Fe& u, const Fe& X, const Fe& Y, const Fe& Z, int role, bool negate_y) {
+    const int m = form(role);
+    const u32 mx = (m == 0 || m == 3 || m == 5) ? 0xffffffffu : 0u, my = (m == 1 || m == 3 || m == 4) ? 0xffffffffu : 0u,
+              mz = (m == 2 || m == 4 || m == 5) ? 0xffffffffu : 0u;
+    Fe yy;
+    Fp::neg(yy, Y);
+    fe_select(yy, yy, Y, negate_y);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) u.v[i] = (X.v[i] & mx) + (yy.v[i] & my) + (Z.v[i] & mz);
+  }
+  __device__ static void load(St& s, const u32* __restrict__ pt, int role) {
+    Fe X, Y, Z;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      X.v[i] = pt[i];
+      Y.v[i] = pt[10 + i];
+      Z.v[i] = pt[20 + i];
+    }
+    from_xyz(s.u, X, Y, Z, role, false);
+  }
+  __device__ static void identity(St& s, int role) {        // (0 : 1 : 0)
+    const int m = form(role);
+    Fp::zero(s.u);
+    s.u.v[0] = (m == 1 || m == 3 || m == 4) ? 1u : 0u;
+  }
+  __device__ static const Fe& primary(const St& s) { return s.u; }
+  __device__ static void select(St& r, const St& a, bool take_a) { fe_select(r.u, a.u, r.u, take_a); }
+  __device__ static void nb_from_primary(Nb& q, const Fe& prim, int) { q.u = prim; }
+  // one word of lane `src` of this lane's group
+  __device__ static void gather(Fe& r, const Fe& a, int src) {
+    const int lane = (threadIdx.x & 63 & ~7) + src;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      u32 x = a.v[i];
+      asm("" : "+v"(x));
+      r.v[i] = (u32)__shfl((int)x, lane);
+    }
+  }
+  __device__ static void neg(St& s, int role) {            // (X, -Y, Z): the forms again from the coordinates in lanes 0, 1, 2
+    Fe X, Y, Z;
+    gather(X, s.u, 0);
+    gather(Y, s.u, 1);
+    gather(Z, s.u, 2);
+    from_xyz(s.u, X, Y, Z, role, true);
+  }
+  __device__ static void add(St& s, const Nb& q, int role, u32* lds) {
+    const int m = form(role), lane = threadIdx.x & 63, g0 = lane & ~7;
+    // mid_m = K (t_A + sB kB t_B - [useC] t_C):   A, B, C: lanes of the group; sB: B enters negated
+    const int iA = m == 0 ? 3 : m == 1 ? 4 : m == 2 ? 5 : m == 5 ? 0 : 1;
+    const int iB = m == 1 ? 1 : (m == 3 || m == 4) ? 2 : 0;
+    const int iC = m == 0 ? 1 : 2;
+    const u32 kB = (m == 3 || m == 4) ? 21u : 1u, K = m == 2 ? 21u : m == 5 ? 3u : 1u;
+    const bool negB = m != 4, useB = m != 5, useC = m < 3;
+    // p_m = mid_a mid_b
+    const int ia = m == 0 ? 1 : m == 1 ? 0 : m == 2 ? 2 : m == 3 ? 3 : m == 4 ? 5 : 4;
+    const int ib = m == 0 ? 2 : m == 1 ? 3 : m == 2 ? 5 : m == 3 ? 4 : m == 4 ? 0 : 1;
+    // u'_m = (X3 = p1 - p0 if wx) + (Y3 = p3 + p2 if wy) + (Z3 = p5 + p4 if wz)
+    const bool wx = m == 0 || m == 3 || m == 5, wy = m == 1 || m == 3 || m == 4, wz = m == 2 || m == 4 || m == 5;
+    u32* r0 = lds;
+    u32* r1 = lds + 10 * 64;
+    u32* r2 = lds + 20 * 64;
+    Fe t, A, B, Cc, x, mid, ma, mb, pr;
+    Fp::mul(t, s.u, q.u);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) r0[i * 64 + lane] = t.v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      A.v[i] = r0[i * 64 + g0 + iA];
+      B.v[i] = r0[i * 64 + g0 + iB];
+      Cc.v[i] = r0[i * 64 + g0 + iC];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Fp::mul_small(B, B, kB);
+    {
+      const u32 mB = useB ? 0xffffffffu : 0u, mC = useC ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const u32 pad = PrimeConsts<PrimeSecp>::subpad(i);
+        const u32 bt = negB ? pad - B.v[i] : B.v[i];
+        x.v[i] = A.v[i] + (bt & mB) + ((pad - Cc.v[i]) & mC);      // < 2^27.1 + 2^29 + 2^29
+      }
+    }
+    Fp::mul_small(mid, x, K);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) r1[i * 64 + lane] = mid.v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      ma.v[i] = r1[i * 64 + g0 + ia];
+      mb.v[i] = r1[i * 64 + g0 + ib];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Fp::mul(pr, ma, mb);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) r2[i * 64 + lane] = pr.v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const u32 mX = wx ? 0xffffffffu : 0u, mY = wy ? 0xffffffffu : 0u, mZ = wz ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const u32 p0 = r2[i * 64 + g0 + 0], p1 = r2[i * 64 + g0 + 1], p2 = r2[i * 64 + g0 + 2], p3 = r2[i * 64 + g0 + 3],
+                  p4 = r2[i * 64 + g0 + 4], p5 = r2[i * 64 + g0 + 5];
+        const u32 x3 = p1 + (PrimeConsts<PrimeSecp>::subpad(i) - p0), y3 = p3 + p2, z3 = p5 + p4;     // < 2^29.3, 2^28.1, 2^28.1
+        s.u.v[i] = (x3 & mX) + (y3 & mY) + (z3 & mZ);                                                  // < 2^30
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Fp::carry(s.u);
+  }
+  __device__ static int out_offset(int role) { return role * 10; }
+  __device__ static bool out_lane(int role) { return role < 3; }
+  __device__ static void out_words(Fe& o, const St& s, int) { o = s.u; }
 };
 
 }  // namespace ec

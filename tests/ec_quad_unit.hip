@@ -2,7 +2,7 @@
 // addition and negation of mpvss_rs_amd/csrc/ec_quad.h against the one-lane complete formulas of ec_curves.h, one pair of
 // points per quad:  P = a G, Q = +-b G for 64-bit a, b from the input (a = 0 / b = 0: the identity; b = a: a doubling;
 // b = -a: P + (-P)), results compared projectively in the kernel.
-//   ec_quad_unit <group 1|2> <in.bin> <n>        in.bin: n x (a, b, flags) u64; flags bit 0: negate Q
+//   ec_quad_unit <1 secp256k1 quads | 2 ristretto255 quads | 3 secp256k1 eight lanes> <in.bin> <n>        in.bin: n x (a, b, flags) u64; flags bit 0: negate Q
 // prints "bad <count>" and the first failing indices; exit code 0 when every pair agrees
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(64) k_unit(const uint64_t* __restrict__ in, in
   typedef typename Q::C C;
   extern __shared__ u32 lds[];
   constexpr int PW = C::POINT_WORDS;
-  const int gl = blockIdx.x * 64 + threadIdx.x, qi = gl >> 2, role = gl & 3;
+  const int gl = blockIdx.x * 64 + threadIdx.x, qi = gl / Q::LANES, role = gl % Q::LANES;
   const int i = qi < n ? qi : n - 1;
   const uint64_t a = in[3 * i], b = in[3 * i + 1], flags = in[3 * i + 2];
   typename C::Point g, P, Qp, t;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64) k_unit(const uint64_t* __restrict__ in, in
   small_scalar_mul<C>(t, g, b, 64);
   if (flags & 1) C::neg(Qp, t); else Qp = t;
   // the four points of a quad (P, Q, P + Q, -P + Q) travel between its lanes through LDS
-  u32* mine = lds + Q::LDS_WORDS + (threadIdx.x >> 2) * 6 * PW;
+  u32* mine = lds + Q::LDS_WORDS + (threadIdx.x / Q::LANES) * 6 * PW;
   if (role == 0) {
     store_pt<C>(mine, P);
     store_pt<C>(mine + PW, Qp);
@@ -134,13 +134,17 @@ int main(int argc, char** argv) {
   fclose(f);
   uint64_t* din;
   int* bad;
-  const int quads = (n + 15) / 16 * 16;
   CHECK(hipMalloc(&din, in.size() * 8));
   CHECK(hipMalloc(&bad, 32 * 4));
   CHECK(hipMemcpy(din, in.data(), in.size() * 8, hipMemcpyHostToDevice));
   CHECK(hipMemset(bad, 0, 32 * 4));
-  if (group == 1) hipLaunchKernelGGL(k_unit<QuadSecp>, dim3(quads / 16), dim3(64), (QuadSecp::LDS_WORDS + 16 * 6 * 30) * 4, 0, din, n, bad);
-  else hipLaunchKernelGGL(k_unit<QuadRist>, dim3(quads / 16), dim3(64), (QuadRist::LDS_WORDS + 16 * 6 * 40) * 4, 0, din, n, bad);
+  // group 1: secp256k1 by quads, 2: ristretto255 by quads, 3: secp256k1 by eight lanes (six products side by side)
+  if (group == 1)
+    hipLaunchKernelGGL(k_unit<QuadSecp>, dim3((n + 15) / 16), dim3(64), (QuadSecp::LDS_WORDS + 16 * 6 * 30) * 4, 0, din, n, bad);
+  else if (group == 2)
+    hipLaunchKernelGGL(k_unit<QuadRist>, dim3((n + 15) / 16), dim3(64), (QuadRist::LDS_WORDS + 16 * 6 * 40) * 4, 0, din, n, bad);
+  else
+    hipLaunchKernelGGL(k_unit<OctSecp>, dim3((n + 7) / 8), dim3(64), (OctSecp::LDS_WORDS + 8 * 6 * 30) * 4, 0, din, n, bad);
   CHECK(hipDeviceSynchronize());
   int h[32];
   CHECK(hipMemcpy(h, bad, sizeof h, hipMemcpyDeviceToHost));

@@ -64,6 +64,9 @@ def test_ec_fd_equals_horner():
         a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": l1, "MPVSS_EC_FD_QUAD": quad, "CHECK_ORACLE": "1" if quad == "2" else ""})
         for case, ha, hb in zip(CASES, a, b):
             assert ha == hb, (case, quad, l1)
+    # secp256k1 with eight lanes per point addition (OctSecp; off by default)
+    a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "0", "MPVSS_EC_FD_QUAD": "2", "MPVSS_EC_FD_OCT": "1"})
+    assert a == b
     # the quad stepping alone: seeds by 8 lanes bit by bit, tables by one workgroup per chain
     a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "0", "MPVSS_EC_FD_QUAD": "2", "MPVSS_EC_FD_SEEDS_WIN": "0", "MPVSS_EC_FD_TABLE_QUAD": "0"})
     assert a == b
@@ -100,6 +103,6 @@ def test_quad_lane_addition_against_the_one_lane_formulas(tmp_path):
         rows.append((a, b, fl))
     path = tmp_path / "pairs.bin"
     path.write_bytes(b"".join(struct.pack("<QQQ", *r) for r in rows))
-    for group in (1, 2):
+    for group in (1, 2, 3):       # secp256k1 by quads, ristretto255 by quads, secp256k1 by eight lanes
         out = subprocess.run([exe, str(group), str(path), str(len(rows))], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and out.stdout.startswith("bad 0"), (group, out.stdout[:600], out.stderr[-600:])
