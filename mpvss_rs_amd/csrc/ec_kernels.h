@@ -64,6 +64,8 @@ int ec_launch_build_tables(int group, const uint8_t* enc, size_t enc_stride, con
 int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_t* tab1, const uint8_t* k1, size_t k1_stride,
                        const uint32_t* tab2, const uint8_t* k2, size_t k2_stride, int count, uint32_t* out_pts, hipStream_t s);
 int ec_launch_encode(int group, const uint32_t* pts, int count, uint8_t* enc, hipStream_t s);
+/* out[x] = a[x] + b[x], internal coordinates */
+int ec_launch_add_pts(int group, const uint32_t* a, const uint32_t* b, int count, uint32_t* out, hipStream_t s);
 /* out (one internal point, may alias pts) = sum of the m internal points at pts */
 int ec_launch_sum(int group, const uint32_t* pts, int m, uint32_t* out, hipStream_t s);
 int ec_launch_encode_gated(int group, const uint32_t* pts, int count, uint8_t* enc, const int* gate, hipStream_t s);

@@ -974,6 +974,13 @@ __device__ __forceinline__ void secp_encode_batch_body(const u32* __restrict__ p
       size_t k2_stride, int count, u32* out_pts)                                                                             \
       BODY(extern __shared__ u32 lds[];                                                                                      \
            dual_win_body<CURVE>(comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts, lds);)                       \
+  extern "C" __global__ void __launch_bounds__(64) k_##NAME##_add_pts(const u32* a, const u32* b, int count, u32* out)       \
+      BODY(const int x = blockIdx.x * blockDim.x + threadIdx.x; if (x >= count) return;                                      \
+           typename CURVE::Point p, q, r;                                                                                    \
+           load_point_aos<CURVE>(p, a + (size_t)x * CURVE::POINT_WORDS);                                                     \
+           load_point_aos<CURVE>(q, b + (size_t)x * CURVE::POINT_WORDS);                                                     \
+           CURVE::add(r, p, q);                                                                                              \
+           store_point_aos<CURVE>(out + (size_t)x * CURVE::POINT_WORDS, r);)                                                 \
   extern "C" __global__ void __launch_bounds__(256) k_##NAME##_sum_points(const u32* pts, int m, u32* out)                   \
       BODY(extern __shared__ u32 lds[]; sum_points_body<CURVE>(pts, m, out, lds);)
 
@@ -1241,6 +1248,13 @@ extern "C" int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_
     hipLaunchKernelGGL(k_secp_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);
   else
     hipLaunchKernelGGL(k_rist_dual_win, grid, dim3(DW_THREADS), lds, s, comb, tab1, k1, k1_stride, tab2, k2, k2_stride, count, out_pts);
+  return (int)hipGetLastError();
+}
+// out[x] = a[x] + b[x] in internal coordinates (out may alias a or b)
+extern "C" int ec_launch_add_pts(int group, const uint32_t* a, const uint32_t* b, int count, uint32_t* out, hipStream_t s) {
+  if (count <= 0) return 0;
+  if (group == 1) hipLaunchKernelGGL(k_secp_add_pts, dim3(blocks_for(count)), dim3(64), 0, s, a, b, count, out);
+  else hipLaunchKernelGGL(k_rist_add_pts, dim3(blocks_for(count)), dim3(64), 0, s, a, b, count, out);
   return (int)hipGetLastError();
 }
 // internal points -> canonical encodings (secp256k1: eight points per lane share an inversion); gate: run only if gate[b] == 1

@@ -58,10 +58,11 @@ struct EcWork {   // device workspace of the elliptic-curve entry points (one pe
   DevBuf tab1, tab2, tab3;       // window tables of per-share bases: [n][8][cached words]
   DevBuf p1, p2;                 // results of the double-scalar multiplications in internal coordinates
   DevBuf flags;                  // ints: [0] forward-difference gate, [1] first bad response, [2] first bad challenge
+  DevBuf pg;                     // r G of a lone block, computed beside the X path (a1 = r G + c X is then one table multiplication and an addition)
   DevBuf hand, wtab;             // hand-over space of the quad-lane stepping pipeline, window tables of its seed kernel (a box that has the chip to itself)
   std::vector<DevBuf*> all() {
     return {&a, &b, &c, &d, &e, &pos, &cm, &cmenc, &x, &o1, &o2, &ok, &gen, &chal, &pts, &fdst, &tab1, &tab2, &tab3, &p1, &p2,
-            &flags, &hand, &wtab};
+            &flags, &hand, &wtab, &pg};
   }
 };
 
