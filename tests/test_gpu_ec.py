@@ -293,6 +293,10 @@ def test_ec_verify_many_batches_the_x_paths_of_several_boxes(engine, name):
     assert one_by_one[0][1] == digests[0] and one_by_one[5][1] == dg_scattered and one_by_one[8][1] == dg_small
     for depth, threads in ((2, 1), (8, 3)):
         assert engine.ec_verify_many(gid, seq, depth=depth, hash_threads=threads) == one_by_one
+    # two boxes with nothing else in flight: one batch of two through the quad-lane stage pipelines (box = second grid dimension
+    # of the stepping / table launches, hand-over space and tickets per box)
+    assert engine.ec_verify_many(gid, seq[:2], depth=2, hash_threads=1) == one_by_one[:2]
+    assert engine.ec_verify_many(gid, [boxes[3], boxes[4]], depth=1, hash_threads=1) == [one_by_one[3], one_by_one[4]]
     # a commitment that is no group element, inside a batch: reported by the box it belongs to, as on the per-box path
     bad_cm = bytearray(boxes[2]["commitments"])
     bad_cm[3 * L:4 * L] = (b"\x05" + bytes(32)) if name == "secp256k1" else bytes.fromhex("01" + "00" * 31)
