@@ -23,6 +23,9 @@
 #ifndef MODP_WAVES_PER_EU_MAX
 #define MODP_WAVES_PER_EU_MAX MODP_WAVES_PER_EU
 #endif
+#ifndef FD_STEP_PREFETCH
+#define FD_STEP_PREFETCH 1      // stepping stages request the next step's handed number under this step's product
+#endif
 #ifndef MODP_SETPRIO
 #define MODP_SETPRIO 3          // wave priority of the latency-bound launches (seeds, inversion tree, pipeline stages)
 #endif
@@ -568,6 +571,35 @@ __device__ __forceinline__ bool hand_receive(const u32* __restrict__ src, u32* d
   return __builtin_amdgcn_ballot_w64(!ok) == 0;
 }
 
+// The same for a number whose words were REQUESTED EARLIER (v holds what the loads returned: the stepping kernel asks for the
+// entry of the next step under this step's product, so that the hand-over's memory latency -- several microseconds when the
+// wide launches keep HBM busy -- is not part of the step); polls as hand_receive does when the words are not there yet.
+__device__ __forceinline__ bool hand_receive_requested(u32 (&v)[LPL], const u32* __restrict__ src, u32* dst, bool is_reader,
+                                                       const Lane& ln) {
+  bool ok = true;
+  if (is_reader) {
+    const long long t0 = wall_clock64();
+    u32 all = 0xffffffffu, any = 0;
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) {
+      all &= v[k];
+      any |= v[k];
+    }
+    u32 st = (any & HAND_POISON) ? HAND_POISON : (all & HAND_VALID);
+    while (true) {
+      const uint64_t good = __builtin_amdgcn_ballot_w64(st == HAND_VALID) >> 60;
+      const uint64_t bad = __builtin_amdgcn_ballot_w64(st == HAND_POISON) >> 60;
+      if (good == 0xf) break;
+      if (bad != 0 || wall_clock64() - t0 > FD_TIMEOUT_TICKS) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+      st = hand_poll(src, v, ln);
+    }
+#pragma unroll
+    for (int k = 0; k < LPL; ++k) dst[ln.q * LPL + k] = v[k] & 0x3fffffffu;
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
+
 // (two products per level keep E, F, T1 and the modulus live: 2 waves per SIMD's worth of registers instead of 3 --
 // the launch is a few dozen latency-bound waves, occupancy is not its problem, spilling would be)
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
@@ -708,6 +740,12 @@ k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back
     for (int i = 0; i < LPL; ++i) inslot[ln.q * LPL + i] = src[ln.q * LPL + i];
   }
   const bool writer = kbase == 0 && quad == 0;
+#if FD_STEP_PREFETCH
+  u32 pre[LPL];
+#pragma unroll
+  for (int i = 0; i < LPL; ++i) pre[i] = 0;
+  if (has_up && reader && steps >= 2) hand_poll(up + (size_t)1 * L, pre, ln);
+#endif
   for (int step = 1; step <= steps; ++step) {
     slot_store(slot, D, ln);
     // test hooks (MPVSS_FD_TEST_FAULT): behave like a stage whose wait timed out -- 1: the top stage of the first forward
@@ -720,11 +758,19 @@ k_modp_fd_step(const u32* __restrict__ state, const u32* __restrict__ state_back
       return;
     }
     if (has_up && step > 1) {
-      if (!hand_receive(up + (size_t)(step - 1) * L, inslot, reader, ln)) {
+#if FD_STEP_PREFETCH
+      const bool got = hand_receive_requested(pre, up + (size_t)(step - 1) * L, inslot, reader, ln);
+#else
+      const bool got = hand_receive(up + (size_t)(step - 1) * L, inslot, reader, ln);
+#endif
+      if (!got) {
         if (threadIdx.x == 0) *gate = 0;
         if (has_down && quad == 0) hand_publish(mine + (size_t)step * L, D, ln, HAND_POISON);
         return;
       }
+#if FD_STEP_PREFETCH
+      if (reader && step < steps) hand_poll(up + (size_t)step * L, pre, ln);      // the next step's, under this step's product
+#endif
     }
     __builtin_amdgcn_wave_barrier();
     mont_mul<MODP_N0INV_C>(D, D, bptr, n, ln);
