@@ -60,7 +60,9 @@ def test_fd_equals_horner():
     c = run(CASES, {"MPVSS_FD": "1", "MPVSS_FD_L1": "0", "MPVSS_FD_MIN_SHARES": "2048"})
     # the stepping kernels on the pair layout (stages of 32 levels; by default only from t = 512) for every case
     pair_cases = [k for k, cs in enumerate(CASES) if cs[0] != 64 or cs[3]]       # (three plain t = 64 cases less: time)
-    d = run([CASES[k] for k in pair_cases], {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_MIN_SHARES": "2048", "MPVSS_FD_PAIR_MIN_T": "16"})
+    # (with its own oracle positions: the pair-layout stepping is not only compared with the other runs)
+    d = run([CASES[k] for k in pair_cases], {"MPVSS_FD": "1", "MPVSS_FD_L1": "2", "MPVSS_FD_MIN_SHARES": "2048", "MPVSS_FD_PAIR_MIN_T": "16",
+                                             "CHECK_ORACLE": "1"})
     assert len(a) == len(CASES) and all(len(h) == 64 for h in a) and len(d) == len(pair_cases)
     for case, ha, hb, hc in zip(CASES, a, b, c):
         assert ha == hb == hc, case
