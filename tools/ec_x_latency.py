@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import bench
     from mpvss_rs_amd import capi
     eng = capi.Engine(0)
-    n, t = 65536, 256
+    n, t = int(os.environ.get("EC_N", "65536")), 256
     for name in ("secp256k1", "ristretto255"):
         cfg = bench.EC[name]
         gid, order = cfg["gid"], cfg["order"]
