@@ -80,6 +80,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+import bench_line  # noqa: E402
 from mpvss_rs_amd import capi  # noqa: E402
 
 EB = 256
@@ -1086,10 +1087,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 limbs (radix 2^29), u64 accumulators",
+        "dtype": "u32",
+        "dtype_detail": "u32 limbs (radix 2^29), u64 accumulators; the Montgomery reduction as int8 digit products on the matrix cores",
         "data": "synthetic",
-        "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n} t={t} per GPU "
-                               f"({n_total} participants in the box), honest-dealer boxes, inputs resident in HBM",
+        "config": {"workload": f"ModpGroup 2048-bit verify_distribution_shares n={n} t={t} per GPU",
+                   "workload_detail": f"{n_total} participants in the box, honest-dealer boxes, inputs resident in HBM",
                    "n_per_gpu": n, "t": t, "parallelism": f"participants sharded x{world}",
                    "distinct_boxes": len(boxes),
                    "boxes": "every timed step verifies another dealer's box (own polynomial, witnesses, shares, challenge, "
@@ -1490,9 +1492,10 @@ def main():
             result["cpu_baseline"] = {
                 "value": len(idx) / cpu_s, "unit": "share verifications/s", "cores": cores, "kind": "port",
                 "cpu_model": cpu_model, "hardware_threads": os.cpu_count(),
-                "sample": f"{len(idx)} of {n} shares (positions spread over [1,{n}], all t={t} commitments), "
-                          f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
-                          f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
+                "sample": f"{len(idx)} of {n} shares, oracle/modp_ref.c on {cores} threads, {cpu_s:.1f} s",
+                "sample_detail": f"{len(idx)} of {n} shares (positions spread over [1,{n}], all t={t} commitments), "
+                                 f"reference operation sequence (t+4 modpow, t+2 mul per share) in oracle/modp_ref.c on {cores} "
+                                 f"threads, {cpu_s:.1f}s; GPU X/a1/a2 of those shares checked equal",
                 "single_thread": {"value": len(idx1) / s1, "unit": "share verifications/s", "cores": 1, "kind": "port",
                                   "sample": f"{len(idx1)} share(s), same C port on one thread ({s1:.1f}s) -- the reference runs "
                                             "this path on one thread (src/participant.rs:408-448 has no rayon)"},
@@ -1665,7 +1668,20 @@ def main():
     result["compute"]["fd_blocks"] = fd_blocks
     result["compute"]["fd_fallbacks"] = fd_fallbacks          # boxes whose pipeline gave up and were recomputed by Horner
     if rank == 0:
-        print(json.dumps(result))
+        # The driver parses the LAST stdout line: a compact object (bench_line.py: the contract's keys, `roofline`, `compute`,
+        # `cpu_baseline`, one number per secondary leg; < 4 KB).  Everything measured, prose included, goes to the detail file
+        # and to stderr.
+        detail = json.dumps(result)
+        detail_path = os.environ.get("MPVSS_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        try:
+            with open(detail_path, "w") as fh:
+                fh.write(detail + "\n")
+            result["detail"] = os.path.relpath(detail_path, ROOT)
+        except OSError:
+            result["detail"] = "stderr"
+        sys.stderr.write(detail + "\n")
+        sys.stderr.flush()
+        print(bench_line.compact_line(result), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -19,6 +19,23 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _line(out):
+    """(compact, detail): the ONE stdout line the driver parses -- held to bench_line.py's contract here, on a real run --
+    and the full object bench.py writes to stderr (and bench_detail.json) beside it."""
+    sys.path.insert(0, ROOT)
+    import bench_line
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines[0].encode()) < bench_line.MAX_LINE_BYTES
+    compact = json.loads(lines[0])
+    for k in bench_line.REQUIRED:
+        if k != "cpu_baseline":              # rank 0 at N = 1 only
+            assert k in compact, k
+    detail = json.loads([ln for ln in out.stderr.splitlines() if ln.startswith("{\"metric\"")][-1])
+    assert compact["value"] == pytest.approx(detail["value"], rel=1e-5) and compact["n_gpus"] == detail["n_gpus"]
+    return compact, detail
+
+
 def _run(ranks, steps, n, depth, timeout=900, extra_env=None, config_boxes="0"):
     env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     if depth is not None:                  # None: the boxes in flight per rank follow bench.py's own formula for that world size
@@ -46,9 +63,10 @@ def test_the_drivers_own_command_starts_its_ranks():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith("{\"metric\""), out.stdout[-2000:]           # ONE line on stdout
-    res = json.loads(lines[0])
+    compact, res = _line(out)
+    assert compact["rccl"]["rccl_world_size"] == 2 and compact["roofline"]["bound"] == "hbm" and compact["config"]["t"] == 256
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
-    assert res["config"]["n_per_gpu"] == 65536 and "131072 participants in the box" in res["config"]["workload"]
+    assert res["config"]["n_per_gpu"] == 65536 and "131072 participants in the box" in res["config"]["workload_detail"]
     assert res["config"]["distinct_boxes"] == 3
     assert res["value"] > 0 and res["compute"]["fd_fallbacks"] == 0
     assert res["host"]["pipeline"].startswith("mpvss_modp_verify_many_chained")      # N > 1 runs the library's own pipeline
@@ -63,8 +81,8 @@ def test_four_ranks_many_boxes_every_rank_absorbing_several_at_once():
     bench.py's digest check, a missing recv would hang into the timeout."""
     out = _run(4, 14, 4096, 6, timeout=420)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
-    assert res["n_gpus"] == 4 and res["steps"] == 14 and "16384 participants in the box" in res["config"]["workload"]
+    _, res = _line(out)
+    assert res["n_gpus"] == 4 and res["steps"] == 14 and "16384 participants in the box" in res["config"]["workload_detail"]
     assert res["host"]["hash_threads"] >= 2 and res["compute"]["fd_fallbacks"] == 0
     assert res["rccl"]["rccl_world_size"] == 4 and res["rccl"]["data_collectives"] >= 14
 
@@ -77,7 +95,7 @@ def test_the_c5_object_of_an_eight_gpu_run_in_small():
     out = _run(2, 3, 8192, 3, extra_env={"MPVSS_BENCH_C5": "1", "MPVSS_BENCH_C5_N": "16384", "MPVSS_BENCH_C5_T": "64"},
                config_boxes="3")
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+    _, res = _line(out)
     assert "secondary_error" not in res
     c5 = res["c5"]
     assert c5["boxes"] == 3 and c5["value"] > 0 and "32768 participants over 2 GPUs" in c5["config"]["workload"]
@@ -94,9 +112,9 @@ def test_eight_ranks_at_the_real_world_size():
     out = _run(8, 6, 2048, None, timeout=600, extra_env={"MPVSS_BENCH_C5_N": "4096", "MPVSS_BENCH_C5_T": "64", "OMP_NUM_THREADS": "2"},
                config_boxes="3")
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+    _, res = _line(out)
     assert "secondary_error" not in res
-    assert res["n_gpus"] == 8 and res["steps"] == 6 and "16384 participants in the box" in res["config"]["workload"]
+    assert res["n_gpus"] == 8 and res["steps"] == 6 and "16384 participants in the box" in res["config"]["workload_detail"]
     assert res["rccl"]["rccl_world_size"] == 8 and res["rccl"]["data_collectives"] >= 6
     assert res["host"]["boxes_in_flight"] >= 8 + 5            # 8 + one more box per 58 ms of chain latency at eight ranks + 2
     assert res["host"]["hbm"]["bytes_in_use_on_this_rank"] > 0 and res["host"]["hbm"]["bytes_total"] > 2 ** 37
@@ -111,5 +129,5 @@ def test_the_python_driven_blocks_still_agree_with_the_chained_pipeline():
     for mode, name in (("0", "verify_block_compute / block_claim / absorb_claimed"), ("1", "mpvss_modp_verify_many_chained")):
         out = _run(2, 5, 4096, 4, timeout=420, extra_env={"MPVSS_BENCH_CHAINED": mode})
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-        res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")][0])
+        _, res = _line(out)
         assert res["host"]["pipeline"].startswith(name) and res["rccl"]["data_collectives"] >= 5 and res["value"] > 0
