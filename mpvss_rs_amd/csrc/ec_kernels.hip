@@ -1242,6 +1242,9 @@ extern "C" int ec_launch_dual_win(int group, const uint32_t* comb, const uint32_
                                   const uint32_t* tab2, const uint8_t* k2, size_t k2_stride, int count, uint32_t* out_pts,
                                   hipStream_t s) {
   if (count <= 0) return 0;
+  // with a comb the generator takes the first table's place: LDS holds the comb's 9 rows of recoded scalar + one table's 10
+  // (DW_K_ROWS = 20); a comb AND two tables would write rows 9..28
+  if (comb != nullptr && tab1 != nullptr) return (int)hipErrorInvalidValue;
   const size_t lds = ((comb != nullptr ? (size_t)ec_comb_words(group) : 0) + (size_t)DW_K_ROWS * DW_THREADS) * 4;
   const dim3 grid((count + DW_THREADS - 1) / DW_THREADS);
   if (group == 1)

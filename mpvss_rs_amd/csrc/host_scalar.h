@@ -181,15 +181,31 @@ inline void to_bytes(uint8_t* b, const uint64_t* a, bool big_endian) {
     for (int k = 0; k < 8; ++k) b[big_endian ? N * 8 - 1 - (8 * i + k) : 8 * i + k] = (uint8_t)(a[i] >> (8 * k));
 }
 
+// run fn(k) for k in [0, nt): nt - 1 helper threads and the caller.  Every caller of this sits under an extern "C" entry
+// point, so a thread that cannot be created (EAGAIN, a cgroup pids limit: std::system_error) must not unwind through the
+// C ABI or past a joinable std::thread (std::terminate) -- the indices that found no thread run on the caller instead.
+template <class Fn>
+inline void parallel_indices(unsigned nt, Fn fn) {
+  if (nt < 1) nt = 1;
+  std::vector<std::thread> pool;
+  unsigned started = 0;
+  try {
+    pool.reserve(nt);
+    for (; started + 1 < nt; ++started) pool.emplace_back(fn, started);
+  } catch (...) {
+  }
+  for (unsigned k = started; k < nt; ++k) fn(k);
+  for (auto& t : pool) t.join();
+}
+
 // run fn(lo, hi) over [0, n) on up to `threads` host threads
 template <class Fn>
 inline void parallel_for(size_t n, int threads, Fn fn) {
   if (threads < 1) threads = 1;
   const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
   if (threads == 1 || n < 256) { fn((size_t)0, n); return; }
-  std::vector<std::thread> pool;
-  for (size_t lo = 0; lo < n; lo += per) pool.emplace_back(fn, lo, lo + per < n ? lo + per : n);
-  for (auto& t : pool) t.join();
+  const unsigned parts = (unsigned)((n + per - 1) / per);
+  parallel_indices(parts, [&](unsigned k) { const size_t lo = (size_t)k * per; fn(lo, lo + per < n ? lo + per : n); });
 }
 
 }  // namespace hsc

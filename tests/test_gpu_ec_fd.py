@@ -104,3 +104,45 @@ def test_quad_lane_addition_against_the_one_lane_formulas(tmp_path):
     for group in (1, 2, 3):       # secp256k1 by quads, ristretto255 by quads, secp256k1 by eight lanes
         out = subprocess.run([exe, str(group), str(path), str(len(rows))], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and out.stdout.startswith("bad 0"), (group, out.stdout[:600], out.stderr[-600:])
+
+
+NOMEM_CODE = r'''
+import os, sys, random, hashlib
+sys.path.insert(0, %r)
+from mpvss_rs_amd import Engine, capi
+eng = Engine(0)
+for gid, sb in ((capi.GROUP_SECP256K1, "big"), (capi.GROUP_RISTRETTO255, "little")):
+    rng = random.Random(gid)
+    n, t = 4200, 20
+    sc = lambda: rng.randrange(1, 2**250).to_bytes(32, sb)
+    pk = eng.ec_batch_exp_generator(gid, b"".join(sc() for _ in range(n)))
+    coeffs = b"".join(sc() for _ in range(t))
+    cm = eng.ec_batch_exp_generator(gid, coeffs)
+    pos = list(range(3, 3 + n))
+    box = eng.ec_deal(gid, coeffs, pos, pk, b"".join(sc() for _ in range(n)))
+    one = eng.ec_verify_distribution(gid, cm, pos, pk, box["Y"], box["responses"], box["challenge"], dump=True)
+    assert one["verdict"] and one["digest"] == box["digest"] and one["X"] == box["X"], "lone box"
+    b = dict(commitments=cm, positions=pos, pubkeys=pk, shares=box["Y"], responses=box["responses"], challenge=box["challenge"])
+    bad = dict(b, responses=bytes([box["responses"][0] ^ 1]) + box["responses"][1:])
+    res = eng.ec_verify_many(gid, [b, bad, b, b], depth=4, hash_threads=2)
+    assert [v for v, _ in res] == [True, False, True, True] and all(d == box["digest"] for v, d in res if v), "batched boxes"
+    print(hashlib.sha256(one["X"]).hexdigest())
+assert "hipMalloc" not in eng.last_error() and "memory" not in eng.last_error().lower(), eng.last_error()
+'''
+
+
+def test_optional_buffers_that_cannot_be_allocated_cost_speed_not_the_call():
+    """ADVICE r4 (medium): the hand-over space of the quad-lane pipelines (177 MB at n = 65536, up to 4 GB per slot) and the seeds'
+    window tables are OPTIONAL -- without them the one-workgroup-per-chain kernels run.  MPVSS_TEST_OPTIONAL_NOMEM=1 makes every such
+    allocation fail through hipMalloc itself, so HIP's sticky last error is really set; before the fix the next launcher's
+    `return hipGetLastError()` turned it into MPVSS_E_DEVICE for the whole call.  Same X as Horner, same verdicts and digests, rc OK,
+    nothing recorded as the context's last error: X alone, a lone box, and boxes whose X paths are batched (xb.hand)."""
+    env = {"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "0", "MPVSS_EC_FD_QUAD": "2", "MPVSS_TEST_OPTIONAL_NOMEM": "1"}
+    assert run(env) == horner()
+    out = {}
+    for nomem in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", NOMEM_CODE % ROOT], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, MPVSS_EC_FD_QUAD="2", MPVSS_TEST_OPTIONAL_NOMEM=nomem))
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[nomem] = r.stdout.split()
+    assert out["1"] == out["0"] and len(out["1"]) == 2
