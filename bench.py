@@ -1067,6 +1067,8 @@ def main():
     a2_launch_ms_overlapped = a2_ms / a2_n
     a2_one_box_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else None
     a2_launch_ms = alone_ms if alone_ms else (a2_one_box_ms if a2_one_box_ms else a2_launch_ms_overlapped)
+    if alone_ms or a2_one_box_ms:          # those launches cover all n shares; in the pipeline a box's a2 goes out in `a2_n` share ranges
+        shares_per_a2_launch = n
 
     # work accounting: Montgomery products the kernels execute per step on this rank (averaged over the timed boxes)
     wk = modp_work(n, t, positions, [bx.c for _, _, bx in results])

@@ -171,6 +171,13 @@ struct mpvss_ctx {
     EcWork ecw;
     double enqueue_ms = 0;         // host time spent enqueueing this block's GPU work
     hipEvent_t done = nullptr;
+    // kind 0, one box, one chunk: a2 = y^r Y^c is launched as `slices` consecutive share ranges, each followed by its own copy
+    // to the staging and an event; X, Y, a1 (the high-priority stream) are on the host at ev_xa1.  The absorbing thread then
+    // hashes range k while range k + 1 is still on the GPU (slice_end[k]: one past its last share).  0: not sliced.
+    static constexpr unsigned MAX_SLICES = 8;
+    unsigned slices = 0;
+    size_t slice_end[MAX_SLICES] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev_xa1 = nullptr, ev_slice[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     SpanSet spans;
     double kernel_ms[4] = {0, 0, 0, 0};
     Work work;
@@ -193,6 +200,7 @@ struct mpvss_ctx {
   // MPVSS_PIPELINED=1): a block then never takes the configuration meant for a call that has the GPU to itself, not even
   // the first ones of the run
   bool pipelined_hint = false;
+  int pipeline_depth = 0;        // boxes the running library pipeline keeps in flight (0: none running)
   bool busy_with_others() const { return pipelined_hint || NSLOT - free_top >= 2; }
   BlockSlot& head_slot() {
     if (ring[head % NSLOT] >= 0 || free_top == 0) return full_slot;
@@ -706,6 +714,9 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   for (auto& sl : ctx->slot) {
     if (sl.pin) (void)hipHostFree(sl.pin);
     if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.ev_xa1) (void)hipEventDestroy(sl.ev_xa1);
+    for (hipEvent_t e : sl.ev_slice)
+      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
   }
   delete ctx;
@@ -1348,6 +1359,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   sl.fd_used = false;
   sl.fd_chunks = 0;
   sl.enqueue_ms = 0;
+  sl.slices = 0;
   if (n == 0) {
     sl.busy = true;
     ctx->commit_head(sl);
@@ -1508,6 +1520,39 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           dsched = (const uint16_t*)ctx->w->csched.p;
         }
       }
+      // MPVSS_A2_SLICES (default 4; 1 = off): see the a2 launch below.  Only for a box that is ONE block of one chunk and is
+      // absorbed by a thread of the library's pipeline with other boxes in flight (pipelined_hint) -- a lone call gains nothing.
+      static const unsigned a2_slices = (unsigned)fd_env("MPVSS_A2_SLICES", 4);
+      static const size_t a2_slice_min = (size_t)fd_env("MPVSS_A2_SLICE_MIN", 8192);
+      unsigned nsl = 1;
+      if (a2_slices > 1 && a2_w6 && c_windows == 64 && !use_keys && off == 0 && cnt == n && ctx->pipelined_hint &&
+          ctx->pipeline_depth >= 4 && n >= 2 * a2_slice_min) {
+        // (d boxes in flight run d ranges at a time: the chip's 2048 a2 wave slots stay full while d >= the number of ranges)
+        nsl = (unsigned)std::min<size_t>(std::min<size_t>(a2_slices, mpvss_ctx::BlockSlot::MAX_SLICES), n / a2_slice_min);
+        nsl = std::min<unsigned>(nsl, (unsigned)ctx->pipeline_depth);
+        for (unsigned k = 0; k < nsl; ++k) {
+          sl.slice_end[k] = k + 1 == nsl ? n : ((n * (k + 1) / nsl) & ~(size_t)63);
+          if (!sl.ev_slice[k]) {
+            static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+            HIPCHK(ctx, hipEventCreateWithFlags(&sl.ev_slice[k], hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+          }
+        }
+        if (!sl.ev_xa1) {
+          static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
+          HIPCHK(ctx, hipEventCreateWithFlags(&sl.ev_xa1, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+        }
+      }
+      auto launch_gr = [&]() -> int {
+        if ((pair_mask() & 4) && comb_bits_of(ctx, cg) == 16)
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, (const uint8_t*)dr, (int)cnt, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
+                                                           ctx->pair_tables, ctx->stream));
+        else
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
+                                                               (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
+                                                               ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
+        return 0;
+      };
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
         // the schedule travels on THIS stream, ahead of a2; the a1 launch on the other stream waits for ev_gr, recorded below
@@ -1526,7 +1571,22 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, launch_table64(ctx, (const uint8_t*)dy, cnt, t1p));
-          TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
+          if (nsl > 1) {
+            // a2 in `nsl` launches over consecutive share ranges, each followed by ITS copy to the staging and an event: the
+            // absorbing thread hashes range k (X, Y, a1 are on the host by then -- the other stream has the priority, and g^r,
+            // which a1 waits for, went ahead of a2) while range k + 1 is on the GPU.  A wave of this kernel works for the same
+            // 36 ms whatever the grid, so a range costs nothing as long as other boxes fill the chip -- which is when this is used.
+            RET_IF(launch_gr());
+            for (unsigned k = 0; k < nsl; ++k) {
+              const size_t lo = k == 0 ? 0 : sl.slice_end[k - 1], hi = sl.slice_end[k];
+              TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p + lo * 4 * TABW, t2p + lo * TABW, (const uint8_t*)dr + lo * EB,
+                                                      (const uint8_t*)dchal, 0, dsched, hi - lo, da2 + lo * EB));
+              HIPCHK(ctx, hipMemcpyAsync(h2 + (off + lo) * EB, da2 + lo * EB, (hi - lo) * EB, hipMemcpyDeviceToHost, ctx->stream));
+              HIPCHK(ctx, hipEventRecord(sl.ev_slice[k], ctx->stream));
+            }
+          } else {
+            TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
+          }
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
@@ -1539,15 +1599,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           if (!mine) HIPCHK(ctx, hipEventCreateWithFlags(&mine, hipEventDisableTiming));
           HIPCHK(ctx, hipEventRecord(mine, ctx->stream));
         }
-        // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase
-        if ((pair_mask() & 4) && comb_bits_of(ctx, cg) == 16)
-          TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, (const uint8_t*)dr, (int)cnt, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
-                                                           ctx->pair_tables, ctx->stream));
-        else
-          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
-                                                               (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
-                                                               ctx->stream));
-        HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
+        // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase (ahead of a sliced a2)
+        if (nsl <= 1) RET_IF(launch_gr());
       }
       mark(2);
       RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
@@ -1574,6 +1627,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                                c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                                comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
+      if (nsl > 1) {      // X, Y, a1 leave as soon as a1 is done; a2 has left range by range on the other stream
+        HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(sl.ev_xa1, ctx->stream));
+        sl.slices = nsl;
+      }
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
     } else {
       // X_i                                                  participant.rs:423-434
@@ -1583,10 +1643,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
                        0, c_windows, cnt, da2));
     }
-    HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    if (sl.slices <= 1) {
+      HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (sl.work.fd_used) {     // the device's decision for this chunk (1 = forward differences held, 0 = fell back)
       sl.fd_used = true;
       if (sl.fd_chunks < FLAGS)
@@ -1650,6 +1712,7 @@ int verify_group_compute_locked(mpvss_ctx* ctx, int space, const mpvss_modp_box*
   sl.n = N;
   sl.nbox = (unsigned)B;
   sl.kind = 0;
+  sl.slices = 0;
   sl.check_positions = false;
   sl.fd_used = false;
   sl.fd_chunks = 0;
@@ -1853,14 +1916,39 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   }
   lk.unlock();
   const auto t_w0 = std::chrono::steady_clock::now();
-  const hipError_t e = hipEventSynchronize(sl.done);
-  const auto t_w1 = std::chrono::steady_clock::now();
-  ctx->gpu_done.fetch_add(1);
   const uint8_t* hX = (const uint8_t*)sl.pin;
   const uint8_t* hY = hX + n * EB;
   const uint8_t* h1 = hY + n * EB;
   const uint8_t* h2 = h1 + n * EB;
   bool positions_ok = true;
+  double sliced_hash_ms = 0;
+  size_t hashed = 0;                 // shares of a sliced block already in the transcript
+  mpvss::Sha256 tr_sl;
+  if (sl.slices > 1 && nbox == 1) {
+    // a2 arrives range by range (verify_block_compute_locked): hash range k while range k + 1 is still on the GPU
+    hipError_t es = hipEventSynchronize(sl.ev_xa1);
+    if (es == hipSuccess && sl.check_positions) {
+      const int64_t* pos = (const int64_t*)(h2 + n * EB);
+      for (size_t i = 0; i < n && positions_ok; ++i) positions_ok = pos[i] >= 0;
+    }
+    memcpy(&tr_sl, state, sizeof(tr_sl));
+    for (unsigned k = 0; k + 1 < sl.slices && es == hipSuccess && positions_ok; ++k) {     // (the last range after sl.done, below)
+      es = hipEventSynchronize(sl.ev_slice[k]);
+      if (es != hipSuccess) break;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (size_t i = hashed; i < sl.slice_end[k]; ++i) {
+        frame_update(tr_sl, hX + i * EB);
+        frame_update(tr_sl, hY + i * EB);
+        frame_update(tr_sl, h1 + i * EB);
+        frame_update(tr_sl, h2 + i * EB);
+      }
+      hashed = sl.slice_end[k];
+      sliced_hash_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+  const hipError_t e = hipEventSynchronize(sl.done);
+  const auto t_w1 = std::chrono::steady_clock::now();
+  ctx->gpu_done.fetch_add(1);
   if (e == hipSuccess) {
     if (sl.check_positions && nbox == 1) {
       const int64_t* pos = (const int64_t*)(h2 + n * EB);
@@ -1887,8 +1975,8 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
       }
     } else if (positions_ok) {
       mpvss::Sha256 tr;
-      memcpy(&tr, state, sizeof(tr));
-      for (size_t i = 0; i < n; ++i) {                     // dleq.rs:87-99, share order = array order
+      if (hashed > 0) memcpy(&tr, &tr_sl, sizeof(tr)); else memcpy(&tr, state, sizeof(tr));
+      for (size_t i = hashed; i < n; ++i) {                // dleq.rs:87-99, share order = array order
         frame_update(tr, hX + i * EB);
         frame_update(tr, hY + i * EB);
         frame_update(tr, h1 + i * EB);
@@ -1918,8 +2006,8 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   {
     mpvss_ctx::PipeStats& ps = ctx->pstats;
     ps.enqueue_ms += sl.enqueue_ms;
-    ps.wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count();
-    ps.hash_ms += std::chrono::duration<double, std::milli>(t_h1 - t_w1).count();
+    ps.wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count() - sliced_hash_ms;
+    ps.hash_ms += std::chrono::duration<double, std::milli>(t_h1 - t_w1).count() + sliced_hash_ms;
     for (int k = 0; k < 4; ++k) {
       ps.kernel_ms[k] += ctx->kernel_ms[k];
       ps.kernel_launches[k] += (unsigned long long)ctx->kernel_launches[k];
@@ -2109,10 +2197,14 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   if (depth < 1) depth = 1;
   if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
   struct Hint {
-    mpvss_ctx* c; bool was;
-    Hint(mpvss_ctx* c_, bool on) : c(c_) { std::lock_guard<std::mutex> lk(c->mu); was = c->pipelined_hint; if (on) c->pipelined_hint = true; }
-    ~Hint() { std::lock_guard<std::mutex> lk(c->mu); c->pipelined_hint = was; }
-  } hint(ctx, count > 2 && depth > 1);
+    mpvss_ctx* c; bool was; int was_depth;
+    Hint(mpvss_ctx* c_, bool on, int d) : c(c_) {
+      std::lock_guard<std::mutex> lk(c->mu);
+      was = c->pipelined_hint; was_depth = c->pipeline_depth;
+      if (on) { c->pipelined_hint = true; c->pipeline_depth = d; }
+    }
+    ~Hint() { std::lock_guard<std::mutex> lk(c->mu); c->pipelined_hint = was; c->pipeline_depth = was_depth; }
+  } hint(ctx, count > 2 && depth > 1, depth);
   struct Ent { size_t box; unsigned parts; bool bad; unsigned nbox; };   // one entry per enqueued block; parts: blocks of its box (first entry); nbox > 1: a group block of boxes box .. box+nbox-1
   struct Shared {
     std::mutex m;
@@ -2689,6 +2781,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   }
   sl.n = n;
   sl.kind = 0;                 // absorbed like a verifier's block: same staging layout, same hash
+  sl.slices = 0;
   sl.nbox = 1;
   sl.check_positions = false;
   sl.fd_used = false;

@@ -51,7 +51,10 @@ def poly(coeffs, i):
 
 
 @pytest.fixture(scope="module")
-def c5(engine):
+def c5():
+    # engines of this module's own, closed when their work is done: a block slot of this shape is several GB, and the eight ranks of
+    # the last test need the HBM (the session's engine keeps what it once allocated)
+    engine = Engine(0)
     rng = random.Random(0xC5)
     coeffs = [rng.randrange(ORDER) for _ in range(T)]
     priv = below_q(b"".join(rng.randbytes(1 << 24) for _ in range(N * EB >> 24)))      # (randbytes cannot make 256 MB at once)
@@ -60,6 +63,7 @@ def c5(engine):
     pk = engine.batch_exp_fixed_base(fx(2), priv)
     cm = engine.batch_exp_fixed_base(fx(4), b"".join(map(fx, coeffs)))
     box = engine.deal(b"".join(map(fx, coeffs)), pos, pk, wit)
+    engine.close()
     return {"coeffs": coeffs, "wit": wit, "pos": pos, "pk": pk, "cm": cm, "box": box}
 
 
@@ -88,9 +92,10 @@ def test_the_dealers_box_against_python_integers_and_hashlib(c5):
         assert sl(box["responses"], i, i + 1) == fx((w - p * c) % ORDER), i                   # dleq.rs:42-50
 
 
-def test_one_call_and_eight_chained_blocks_agree_with_the_dealer_and_the_oracle(engine, c5):
+def test_one_call_and_eight_chained_blocks_agree_with_the_dealer_and_the_oracle(c5):
     box, pk, cm, pos = c5["box"], c5["pk"], c5["cm"], c5["pos"]
     Y, r, c = box["Y"], box["responses"], box["challenge"]
+    engine = Engine(0)
     blocks0, fallbacks0 = engine.fd_stats()
     # (a) one call, as the crate's verify_distribution_shares would make it
     one = engine.verify_distribution(cm, pos, pk, Y, r, c)
@@ -110,6 +115,7 @@ def test_one_call_and_eight_chained_blocks_agree_with_the_dealer_and_the_oracle(
     assert capi.transcript_verdict(state, c) == (True, box["digest"])
     blocks1, fallbacks1 = engine.fd_stats()
     assert blocks1 > blocks0 and fallbacks1 == fallbacks0, "a forward-difference pipeline gave up"
+    engine.close()
     # the oracle on sampled shares: the verifier's X / a1 / a2 equal the dealer's everywhere (above), so the dealer's arrays are compared
     from modp_ref import ModpRef
     ref = ModpRef()
@@ -181,7 +187,7 @@ def test_eight_in_process_ranks_chained_and_one_flipped_bit_per_block(c5):
             verdicts = (C.c_int * 4)()
             digests = (C.c_uint8 * 128)()
             f0 = eng.fd_stats()
-            rc = eng.lib.mpvss_modp_verify_many_chained(eng.ctx, capi.MPVSS_HOST, arr, 4, 2, 2, None, c_in, c_out, None, verdicts,
+            rc = eng.lib.mpvss_modp_verify_many_chained(eng.ctx, capi.MPVSS_HOST, arr, 4, 1, 2, None, c_in, c_out, None, verdicts,
                                                         C.cast(digests, C.c_void_p))
             eng._check(rc, "verify_many_chained")
             f1 = eng.fd_stats()

@@ -308,3 +308,47 @@ print("parts ok")
     env = dict(os.environ, MPVSS_TAIL_PARTS="4", MPVSS_TAIL_MIN_PART="16")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "parts ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_a2_in_share_ranges_hashed_while_the_next_range_computes():
+    """With several boxes in flight mpvss_modp_verify_many launches a box's a2 = y^r Y^c as MPVSS_A2_SLICES consecutive share ranges,
+    each followed by its own copy and event, and the absorbing thread hashes range k while range k + 1 is on the GPU (round 5: the
+    K = 20 tail).  Same verdicts and digests as one unsliced verify_distribution per box: honest boxes of two shapes (so that they are
+    not grouped into one block; 4200 shares: ranges end at 1024 / 2048 / 3136 / 4200), one bit flipped in the first, a middle and the
+    last range, a negative position (malformed: verdict False, zero digest), few and many threads.  Child process: the switches are
+    read once."""
+    code = r"""
+import sys, random
+sys.path.insert(0, %r)
+from mpvss_rs_amd import Engine
+EB = 256
+eng = Engine(0)
+rng = random.Random(11)
+def make(n, t):
+    sc = lambda k: b"".join(rng.randrange(1, 2**2040).to_bytes(EB, "big") for _ in range(k))
+    coeffs, pos = sc(t), list(range(7, 7 + n))
+    pk = eng.batch_exp_fixed_base((2).to_bytes(EB, "big"), sc(n))
+    cm = eng.batch_exp_fixed_base((4).to_bytes(EB, "big"), coeffs)
+    d = eng.deal(coeffs, pos, pk, sc(n))
+    return dict(commitments=cm, positions=pos, pubkeys=pk, shares=d["Y"], responses=d["responses"], challenge=d["challenge"]), d["digest"]
+A, dA = make(4200, 16)
+B, dB = make(4352, 20)
+def tamper(b, share, field="responses"):
+    x = bytearray(b[field]); x[share * EB + 100] ^= 1; return dict(b, **{field: bytes(x)})
+one = lambda b: (lambda r: (r["verdict"], r["digest"]))(eng.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
+assert one(A) == (True, dA) and one(B) == (True, dB)
+boxes = [A, B, tamper(A, 3), B, tamper(A, 2500), tamper(B, 4351, "shares"), A, tamper(B, 1024), A, B]
+want = [one(b) for b in boxes]
+assert [w[0] for w in want] == [True, True, False, True, False, False, True, False, True, True]
+for depth, threads in ((4, 1), (8, 4), (10, 8)):
+    assert eng.verify_many(boxes, depth=depth, hash_threads=threads) == want, (depth, threads)
+neg = dict(A, positions=A["positions"][:4000] + [-5] + A["positions"][4001:])
+assert eng.verify_many([A, B, neg, B, A], depth=5, hash_threads=2) == [(True, dA), (True, dB), (False, bytes(32)), (True, dB), (True, dA)]
+assert eng.blocks_in_flight() == (0, 0) and eng.fd_stats()[1] == 0
+st = eng.pipeline_stats()
+assert st["kernel_launches"][3] >= 4 * 30, st       # the a2 launches really went out in ranges
+print("slices ok")
+""" % ROOT
+    env = dict(os.environ, MPVSS_A2_SLICES="4", MPVSS_A2_SLICE_MIN="512")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "slices ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -16,17 +16,27 @@ STEPS=20; REPS=1; STEADY=0
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do
   case "$1" in -k) STEPS=$2; shift 2;; -r) REPS=$2; shift 2;; -s) STEADY=$2; shift 2;; *) echo "bad option $1"; exit 2;; esac
 done
+# variants are collected first and run INTERLEAVED (rep 1 of every variant, then rep 2, ...): the boxes of the pool drift by a few
+# per cent over minutes, which a block of runs per variant would read as a difference between variants
+NAMES=(); ENVSTR=()
 while [ $# -gt 0 ]; do
   shift                      # the "--"
-  NAME=$1; shift
-  ENVS=()
-  while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
-  for rep in $(seq $REPS); do
-    env "${ENVS[@]}" python3 bench.py --gpus 1 --steps $STEPS --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 \
-        --host-boxes 0 --config-boxes 0 --lone-boxes 1 --steady-steps $STEADY 2>/dev/null | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
+  NAMES+=("$1"); shift
+  E=""
+  while [ $# -gt 0 ] && [ "$1" != "--" ]; do E="$E $1"; shift; done
+  ENVSTR+=("$E")
+done
+for rep in $(seq $REPS); do
+  for v in "${!NAMES[@]}"; do
+    NAME=${NAMES[$v]}
+    # shellcheck disable=SC2086
+    env ${ENVSTR[$v]} MPVSS_BENCH_DETAIL=/tmp/ab_detail.json python3 bench.py --gpus 1 --steps $STEPS --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 \
+        --host-boxes 0 --config-boxes 0 --lone-boxes 1 --steady-steps $STEADY >/dev/null 2>/dev/null
+    python3 -c "
+import json
+d = json.load(open('/tmp/ab_detail.json'))
 print('$NAME', round(d['value']), round(d['ms_per_step'], 2), round(d['roofline']['kernel_ms'], 1), 'steady', round(d['value_steady_state'] or 0),
-      {k: round(v) for k, v in d['compute']['kernel_ms_sums'].items() if k != 'note'})" | tee -a "$OUT"
+      {k: round(v) for k, v in d['compute']['kernel_ms_sums'].items() if k != 'note'},
+      {k: round(v, 1) for k, v in d['host']['per_box_ms'].items()})" | tee -a "$OUT"
   done
 done
