@@ -407,18 +407,31 @@ class Engine:
         self._check(self.lib.mpvss_modp_deal_compute(self.ctx, pc, len(coeffs) // EB, positions_dev_ptr, pubkeys_dev_ptr,
                                                      witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None), "deal_compute")
 
-    def deal(self, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes) -> dict:
-        """the dealer's whole box from host buffers in one call: X, Y, a1, a2, digest, challenge, responses"""
+    def deal_call(self, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes):
+        """(call, outputs) for mpvss_modp_deal over ctypes buffers made ONCE: `call()` is the library call alone -- what a compiled
+        caller (the Rust crate's distribute_secret over its own Vec<u8>s) pays per box --, `outputs()` the dict of deal()."""
         n = len(positions)
         pos = (C.c_int64 * max(n, 1))(*positions)
         k = [_buf(b) for b in (coeffs, pubkeys, witnesses)]
         outs = [_out(n * EB) for _ in range(5)]
         kd, pd = _out(32)
         kc, pc = _out(EB)
-        self._check(self.lib.mpvss_modp_deal(self.ctx, k[0][1], len(coeffs) // EB, C.cast(pos, C.c_void_p), k[1][1], k[2][1], n,
-                                             outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd, pc, outs[4][1]), "deal")
-        X, Y, a1, a2, r = (bytes(o[0])[: n * EB] for o in outs)
-        return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32], "challenge": bytes(kc)[:EB], "responses": r}
+        t = len(coeffs) // EB
+
+        def call():
+            self._check(self.lib.mpvss_modp_deal(self.ctx, k[0][1], t, C.cast(pos, C.c_void_p), k[1][1], k[2][1], n,
+                                                 outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd, pc, outs[4][1]), "deal")
+
+        def outputs():
+            X, Y, a1, a2, r = (bytes(o[0])[: n * EB] for o in outs)
+            return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32], "challenge": bytes(kc)[:EB], "responses": r}
+        return call, outputs
+
+    def deal(self, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes) -> dict:
+        """the dealer's whole box from host buffers in one call: X, Y, a1, a2, digest, challenge, responses"""
+        call, outputs = self.deal_call(coeffs, positions, pubkeys, witnesses)
+        call()
+        return outputs()
 
     def dleq_responses_device(self, w_dev_ptr: int, alpha_dev_ptr: int, c: bytes, n: int, out_dev_ptr: int) -> None:
         """r[i] = w[i] - alpha[i] c mod (q-1), everything but the shared c in HBM"""
@@ -647,8 +660,8 @@ class Engine:
         self._check(self.lib.mpvss_ec_deal_compute(self.ctx, group, pc, len(coeffs) // 32, positions_dev_ptr, pubkeys_dev_ptr,
                                                    witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None), "ec_deal_compute")
 
-    def ec_deal(self, group: int, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes) -> dict:
-        """a curve group's whole box from host buffers in one call: X, Y, a1, a2, digest, challenge, responses"""
+    def ec_deal_call(self, group: int, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes):
+        """(call, outputs) for mpvss_ec_deal over ctypes buffers made once (see deal_call)"""
         n = len(positions)
         L = 33 if group == GROUP_SECP256K1 else 32
         pos = (C.c_int64 * max(n, 1))(*positions)
@@ -657,10 +670,23 @@ class Engine:
         kr, pr = _out(n * 32)
         kd, pd = _out(32)
         kc, pc = _out(32)
-        self._check(self.lib.mpvss_ec_deal(self.ctx, group, k[0][1], len(coeffs) // 32, pos, k[1][1], k[2][1], n,
-                                           outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd, pc, pr), "ec_deal")
-        X, Y, a1, a2 = (bytes(o[0])[: n * L] for o in outs)
-        return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32], "challenge": bytes(kc)[:32], "responses": bytes(kr)[: n * 32]}
+        t = len(coeffs) // 32
+
+        def call():
+            self._check(self.lib.mpvss_ec_deal(self.ctx, group, k[0][1], t, pos, k[1][1], k[2][1], n,
+                                               outs[0][1], outs[1][1], outs[2][1], outs[3][1], pd, pc, pr), "ec_deal")
+
+        def outputs():
+            X, Y, a1, a2 = (bytes(o[0])[: n * L] for o in outs)
+            return {"X": X, "Y": Y, "a1": a1, "a2": a2, "digest": bytes(kd)[:32], "challenge": bytes(kc)[:32],
+                    "responses": bytes(kr)[: n * 32]}
+        return call, outputs
+
+    def ec_deal(self, group: int, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes) -> dict:
+        """a curve group's whole box from host buffers in one call: X, Y, a1, a2, digest, challenge, responses"""
+        call, outputs = self.ec_deal_call(group, coeffs, positions, pubkeys, witnesses)
+        call()
+        return outputs()
 
     def ec_distribute_absorb(self, group: int, state: bytes, n: int):
         """(state, X, Y, a1, a2) of the oldest dealer block"""

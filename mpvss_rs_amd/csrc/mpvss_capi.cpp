@@ -1520,9 +1520,9 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           dsched = (const uint16_t*)ctx->w->csched.p;
         }
       }
-      // MPVSS_A2_SLICES (default 4; 1 = off): see the a2 launch below.  Only for a box that is ONE block of one chunk and is
+      // MPVSS_A2_SLICES (default 1 = off: measured, profiles/r05_a2_slices_ab.txt -- 4 ranges cost 2-3 % of steady-state throughput and give nothing back at K = 20): see the a2 launch below.  Only for a box that is ONE block of one chunk and is
       // absorbed by a thread of the library's pipeline with other boxes in flight (pipelined_hint) -- a lone call gains nothing.
-      static const unsigned a2_slices = (unsigned)fd_env("MPVSS_A2_SLICES", 4);
+      static const unsigned a2_slices = (unsigned)fd_env("MPVSS_A2_SLICES", 1);
       static const size_t a2_slice_min = (size_t)fd_env("MPVSS_A2_SLICE_MIN", 8192);
       unsigned nsl = 1;
       if (a2_slices > 1 && a2_w6 && c_windows == 64 && !use_keys && off == 0 && cnt == n && ctx->pipelined_hint &&
