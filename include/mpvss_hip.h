@@ -497,7 +497,8 @@ double mpvss_last_kernel_ms(const mpvss_ctx* ctx, int kernel_id);
 int mpvss_last_kernel_launches(const mpvss_ctx* ctx, int kernel_id);
 /* Absorbed verify blocks whose X_i went through the forward-difference path, and how many of those fell back to
  * Horner's rule on the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up):
- * same results either way, the fall-back is just slower -- a counter for operators and tests. */
+ * same results either way, the fall-back is just slower -- a counter for operators and tests.  The curve groups' blocks whose
+ * X path ran behind a device gate (stage pipelines, device-resident positions) count the same way. */
 int mpvss_modp_fd_stats(mpvss_ctx* ctx, unsigned long long* blocks, unsigned long long* fallbacks);
 
 /* Host-side accounting of the block pipeline (verify_block_compute / _absorb / verify_many), sums over the blocks

@@ -61,7 +61,8 @@ for name in ("secp256k1", "ristretto255"):
         th = threading.Thread(target=hammer)
         th.start()
         time.sleep(1.0)
-    times = []
+    times, on_gpu = [], []
+    fd0 = eng.fd_stats()
     for k in range(N):
         verdict = C.c_int(0)
         dg = (C.c_uint8 * 32)()
@@ -70,13 +71,21 @@ for name in ("secp256k1", "ristretto255"):
                                                         d_Y.data_ptr(), d_r.data_ptr(), n, C.cast(chal, C.c_void_p), C.byref(verdict),
                                                         C.cast(dg, C.c_void_p), None, None, None), "ec_verify_distribution")
         times.append(time.perf_counter() - t0)
+        st_ = eng.pipeline_stats(reset=True)
+        on_gpu.append(st_["enqueue_ms"] + st_["wait_ms"])          # the box on the GPU: first launch to last copy
         assert verdict.value == 1 and bytes(dg) == d["digest"], (name, k)
     if LOAD:
         stop[0] = True
         th.join()
-    ts = sorted(times)
+    ts, gs = sorted(times), sorted(on_gpu)
+    fd1 = eng.fd_stats()
     print(f"{name}: {N} boxes alone, every digest right; call wall ms min {ts[0] * 1e3:.2f} median {ts[N // 2] * 1e3:.2f} "
-          f"p99 {ts[int(N * 0.99)] * 1e3:.2f} max {ts[-1] * 1e3:.2f}" + (f"; {loaded[0]} boxes verified by the second context meanwhile" if LOAD else ""))
+          f"p99 {ts[int(N * 0.99)] * 1e3:.2f} max {ts[-1] * 1e3:.2f}; box on the GPU ms median {gs[N // 2]:.2f} p99 {gs[int(N * 0.99)]:.2f} "
+          f"max {gs[-1]:.2f}; X paths gated {fd1[0] - fd0[0]}, FELL BACK to Horner {fd1[1] - fd0[1]}"
+          + (f"; {loaded[0]} boxes verified by the second context meanwhile" if LOAD else ""))
+    slow = [(k, round(times[k] * 1e3, 1), round(on_gpu[k], 1)) for k in range(N) if times[k] > 10 * ts[N // 2]]
+    if slow:
+        print(f"  calls slower than 10 x median (index, wall ms, on-GPU ms): {slow[:20]}")
 eng.close()
 if eng2:
     eng2.close()
