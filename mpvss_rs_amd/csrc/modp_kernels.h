@@ -115,6 +115,11 @@ int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupanc
 int modp_launch_fd_step_pair_boxes(const uint32_t* state, const uint32_t* state_back, size_t box_state, int chains, int t, int w0,
                                    int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand, size_t box_hand, int boxes,
                                    int* gate, int inject_fault, const void* cs, const void* pair_tables, hipStream_t s);
+/* the same stepping as one wide launch per anti-diagonal of the (stage, block of tile_steps steps) grid: no wave waits for another,
+ * no time-out; `state` / `state_back` are updated in place (modp_pair_kernels.hip: k_modp_fd_step_pair_tile) */
+int modp_launch_fd_step_pair_tiled_boxes(uint32_t* state, uint32_t* state_back, size_t box_state, int chains, int t, int w0, int chain_len,
+                                         int count, uint32_t* x_m, size_t box_xm, uint32_t* hand, size_t box_hand, int boxes,
+                                         const int* gate, int tile_steps, const void* cs, const void* pair_tables, hipStream_t s);
 /* scalar ring Z/(q-1) on the device (constants of q' = (q-1)/2: modq_consts_upload) */
 int modq_consts_upload(void** dev_consts);
 int modq_launch_poly_eval(const uint32_t* coef, int t, const int64_t* positions, int count, int par_even, int par_odd, uint8_t* out_be,

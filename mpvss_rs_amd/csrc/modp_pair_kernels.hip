@@ -784,6 +784,98 @@ k_modp_fd_step_pair(const u32* __restrict__ state, const u32* __restrict__ state
 }
 
 // ---------------------------------------------------------------------------------------
+// The same stepping as a sequence of WIDE launches in which no wave ever waits for another (round 5).  The cell (level k,
+// step s) needs (k, s-1) and (k+1, s-1) only, so the (stage, block of `tile_steps` steps) grid can be walked by anti-diagonals:
+// tile (stage sidx, block b) runs in launch number sidx + b, after tile (sidx - 1, b) -- the stage above, which handed down the
+// values of its steps [b M, (b + 1) M) -- and tile (sidx, b - 1), its own state.  The kernel boundary orders everything: plain
+// stores, no validity tags, no spinning, no time-out, no residency requirement; a wave occupies its slot exactly for the
+// tile_steps products it computes, where a persistent stage occupies it for the whole chain and spins whenever the stage above is
+// late (which, with ten boxes in flight, is most of the time: 512 waves of 252 registers per box for 93-240 ms).
+// The handed value of the NEXT step comes in by LDS-DMA under the current product (two in-slots), so the wave never sees the
+// load's latency either.  State lives in the `state` arrays between tiles (level k of a chain at its step b M); entry 0 of a
+// stage's hand-over area holds its bottom level's INITIAL value (the persistent kernel reads that from `state`, which is
+// overwritten here).  Same hand-over layout and outputs as k_modp_fd_step_pair.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct FdTileShared {
+  Tables tb;
+  __attribute__((aligned(16))) u32 slots[32 * SLOTW];
+  __attribute__((aligned(16))) u32 inslot[2][SLOTW];
+  __attribute__((aligned(16))) u32 oneslot[SLOTW];
+  u32 junk[L];
+};
+// 72 words at `src` -> `dst` (LDS) without registers: lanes 0 .. 17 move 16 bytes each
+__device__ __forceinline__ void fd_tile_fetch(u32* dst, const u32* __restrict__ src, const PairLane& pl) {
+  if (pl.lane < 18)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(src + 4 * pl.lane),
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(64) PAIR_OCC_ATTR
+k_modp_fd_step_pair_tile(u32* __restrict__ state, u32* __restrict__ state_back, int chains, int t, int tpad, int w0, int chain_len,
+                         int count, u32* __restrict__ x_m, u32* __restrict__ hand, const int* __restrict__ gate, int diag,
+                         int tile_steps, const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab, size_t box_state,
+                         size_t box_xm, size_t box_hand) {
+  __shared__ FdTileShared sh;
+  if (*gate != 1) return;
+  const int stages = tpad / 32;
+  const int sidx = blockIdx.x / (2 * chains);                       // 0 = the top levels
+  const int dir = (blockIdx.x / chains) & 1;
+  const int chain = blockIdx.x % chains;
+  const int kbase = tpad - 32 * (sidx + 1);
+  if (kbase >= t || (dir == 1 && w0 == 0)) return;
+  const int s_first = (tpad - t) / 32;                              // stages above this one hold no level
+  const int b = diag - (sidx - s_first);
+  const int steps = dir == 0 ? chain_len - 1 - w0 : w0 + t - 1;
+  if (b < 0 || b * tile_steps + 1 > steps) return;
+  const int step_lo = b * tile_steps + 1;
+  const int step_hi = step_lo + tile_steps - 1 < steps ? step_lo + tile_steps - 1 : steps;
+  state += blockIdx.y * box_state;
+  state_back += blockIdx.y * box_state;
+  x_m += blockIdx.y * box_xm;
+  hand += blockIdx.y * box_hand;
+  tables_to_lds(&sh.tb, gtab);
+  const PairLane pl = make_pair_lane();
+  const int j = (int)(pl.lane & 31);
+  const int hand_len = chain_len + t;
+  const int k = kbase + j;
+  const bool has_up = kbase + 32 < t;
+  const bool has_down = kbase > 0;
+  u32* slot = sh.slots + j * SLOTW;
+  const bool reader = j == 31;
+  const size_t lane_area = ((size_t)dir * chains + chain) * stages;
+  u32* mine = hand + (lane_area + sidx) * (size_t)hand_len * L;
+  const u32* up = hand + (lane_area + sidx - 1) * (size_t)hand_len * L;
+  u32* st = (dir == 0 ? state : state_back) + (size_t)chain * t * L;
+  u32 D[LP];
+  if (k < t) load_pair_limbs(D, st + (size_t)k * L, pl); else load_pair_limbs(D, cs->one_m, pl);
+  if (j == 0) slot_fill_pair(sh.oneslot, cs->one_m, pl);
+  if (b == 0 && has_down && j == 0) fd_publish(mine, D, pl, 0);                        // entry 0: the initial value
+  if (has_up) fd_tile_fetch(sh.inslot[step_lo & 1], up + (size_t)(step_lo - 1) * L, pl);
+  const bool writer = kbase == 0 && j == 0;
+  for (int step = step_lo; step <= step_hi; ++step) {
+    slot_store_pair(slot, D, pl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this step's handed value has landed
+    __builtin_amdgcn_wave_barrier();
+    if (has_up && step < step_hi) fd_tile_fetch(sh.inslot[(step + 1) & 1], up + (size_t)step * L, pl);     // the next one under this product
+    const u32* bsrc = (k + 1 < t) ? (reader ? sh.inslot[step & 1] : slot + SLOTW) : sh.oneslot;
+    u64 T[LP];
+    phase_a<false>(T, D, slot, sh.junk, pl, bsrc);
+    u32 r[LP];
+    reduce(r, T, slot, &sh.tb, pl);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < LP; ++i) D[i] = r[i];
+    if (has_down && j == 0) fd_publish(mine + (size_t)step * L, D, pl, 0);
+    const int jj = dir == 0 ? w0 + step : w0 + t - 1 - step;
+    const size_t idx = (size_t)chain + (size_t)chains * jj;
+    if (writer && step >= t && idx < (size_t)count) store_pair_limbs(x_m + idx * L, D, pl);
+  }
+  if (k < t) store_pair_limbs(st + (size_t)k * L, D, pl);            // this level at step step_hi: where the next tile starts
+}
+
+// ---------------------------------------------------------------------------------------
 extern "C" int modp_pair_tables_upload(void** dev_tables) {
   static_assert(sizeof(MM_GT1) == sizeof(Tables::gt1) && sizeof(MM_GT2) == sizeof(Tables::gt2) && sizeof(MM_C1) == sizeof(Tables::c1) &&
                     sizeof(MM_C2) == sizeof(Tables::c2), "generated tables do not match bn_pair.h");
@@ -863,5 +955,24 @@ extern "C" int modp_launch_fd_step_pair_boxes(const uint32_t* state, const uint3
   hipLaunchKernelGGL(k_modp_fd_step_pair, dim3(2 * chains * (tpad / 32), boxes), dim3(64), 0, s, state, state_back, chains, t, tpad, w0,
                      chain_len, count, x_m, hand, gate, inject_fault, (const ModpConsts*)cs, (const Tables*)pair_tables, box_state,
                      box_xm, box_hand);
+  return (int)hipGetLastError();
+}
+
+// the tiled form of the same stepping: one launch per anti-diagonal of the (stage, block of tile_steps steps) grid
+extern "C" int modp_launch_fd_step_pair_tiled_boxes(uint32_t* state, uint32_t* state_back, size_t box_state, int chains, int t, int w0,
+                                                    int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand,
+                                                    size_t box_hand, int boxes, const int* gate, int tile_steps, const void* cs,
+                                                    const void* pair_tables, hipStream_t s) {
+  const int tpad = modp_fd_tpad_pair(t);
+  const int stages_used = tpad / 32 - (tpad - t) / 32;
+  const int steps_f = chain_len - 1 - w0, steps_b = w0 > 0 ? w0 + t - 1 : 0;
+  const int steps = steps_f > steps_b ? steps_f : steps_b;
+  if (steps <= 0) return 0;
+  if (tile_steps < 1) tile_steps = 1;
+  const int nblk = (steps + tile_steps - 1) / tile_steps;
+  for (int diag = 0; diag < stages_used + nblk - 1; ++diag)
+    hipLaunchKernelGGL(k_modp_fd_step_pair_tile, dim3(2 * chains * (tpad / 32), boxes), dim3(64), 0, s, state, state_back, chains, t, tpad,
+                       w0, chain_len, count, x_m, hand, gate, diag, tile_steps, (const ModpConsts*)cs, (const Tables*)pair_tables, box_state,
+                       box_xm, box_hand);
   return (int)hipGetLastError();
 }

@@ -954,6 +954,14 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   const bool step_pair = (pair_mask() & 32) != 0 && t >= pair_min_t;
   auto launch_step = [&](const uint32_t* sf, const uint32_t* sb, size_t bx_st, int chains, int tt, int w0_, int clen, int cnt_, uint32_t* xm_,
                          size_t bx_xm_, uint32_t* hand_, size_t bx_hand_, int fault) -> int {
+    // MPVSS_FD_TILE (with the pair-layout stepping): the stepping as wide launches over the anti-diagonals of the (stage, block of
+    // MPVSS_FD_TILE_STEPS steps) grid instead of a pipeline of persistent stages -- no wave waits for another one.  0: never,
+    // 1: when other blocks are in flight (a lone call keeps the pipeline: its latency is shorter), 2: always.
+    static const int tile_mode = fd_env("MPVSS_FD_TILE", 0), tile_steps = fd_env("MPVSS_FD_TILE_STEPS", 64);
+    if (step_pair && fault == 0 && (tile_mode >= 2 || (tile_mode == 1 && ctx->busy_with_others())))
+      return modp_launch_fd_step_pair_tiled_boxes(const_cast<uint32_t*>(sf), const_cast<uint32_t*>(sb), bx_st, chains, tt, w0_, clen, cnt_, xm_,
+                                                  bx_xm_, hand_, bx_hand_, B, (const int*)ctx->w->fd_flag.p, tile_steps, ctx->consts,
+                                                  ctx->pair_tables, ctx->stream);
     if (step_pair)
       return modp_launch_fd_step_pair_boxes(sf, sb, bx_st, chains, tt, w0_, clen, cnt_, xm_, bx_xm_, hand_, bx_hand_, B, (int*)ctx->w->fd_flag.p,
                                             fault, ctx->consts, ctx->pair_tables, ctx->stream);

@@ -68,6 +68,14 @@ def test_fd_equals_horner():
         assert ha == hb == hc, case
     for k, hd in zip(pair_cases, d):
         assert hd == a[k], CASES[k]
+    # ... and the same stepping as wide launches over the anti-diagonals of the (stage, block of steps) grid (round 5:
+    # k_modp_fd_step_pair_tile, no wave waits for another): blocks of 64 steps with two-level seeding, ragged blocks of 37 steps
+    # with Horner's rule for every seed -- every case, the seeding chain and both directions of the strided chains
+    for env in ({"MPVSS_FD_L1": "2", "MPVSS_FD_TILE_STEPS": "64", "CHECK_ORACLE": "1"}, {"MPVSS_FD_L1": "0", "MPVSS_FD_TILE_STEPS": "37"}):
+        e = run([CASES[k] for k in pair_cases], dict({"MPVSS_FD": "1", "MPVSS_FD_MIN_SHARES": "2048", "MPVSS_FD_PAIR_MIN_T": "16",
+                                                      "MPVSS_FD_TILE": "2"}, **env))
+        for k, he in zip(pair_cases, e):
+            assert he == a[k], (CASES[k], env)
 
 
 @pytest.mark.parametrize("mode", ["1", "2", "3", "4", "1p", "2p", "3p"])
