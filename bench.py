@@ -506,6 +506,32 @@ PAIR_MUL_SLOTS, PAIR_SQ_SLOTS = (3690 + 2 * 114) / 32.0, (2501 + 2 * 114) / 32.0
 # lowers its clock under load: about 2.0-2.1 GHz in these kernels, and a v_mad_u64_u32 issues in ~4.35 cycles): that figure is
 # measured live in every run by mpvss_issue_probe (`compute.sustained_probe`) and the achieved rate is also given relative to
 # it (`vs_sustained_mad64`, a ratio of two measurements of different instruction mixes: it is not called a fraction).
+# Instruction mix per Montgomery operation and wave, by issue class (tools/isa_mix.py over the ISA of the shipped a2 kernel,
+# profiles/r05_a2_isa_mix.json; the quad layout from bn_quad.h's row: 36 / 27.5 v_mad_u64_u32, 2 DPP ands, v_mov_b64, v_lshrrev_b64,
+# v_lshl_add_u64 per row, ~110 instructions of final passes).  `compute.peak_mix_weighted` prices these with what mpvss_issue_probe
+# measures for every class IN THIS RUN (four waves per SIMD back to back): the time the chip needs for the run's instructions if
+# every class issued at its own sustained rate -- a v_add_u32 is not a v_mad_u64_u32 (round 4's flat 4-cycle slot said it was).
+MIX_CLASSES = ("mad64", "alu32", "shift64", "swap", "mov64", "vop2")
+PAIR_MIX = {"numbers": 32,
+            "sq": {"mad64": 1441, "alu32": 745, "shift64": 223, "swap": 84, "mov64": 72, "mfma": 114},
+            "mul": {"mad64": 2701, "alu32": 675, "shift64": 223, "swap": 84, "mov64": 72, "mfma": 114}}
+QUAD_MIX = {"numbers": 16,
+            "sq": {"mad64": 72 * 27.5, "alu32": 72 * 2 + 110, "shift64": 144, "mov64": 72},
+            "mul": {"mad64": 72 * 36, "alu32": 72 * 2 + 110, "shift64": 144, "mov64": 72}}
+
+
+def mix_seconds_per_simd(by_layout, tau):
+    """SIMD-seconds the operations in `by_layout` (numbers x operations, keys pair_sq / pair_mul / quad_sq / quad_mul) need when
+    every instruction class issues at the rate measured for it: tau[c] = seconds per wave-instruction per SIMD; an MFMA holds the
+    issue for two alu32 slots."""
+    total = 0.0
+    for key, cnt in by_layout.items():
+        mix = PAIR_MIX if key.startswith("pair") else QUAD_MIX
+        per_wave = sum(v * (2 * tau["alu32"] if c == "mfma" else tau[c]) for c, v in mix["sq" if key.endswith("sq") else "mul"].items())
+        total += cnt / mix["numbers"] * per_wave
+    return total
+
+
 NOMINAL_CLOCK_GHZ = 2.4
 PEAK_VALU_SLOTS_PER_S = 1024 * NOMINAL_CLOCK_GHZ * 1e9 / 4.0
 PEAK_SOURCE = "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: chip parameters, cycle constants)"
@@ -572,10 +598,16 @@ def modp_work(n, t, positions, cs):
     mm_total = sum(mul_n.values()) + SQ_COST * sum(sq_n.values())
     pair_bit = {"a2": 1, "tab": 2, "a1": 8}                     # MPVSS_PAIR bits (g^r, bit 2, is counted with a1)
     slots = mul_n.get("x_pair", 0.0) * PAIR_MUL_SLOTS
+    by_layout = {"pair_sq": 0.0, "pair_mul": mul_n.get("x_pair", 0.0), "quad_sq": 0.0, "quad_mul": 0.0}     # operations of the block
     for key in ("x", "a1", "a2", "tab"):
         pair = bool(PAIR_MASK & pair_bit.get(key, 0)) and n >= 16
         slots += sq_n[key] * (PAIR_SQ_SLOTS if pair else QUAD_SQ_SLOTS) + mul_n[key] * (PAIR_MUL_SLOTS if pair else QUAD_MUL_SLOTS)
+        by_layout["pair_sq" if pair else "quad_sq"] += sq_n[key]
+        by_layout["pair_mul" if pair else "quad_mul"] += mul_n[key]
+    a2_pair = bool(PAIR_MASK & 1)
     return {"mm_total": mm_total, "mm_x": mm_x, "x_path": x_path, "a2_products": tot_a2 / k, "w6": w6, "fd": fd, "slots": slots,
+            "by_layout": by_layout,
+            "a2_by_layout": {("pair_sq" if a2_pair else "quad_sq"): sq_n["a2"], ("pair_mul" if a2_pair else "quad_mul"): mul_n["a2"]},
             "a2_slots": sq_n["a2"] * (PAIR_SQ_SLOTS if PAIR_MASK & 1 else QUAD_SQ_SLOTS) + mul_n["a2"] * (PAIR_MUL_SLOTS if PAIR_MASK & 1 else QUAD_MUL_SLOTS),
             "ops": {"squarings": sum(sq_n.values()) / n, "products": sum(mul_n.values()) / n}}
 
@@ -1068,6 +1100,16 @@ def main():
                  "how": "mpvss_issue_probe, live in this run after the timed region: 4 waves per SIMD on every CU issue v_mad_u64_u32 "
                         "(mad64) / v_add3_u32, v_and_b32, v_lshl_add_u32 (alu32) back to back for ~40 ms; the clock is s_memtime "
                         "against s_memrealtime inside the kernel"}
+    # the other instruction classes of the kernels' mix, same probe (kinds 2-5): seconds per wave-instruction per SIMD
+    tau = None
+    if probe and probe["mad64_insts_per_s"]:
+        rates = {"mad64": probe["mad64_insts_per_s"], "alu32": probe["alu32_insts_per_s"]}
+        for kind, cname in ((2, "shift64"), (3, "swap"), (4, "mov64"), (5, "vop2")):
+            pk = eng.issue_probe(kind, 30.0)
+            rates[cname] = pk["insts_per_s"]
+            probe[cname + "_insts_per_s"] = pk["insts_per_s"]
+            probe[cname + "_shader_clock_ghz"] = pk["shader_clock_ghz"]
+        tau = {c: 1024.0 / r for c, r in rates.items() if r}
     a2_launch_ms_overlapped = a2_ms / a2_n
     a2_one_box_ms = lone["a2_dual_exp"] / lone["a2_launches"] if lone else None
     a2_launch_ms = alone_ms if alone_ms else (a2_one_box_ms if a2_one_box_ms else a2_launch_ms_overlapped)
@@ -1128,6 +1170,12 @@ def main():
                     "SIMD; an MFMA holds the issue for two slots)",
             "frac": wk["slots"] / (ms_per_step * 1e-3) / PEAK_VALU_SLOTS_PER_S,
             "sustained_probe": probe,
+            **({"frac_mix_weighted": mix_seconds_per_simd(wk["by_layout"], tau) / 1024.0 / (ms_per_step * 1e-3),
+                "peak_mix_weighted": wk["slots"] / (mix_seconds_per_simd(wk["by_layout"], tau) / 1024.0),
+                "mix_weighted_is": "the time the step's instructions need when every class (v_mad_u64_u32 / 32-bit VOP3 / 64-bit shifts / "
+                                   "v_permlane32_swap / v_mov_b64; an MFMA = two 32-bit slots) issues at the rate mpvss_issue_probe measured "
+                                   "for it in this run, over the step's wall time; peak_mix_weighted = the same as issue slots/s"}
+               if tau else {}),
             "vs_sustained_mad64": (wk["slots"] / (ms_per_step * 1e-3) / probe["mad64_insts_per_s"]) if probe and probe["mad64_insts_per_s"] else None,
             "vs_sustained_mad64_is": "achieved slots/s over the v_mad_u64_u32 rate the probe sustained in this run (a ratio of two "
                                      "measurements: a kernel whose mix is lighter than pure 64-bit mads can exceed 1)",
@@ -1148,6 +1196,7 @@ def main():
             "a2_kernel_alone": ({"ms": alone_ms, "valu_slots_per_s": wk["a2_slots"] / (alone_ms * 1e-3),
                                  "frac": wk["a2_slots"] / (alone_ms * 1e-3) / PEAK_VALU_SLOTS_PER_S,
                                  "vs_sustained_mad64": (wk["a2_slots"] / (alone_ms * 1e-3) / probe["mad64_insts_per_s"]) if probe else None,
+                                 "frac_mix_weighted": (mix_seconds_per_simd(wk["a2_by_layout"], tau) / 1024.0 / (alone_ms * 1e-3)) if tau else None,
                                  "products_per_share": a2_products} if alone_ms else None),
             "kernel_ms_sums": {"x_path": x_ms, "a1_comb_dual_exp": a1_ms, "a2_dual_exp": a2_ms, "tables": tb_ms,
                                "note": "per-kind sums of launch durations per step in the timed region; boxes and kinds "

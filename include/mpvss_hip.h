@@ -518,7 +518,9 @@ int mpvss_blocks_in_flight(mpvss_ctx* ctx, int* in_flight_out, int* gpu_pending_
 int mpvss_sha256_uses_shani(void);
 /* Measurement aid (no reference counterpart): what this device sustains, now, of the instruction the kernels are made of -- four
  * waves per SIMD on every CU issue it back to back for about target_ms.  kind 0: v_mad_u64_u32 (the limb product of all three
- * groups), kind 1: 32-bit integer work.  Wave-instructions per second over the whole chip, the shader clock the waves saw
+ * groups), kind 1: 32-bit integer work (v_add3_u32, v_and_b32, v_lshl_add_u32), 2: the 64-bit shifts of a retire step (v_lshl_add_u64,
+ * v_lshrrev_b64), 3: v_permlane32_swap, 4: v_mov_b64, 5: VOP2 v_add_u32 -- the classes bench.py prices the kernels' instruction mix
+ * with (`compute.peak_mix_weighted`).  Wave-instructions per second over the whole chip, the shader clock the waves saw
  * (s_memtime against the 100 MHz s_memrealtime) and the duration; the last two are optional. */
 int mpvss_issue_probe(mpvss_ctx* ctx, int kind, double target_ms, double* insts_per_s_out, double* shader_clock_ghz_out,
                       double* ms_out);

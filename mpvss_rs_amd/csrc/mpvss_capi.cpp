@@ -2534,7 +2534,7 @@ extern "C" int mpvss_issue_probe(mpvss_ctx* ctx, int kind, double target_ms, dou
                                  double* ms_out) {
   if (!ctx) return MPVSS_E_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if ((kind != 0 && kind != 1) || !insts_per_s_out || target_ms <= 0 || target_ms > 2000)
+  if (kind < 0 || kind > 5 || !insts_per_s_out || target_ms <= 0 || target_ms > 2000)
     return fail(ctx, MPVSS_E_INVALID, "issue_probe: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipDeviceProp_t prop;

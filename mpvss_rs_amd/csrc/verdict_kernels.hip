@@ -481,7 +481,7 @@ extern "C" __global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, u
       PROBE_REP64(X)
 #undef X
     }
-  } else {
+  } else if (kind == 1) {
     for (int it = 0; it < iters; ++it) {
 #define X(k) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(a), "v"(b));
       PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
@@ -491,6 +491,34 @@ extern "C" __global__ void __launch_bounds__(256) k_issue_probe(uint32_t* out, u
 #undef X
 #define X(k) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(q[k]) : "v"(a));
       PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
+#undef X
+    }
+  } else if (kind == 2) {          // the 64-bit shifts and shift-adds of a retire step (two passes each)
+    const uint64_t c64 = ((uint64_t)b << 32) | a;
+    for (int it = 0; it < iters; ++it) {
+#define X(k) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(p[k]) : "v"(c64));
+      PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
+#undef X
+#define X(k) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(p[k]));
+      PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X) PROBE_REP8(X)
+#undef X
+    }
+  } else if (kind == 3) {          // the lane-half exchange of the pair layout
+    for (int it = 0; it < iters; ++it) {
+#define X(k) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(q[k]), "+v"(q[(k + 1) & 7]));
+      PROBE_REP64(X)
+#undef X
+    }
+  } else if (kind == 4) {
+    for (int it = 0; it < iters; ++it) {
+#define X(k) asm volatile("v_mov_b64 %0, %1" : "=v"(p[k]) : "v"(p[(k + 1) & 7]));
+      PROBE_REP64(X)
+#undef X
+    }
+  } else {                         // VOP2 32-bit add
+    for (int it = 0; it < iters; ++it) {
+#define X(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(q[k]) : "v"(a));
+      PROBE_REP64(X)
 #undef X
     }
   }

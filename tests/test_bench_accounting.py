@@ -42,3 +42,27 @@ def test_slots_follow_the_layout_and_operations_do_not():
             assert 2500 < per_share < 4500, per_share
     finally:
         bench.PAIR_MASK = saved
+
+
+def test_the_mix_weighted_budget_agrees_with_the_flat_slot_count_when_every_class_costs_a_slot():
+    """`compute.peak_mix_weighted` prices every instruction class with its own measured rate; with all classes at one slot (4 cycles at
+    2.4 GHz) it must give back the flat issue-slot accounting of the same operations to within the few instructions the two counts
+    differ by (table addressing in the shipped kernel), and with the rates round 4 measured (a v_mad_u64_u32 4.38 cycles at 1.9 GHz,
+    the 64-bit shifts two passes) the a2 launch needs more time than its slot count says."""
+    bench = load_bench()
+    slot = 4.0 / 2.4e9
+    flat = {c: slot for c in bench.MIX_CLASSES}
+    wk = bench.modp_work(65536, 256, list(range(1, 65537)), [(1 << 255) | 12345])
+    by_slots = wk["slots"] * slot
+    by_mix = bench.mix_seconds_per_simd(wk["by_layout"], flat)
+    assert abs(by_mix / by_slots - 1) < 0.04, (by_mix, by_slots)
+    assert sum(wk["by_layout"].values()) == pytest_approx(65536 * (wk["ops"]["squarings"] + wk["ops"]["products"]))
+    measured = dict(flat, mad64=4.38 / 1.9e9, shift64=2 * 4.0 / 2.35e9, swap=6.0 / 2.35e9)
+    a2_flat = bench.mix_seconds_per_simd(wk["a2_by_layout"], flat)
+    assert bench.mix_seconds_per_simd(wk["a2_by_layout"], measured) > 1.2 * a2_flat
+    assert abs(a2_flat / (wk["a2_slots"] * slot) - 1) < 0.04
+
+
+def pytest_approx(x):
+    import pytest
+    return pytest.approx(x, rel=1e-9)
