@@ -232,6 +232,19 @@ struct mpvss_ctx {
     std::vector<DevBuf*> all() { return {&cmenc, &cm, &okcm, &pos, &pts, &xenc, &state, &flags, &hand, &wtab}; }
   };
   std::vector<XBatch*> ec_xb;
+  // the same for MODP boxes too large to travel as one group block (modp_x_batch_compute): the X paths of a run of boxes of one
+  // shape by the same launches (the box as the second grid dimension), in a workspace of their own; every box's block then
+  // waits for `done` and goes on with the tables of X and a1
+  struct ModpXBatch {
+    Work work;
+    DevBuf x;                      // [B][n][256]: X of the batch's boxes, canonical bytes
+    SpanSet spans;
+    hipEvent_t done = nullptr;
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    std::vector<hipEvent_t> readers;   // completion events of the blocks that read `x` (the batch that reuses this workspace waits for them on the device)
+  };
+  std::vector<ModpXBatch*> modp_xb;
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
@@ -717,6 +730,15 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (xb->pin) (void)hipHostFree(xb->pin);
     for (DevBuf* b : xb->all())
       if (b->p) (void)hipFree(b->p);
+    delete xb;
+  }
+  for (mpvss_ctx::ModpXBatch* xb : ctx->modp_xb) {
+    work_destroy(xb->work, true);
+    if (xb->x.p) (void)hipFree(xb->x.p);
+    if (xb->done) (void)hipEventDestroy(xb->done);
+    if (xb->pin) (void)hipHostFree(xb->pin);
+    for (hipEvent_t e : xb->spans.ev_pool)
+      if (e) (void)hipEventDestroy(e);
     delete xb;
   }
   for (hipEvent_t e : ctx->a2_done)
@@ -1360,10 +1382,95 @@ int wellformed_bounds(mpvss_ctx* ctx, const uint8_t** out) {
   return 0;
 }
 
+// X of one box as a batch launch left it (modp_x_batch_compute): canonical bytes, the event after which they are there, the
+// batch's forward-difference flag (one for the whole batch: a box out of line sends all of them down Horner's rule, still right)
+struct ModpPre {
+  const uint8_t* x_dev = nullptr;
+  hipEvent_t ready = nullptr;
+  const int* flag_dev = nullptr;
+  bool fd_used = false;
+  mpvss_ctx::ModpXBatch* owner = nullptr;
+};
+
+// Why: the device runs eight launches at a time (its hardware queues; more make every kernel slower: profiles/r05_c5_queues_ab.txt),
+// and a box's X path is a chain of NARROW launches -- 64 waves of Horner seeds for up to 330 ms, a few hundred stepping waves for
+// 150-240 ms at (131072, 1024) -- each of which holds a queue while it leaves the chip to others.  With ten boxes in flight the
+// queues are full of such launches and the wide ones (a2: 4096 waves) wait.  The curve groups had the same disease and the same
+// cure (ec_x_batch_compute): the X paths of a run of boxes in ONE set of launches.
+bool modp_x_box_batchable(int space, const mpvss_modp_box& bx, size_t n, size_t t) {
+  static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
+  if (!(two_streams && bx.n == n && bx.t == t && n <= MAX_CHUNK && bx.commitments && bx.positions && (bx.pubkeys || bx.keyset) && bx.shares &&
+        bx.responses && bx.challenge_host && fd_applies(t, space == MPVSS_HOST ? bx.positions : nullptr, n)))
+    return false;
+  return true;
+}
+
+int modp_x_batch_compute(mpvss_ctx* ctx, int space, const mpvss_modp_box* bx, size_t B, mpvss_ctx::ModpXBatch& xb, ModpPre* pre) {
+  const size_t n = bx[0].n, t = bx[0].t;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!xb.done) HIPCHK(ctx, hipEventCreateWithFlags(&xb.done, hipEventDisableTiming));
+  RET_IF(work_init(ctx, xb.work, nullptr));
+  struct Restore {
+    mpvss_ctx* c;
+    hipStream_t a, b;
+    mpvss_ctx::Work* w;
+    mpvss_ctx::SpanSet* sp;
+    ~Restore() { c->sp = sp; c->w = w; c->stream = a; c->stream_b = b; }
+  } restore{ctx, ctx->stream, ctx->stream_b, ctx->w, ctx->sp};
+  mpvss_ctx::Work& w = xb.work;
+  ctx->w = &w;
+  w.fd_used = false;
+  ctx->stream = w.sa;
+  ctx->stream_b = w.sb;
+  ctx->sp = &xb.spans;
+  spans_reset(ctx);
+  // the workspace comes round again after MPVSS_X_BATCH_RING batches: whatever still reads the X of its previous batch (the
+  // blocks of those boxes: tables of X, the copy to the host) is waited for ON THE DEVICE, in stream order -- no host thread blocks
+  for (hipEvent_t e : xb.readers) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
+  xb.readers.clear();
+  RET_IF(ensure(ctx, w.cbuf, B * t * EB));
+  RET_IF(ensure(ctx, w.cm, B * t * MODP_L * 4));
+  RET_IF(ensure(ctx, w.pos, B * n * 8));
+  RET_IF(ensure(ctx, xb.x, B * n * EB));
+  const size_t pin_need = space == MPVSS_HOST ? B * (t * EB + n * 8) : 0;
+  if (pin_need > xb.pin_cap) {
+    if (xb.pin) HIPCHK(ctx, hipHostFree(xb.pin));
+    xb.pin = nullptr;
+    xb.pin_cap = 0;
+    hipError_t e = hipHostMalloc(&xb.pin, pin_need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(batch staging)", e);
+    xb.pin_cap = pin_need;
+  }
+  uint8_t* dcm = (uint8_t*)w.cbuf.p;
+  int64_t* dpos = (int64_t*)w.pos.p;
+  uint8_t* hin = (uint8_t*)xb.pin;
+  for (size_t b = 0; b < B; ++b) {
+    if (space == MPVSS_HOST) {      // pinned copies: nothing of the caller's is referenced after the call returns
+      memcpy(hin, bx[b].commitments, t * EB);
+      HIPCHK(ctx, hipMemcpyAsync(dcm + b * t * EB, hin, t * EB, hipMemcpyHostToDevice, ctx->stream));
+      hin += t * EB;
+      memcpy(hin, bx[b].positions, n * 8);
+      HIPCHK(ctx, hipMemcpyAsync(dpos + b * n, hin, n * 8, hipMemcpyHostToDevice, ctx->stream));
+      hin += n * 8;
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(dcm + b * t * EB, bx[b].commitments, t * EB, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(dpos + b * n, bx[b].positions, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  w.cm_bytes_dev = dcm;
+  LAUNCHCHK(ctx, modp_launch_to_mont(dcm, (uint32_t*)w.cm.p, (int)(B * t), ctx->consts, ctx->stream));
+  uint8_t* dX = (uint8_t*)xb.x.p;
+  RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));        // (positions judged on the device: one flag for the batch)
+  HIPCHK(ctx, hipEventRecord(xb.done, ctx->stream));
+  for (size_t b = 0; b < B; ++b) pre[b] = ModpPre{dX + b * n * EB, xb.done, (const int*)w.fd_flag.p, w.fd_used, &xb};
+  return MPVSS_OK;
+}
+
 int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                 const uint8_t* responses, size_t n, const uint8_t* challenge_host,
-                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr) {
+                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr,
+                                const ModpPre* pre = nullptr) {
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
   if (n > 0 && (!commitments || !positions || (!pubkeys && !ks) || !shares || !responses || t == 0 || t > 0x7fffffff ||
                 n > 0x7fffffff))
@@ -1469,7 +1576,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     if (trace_enq) marks[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
   };
   mark(0);
-  RET_IF(stage_commitments(ctx, space, commitments, t));
+  if (pre && n > MAX_CHUNK) return fail(ctx, MPVSS_E_INVALID, "verify: a batched X path needs a one-chunk block");
+  if (!pre) RET_IF(stage_commitments(ctx, space, commitments, t));       // (a batch launch has evaluated X: nothing else reads them)
   mark(1);
   const uint32_t* cg;
   RET_IF(comb_table(ctx, 0, &cg, n));
@@ -1509,7 +1617,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     sl.work.fd_used = false;
     const int64_t* hp = space == MPVSS_HOST ? hpos + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
-    if (two_streams && ctx->w->sb && fd_applies(t, hp, cnt)) {
+    if (two_streams && ctx->w->sb && (pre || fd_applies(t, hp, cnt))) {
       // The forward-difference X path is a chain of latency-bound launches that occupy few wave slots (seeds,
       // inversion tree, difference tables, stepping) and runs on the block slot's high-priority stream.  a2 = y^r Y^c
       // and g^r do not depend on X: they run beside it on the slot's low-priority stream.
@@ -1635,7 +1743,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         if (nsl <= 1) RET_IF(launch_gr());
       }
       mark(2);
-      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
+      if (pre) {        // X came from a batch launch: wait for it (the a2 side is already running)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, pre->ready, 0));
+        dX = const_cast<uint8_t*>(pre->x_dev);
+      } else {
+        RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
+      }
       mark(3);
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
@@ -1681,16 +1794,18 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (sl.work.fd_used) {     // the device's decision for this chunk (1 = forward differences held, 0 = fell back)
+    if (sl.work.fd_used || (pre && pre->fd_used)) {     // the device's decision for this chunk (1 = forward differences held, 0 = fell back)
       sl.fd_used = true;
       if (sl.fd_chunks < FLAGS)
-        HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, pre ? (const void*)pre->flag_dev : (const void*)sl.work.fd_flag.p, 4,
+                                   hipMemcpyDeviceToHost, ctx->stream));
       ++sl.fd_chunks;
     }
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
   mark(4);
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
+  if (pre && pre->owner) pre->owner->readers.push_back(sl.done);
   sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
   sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
   if (trace_enq && sl.enqueue_ms > 3.0)
@@ -2411,6 +2526,15 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   static const int tail_parts = fd_env("MPVSS_TAIL_PARTS", 1);
   static const size_t tail_boxes = (size_t)fd_env("MPVSS_TAIL_BOXES", 1);
   static const size_t tail_min_part = (size_t)fd_env("MPVSS_TAIL_MIN_PART", 8192);     // shares per part at least (tests lower it)
+  // MPVSS_X_BATCH: X paths of up to this many consecutive large boxes of one shape in the same launches (0 / 1: every box on its own).
+  // A batch workspace (several GB at (131072, 1024): the hand-over buffers of four boxes' stepping) is reused after `xring` batches; the
+  // new batch waits on the device for the blocks that still read the old one's X (ModpXBatch::readers).
+  static const int xbatch = fd_env("MPVSS_X_BATCH", 1);
+  const size_t xB = xbatch > 1 ? (size_t)std::min(xbatch, 16) : 1;
+  static const size_t xring = (size_t)std::max(2, fd_env("MPVSS_X_BATCH_RING", 5));
+  std::vector<ModpPre> pre(xB > 1 ? count : 0);
+  std::vector<char> has_pre(count, 0), looked(count, 0);
+  size_t batch_no = 0;
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
       [&](size_t b, unsigned* parts, unsigned* nbox) {
@@ -2431,11 +2555,24 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
         const size_t P = (b + tail_boxes >= count && count >= 3 && tail_parts > 1 && tail_parts <= 8 && bx.n >= (size_t)tail_parts * tail_min_part &&
                           bx.commitments && bx.positions && (bx.pubkeys || bx.keyset) && bx.shares && bx.responses)
                              ? (size_t)tail_parts : 1;
+        // the X paths of a run of large boxes of one shape by the same launches (modp_x_batch_compute); every box keeps its own block
+        if (xB > 1 && P == 1 && !looked[b]) {
+          size_t Bx = 0;
+          while (Bx < xB && b + Bx < count && modp_x_box_batchable(space, boxes[b + Bx], bx.n, bx.t)) ++Bx;
+          for (size_t i = 0; i < std::max<size_t>(Bx, 1); ++i) looked[b + i] = 1;
+          if (Bx >= 2) {
+            while (ctx->modp_xb.size() < xring) ctx->modp_xb.push_back(new mpvss_ctx::ModpXBatch());
+            const int rc = modp_x_batch_compute(ctx, space, boxes + b, Bx, *ctx->modp_xb[batch_no++ % xring], &pre[b]);
+            if (rc != MPVSS_OK) return rc;
+            for (size_t i = 0; i < Bx; ++i) has_pre[b + i] = 1;
+          }
+        }
         for (size_t p = 0; p < P; ++p) {
           const size_t lo = (bx.n * p / P) & ~(size_t)15, hi = p + 1 == P ? bx.n : ((bx.n * (p + 1) / P) & ~(size_t)15);
           const int rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions + lo,
                                                      bx.pubkeys ? bx.pubkeys + lo * EB : nullptr, bx.shares + lo * EB,
-                                                     bx.responses + lo * EB, hi - lo, bx.challenge_host, bx.keyset, bx.key_offset + lo);
+                                                     bx.responses + lo * EB, hi - lo, bx.challenge_host, bx.keyset, bx.key_offset + lo, nullptr,
+                                                     (P == 1 && has_pre[b]) ? &pre[b] : nullptr);
           if (rc != MPVSS_OK) return rc;
           ++*parts;
         }

@@ -352,3 +352,68 @@ print("slices ok")
     env = dict(os.environ, MPVSS_A2_SLICES="4", MPVSS_A2_SLICE_MIN="512")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "slices ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_x_paths_of_several_large_boxes_in_the_same_launches():
+    """MPVSS_X_BATCH: mpvss_modp_verify_many evaluates the X paths of a run of large boxes of one shape by the SAME launches (the box as
+    the second grid dimension, a workspace of the batch's own), every box keeping its own block for the rest (round 5: the device runs
+    eight launches at a time and a box's X path is a chain of narrow ones).  Same verdicts and digests as one verify_distribution per
+    box: runs of 3 + 3 + 1 boxes with another shape in between, one bit flipped in a commitment / a response / a share of boxes inside
+    a batch, a box whose positions are not consecutive (host memory: it is left out of the batch; device memory: the batch's flag
+    falls and Horner's rule computes every X of that batch), a ring of two batch workspaces so that they are reused while blocks of
+    the previous batch are still in flight."""
+    code = r"""
+import sys, random, ctypes as C
+sys.path.insert(0, %r)
+import torch
+from mpvss_rs_amd import Engine, capi
+EB = 256
+eng = Engine(0)
+rng = random.Random(12)
+def make(n, t, p0):
+    sc = lambda k: b"".join(rng.randrange(1, 2**2040).to_bytes(EB, "big") for _ in range(k))
+    coeffs, pos = sc(t), list(range(p0, p0 + n))
+    pk = eng.batch_exp_fixed_base((2).to_bytes(EB, "big"), sc(n))
+    cm = eng.batch_exp_fixed_base((4).to_bytes(EB, "big"), coeffs)
+    d = eng.deal(coeffs, pos, pk, sc(n))
+    return dict(commitments=cm, positions=pos, pubkeys=pk, shares=d["Y"], responses=d["responses"], challenge=d["challenge"]), d["digest"]
+A, dA = make(16500, 16, 1)
+A2, dA2 = make(16500, 16, 40001)
+B, dB = make(17000, 20, 5)
+def tamper(b, field, at):
+    x = bytearray(b[field]); x[at] ^= 1; return dict(b, **{field: bytes(x)})
+one = lambda b: (lambda r: (r["verdict"], r["digest"]))(eng.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
+swapped = dict(A, positions=A["positions"][:100] + [A["positions"][101], A["positions"][100]] + A["positions"][102:])
+boxes = [A, tamper(A2, "commitments", 5 * EB + 17), A2, B, tamper(A, "responses", 16499 * EB + 255), A2, tamper(A, "shares", 3), A, swapped, A2, A, B, B]
+want = [one(b) for b in boxes]
+assert [w[0] for w in want] == [True, False, True, True, False, True, False, True, False, True, True, True, True]
+assert want[0] == (True, dA) and want[2] == (True, dA2) and want[3] == (True, dB)
+f0 = eng.fd_stats()
+for depth, threads in ((3, 1), (6, 3), (12, 6)):
+    assert eng.verify_many(boxes, depth=depth, hash_threads=threads) == want, (depth, threads)
+f1 = eng.fd_stats()
+assert f1[0] - f0[0] == 3 * len(boxes) - 3 and f1[1] == f0[1], (f0, f1)        # every box but the swapped one took forward differences, none fell back
+# the same boxes in device memory: positions are judged on the device, the swapped box sits INSIDE a batch and drops its flag
+dev = torch.device("cuda", 0)
+keep = []
+def dbox(b):
+    t8 = lambda x: torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev)
+    ts = [t8(b[k]) for k in ("commitments", "pubkeys", "shares", "responses")] + [torch.tensor(b["positions"], dtype=torch.int64, device=dev)]
+    ch = (C.c_uint8 * EB).from_buffer_copy(b["challenge"])
+    keep.append((ts, ch))
+    return capi.ModpBox(ts[0].data_ptr(), len(b["commitments"]) // EB, ts[4].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(),
+                        len(b["positions"]), C.cast(ch, C.c_void_p), None, 0)
+arr = (capi.ModpBox * len(boxes))(*[dbox(b) for b in boxes])
+torch.cuda.synchronize()
+verdicts = (C.c_int * len(boxes))(); digests = (C.c_uint8 * (32 * len(boxes)))()
+eng._check(eng.lib.mpvss_modp_verify_many(eng.ctx, capi.MPVSS_DEVICE, arr, len(boxes), 6, 3, verdicts, C.cast(digests, C.c_void_p)), "verify_many(device)")
+got = [(bool(verdicts[i]), bytes(digests)[32 * i:32 * i + 32]) for i in range(len(boxes))]
+assert got == want, got
+f2 = eng.fd_stats()
+assert f2[1] - f1[1] >= 1, (f1, f2)                 # the batch around the swapped box fell back to Horner's rule -- and was still right
+assert eng.blocks_in_flight() == (0, 0)
+print("xbatch ok")
+""" % ROOT
+    env = dict(os.environ, MPVSS_X_BATCH="3", MPVSS_X_BATCH_RING="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "xbatch ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
