@@ -11,7 +11,7 @@ for kv in "$@"; do export "$kv"; done
 rocprofv3 --kernel-trace --output-format csv -d $OUT/raw -- python3 bench.py --gpus 1 --steps 2 --warmup 1 --cpu-sample 0 --wb-shares 0 --registered-keys 0 \
   --ec-boxes 0 --host-boxes 0 --config-boxes 96 --lone-boxes 0 --steady-steps 0 > $OUT/line.json 2> $OUT/err.txt
 CSV=$(find $OUT/raw -name '*kernel_trace.csv' | head -1)
-python3 tools/trace_occupancy.py "$CSV" k_modp_fd_step > $OUT/summary.txt 2>&1
+python3 tools/trace_occupancy.py "$CSV" k_modp_fd_step_pair > $OUT/summary.txt 2>&1
 python3 -c "
 import json
 d = json.load(open('/tmp/trace_c5_detail.json'))['configs']['c5_slice']
