@@ -111,6 +111,9 @@ int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* e1, const u
                               uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s);
 int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupancy, int count, uint8_t* out1, uint8_t* out2,
                                const void* cs, hipStream_t s);
+/* a2 = y^r Y^c against a registered key's table, pair layout (same table and program as modp_launch_keyset_dual_exp) */
+int modp_launch_keyset_dual_exp_pair(const uint32_t* ks, const uint32_t* tab2, const uint8_t* r, const uint8_t* c, int count, uint8_t* out,
+                                     const void* cs, const void* pair_tables, hipStream_t s);
 /* forward-difference stepping on the pair layout (stages of 32 levels; same state, hand-over buffers and outputs) */
 int modp_launch_fd_step_pair_boxes(const uint32_t* state, const uint32_t* state_back, size_t box_state, int chains, int t, int w0,
                                    int chain_len, int count, uint32_t* x_m, size_t box_xm, uint32_t* hand, size_t box_hand, int boxes,

@@ -554,6 +554,48 @@ k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, cons
 }
 
 // ---------------------------------------------------------------------------------------
+// a2 = y^r * Y^c against a REGISTERED key's table (k_modp_keyset_dual_exp of modp_kernels.hip on the pair layout: the same table
+// ks[key][j][d] = y^(d 2^(256 j)), the same program -- per byte position p of the 32-byte rows: four squarings and the product with
+// Y^(high nibble of c), four squarings and Y^(low nibble), then the eight table entries ks[j][byte p of r_j] -- 252 squarings
+// and 320 products at 85 / 122 instead of 153 / 191 issue slots).  dleq.rs:79-81 with y a long-lived participant key.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
+k_modp_keyset_dual_exp_pair(const u32* __restrict__ ks, size_t key_words, const u32* __restrict__ tab2, const uint8_t* __restrict__ r_be,
+                            const uint8_t* __restrict__ c_be, int count, uint8_t* __restrict__ out_be,
+                            const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  u32 acc[LP];
+  load_pair_limbs(acc, tab2 + ((size_t)pc.x * 16 + (c_be[224] >> 4)) * L, pl);
+  int p = 0, s = 5;
+  while (true) {
+    const u32* fill = nullptr;
+    const bool sq = s < 4 || (s >= 5 && s < 9);
+    if (!sq) {
+      if (s == 4 || s == 9) {
+        const u32 byte = c_be[224 + p];
+        fill = tab2 + ((size_t)pc.x * 16 + ((s == 4) ? (byte >> 4) : (byte & 15))) * L;
+      } else if (s < 18) {
+        const int j = s - 10;
+        const u32 d = r_be[(size_t)pc.x * 256 + 224 - 32 * j + p];
+        fill = ks + (size_t)pc.x * key_words + ((size_t)j * 256 + d) * L;
+      } else {
+        fill = cs->one;                                  // leave the Montgomery domain
+      }
+    }
+    pair_step<true>(acc, sq, fill, acc, pc.slot, pc.junk, pc.tb, pl);
+    if (s == 18) break;
+    ++s;
+    if (s == 18) {
+      if (p == 31) continue;                             // the closing product
+      ++p;
+      s = 0;
+    }
+  }
+  store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);
+}
+
+// ---------------------------------------------------------------------------------------
 // One base, two exponents (the dealer: Y_i = y_i^P(i) and a2_i = y_i^w_i, participant.rs:219, dleq.rs:213-216; the
 // participant: S_i = Y_i^(1/x_i) and a2_i = S_i^w_i, participant.rs:310-314): the right-to-left bucket phase of
 // k_modp_twin_exp_buckets (modp_kernels.hip -- same windows, same buckets and occupancy masks in HBM, the same combine kernel
@@ -974,5 +1016,13 @@ extern "C" int modp_launch_fd_step_pair_tiled_boxes(uint32_t* state, uint32_t* s
     hipLaunchKernelGGL(k_modp_fd_step_pair_tile, dim3(2 * chains * (tpad / 32), boxes), dim3(64), 0, s, state, state_back, chains, t, tpad,
                        w0, chain_len, count, x_m, hand, gate, diag, tile_steps, (const ModpConsts*)cs, (const Tables*)pair_tables, box_state,
                        box_xm, box_hand);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_keyset_dual_exp_pair(const uint32_t* ks, const uint32_t* tab2, const uint8_t* r, const uint8_t* c, int count,
+                                                uint8_t* out, const void* cs, const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_keyset_dual_exp_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, ks, modp_keyset_words_per_key(), tab2, r,
+                     c, count, out, (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }

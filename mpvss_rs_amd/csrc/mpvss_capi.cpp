@@ -1705,6 +1705,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         if (use_keys) {
           // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
           const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
+          // (MPVSS_KEYSET_PAIR, default on with the a2 kernel's pair bit: 85 / 122 instead of 153 / 191 issue slots per operation)
+          static const int ks_pair = fd_env("MPVSS_KEYSET_PAIR", 1);
+          if (ks_pair && (pair_mask() & 1) && cnt >= 64)
+            TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp_pair(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2, ctx->consts,
+                                                                  ctx->pair_tables, ctx->stream));
+          else
           TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
                                                            ctx->consts, ctx->stream));
         } else if (a2_w6 && c_windows == 64) {
