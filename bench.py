@@ -1685,7 +1685,7 @@ def main():
             try:
                 eng._check(lib.mpvss_modp_keyset_create(ctx, capi.MPVSS_DEVICE, vp(d_pk), n, C.byref(h)), "keyset_create")
                 keyset_ok = True
-            except capi.EngineError as err:      # 622 KB per key: very large key sets do not fit beside the workspaces
+            except capi.EngineError as err:      # 295 KB per key: very large key sets do not fit beside the workspaces
                 result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
         if keyset_ok:
             try:
@@ -1703,13 +1703,16 @@ def main():
                 keyset[0] = None
                 table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
                 lib.mpvss_modp_keyset_destroy(ctx, h)
-                mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 256 + 63 + 1)
+                # instead of the y tables and the 2046-squaring chain: 252 squarings, 37 x 8 table products (7-bit windows of the eight
+                # 256-bit rows of r), 64 nibbles of c against Y's full table (15 products instead of the odd-power table's 9), the closing one
+                mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 296 + 64 + 1 + (15 - 9))
                 result["registered_keys"] = {
                     "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
                     "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
                     "modmul_equivalents_per_s": mm_k / (el_k / args.steps),
-                    "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)) in HBM, built once per key set, "
-                            "a2 = y^r Y^c in 571 products instead of 2620; same verdict and transcript digest; not the headline"}
+                    "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)), d < 128, in HBM (295 KB per key), built once per key "
+                            "set; a2 = y^r Y^c in 613 products instead of 2620, on the pair layout with g^r and a1; same verdict and "
+                            "transcript digest; not the headline"}
             except capi.EngineError as err:
                 keyset[0] = None
                 result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}

@@ -1392,14 +1392,24 @@ k_modp_bucket_combine(const u32* __restrict__ buckets, const u32* __restrict__ o
 
 // ---------------------------------------------------------------------------------------
 // Registered public keys (opt-in): per-key tables for y^r, built once per key set and reused by every box that is
-// verified against it.  ks[key][j][d] = y^(d * 2^(256 j)), j < 8, d < 256 (Montgomery form; 8 x 256 x 304 B =
-// 622 KB per key, 41 GB for 65536 keys -- sized for 288 GB of HBM).  With r = sum_j r_j 2^(256 j):
+// verified against it.  ks[key][j][d] = y^(d * 2^(256 j)), j < 8, d < 128 (Montgomery form; 8 x 128 x 288 B =
+// 295 KB per key, 19.3 GB for 65536 keys; round 4 had 256 entries per sub-base: 38.7 GB).  With r = sum_j r_j 2^(256 j):
 //   y^r * Y^c = prod_j (y^(2^(256 j)))^(r_j) * Y^c    -- Straus over 256-bit rows:
-// 252 squarings shared by all nine bases, 256 products from the key table (8-bit windows), 63 from Y's 4-bit
-// table: 571 products instead of 2 620.
+// 252 squarings shared by all nine bases, 37 x 8 = 296 products from the key table (7-bit windows; signed digits would
+// halve the table in a curve group, here an inverse is not free), 64 from Y's 4-bit table: 613 products instead of 2 620.
 // ---------------------------------------------------------------------------------------
 constexpr int KS_SUB = 8;          // sub-bases per key
-constexpr int KS_ENT = 256;        // entries per sub-base (8-bit windows)
+constexpr int KS_WIN = 7;          // window width of the 256-bit rows of r
+constexpr int KS_ENT = 1 << KS_WIN;                  // entries per sub-base
+constexpr int KS_NWIN = (256 + KS_WIN - 1) / KS_WIN; // windows per row (37; the top one holds 4 bits)
+// window w of row j of the 256-byte big-endian r: bits [256 j + 7 w, 256 j + 7 w + 7) of r, without the bits of row j + 1
+__device__ __forceinline__ u32 ks_digit(const uint8_t* __restrict__ r, int j, int w) {
+  const int g = 256 * j + KS_WIN * w, b = g >> 3;
+  const u32 lo = r[255 - b];
+  const u32 hi = (b + 1 < 256) ? r[254 - b] : 0u;
+  const int top = 256 - KS_WIN * w;                  // bits of this window that belong to the row
+  return ((lo | (hi << 8)) >> (g & 7)) & (u32)((1 << (top < KS_WIN ? top : KS_WIN)) - 1);
+}
 
 // sub-bases: ks[key][j][1] = y^(2^(256 j)), ks[key][j][0] = 1   (one quad per key, 7 x 256 squarings)
 extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
@@ -1467,41 +1477,41 @@ k_modp_keyset_dual_exp(const u32* __restrict__ ks, const u32* __restrict__ tab2,
   const u32* kt = ks + (size_t)x * KS_SUB * KS_ENT * L;
   const u32* t2 = tab2 + (size_t)x * 16 * L;
   const uint8_t* r = r_be + (size_t)x * 256;
-  // Program, p = 0..31 (byte p of the 32-byte rows, most significant first):
-  //   [4 squarings] * Y[c hi nibble]   (p = 0: load)      steps 0..4
-  //   4 squarings   * Y[c lo nibble]                       steps 5..9
-  //   * ks[j][byte p of r_j], j = 0..7                     steps 10..17
-  {
-    const u32 d = c_be[224] >> 4;
-    load_lane_limbs(acc, t2 + (size_t)d * L, ln);
-  }
-  int p = 0, s = 5;
+  // Program: from bit 252 down; at every bit a squaring (not at the first), then -- bit divisible by 7 -- the eight products with
+  // ks[j][window of r_j], then -- bit divisible by 4 -- the product with Y^(nibble of c); at the end the product with plain 1.
+  //   s = 0 squaring, 1 .. 8 key table j = s - 1, 9 nibble of c, 10 closing
+  load_lane_limbs(acc, cs->one_m, ln);
+  int cur = KS_WIN * (KS_NWIN - 1), s = 1;
   while (true) {
     const u32* fill = nullptr;
-    const bool sq = s < 4 || (s >= 5 && s < 9);
-    if (sq) {
+    bool skip = false;
+    if (s == 0) {
       slot_store(slot, acc, ln);                       // squaring
-    } else if (s == 4 || s == 9) {
-      const u32 byte = c_be[224 + p];
-      const u32 d = (s == 4) ? (byte >> 4) : (byte & 15);
-      fill = t2 + (size_t)d * L;
-    } else if (s < 10 + KS_SUB) {
-      const int j = s - 10;
-      const u32 d = r[224 - 32 * j + p];
-      fill = kt + ((size_t)j * KS_ENT + d) * L;
+    } else if (s <= KS_SUB) {
+      if (cur % KS_WIN == 0) fill = kt + ((size_t)(s - 1) * KS_ENT + ks_digit(r, s - 1, cur / KS_WIN)) * L; else skip = true;
+    } else if (s == KS_SUB + 1) {
+      if ((cur & 3) == 0) {
+        const u32 byte = c_be[255 - (cur >> 3)];
+        fill = t2 + (size_t)((cur & 4) ? (byte >> 4) : (byte & 15)) * L;
+      } else {
+        skip = true;
+      }
     } else {
       fill = cs->one;                                  // leave the Montgomery domain
     }
-    if (fill != nullptr) slot_fill_from_global(slot, fill, ln);
-    __builtin_amdgcn_wave_barrier();
-    if (sq) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
-    __builtin_amdgcn_wave_barrier();
-    if (s == 10 + KS_SUB) break;
-    ++s;
-    if (s == 10 + KS_SUB) {
-      if (p == 31) continue;                           // final step
-      ++p;
+    if (!skip) {
+      if (fill != nullptr) slot_fill_from_global(slot, fill, ln);
+      __builtin_amdgcn_wave_barrier();
+      if (s == 0) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (s == KS_SUB + 2) break;
+    if (s == KS_SUB + 1) {
+      if (cur == 0) { s = KS_SUB + 2; continue; }
+      --cur;
       s = 0;
+    } else {
+      ++s;
     }
   }
   store_canonical_be256(out_be + (size_t)x * 256, acc, false, slot, cs, n, ln, live);

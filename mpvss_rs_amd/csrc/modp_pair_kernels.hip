@@ -555,9 +555,9 @@ k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, cons
 
 // ---------------------------------------------------------------------------------------
 // a2 = y^r * Y^c against a REGISTERED key's table (k_modp_keyset_dual_exp of modp_kernels.hip on the pair layout: the same table
-// ks[key][j][d] = y^(d 2^(256 j)), the same program -- per byte position p of the 32-byte rows: four squarings and the product with
-// Y^(high nibble of c), four squarings and Y^(low nibble), then the eight table entries ks[j][byte p of r_j] -- 252 squarings
-// and 320 products at 85 / 122 instead of 153 / 191 issue slots).  dleq.rs:79-81 with y a long-lived participant key.
+// ks[key][j][d] = y^(d 2^(256 j)), d < 128, the same program -- 252 squarings, 296 products with table entries (7-bit windows of the
+// eight 256-bit rows of r), 64 with Y^(nibble of c) -- at 85 / 122 instead of 153 / 191 issue slots).  dleq.rs:79-81 with y a
+// long-lived participant key.
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
 k_modp_keyset_dual_exp_pair(const u32* __restrict__ ks, size_t key_words, const u32* __restrict__ tab2, const uint8_t* __restrict__ r_be,
@@ -565,31 +565,43 @@ k_modp_keyset_dual_exp_pair(const u32* __restrict__ ks, size_t key_words, const 
                             const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
   PAIR_KERNEL_PROLOGUE(gtab, count)
   const PairLane& pl = pc.pl;
+  // the program of k_modp_keyset_dual_exp: from bit 252 down, a squaring per bit (not at the first), at bits divisible by 7 the eight
+  // products with ks[j][window of r_j], at bits divisible by 4 the product with Y^(nibble of c), at the end the product with plain 1
+  //   s = 0 squaring, 1 .. 8 key table j = s - 1, 9 nibble of c, 10 closing
+  auto digit = [&](int j, int w) -> u32 {
+    const uint8_t* r = r_be + (size_t)pc.x * 256;
+    const int g = 256 * j + 7 * w, b = g >> 3;
+    const u32 lo = r[255 - b];
+    const u32 hi = (b + 1 < 256) ? r[254 - b] : 0u;
+    const int top = 256 - 7 * w;
+    return ((lo | (hi << 8)) >> (g & 7)) & (u32)((1 << (top < 7 ? top : 7)) - 1);
+  };
   u32 acc[LP];
-  load_pair_limbs(acc, tab2 + ((size_t)pc.x * 16 + (c_be[224] >> 4)) * L, pl);
-  int p = 0, s = 5;
+  load_pair_limbs(acc, cs->one_m, pl);
+  int cur = 7 * 36, s = 1;
   while (true) {
     const u32* fill = nullptr;
-    const bool sq = s < 4 || (s >= 5 && s < 9);
-    if (!sq) {
-      if (s == 4 || s == 9) {
-        const u32 byte = c_be[224 + p];
-        fill = tab2 + ((size_t)pc.x * 16 + ((s == 4) ? (byte >> 4) : (byte & 15))) * L;
-      } else if (s < 18) {
-        const int j = s - 10;
-        const u32 d = r_be[(size_t)pc.x * 256 + 224 - 32 * j + p];
-        fill = ks + (size_t)pc.x * key_words + ((size_t)j * 256 + d) * L;
+    bool skip = false;
+    if (s >= 1 && s <= 8) {
+      if (cur % 7 == 0) fill = ks + (size_t)pc.x * key_words + ((size_t)(s - 1) * 128 + digit(s - 1, cur / 7)) * L; else skip = true;
+    } else if (s == 9) {
+      if ((cur & 3) == 0) {
+        const u32 byte = c_be[255 - (cur >> 3)];
+        fill = tab2 + ((size_t)pc.x * 16 + ((cur & 4) ? (byte >> 4) : (byte & 15))) * L;
       } else {
-        fill = cs->one;                                  // leave the Montgomery domain
+        skip = true;
       }
+    } else if (s == 10) {
+      fill = cs->one;                                    // leave the Montgomery domain
     }
-    pair_step<true>(acc, sq, fill, acc, pc.slot, pc.junk, pc.tb, pl);
-    if (s == 18) break;
-    ++s;
-    if (s == 18) {
-      if (p == 31) continue;                             // the closing product
-      ++p;
+    if (!skip) pair_step<true>(acc, s == 0, fill, acc, pc.slot, pc.junk, pc.tb, pl);
+    if (s == 10) break;
+    if (s == 9) {
+      if (cur == 0) { s = 10; continue; }
+      --cur;
       s = 0;
+    } else {
+      ++s;
     }
   }
   store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);

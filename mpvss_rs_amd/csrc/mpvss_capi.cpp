@@ -1652,7 +1652,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       // of X^c and Y^c (about 51 products each) and their tables hold the odd powers only (8 instead of 14 products)
       static const int sliding = fd_env("MPVSS_C_SLIDING", 1);
       const uint16_t* dsched = nullptr;
-      if (sliding && a2_w6 && c_windows == 64 && !use_keys) {
+      if (sliding && a2_w6 && c_windows == 64) {        // (with registered keys too: a1's X^c follows it; the key-table kernel keeps Y's full table)
         uint16_t* hs = sl.work.root[0].csched;
         sliding_schedule(sl.work.root[0].challenge, hs);
         if (hs[0] > 0) {
@@ -1682,8 +1682,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           HIPCHK(ctx, hipEventCreateWithFlags(&sl.ev_xa1, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
         }
       }
+      // registered keys: without the chain of 2046 squarings beside them, g^r and a1 = g^r X^c pay for their layout -- both on the
+      // pair layout then (MPVSS_KEYSET_PAIR; measured 1.65-1.72 -> 1.80-1.86 M share verifications/s, profiles/r05_keyset_ab.txt)
+      static const int ks_pair_all = fd_env("MPVSS_KEYSET_PAIR", 1);
+      const bool pair_gr = (pair_mask() & 4) || (use_keys && ks_pair_all && (pair_mask() & 1));
+      const bool pair_a1 = (pair_mask() & 8) || (use_keys && ks_pair_all && (pair_mask() & 1));
       auto launch_gr = [&]() -> int {
-        if ((pair_mask() & 4) && comb_bits_of(ctx, cg) == 16)
+        if (pair_gr && comb_bits_of(ctx, cg) == 16)
           TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, (const uint8_t*)dr, (int)cnt, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
                                                            ctx->pair_tables, ctx->stream));
         else
@@ -1700,7 +1705,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, sl.work.root[0].csched, (1 + 2 * (size_t)sl.work.root[0].csched[0]) * 2,
                                      hipMemcpyHostToDevice, ctx->stream));
         uint32_t* t2p = (uint32_t*)ctx->w->tab2.p;
-        if (dsched) TIMED_LAUNCH(ctx, 2, launch_table_odd(ctx, (const uint8_t*)dY, cnt, t2p));
+        if (dsched && !use_keys) TIMED_LAUNCH(ctx, 2, launch_table_odd(ctx, (const uint8_t*)dY, cnt, t2p));
         else TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
         if (use_keys) {
           // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
@@ -1767,7 +1772,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           RET_IF(number_tables(ctx, dX, cnt, ctx->w->tab3, &tx));
         }
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_gr, 0));
-        if (dsched && (pair_mask() & 8))
+        if (dsched && pair_a1)
           TIMED_LAUNCH(ctx, 1, modp_launch_sched_exp_mul_pair(tx, TABW, dsched, (const uint32_t*)ctx->w->gr_m.p, (int)cnt, da1, ctx->consts,
                                                               ctx->pair_tables, ctx->stream));
         else if (dsched)

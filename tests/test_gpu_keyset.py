@@ -42,7 +42,7 @@ def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
 
     ks = engine.keyset_create(pk)
     try:
-        assert engine.keyset_bytes(ks) == nk * (8 * 256 * 288 + 256)
+        assert engine.keyset_bytes(ks) == nk * (8 * 128 * 288 + 256)            # 7-bit windows of the eight 256-bit rows of r
         engine.verify_block_compute_keyset(cm, pos, ks, key_offset, shares, resp, chal)
         st1, X1, A11, A21 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
         # a challenge that does not fit 256 bits takes the plain path inside the same entry point
