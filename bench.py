@@ -865,6 +865,8 @@ def main():
     else:
         RANK_DEPTH = min(8 + (7 * (world - 1) + 9) // 10 + (2 if world > 1 else 0), capi.BLOCK_SLOTS - max(HASH_THREADS, 1) - 4)
 
+    hash_threads_now = [HASH_THREADS]          # (the registered-keys leg raises it: its boxes are shorter on the GPU than their hash)
+
     def run_steps_many(seq_boxes, depth):
         """N = 1: complete verifications of the given boxes in ONE library call (mpvss_modp_verify_many): the calling thread
         enqueues the GPU work of up to `depth` boxes ahead, HASH_THREADS library threads absorb (wait for and hash)
@@ -876,7 +878,7 @@ def main():
                                    for bx in seq_boxes])
         verdicts = (C.c_int * k)()
         digests = (C.c_uint8 * (32 * k))()
-        eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_DEVICE, arr, k, depth, max(HASH_THREADS, 1), verdicts,
+        eng._check(lib.mpvss_modp_verify_many(ctx, capi.MPVSS_DEVICE, arr, k, depth, max(hash_threads_now[0], 1), verdicts,
                                               C.cast(digests, C.c_void_p)), "verify_many")
         raw = bytes(digests)
         return [(bool(verdicts[i]), raw[32 * i:32 * i + 32]) for i in range(k)]
@@ -1692,14 +1694,26 @@ def main():
                 torch.cuda.synchronize()
                 build_s = time.perf_counter() - tk
                 keyset[0] = h
-                if args.warmup > 0:
-                    gate(run_steps(min(args.warmup, 2)), "registered keys, warm-up")
+                # a box is ~37 ms on the GPU now and ~35 ms of hashing: more boxes in flight and more hash threads than the headline's
+                # (measured, profiles/r05_keyset_ab.txt: 10 / 8 -> 1.64 M, 16 / 12 -> 1.78 M, 24 -> 1.3-1.4 M)
+                ks_depth = int(os.environ.get("MPVSS_BENCH_KEYSET_DEPTH", "16"))
+                hash_threads_now[0] = int(os.environ.get("MPVSS_BENCH_KEYSET_HASH_THREADS", "12"))
+                gate(run_steps(ks_depth + hash_threads_now[0] + 2, depth=ks_depth), "registered keys, slot initialisation and warm-up")
                 barrier()
                 t1 = time.perf_counter()
-                res_k = run_steps(args.steps)
+                res_k = run_steps(args.steps, depth=ks_depth)
                 barrier()
                 el_k = time.perf_counter() - t1
                 gate(res_k, "registered keys")
+                ks_steady = None
+                if args.steady_steps > 0:
+                    barrier()
+                    t1 = time.perf_counter()
+                    res_s = run_steps(args.steady_steps, depth=ks_depth)
+                    barrier()
+                    ks_steady = n * args.steady_steps / (time.perf_counter() - t1)
+                    gate(res_s, "registered keys, steady state")
+                hash_threads_now[0] = HASH_THREADS
                 keyset[0] = None
                 table_bytes = int(lib.mpvss_modp_keyset_bytes(h))
                 lib.mpvss_modp_keyset_destroy(ctx, h)
@@ -1707,7 +1721,8 @@ def main():
                 # 256-bit rows of r), 64 nibbles of c against Y's full table (15 products instead of the odd-power table's 9), the closing one
                 mm_k = mm_total - n * a2_products - n * (63 if w6 else 15) + n * (252 * SQ_COST + 296 + 64 + 1 + (15 - 9))
                 result["registered_keys"] = {
-                    "value": n * args.steps / el_k, "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
+                    "value": n * args.steps / el_k, "value_steady_state": ks_steady, "boxes_in_flight": ks_depth,
+                    "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
                     "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
                     "modmul_equivalents_per_s": mm_k / (el_k / args.steps),
                     "note": "opt-in mpvss_modp_keyset_*: per-key tables y^(d 2^(256 j)), d < 128, in HBM (295 KB per key), built once per key "
@@ -1715,6 +1730,7 @@ def main():
                             "transcript digest; not the headline"}
             except capi.EngineError as err:
                 keyset[0] = None
+                hash_threads_now[0] = HASH_THREADS
                 result["registered_keys"] = {"value": None, "note": f"skipped: {err}"}
 
         # ---------------- C3 / C4: the curve groups at n=65536, t=256 (rank 0, N == 1) ----------------
