@@ -205,7 +205,7 @@ int mpvss_modp_verify_many_chained(mpvss_ctx* ctx, int space, const mpvss_modp_b
  * a verifier checks many boxes against one key set (src/participant.rs:399-455 takes the same `publickeys` each
  * time).  A key set holds, in HBM, per-key tables for y_i^r (295 KB per key: 19.3 GB for 65536 keys) built once
  * (about as much work as verifying 1.5 boxes); verify_block_compute_keyset then computes a2_i = y_i^r_i * Y_i^c with
- * 571 products instead of 2 620.  Results are identical to mpvss_modp_verify_block_compute on the same keys.
+ * 613 products instead of 2 620.  Results are identical to mpvss_modp_verify_block_compute on the same keys.
  * Shares i of the call use keys key_offset + i of the set.  Destroy a key set only after the blocks using it have
  * been absorbed. */
 int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out);

@@ -1615,6 +1615,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     sl.work.fd_used = false;
+    bool early_copies = false;
     const int64_t* hp = space == MPVSS_HOST ? hpos + off : nullptr;
     static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
     if (two_streams && ctx->w->sb && (pre || fd_applies(t, hp, cnt))) {
@@ -1700,6 +1701,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       };
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
+        // Y is an input: its copy into the staging (the transcript hashes it) leaves first, not with the outputs at the end -- the
+        // boxes of a run's last convoy finish together, and 4 x 16 MB per box behind the last kernel is what the hashes then wait for
+        static const int early_env = fd_env("MPVSS_EARLY_COPIES", 1);
+        if (nsl <= 1 && early_env) {
+          HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+          early_copies = true;
+        }
         // the schedule travels on THIS stream, ahead of a2; the a1 launch on the other stream waits for ev_gr, recorded below
         if (dsched)
           HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, sl.work.root[0].csched, (1 + 2 * (size_t)sl.work.root[0].csched[0]) * 2,
@@ -1783,6 +1791,10 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                                c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                                comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
+      if (early_copies) {      // X and a1 leave as soon as a1 is done (a2, on the other stream, usually is not yet)
+        HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+      }
       if (nsl > 1) {      // X, Y, a1 leave as soon as a1 is done; a2 has left range by range on the other stream
         HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
@@ -1799,7 +1811,9 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
                        0, c_windows, cnt, da2));
     }
-    if (sl.slices <= 1) {
+    if (early_copies) {
+      HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (sl.slices <= 1) {
       HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
