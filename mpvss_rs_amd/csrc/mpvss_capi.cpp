@@ -1703,7 +1703,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
         // Y is an input: its copy into the staging (the transcript hashes it) leaves first, not with the outputs at the end -- the
         // boxes of a run's last convoy finish together, and 4 x 16 MB per box behind the last kernel is what the hashes then wait for
-        static const int early_env = fd_env("MPVSS_EARLY_COPIES", 1);
+        static const int early_env = fd_env("MPVSS_EARLY_COPIES", 0);      // measured (profiles/r05_tail_ab.txt): no gain at K = 20, off
         if (nsl <= 1 && early_env) {
           HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
           early_copies = true;
