@@ -2138,12 +2138,19 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
     } else if (positions_ok) {
       mpvss::Sha256 tr;
       if (hashed > 0) memcpy(&tr, &tr_sl, sizeof(tr)); else memcpy(&tr, state, sizeof(tr));
-      frame_shares(tr, hX, hY, h1, h2, hashed, n);         // dleq.rs:87-99, share order = array order
+      // the caller's copies of the arrays (the one-call entry points: 64 MB per 65536 shares) beside the hash, not behind it
+      const bool copies = (x_out || y_out || a1_out || a2_out) && n * EB >= ((size_t)1 << 20);
+      hsc::parallel_indices(copies ? 2 : 1, [&](unsigned k) {
+        if (k == 0) {
+          frame_shares(tr, hX, hY, h1, h2, hashed, n);     // dleq.rs:87-99, share order = array order
+          if (copies) return;
+        }
+        if (x_out) memcpy(x_out, hX, n * EB);
+        if (y_out) memcpy(y_out, hY, n * EB);
+        if (a1_out) memcpy(a1_out, h1, n * EB);
+        if (a2_out) memcpy(a2_out, h2, n * EB);
+      });
       memcpy(state, &tr, sizeof(tr));
-      if (x_out) memcpy(x_out, hX, n * EB);
-      if (y_out) memcpy(y_out, hY, n * EB);
-      if (a1_out) memcpy(a1_out, h1, n * EB);
-      if (a2_out) memcpy(a2_out, h2, n * EB);
     }
   }
   const auto t_h1 = std::chrono::steady_clock::now();
