@@ -139,11 +139,11 @@ def horner_modmuls(positions, t):
     return total
 
 
-EC_COUNTERS_FILE = os.path.join("profiles", "r04_ec_counters.json")      # PMC evidence taken on the headline shapes (committed files)
-TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
-for _name in ("EC_COUNTERS_FILE", "TRAFFIC_FILE"):                          # (round 3's files until round 4's exist)
+EC_COUNTERS_FILE = os.path.join("profiles", "r04_ec_counters.json")      # PMC evidence taken on the headline shapes (committed files;
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")          # the curve kernels have not changed since round 4's passes)
+for _name, _old in (("EC_COUNTERS_FILE", ("r04_", "r03_")), ("TRAFFIC_FILE", ("r05_", "r04_"))):      # (the round before's file until this round's exists)
     if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), globals()[_name])):
-        globals()[_name] = globals()[_name].replace("r04_", "r03_")
+        globals()[_name] = globals()[_name].replace(*_old)
 
 EC = {
     "secp256k1": {"gid": 1, "enc": 33, "be": True, "algo_bytes": 197,     # 33+33+32 in, 3 x 33 out
