@@ -159,3 +159,10 @@ def test_fd_step_pair_kernel_with_edge_commitments():
     no inverse, the device flag must send them down Horner's rule) -- against O.commitment_eval in the reference order on 6
     positions per box (24 in all) and the fast form on 72 more each."""
     _child("fd", {"MPVSS_FD_PAIR_MIN_T": "16", "MPVSS_FD_L1": "2"})
+
+
+def test_fd_step_pair_tile_kernel_with_edge_commitments():
+    """The same boxes through k_modp_fd_step_pair_tile (round 5: the stepping as wide launches over the anti-diagonals of the
+    (stage, block of steps) grid, MPVSS_FD_TILE=2; ragged blocks of 50 steps): same oracle positions, same fall-back for the
+    boxes whose X is 0."""
+    _child("fd", {"MPVSS_FD_PAIR_MIN_T": "16", "MPVSS_FD_L1": "2", "MPVSS_FD_TILE": "2", "MPVSS_FD_TILE_STEPS": "50"})
