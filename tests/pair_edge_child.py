@@ -61,7 +61,7 @@ def tables():
     # X_i in {1, Q-1}: C_0 = 1, C_1 = Q-1; then random commitments (t = 5: Horner, no forward differences)
     c = rng.randrange(1 << 256)
     check_box(eng, [1, Q - 1], pos, ys, Ys, rs, c, "X = +-1, shared 256-bit c")
-    part = [i for i in range(n) if i % 6 == 0 or i >= n - 70]           # (the oracle's time: a sixth of the shares + the ragged end)
+    part = [i for i in range(n) if i % 4 == 0 or i >= n - 70]           # (the oracle's time: a quarter of the shares + the ragged end)
     m = 4133                           # (the wide comb of g^r was exercised above; these two differ in the schedule of c only)
     check_box(eng, [1, Q - 1], pos[:m], ys[:m], Ys[:m], rs[:m], 0, "X = +-1, c = 0", [i for i in part if i < m] + list(range(m - 70, m)))
     check_box(eng, [1, Q - 1], pos[:m], ys[:m], Ys[:m], rs[:m], (1 << 256) - 1, "X = +-1, c = 2^256 - 1", [i for i in part if i < m] + list(range(m - 70, m)))
