@@ -207,7 +207,20 @@ struct PairNext {
 };
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
+// A2_NUM_VGPR (round 5): a cap on the a2 kernel's registers below the 256 that two waves per SIMD allow.  Two a2 waves of 240 registers
+// leave 32 of a SIMD's 512: no wave of any other kernel (68-88 registers) fits beside them, and a SIMD that already holds one such wave
+// takes only ONE a2 wave -- a lone box's a2 launch then needs two rounds (71 instead of 37 ms beside the Horner seeds,
+// profiles/r05_rocprofv3/kernel_trace_one_box_at_a_time.csv).  At <= 216 two a2 waves and a quad wave share a SIMD.  (The attribute
+// counts the unified file in halves on gfx90a and later: amdgpu_num_vgpr(N / 2) caps the kernel at N.)
+#ifndef A2_NUM_VGPR
+#define A2_NUM_VGPR 0
+#endif
+#if A2_NUM_VGPR > 0
+#define A2_VGPR_ATTR __attribute__((amdgpu_num_vgpr(A2_NUM_VGPR / 2)))
+#else
+#define A2_VGPR_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR A2_VGPR_ATTR
 k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
                         const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
                         const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched,
