@@ -62,6 +62,9 @@ if __name__ == "__main__":
 # of more boxes run side by side (no effect on the headline shape, +60 % for 4096-share boxes; more than 16 queues
 # oversubscribe the hardware and hurt).  Must be set before the HIP runtime initialises; an explicit setting wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# RCCL between processes needs dmabuf IPC on this pool's host driver (already exported on the GPU boxes; kept here so that a rank
+# started by a launcher with a scrubbed environment still has it)
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import argparse
 import collections
