@@ -164,6 +164,10 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
                                 // (tools/bench_dealer.py, profiles/r04_twin_prefetch_ab.txt): 1.10 / 1.08 / 1.11 M shares/s without, 1.09 / 1.07 /
                                 // 1.10 M with -- the prefetch loses 1 %.  Off.
 #endif
+#ifndef TWIN_DIAG_NOMEM
+#define TWIN_DIAG_NOMEM 0       // diagnosis only: k_modp_twin_exp_buckets_pair without its bucket / running-power loads and stores (results are wrong):
+                                // what the kernel would take if its memory operations were free (profiles/r05_twin_nomem_diag.txt)
+#endif
 #ifndef PAIR_PREFETCH
 #define PAIR_PREFETCH 0         // 1: the operand of the NEXT product comes in by LDS-DMA (global_load_lds_dwordx4 into the number's slot, which is free
                                 // once the reduction holds T_lo in registers) while the current operation reduces; 0: fetched when needed.
@@ -675,8 +679,12 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
         occ[op - 1] |= 1u << d;
       }
       fill = (bk != nullptr && has) ? bk : cs->one_m;
+#if TWIN_DIAG_NOMEM                 // diagnosis only (wrong results): the same operations without the window's loads and stores
+      fill = cs->one_m;
+#else
       load_pair_limbs(acc, mycur, pl);
       if (bk != nullptr && !has && pc.live) store_pair_limbs(bk, acc, pl);        // a bucket's first factor is stored, not multiplied
+#endif
     }
     u64 T[LP];
     if (sq) {
@@ -710,12 +718,18 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
     if (sq || op == 0) {
 #pragma unroll
       for (int i = 0; i < LP; ++i) acc[i] = r[i];
+#if !TWIN_DIAG_NOMEM
       if (op == 0 || op == 2 + BW) store_pair_limbs(mycur, acc, pl);               // the window's cur
+#endif
     } else if (bk != nullptr && has && pc.live) {
+#if !TWIN_DIAG_NOMEM
       store_pair_limbs(bk, r, pl);
+#endif
     }
     if (op == 2 && k == BWIN - 1) break;
+#if !TWIN_DIAG_NOMEM
     if (op == 2) load_pair_limbs(acc, mycur, pl);                                  // back to the chain of squarings
+#endif
     if (op == 2 + BW) { op = 1; ++k; } else ++op;
   }
   if (pc.live && pl.h == 0) {
