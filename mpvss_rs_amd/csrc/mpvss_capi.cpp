@@ -2245,9 +2245,12 @@ extern "C" int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t
     delete ks;
     return rc;
   };
+  static const int trace_ks = fd_env("MPVSS_TRACE_KEYSET", 0);      // stderr: allocation against table build
+  const auto t_k0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&ks->keys.p, n * EB);
   if (e == hipSuccess) e = hipMalloc(&ks->table.p, n * modp_keyset_words_per_key() * 4);
   if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_NOMEM, "keyset_create: hipMalloc", e));
+  const auto t_k1 = std::chrono::steady_clock::now();
   e = hipMemcpyAsync(ks->keys.p, pubkeys, n * EB, space == MPVSS_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                      ctx->stream);
   if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_DEVICE, "keyset_create: copy", e));
@@ -2255,6 +2258,10 @@ extern "C" int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t
     return cleanup(fail(ctx, MPVSS_E_DEVICE, "keyset_create: launch"));
   e = hipStreamSynchronize(ctx->stream);     // the tables are read from every stream afterwards
   if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_DEVICE, "keyset_create: build", e));
+  if (trace_ks)
+    fprintf(stderr, "[mpvss] keyset_create n=%zu: hipMalloc %.1f ms, copy + table build %.1f ms\n", n,
+            std::chrono::duration<double, std::milli>(t_k1 - t_k0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k1).count());
   *out = ks;
   return MPVSS_OK;
 }
