@@ -209,6 +209,14 @@ int mpvss_modp_verify_many_chained(mpvss_ctx* ctx, int space, const mpvss_modp_b
  * Shares i of the call use keys key_offset + i of the set.  Destroy a key set only after the blocks using it have
  * been absorbed. */
 int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out);
+/* The same behind the UNCHANGED call (round 5): with min_boxes >= 2, mpvss_modp_verify_many builds the tables by itself for every
+ * public-key array that at least min_boxes large boxes (more shares than the grouped small boxes have) of ONE call present -- the
+ * same pointer and n inside one call is the same array: exact, nothing is hashed or compared -- uses them for those boxes and frees
+ * them when the call returns.  Building costs about one box of GPU time (60 ms per 65536 keys, 295 KB of HBM per key); a box then
+ * takes 37 instead of 59 ms: it pays from the third box.  What a verifier of many dealers' boxes against the same participants
+ * (src/participant.rs:399-455 with the same `publickeys` each time) gets without touching its code.  0 (the default): off.
+ * Returns the previous setting, or a negative error. */
+int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes);
 void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* keyset);
 size_t mpvss_modp_keyset_bytes(const mpvss_keyset* keyset);
 int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,

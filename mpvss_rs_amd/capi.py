@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_distribute_compute", "mpvss_ec_distribute_absorb", "mpvss_ec_hash_to_scalar",
     "mpvss_ec_block_absorb_claimed", "mpvss_ec_poly_eval_device", "mpvss_ec_dleq_responses_device", "mpvss_ec_deal_compute", "mpvss_ec_deal",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
-    "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes",
+    "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes", "mpvss_ctx_set_key_cache",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
     "mpvss_modp_verify_many", "mpvss_modp_verify_many_chained", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani", "mpvss_issue_probe",
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
@@ -108,6 +108,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_ctx_synchronize.argtypes = [vp]
     lib.mpvss_modp_fd_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.mpvss_modp_keyset_create.argtypes = [vp, ci, u8p, sz, C.POINTER(vp)]
+    lib.mpvss_ctx_set_key_cache.argtypes = [vp, ci]
     lib.mpvss_modp_keyset_destroy.argtypes = [vp, vp]
     lib.mpvss_modp_keyset_destroy.restype = None
     lib.mpvss_modp_keyset_bytes.argtypes = [vp]
@@ -351,6 +352,12 @@ class Engine:
         self._check(self.lib.mpvss_modp_keyset_create(self.ctx, MPVSS_HOST, pk, len(pubkeys) // EB, C.byref(h)),
                     "keyset_create")
         return h
+
+    def set_key_cache(self, min_boxes: int) -> int:
+        """verify_many builds per-key tables by itself for key arrays that >= min_boxes large boxes of one call share (0: off)"""
+        rc = int(self.lib.mpvss_ctx_set_key_cache(self.ctx, int(min_boxes)))
+        self._check(rc if rc < 0 else 0, "set_key_cache")
+        return rc
 
     def keyset_destroy(self, keyset) -> None:
         self.lib.mpvss_modp_keyset_destroy(self.ctx, keyset)

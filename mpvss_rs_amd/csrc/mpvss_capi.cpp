@@ -199,6 +199,7 @@ struct mpvss_ctx {
   // a run of many boxes is under way (mpvss_*_verify_many with more than two boxes, or the caller said so through
   // MPVSS_PIPELINED=1): a block then never takes the configuration meant for a call that has the GPU to itself, not even
   // the first ones of the run
+  int key_cache_min_boxes = 0;   // mpvss_ctx_set_key_cache: verify_many registers key arrays that this many large boxes of a call share (0: off)
   bool pipelined_hint = false;
   int pipeline_depth = 0;        // boxes the running library pipeline keeps in flight (0: none running)
   bool busy_with_others() const { return pipelined_hint || NSLOT - free_top >= 2; }
@@ -2266,6 +2267,15 @@ extern "C" int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t
   return MPVSS_OK;
 }
 
+extern "C" int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (min_boxes < 0 || min_boxes == 1) return fail(ctx, MPVSS_E_INVALID, "set_key_cache: min_boxes must be 0 (off) or >= 2");
+  const int prev = ctx->key_cache_min_boxes;
+  ctx->key_cache_min_boxes = min_boxes;
+  return prev;
+}
+
 extern "C" void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* ks) {
   if (!ks) return;
   if (ctx) {
@@ -2574,6 +2584,38 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   std::vector<ModpPre> pre(xB > 1 ? count : 0);
   std::vector<char> has_pre(count, 0), looked(count, 0);
   size_t batch_no = 0;
+  // The key cache (mpvss_ctx_set_key_cache): a public-key array that enough large boxes of THIS call present -- same pointer, same n:
+  // inside one call that is the same array -- gets its tables built once, now; those boxes then take the registered-key path
+  // (a2 in 613 instead of 2 620 products), the tables are freed when the call returns.  Boxes that bring a key set of their own, small
+  // boxes (they travel in groups) and boxes whose challenge does not fit 256 bits (decided per block) are left as they are.
+  std::vector<const mpvss_keyset*> auto_ks(count, nullptr);
+  struct AutoKeys {
+    mpvss_ctx* c;
+    std::vector<mpvss_keyset*> made;
+    ~AutoKeys() { for (mpvss_keyset* k : made) mpvss_modp_keyset_destroy(c, k); }
+  } auto_keys{ctx, {}};
+  const int cache_min = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->key_cache_min_boxes; }();
+  if (cache_min >= 2) {
+    static const size_t small_max = (size_t)fd_env("MPVSS_GROUP_MAX_BOX", 16384);
+    std::vector<char> seen(count, 0);
+    for (size_t b = 0; b < count; ++b) {
+      const mpvss_modp_box& bx = boxes[b];
+      if (seen[b] || bx.keyset || !bx.pubkeys || bx.n <= small_max || bx.n > MAX_CHUNK) continue;
+      std::vector<size_t> same;
+      for (size_t k = b; k < count; ++k)
+        if (!boxes[k].keyset && boxes[k].pubkeys == bx.pubkeys && boxes[k].n == bx.n) { same.push_back(k); seen[k] = 1; }
+      if ((int)same.size() < cache_min) continue;
+      mpvss_keyset* ks = nullptr;
+      const int rc = mpvss_modp_keyset_create(ctx, space, bx.pubkeys, bx.n, &ks);
+      if (rc == MPVSS_E_NOMEM) {        // no room for the tables: these boxes are verified the plain way
+        (void)hipGetLastError();
+        continue;
+      }
+      if (rc != MPVSS_OK) return rc;
+      auto_keys.made.push_back(ks);
+      for (size_t k : same) auto_ks[k] = ks;
+    }
+  }
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
       [&](size_t b, unsigned* parts, unsigned* nbox) {
@@ -2608,10 +2650,11 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
         }
         for (size_t p = 0; p < P; ++p) {
           const size_t lo = (bx.n * p / P) & ~(size_t)15, hi = p + 1 == P ? bx.n : ((bx.n * (p + 1) / P) & ~(size_t)15);
+          const mpvss_keyset* use_ks = bx.keyset ? bx.keyset : auto_ks[b];
           const int rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions + lo,
                                                      bx.pubkeys ? bx.pubkeys + lo * EB : nullptr, bx.shares + lo * EB,
-                                                     bx.responses + lo * EB, hi - lo, bx.challenge_host, bx.keyset, bx.key_offset + lo, nullptr,
-                                                     (P == 1 && has_pre[b]) ? &pre[b] : nullptr);
+                                                     bx.responses + lo * EB, hi - lo, bx.challenge_host, use_ks,
+                                                     (bx.keyset ? bx.key_offset : 0) + lo, nullptr, (P == 1 && has_pre[b]) ? &pre[b] : nullptr);
           if (rc != MPVSS_OK) return rc;
           ++*parts;
         }

@@ -64,3 +64,54 @@ def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
         Y = int.from_bytes(shares[i * EB:(i + 1) * EB], "big")
         r = int.from_bytes(resp[i * EB:(i + 1) * EB], "big")
         assert int.from_bytes(A21[i * EB:(i + 1) * EB], "big") == pow(y, r, Q) * pow(Y, c, Q) % Q, i
+
+
+def test_key_cache_behind_the_unchanged_verify_many(engine):
+    """mpvss_ctx_set_key_cache(ctx, 3): mpvss_modp_verify_many registers by itself a public-key array that at least three large boxes
+    of the call present (same pointer, same n) and verifies those boxes against the tables -- same verdicts and digests as with the
+    cache off: honest boxes of three dealers against one key array, a tampered response, a tampered share, a box with a second key
+    array (only one box has it: left alone), a box whose challenge does not fit 256 bits (plain path inside the same call), host
+    memory.  The kernel counter of the key-table path says the cache was really used."""
+    import ctypes as C
+    n, t = 16500, 16
+    rng = random.Random(77)
+    sc = lambda k: b"".join(rng.randrange(1, 1 << 2040).to_bytes(EB, "big") for _ in range(k))
+    pos = list(range(9, 9 + n))
+    pkA = engine.batch_exp_fixed_base(fx(2), sc(n))
+    pkB = engine.batch_exp_fixed_base(fx(2), sc(n))
+    def deal(pk):
+        coeffs = sc(t)
+        d = engine.deal(coeffs, pos, pk, sc(n))
+        return dict(cm=engine.batch_exp_fixed_base(fx(4), coeffs), Y=d["Y"], r=d["responses"], c=d["challenge"], digest=d["digest"])
+    d1, d2, d3, dB = deal(pkA), deal(pkA), deal(pkA), deal(pkB)
+    flip = lambda b, at: b[:at] + bytes([b[at] ^ 1]) + b[at + 1:]
+    specs = [(pkA, d1), (pkA, dict(d2, r=flip(d2["r"], 5 * EB + 200))), (pkA, d2), (pkB, dB), (pkA, dict(d3, Y=flip(d3["Y"], 77))), (pkA, d3),
+             (pkA, dict(d1, c=fx((1 << 300) + 5))), (pkA, d1)]
+    bufs = {id(pkA): (C.c_uint8 * len(pkA)).from_buffer_copy(pkA), id(pkB): (C.c_uint8 * len(pkB)).from_buffer_copy(pkB)}
+    posb = (C.c_int64 * n)(*pos)
+    keep, arr = [], (capi.ModpBox * len(specs))()
+    for i, (pk, d) in enumerate(specs):
+        b = [(C.c_uint8 * len(d[k])).from_buffer_copy(d[k]) for k in ("cm", "Y", "r", "c")]
+        keep.append(b)
+        arr[i] = capi.ModpBox(C.addressof(b[0]), t, C.addressof(posb), C.addressof(bufs[id(pk)]), C.addressof(b[1]), C.addressof(b[2]), n,
+                              C.addressof(b[3]), None, 0)
+
+    def run():
+        verdicts = (C.c_int * len(specs))()
+        digests = (C.c_uint8 * (32 * len(specs)))()
+        engine._check(engine.lib.mpvss_modp_verify_many(engine.ctx, capi.MPVSS_HOST, arr, len(specs), 4, 3, verdicts, C.cast(digests, C.c_void_p)),
+                      "verify_many")
+        return [(bool(verdicts[i]), bytes(digests)[32 * i:32 * i + 32]) for i in range(len(specs))]
+
+    assert engine.set_key_cache(0) == 0
+    plain = run()
+    assert [v for v, _ in plain] == [True, False, True, True, False, True, False, True]
+    assert plain[0][1] == d1["digest"] and plain[3][1] == dB["digest"] and plain[5][1] == d3["digest"]
+    assert engine.set_key_cache(3) == 0
+    try:
+        cached = run()
+    finally:
+        assert engine.set_key_cache(0) == 3
+    assert cached == plain
+    with pytest.raises(capi.EngineError):
+        engine.set_key_cache(1)
