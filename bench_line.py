@@ -45,7 +45,7 @@ _PATHS = (
     ("verify_share", "value"), ("extract_shares", "value"),
     ("distribute", "value"), ("distribute", "value_end_to_end"), ("distribute", "value_one_call_host_buffers_end_to_end"),
     ("host_buffers", "value"),
-    ("registered_keys", "value"), ("registered_keys", "value_steady_state"), ("registered_keys", "table_bytes"), ("registered_keys", "table_build_s"),
+    ("registered_keys", "value"), ("registered_keys", "value_steady_state"), ("registered_keys", "value_transparent"), ("registered_keys", "table_bytes"), ("registered_keys", "table_build_s"),
     ("ec", "secp256k1", "value"), ("ec", "secp256k1", "compute", "frac"),
     ("ec", "secp256k1", "kernel_ms_isolated", "box_on_the_gpu_ms"),
     ("ec", "secp256k1", "distribute", "value_end_to_end"), ("ec", "secp256k1", "distribute", "value_one_call_host_buffers_end_to_end"),

@@ -71,7 +71,7 @@ def test_key_cache_behind_the_unchanged_verify_many(engine):
     of the call present (same pointer, same n) and verifies those boxes against the tables -- same verdicts and digests as with the
     cache off: honest boxes of three dealers against one key array, a tampered response, a tampered share, a box with a second key
     array (only one box has it: left alone), a box whose challenge does not fit 256 bits (plain path inside the same call), host
-    memory.  The kernel counter of the key-table path says the cache was really used."""
+    memory.  The launch counter of the table builds says the cache was really used."""
     import ctypes as C
     n, t = 16500, 16
     rng = random.Random(77)
@@ -104,7 +104,9 @@ def test_key_cache_behind_the_unchanged_verify_many(engine):
         return [(bool(verdicts[i]), bytes(digests)[32 * i:32 * i + 32]) for i in range(len(specs))]
 
     assert engine.set_key_cache(0) == 0
+    engine.pipeline_stats(reset=True)
     plain = run()
+    tables_plain = engine.pipeline_stats(reset=True)["kernel_launches"][2]
     assert [v for v, _ in plain] == [True, False, True, True, False, True, False, True]
     assert plain[0][1] == d1["digest"] and plain[3][1] == dB["digest"] and plain[5][1] == d3["digest"]
     assert engine.set_key_cache(3) == 0
@@ -113,5 +115,7 @@ def test_key_cache_behind_the_unchanged_verify_many(engine):
     finally:
         assert engine.set_key_cache(0) == 3
     assert cached == plain
+    # six of the eight boxes went through the key tables: no 64-entry table of y was built for them
+    assert engine.pipeline_stats(reset=True)["kernel_launches"][2] == tables_plain - 6
     with pytest.raises(capi.EngineError):
         engine.set_key_cache(1)
