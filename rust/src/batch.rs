@@ -77,12 +77,19 @@ pub fn verify_many(group: &HipModpGroup, boxes: &[&DistributionSharesBox<HipModp
     let flats: Vec<Option<FlatBox>> = boxes.iter().map(|b| flatten(group, b)).collect();
     let mut descs = Vec::new();
     let mut index = Vec::new();
+    // Boxes of different dealers for the same participants carry the same public keys: hand the engine ONE array for them (the
+    // first box's), so that its key cache (`Engine::set_key_cache`) recognises them -- it goes by pointer and n, never by content.
+    let mut distinct: Vec<&Vec<u8>> = Vec::new();
     for (i, (f, b)) in flats.iter().zip(boxes).enumerate() {
         if let Some(f) = f {
             index.push(i);
+            let keys: &Vec<u8> = match distinct.iter().find(|k| **k == &f.pubkeys) {
+                Some(k) => *k,
+                None => { distinct.push(&f.pubkeys); &f.pubkeys }
+            };
             descs.push(ffi::mpvss_modp_box {
                 commitments: f.commitments.as_ptr(), t: b.commitments.len(), positions: f.positions.as_ptr(),
-                pubkeys: f.pubkeys.as_ptr(), shares: f.shares.as_ptr(), responses: f.responses.as_ptr(), n: f.positions.len(),
+                pubkeys: keys.as_ptr(), shares: f.shares.as_ptr(), responses: f.responses.as_ptr(), n: f.positions.len(),
                 challenge_host: f.challenge.as_ptr(), keyset: std::ptr::null(), key_offset: 0,
             });
         }

@@ -89,6 +89,19 @@ impl Engine {
         })
     }
 
+    /// `batch::verify_many` builds per-key tables by itself for a public-key array that at least `min_boxes` large boxes of one
+    /// call present (the same `Vec<u8>` of flattened keys: same pointer, same n) and frees them when the call returns -- what a
+    /// verifier of many dealers' boxes against the same participants gets without changing its calls
+    /// (`Participant::verify_distribution_shares`, src/participant.rs:399-455, with the same `publickeys` every time).  0: off (the
+    /// default).  Returns the previous setting.
+    pub fn set_key_cache(&self, min_boxes: i32) -> Result<i32, EngineError> {
+        let rc = unsafe { ffi::mpvss_ctx_set_key_cache(self.ctx.0, min_boxes) };
+        if rc < 0 {
+            self.check(rc)?;
+        }
+        Ok(rc)
+    }
+
     /// For trait methods that cannot return an error (`Group::exp`): a failing engine is a programmer / hardware
     /// error there, as a panic in the reference's arithmetic crates would be.
     pub(crate) fn expect(&self, rc: i32, what: &str) {
