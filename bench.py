@@ -538,7 +538,7 @@ def mix_seconds_per_simd(by_layout, tau):
 NOMINAL_CLOCK_GHZ = 2.4
 PEAK_VALU_SLOTS_PER_S = 1024 * NOMINAL_CLOCK_GHZ * 1e9 / 4.0
 PEAK_SOURCE = "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: chip parameters, cycle constants)"
-PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "49")) & (63 if os.environ.get("MPVSS_A2_PAIR", "1") != "0" else 62)
+PAIR_MASK = int(os.environ.get("MPVSS_PAIR", "49")) & 63
 FD_PAIR_MIN_T = int(os.environ.get("MPVSS_FD_PAIR_MIN_T", "512"))     # from this many commitments the X path steps in the pair layout
 
 
@@ -552,7 +552,7 @@ def modp_work(n, t, positions, cs):
     mul_n = {"x": 0.0, "a1": 0.0, "a2": 0.0, "tab": 0.0}
     fd = os.environ.get("MPVSS_FD", "1") != "0" and 16 <= t <= 1024 and n >= 16 * t and n >= int(os.environ.get("MPVSS_FD_MIN_SHARES", "4096"))
     if fd:
-        chains = max(1, min(int(os.environ.get("MPVSS_FD_CHAINS", "0")) or max(min(2048 // t, n // 8192), n // 16384, 4),
+        chains = max(1, min(max(min(2048 // t, n // 8192), n // 16384, 4),
                             n // (4 * t)))                                   # as eval_x() in mpvss_capi.cpp
         chain_len = -(-n // chains)
         w0 = (chain_len - t) // 2                                        # seeds sit in the middle of every chain
@@ -577,12 +577,12 @@ def modp_work(n, t, positions, cs):
     mul_n["x"] = mm_x - mul_n.get("x_pair", 0.0)               # (Horner's squarings are folded in at SQ_COST: a few % of the X path)
     comb_min = int(os.environ.get("MPVSS_COMB16_MIN", "8192"))
     gr = 127 if (comb_min > 0 and n >= comb_min) else 511     # g^r: wide comb (16-bit windows) or 4-bit comb
-    w6 = os.environ.get("MPVSS_A2_W6", "1") != "0" and n >= 1024   # 6-bit windows for y^r (64-entry table) or 4-bit
+    w6 = n >= 1024   # 6-bit windows for y^r (64-entry table) or 4-bit
     # X^c and Y^c: 64 fixed 4-bit windows, or -- one c for the whole box, forward-difference path -- the sliding-window
     # schedule the library makes from it (width 4, odd digits; the tables of X and Y then hold the odd powers only)
     tot_a2 = 0.0
     for c in cs:
-        sliding = fd and w6 and os.environ.get("MPVSS_C_SLIDING", "1") != "0" and c > 0
+        sliding = fd and w6 and c > 0
         c_win, c_top = sliding_windows(c) if sliding else (0, 0)
         yc = c_win if sliding else 64                          # products with the table of Y (a2) / X (a1; its first is a load)
         xc_sq, xc = (c_top, c_win - 1) if sliding else (252, 63)
@@ -1052,8 +1052,7 @@ def main():
     nb = max(pst["blocks"], 1)
     x_ms, a1_ms, tb_ms, a2_ms = (pst["kernel_ms"][k] / nb for k in (0, 1, 2, 3))    # overlapped: boxes share the chip
     a2_n = max(pst["kernel_launches"][3] / nb, 1.0)   # a2 launches per step (1 unless the box is split)
-    a2_kernel = (("k_modp_dual_exp_w6_pair" if PAIR_MASK & 1 else "k_modp_dual_exp_w6") if os.environ.get("MPVSS_A2_W6", "1") != "0"
-                 else "k_modp_dual_exp")
+    a2_kernel = "k_modp_dual_exp_w6_pair" if PAIR_MASK & 1 else "k_modp_dual_exp_w6"
     shares_per_a2_launch = n / a2_n
     # Isolated launches: the same box verified alone (one box in flight, nothing else on the GPU) after the timed
     # region -- the duration of a launch that has the chip to itself is what a roofline can be read from; in the timed

@@ -24,9 +24,6 @@
 #ifndef MM_REDUCE_PRIO
 #define MM_REDUCE_PRIO 1      // wave priority while a wave is in reduce(): measured +1-2 % in the headline pipeline (profiles/r03_pair_occupancy_ab.txt), inside the noise
 #endif
-#ifndef MM_PREFETCH
-#define MM_PREFETCH 0         // A records of the NEXT MFMA stage read ahead (0: every stage reads its own at its top)
-#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -158,24 +155,9 @@ __device__ __forceinline__ void phase_a(u64 (&T)[LP], const u32 (&a)[LP], u32* s
   asm volatile("" ::: "memory");
 }
 
-#ifndef MM_SGB
-#define MM_SGB 0              // 1: every MFMA stage of reduce() is laid out "one MFMA, then its share of the epilogue's VALU work" by
-                              // sched_group_barrier, the MFMA FIRST: left alone the compiler opens a stage with the epilogue of the stage
-                              // before (which has to wait for that stage's last MFMA) and the matrix pipe idles meanwhile
-#endif
 // N groups of [1 MFMA, V VALU instructions] for the scheduling region that ends here
 template <int N, int V, bool FIRST = true>
 __device__ __forceinline__ void sgb_mfma_first() {
-#if MM_SGB
-  if constexpr (N > 0) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#if MM_SGB >= 2               // the stage's own record reads run two MFMAs ahead of their use
-    __builtin_amdgcn_sched_group_barrier(0x100, FIRST ? 2 : 1, 0);
-#endif
-    __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-    sgb_mfma_first<N - 1, V, false>();
-  }
-#endif
 }
 constexpr int mm_row_mfmas2(int R) {
   int n = 0;
@@ -214,29 +196,6 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
   const v16i* c2 = tb->c2 + pl.h;
   u32 saved = 0;                                       // half 0: hi of limb 8R-1 (from half 1, previous tile)
   v16i acc[2];
-#if MM_PREFETCH
-  // The A records and the C-init of a stage come from LDS.  Left to itself the compiler issues all reads of a stage at its
-  // top and the first MFMA waits for them (an LDS round trip per stage, 18 per reduction, with nothing of this wave to put
-  // under it).  Here the first MM_PREFETCH records and the C-init of stage s + 1 are read during stage s -- after the MFMAs
-  // that used the registers have issued and the epilogue of stage s - 1 has read the accumulator they go to --, so that a
-  // stage starts on operands that are already there and its own later reads hide behind its first MFMAs.
-  v4i pre[MM_PREFETCH];
-  auto rec1 = [&](int R, int C) -> v4i { return tb->gt1[pl.rec1 + 8 * (R - C)]; };
-  auto rec2 = [&](int R, int C) -> v4i { return tb->gt2[(R == 8 ? pl.rec2g : pl.rec2) + (4 * R - 8 * C + 64)]; };
-  auto chain1 = [&](int R, v16i& ac) {
-#pragma unroll
-    for (int C = 0; C <= R; ++C) {
-      const v4i A = C < MM_PREFETCH ? pre[C] : rec1(R, C);
-      ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, xw[C], ac, 0, 0, 0);
-    }
-  };
-  auto fetch1 = [&](int R, v16i& ac) {      // operands of GEMM-1 stage R ahead of time
-#pragma unroll
-    for (int C = 0; C < MM_PREFETCH; ++C)
-      if (C <= R) pre[C] = rec1(R, C);
-    ac = c1[2 * R];
-  };
-#else
   auto chain1 = [&](int R, v16i& ac) {
     ac = c1[2 * R];
 #pragma unroll
@@ -245,7 +204,6 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
       ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, xw[C], ac, 0, 0, 0);
     }
   };
-#endif
   auto epi1 = [&](int R, const v16i& ac) {
     u32 lo[4], hi[4];
 #pragma unroll
@@ -267,17 +225,9 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
     mw[R] = m;
   };
   constexpr int EPI1_VALU = 38, EPI2_VALU = 22;         // VALU instructions of one epilogue (ISA count), spread over the stage's MFMAs
-#if MM_PREFETCH
-#define MM_FETCH1(R) if ((R) < 8) fetch1((R) + 1, acc[((R) + 1) & 1]);
-#define MM_FETCH2(R) if ((R) < 7) fetch2((R) + 1, acc[(R) & 1]);
-  fetch1(0, acc[0]);
-  chain1(0, acc[0]);
-  fetch1(1, acc[1]);
-#else
 #define MM_FETCH1(R)
 #define MM_FETCH2(R)
   chain1(0, acc[0]);
-#endif
   __builtin_amdgcn_sched_barrier(0);
 #define MM_STAGE1(R)                                                  \
   chain1(R, acc[(R) & 1]);                                            \
@@ -290,28 +240,6 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
   epi1(8, acc[0]);
   __builtin_amdgcn_sched_barrier(0);
   // ---------------- GEMM 2: high limbs of m'' * N, and the carry out of the low half -----------------------------------
-#if MM_PREFETCH
-  auto chain2 = [&](int R, v16i& ac) {
-    int j = 0;
-#pragma unroll
-    for (int C = 0; C < 9; ++C) {
-      if (MM_SKIP2[9 * R + C]) continue;
-      const v4i A = j < MM_PREFETCH ? pre[j] : rec2(R, C);
-      ++j;
-      ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, mw[C], ac, 0, 0, 0);
-    }
-  };
-  auto fetch2 = [&](int R, v16i& ac) {
-    int j = 0;
-#pragma unroll
-    for (int C = 0; C < 9; ++C) {
-      if (MM_SKIP2[9 * R + C]) continue;
-      if (j < MM_PREFETCH) pre[j] = rec2(R, C);
-      ++j;
-    }
-    ac = c2[2 * R];
-  };
-#else
   auto chain2 = [&](int R, v16i& ac) {
     ac = c2[2 * R];
 #pragma unroll
@@ -321,7 +249,6 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
       ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, mw[C], ac, 0, 0, 0);
     }
   };
-#endif
   auto epi2 = [&](int R, const v16i& ac) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -346,13 +273,7 @@ __device__ __forceinline__ void reduce(u32 (&r)[LP], u64 (&T)[LP], const u32* sl
     }
   };
   // tile 8 first: it carries the guard limb, whose carry goes into limb 0
-#if MM_PREFETCH
-  fetch2(8, acc[0]);
   chain2(8, acc[0]);
-  fetch2(0, acc[1]);
-#else
-  chain2(8, acc[0]);
-#endif
   __builtin_amdgcn_sched_barrier(0);
 #define MM_STAGE2(R)                                                                   \
   chain2(R, acc[((R) + 1) & 1]);                                                       \

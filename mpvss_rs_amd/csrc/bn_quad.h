@@ -24,10 +24,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef MODP_RETIRE_MAD
-#define MODP_RETIRE_MAD 0
-#endif
-
 namespace bn {
 
 typedef uint32_t u32;
@@ -136,17 +132,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[LPL], const u32 (&a)[LPL], con
       // by construction and retires.  No lane-dependent arithmetic: one shift, one 64-bit add, one v_and_b32_dpp.
       {
         const u64 ret = T[rr];
-#if MODP_RETIRE_MAD
-        // Experiment (off by default): ret >> 29 = hi * 8 + (lo >> 29) added with two mads and a 32-bit shift instead of
-        // v_lshrrev_b64 + v_lshl_add_u64 -- 42 instead of 41 VALU instructions per row but no double-cost 64-bit ones.
-        // Measured on MI355X (profiles/r02_retire_step_ab.txt): 917.7 / 913.5 k share verifications/s against
-        // 916.7 / 930.0 k for the shift-and-add form -- the board runs at its power cap and the two extra multiplier
-        // passes cost what the cheaper issue slots save.
-        T[(rr + 1) % LPL] += (u64)(u32)(ret >> 32) * ln.eight;
-        T[(rr + 1) % LPL] += (u64)((u32)ret >> W) * ln.one;
-#else
         T[(rr + 1) % LPL] += ret >> W;
-#endif
         T[rr] = (u64)(quad_from_next((u32)ret) & ln.top28);
       }
       // Pin the row-wise order: without this LLVM reassociates the 19-fold unrolled body into a

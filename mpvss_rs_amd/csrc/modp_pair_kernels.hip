@@ -155,27 +155,6 @@ __device__ __forceinline__ void store_canonical_pair(uint8_t* __restrict__ out, 
 // box has ONE challenge) against the table of Y -- on the pair layout.  tab1 [count][64][72], tab2 [count][16][72] in
 // Montgomery limb form as the quad kernels build them (the limb order in HBM does not depend on the layout).
 // ---------------------------------------------------------------------------------------
-#ifndef FD_STEP_KEEP_PRIO
-#define FD_STEP_KEEP_PRIO 0    // stepping waves at priority 3 inside reduce() too (1) or at reduce()'s own priority there (0)
-#endif
-#ifndef TWIN_PREFETCH
-#define TWIN_PREFETCH 0         // the same for the bucket products of k_modp_twin_exp_buckets_pair (the dealer's and the participant's kernel): built,
-                                // bit-exact (dealer / extract / scalar tests), measured over three interleaved pairs of pipelined dealer runs
-                                // (tools/bench_dealer.py, profiles/r04_twin_prefetch_ab.txt): 1.10 / 1.08 / 1.11 M shares/s without, 1.09 / 1.07 /
-                                // 1.10 M with -- the prefetch loses 1 %.  Off.
-#endif
-#ifndef TWIN_DIAG_NOMEM
-#define TWIN_DIAG_NOMEM 0       // diagnosis only: k_modp_twin_exp_buckets_pair without its bucket / running-power loads and stores (results are wrong):
-                                // what the kernel would take if its memory operations were free (profiles/r05_twin_nomem_diag.txt)
-#endif
-#ifndef PAIR_PREFETCH
-#define PAIR_PREFETCH 0         // 1: the operand of the NEXT product comes in by LDS-DMA (global_load_lds_dwordx4 into the number's slot, which is free
-                                // once the reduction holds T_lo in registers) while the current operation reduces; 0: fetched when needed.
-                                // Built, bit-exact (the whole GPU suite ran with it) and measured: the a2 launch alone 37.5 +- 0.3 ms either way
-                                // (profiles/r04_a2_alone_variants.txt), the pipeline within its run-to-run noise (profiles/r04_pair_variants_ab.txt),
-                                // for 4 % more VALU instructions (80 address instructions per product): two waves per SIMD already hide a product's
-                                // nine scattered 16-byte reads.  Off.
-#endif
 
 namespace {
 // The next product's operands of the wave's 32 numbers, HBM -> LDS slots, without registers (global_load_lds_dwordx4).  One
@@ -314,19 +293,7 @@ k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ ta
       phase_a<false>(T, acc, slot, junk, pl);
     }
     u32 r[LP];
-#if PAIR_PREFETCH
-    fetched = nx.kind > 0;
-    reduce(r, T, slot, tb, pl, [&]() {          // ONE copy of the reduction in the kernel
-      if (nx.kind > 0) {
-        const u32* base;
-        size_t stride;
-        source(nx, base, stride);
-        slots_prefetch_pair(wslots, base, stride, x0, count, nx.ent, pl);
-      }
-    });
-#else
     reduce(r, T, slot, tb, pl);
-#endif
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < LP; ++k) acc[k] = r[k];
@@ -380,13 +347,7 @@ __device__ __forceinline__ void pair_step_pf(u32 (&acc)[LP], bool sq, const u32*
     phase_a<false>(T, acc, slot, junk, pl);
   }
   u32 r[LP];
-#if PAIR_PREFETCH
-  reduce(r, T, slot, tb, pl, [&]() {
-    if (nx.base != nullptr) slots_prefetch_pair(wslots, nx.base, nx.stride, x0, count, nx.ent, pl);
-  });
-#else
   reduce(r, T, slot, tb, pl);
-#endif
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int k = 0; k < LP; ++k) acc[k] = r[k];
@@ -508,7 +469,7 @@ k_modp_comb16_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict
   for (int k = 1; k < 128; ++k) {
     PairNext nx;
     if (k + 1 < 128) { nx.base = row(k + 1); nx.ent = digit16(k + 1); }
-    pair_step_pf<false>(acc, false, row(k) + (size_t)d * L, PAIR_PREFETCH && k > 1, nx, pc.wslots, pc.x0, count, pc.slot, pc.junk, pc.tb, pl);
+    pair_step_pf<false>(acc, false, row(k) + (size_t)d * L, false, nx, pc.wslots, pc.x0, count, pc.slot, pc.junk, pc.tb, pl);
     d = nx.ent;
   }
   if (pc.live) store_pair_limbs(p_m + (size_t)pc.x * L, acc, pl);
@@ -563,7 +524,7 @@ k_modp_sched_exp_mul_pair(const u32* __restrict__ tab2, size_t tab2_stride, cons
     if (op.kind != 3) { nop = next_op(); source(nop, nx); }
     const u32* fill = me.base ? me.base + (size_t)pc.x * me.stride + (size_t)me.ent * L : nullptr;
     pair_step_pf<true>(acc, op.kind == 0, fill, fetched, nx, pc.wslots, pc.x0, count, pc.slot, pc.junk, pc.tb, pl);
-    fetched = PAIR_PREFETCH && nx.base != nullptr;
+    fetched = false;
     if (op.kind == 3) break;
     op = nop;
   }
@@ -679,12 +640,8 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
         occ[op - 1] |= 1u << d;
       }
       fill = (bk != nullptr && has) ? bk : cs->one_m;
-#if TWIN_DIAG_NOMEM                 // diagnosis only (wrong results): the same operations without the window's loads and stores
-      fill = cs->one_m;
-#else
       load_pair_limbs(acc, mycur, pl);
       if (bk != nullptr && !has && pc.live) store_pair_limbs(bk, acc, pl);        // a bucket's first factor is stored, not multiplied
-#endif
     }
     u64 T[LP];
     if (sq) {
@@ -697,39 +654,17 @@ k_modp_twin_exp_buckets_pair(const uint8_t* __restrict__ base_be, const uint8_t*
       phase_a<false>(T, acc, pc.slot, pc.junk, pl);
     }
     u32 r[LP];
-#if TWIN_PREFETCH
-    // which bucket product follows this operation, if any: (exponent e', window k')
-    const int ne = op == 1 ? 1 : (op == 2 + BW ? 0 : -1);
-    const int nk = op == 1 ? k : k + 1;
-    fetched = ne >= 0 && nk < BWIN;
-    reduce(r, T, pc.slot, pc.tb, pl, [&]() {
-      if (fetched) {
-        const u32 nd = digit(ex[ne], nk);
-        const bool nhas = (occ[ne] >> nd) & 1u;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        slots_prefetch_pair(pc.wslots, buckets + (size_t)ne * BENT * L, (size_t)2 * BENT * L, pc.x0, count,
-                            (nd != 0 && nhas) ? nd - 1 : PREFETCH_ALT, pl, cs->one_m);
-      }
-    });
-#else
     reduce(r, T, pc.slot, pc.tb, pl);
-#endif
     __builtin_amdgcn_wave_barrier();
     if (sq || op == 0) {
 #pragma unroll
       for (int i = 0; i < LP; ++i) acc[i] = r[i];
-#if !TWIN_DIAG_NOMEM
       if (op == 0 || op == 2 + BW) store_pair_limbs(mycur, acc, pl);               // the window's cur
-#endif
     } else if (bk != nullptr && has && pc.live) {
-#if !TWIN_DIAG_NOMEM
       store_pair_limbs(bk, r, pl);
-#endif
     }
     if (op == 2 && k == BWIN - 1) break;
-#if !TWIN_DIAG_NOMEM
     if (op == 2) load_pair_limbs(acc, mycur, pl);                                  // back to the chain of squarings
-#endif
     if (op == 2 + BW) { op = 1; ++k; } else ++op;
   }
   if (pc.live && pl.h == 0) {
@@ -848,12 +783,8 @@ k_modp_fd_step_pair(const u32* __restrict__ state, const u32* __restrict__ state
     u64 T[LP];
     phase_a<false>(T, D, slot, sh.junk, pl, bsrc);
     u32 r[LP];
-#if FD_STEP_KEEP_PRIO
-    reduce<NoHook, 3, 3>(r, T, slot, &sh.tb, pl);
-#else
     reduce(r, T, slot, &sh.tb, pl);
     __builtin_amdgcn_s_setprio(3);       // (reduce() leaves the wave at priority 0)
-#endif
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < LP; ++i) D[i] = r[i];

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,12 +89,24 @@ struct mpvss_ctx {
   void* pair_tables = nullptr;   // constant digit matrices of the pair-layout kernels (bn_pair.h), one device copy per context
   std::string err;
   mutable std::mutex err_mu;     // guards `err` alone: mpvss_last_error may run beside calls of other threads
+  std::mutex pipe_mu;                  // one library box pipeline (mpvss_*_verify_many*) per context at a time; taken BEFORE mu
   std::mutex mu;
-  // mpvss_modp_deal: the one-call dealer's inputs and intermediate secrets (keys, P(i), witnesses, responses, positions, the
-  // staged polynomial) in buffers of their own -- the call releases `mu` while it waits for and hashes its blocks, and the
-  // shared workspace of the synchronous entry points is anybody's then.  deal_mu (taken BEFORE mu) admits one deal at a time.
-  struct DealBufs { DevBuf keys, p, w, r, pos, coef, c; void* pin = nullptr; size_t pin_cap = 0; } deal;
-  std::mutex deal_mu;
+  std::condition_variable slot_cv;     // signalled (under mu) whenever a block slot is released: callers waiting for room in the ring
+  // mpvss_modp_deal / mpvss_ec_deal: the one-call dealer's inputs and intermediate secrets (keys, P(i), witnesses, responses,
+  // positions, the staged polynomial) in buffers of their own -- the call releases `mu` while it waits for and hashes its
+  // blocks, and the shared workspace of the synchronous entry points is anybody's then.  Every deal in flight borrows one set
+  // from a pool (grow-only, most recently returned first), so that several host threads can deal on one context at once.
+  struct DealBufs { DevBuf keys, p, w, r, pos, coef, c; void* pin = nullptr; size_t pin_cap = 0; bool in_use = false; };
+  std::vector<DealBufs*> deal_pool;
+  DealBufs* deal_acquire() {
+    for (size_t i = deal_pool.size(); i-- > 0;)
+      if (!deal_pool[i]->in_use) { deal_pool[i]->in_use = true; return deal_pool[i]; }
+    DealBufs* d = new (std::nothrow) DealBufs();
+    if (!d) return nullptr;
+    d->in_use = true;
+    deal_pool.push_back(d);
+    return d;
+  }
   // Device workspace of one call in flight (grow-only buffers, the stream pair and the events that order them).
   // work0 serves the ordinary entry points; every verify-block slot has its own, so that several boxes can be in
   // flight on the GPU at once (the serial phases of one box overlap the wide phases of the next).
@@ -116,8 +129,6 @@ struct mpvss_ctx {
     hipStream_t sa = nullptr, sb = nullptr;  // stream pair: sb runs a2 beside the serial phases of the X path on sa
     hipEvent_t ev_fork = nullptr, ev_gr = nullptr;
     hipEvent_t ev_a2 = nullptr;
-    hipStream_t sx = nullptr;                // MPVSS_X_CUS > 0: the X path's own stream, confined to the first CUs (sa, sb: to the others)
-    hipEvent_t ev_x = nullptr;
     bool ready = false;
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
@@ -157,8 +168,11 @@ struct mpvss_ctx {
     bool busy = false;
     bool absorbing = false;        // a host thread is waiting for / hashing this block (context lock released)
     bool claimed = false;          // taken by mpvss_block_claim, its absorb call has not started yet
-    unsigned ticket = 0;           // value of `tail` when the block was claimed
-    unsigned ring_pos = 0;         // ring position the block occupies
+    bool owned = false;            // enqueued by a caller that absorbs it itself by position (the one-call entry points, the library's
+                                   // box pipeline): the FIFO entry points (absorb without a ticket, mpvss_block_claim) pass it over
+    unsigned pos = 0;              // the block's number in this context's enqueue order (value of `head` when it was committed)
+    std::atomic<unsigned long long>* gpu_done_ctr = nullptr;   // the owning box pipeline's count of blocks whose GPU work is done
+    unsigned ring_pos = 0;         // ring position the block occupies (pos % NSLOT)
     bool dealer = false;           // kind 2: a dealer's block (flag [1] = polynomial values, [2] = witnesses; t may be 0)
     bool fd_used = false;          // the block's X path was the forward-difference one: its final flags are in the staging
     unsigned fd_chunks = 0;        // chunks of the block that took the forward-difference path (one flag each)
@@ -171,20 +185,16 @@ struct mpvss_ctx {
     EcWork ecw;
     double enqueue_ms = 0;         // host time spent enqueueing this block's GPU work
     hipEvent_t done = nullptr;
-    // kind 0, one box, one chunk: a2 = y^r Y^c is launched as `slices` consecutive share ranges, each followed by its own copy
-    // to the staging and an event; X, Y, a1 (the high-priority stream) are on the host at ev_xa1.  The absorbing thread then
-    // hashes range k while range k + 1 is still on the GPU (slice_end[k]: one past its last share).  0: not sliced.
-    static constexpr unsigned MAX_SLICES = 8;
-    unsigned slices = 0;
-    size_t slice_end[MAX_SLICES] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipEvent_t ev_xa1 = nullptr, ev_slice[MAX_SLICES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     SpanSet spans;
     double kernel_ms[4] = {0, 0, 0, 0};
     Work work;
   };
-  // Blocks in flight form a ring of NSLOT positions in enqueue order (head: next to fill, tail: next to hand to an
-  // absorbing thread).  A position borrows a slot from a free stack -- the most recently released one first, so a caller
-  // that keeps k blocks in flight touches k slots' workspaces, not NSLOT of them.
+  // Blocks in flight form a ring of NSLOT positions in enqueue order (head: number of blocks enqueued so far = the next
+  // block's number; tail: no block below it is still waiting for a FIFO consumer).  A position borrows a slot from a free
+  // stack -- the most recently released one first, so a caller that keeps k blocks in flight touches k slots' workspaces,
+  // not NSLOT of them.  Who absorbs a block: whoever enqueued it, by its number (`owned`: the one-call entry points and the
+  // library's box pipeline -- any number of host threads may do that on one context at the same time), or, for blocks of
+  // the explicit block API, the FIFO entry points, oldest first.
   static constexpr unsigned NSLOT = MPVSS_BLOCK_SLOTS;
   BlockSlot slot[NSLOT];
   BlockSlot none_slot, full_slot;          // what ring_slot() / head_slot() answer when there is no block / no room
@@ -200,28 +210,53 @@ struct mpvss_ctx {
   // MPVSS_PIPELINED=1): a block then never takes the configuration meant for a call that has the GPU to itself, not even
   // the first ones of the run
   int key_cache_min_boxes = 0;   // mpvss_ctx_set_key_cache: verify_many registers key arrays that this many large boxes of a call share (0: off)
-  bool pipelined_hint = false;
-  int pipeline_depth = 0;        // boxes the running library pipeline keeps in flight (0: none running)
-  bool busy_with_others() const { return pipelined_hint || NSLOT - free_top >= 2; }
+  bool pipelined_env = false;    // MPVSS_PIPELINED=1
+  int pipelines_running = 0;     // library box pipelines under way on this context (several host threads may each run one)
+  bool pipelined_hint() const { return pipelined_env || pipelines_running > 0; }
+  bool busy_with_others() const { return pipelined_hint() || NSLOT - free_top >= 2; }
   BlockSlot& head_slot() {
     if (ring[head % NSLOT] >= 0 || free_top == 0) return full_slot;
     return slot[free_stack[free_top - 1]];
   }
   void commit_head(BlockSlot& sl) {          // the block in `sl` (from head_slot()) is fully enqueued
     sl.ring_pos = head % NSLOT;
+    sl.pos = head;
+    sl.owned = sl.claimed = sl.absorbing = false;
+    sl.gpu_done_ctr = nullptr;
     ring[sl.ring_pos] = (int)(&sl - slot);
     --free_top;
     sl.busy = true;
     ++head;
   }
-  BlockSlot& ring_slot(unsigned position) {
+  BlockSlot& ring_slot(unsigned position) {  // the block with this number, if it is still in the ring
     const int i = ring[position % NSLOT];
-    return i < 0 ? none_slot : slot[i];
+    return (i < 0 || slot[i].pos != position) ? none_slot : slot[i];
   }
   void release(BlockSlot& sl) {
-    sl.busy = false;
+    sl.busy = sl.owned = sl.claimed = false;
     ring[sl.ring_pos] = -1;
     free_stack[free_top++] = (int)(&sl - slot);
+    slot_cv.notify_all();
+  }
+  // the last `count` blocks this thread enqueued (it still holds the context lock) are its own: it absorbs them by number
+  unsigned own_last(unsigned count, std::atomic<unsigned long long>* gpu_done_ctr = nullptr) {
+    for (unsigned p = head - count; p != head; ++p) {
+      ring_slot(p).owned = true;
+      ring_slot(p).gpu_done_ctr = gpu_done_ctr;
+    }
+    return head - count;
+  }
+  // the oldest block that waits for a FIFO consumer (none_slot when there is none)
+  BlockSlot& fifo_front() {
+    auto waiting = [&](unsigned p) { BlockSlot& s = ring_slot(p); return s.busy && !s.absorbing && !s.claimed && !s.owned; };
+    while (tail != head && !waiting(tail)) ++tail;      // (what is passed over never waits for a FIFO consumer again)
+    return tail == head ? none_slot : ring_slot(tail);
+  }
+  // blocks whose consumer is known and at work (owned, claimed or being absorbed): room in the ring WILL appear
+  bool consumers_at_work() const {
+    for (unsigned i = 0; i < NSLOT; ++i)
+      if (slot[i].busy && (slot[i].owned || slot[i].claimed || slot[i].absorbing)) return true;
+    return false;
   }
   // Curve groups: X paths of several boxes of one mpvss_ec_verify_many call computed by the same launches (capi_ec.inc)
   struct XBatch {
@@ -233,28 +268,9 @@ struct mpvss_ctx {
     std::vector<DevBuf*> all() { return {&cmenc, &cm, &okcm, &pos, &pts, &xenc, &state, &flags, &hand, &wtab}; }
   };
   std::vector<XBatch*> ec_xb;
-  // the same for MODP boxes too large to travel as one group block (modp_x_batch_compute): the X paths of a run of boxes of one
-  // shape by the same launches (the box as the second grid dimension), in a workspace of their own; every box's block then
-  // waits for `done` and goes on with the tables of X and a1
-  struct ModpXBatch {
-    Work work;
-    DevBuf x;                      // [B][n][256]: X of the batch's boxes, canonical bytes
-    SpanSet spans;
-    hipEvent_t done = nullptr;
-    void* pin = nullptr;
-    size_t pin_cap = 0;
-    std::vector<hipEvent_t> readers;   // completion events of the blocks that read `x` (the batch that reuses this workspace waits for them on the device)
-  };
-  std::vector<ModpXBatch*> modp_xb;
   // blocks whose X went through the forward-difference path / of those, blocks that fell back to Horner's rule on
   // the device (positions not consecutive, an X that is 0 mod q, a pipeline stage that gave up)
   unsigned long long fd_blocks = 0, fd_fallbacks = 0;
-  // Wide-launch ordering between boxes in flight: the a2 launches of box k wait for those of box k - A2_CONC, so that the
-  // boxes finish staggered (oldest first) instead of all at once -- see verify_block_compute_locked
-  static constexpr unsigned A2_RING = 8;
-  hipEvent_t a2_done[A2_RING] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  unsigned long long a2_seq = 0;
-  std::atomic<unsigned long long> gpu_done{0};   // blocks whose GPU work has completed (seen by an absorbing thread)
   DevBuf ec_comb[2];             // fixed-base combs of the curve groups' generators (built on first use)
   bool ec_comb_ready[2] = {false, false};
   // host-side accounting of the block pipeline (mpvss_pipeline_stats_get): sums over absorbed blocks
@@ -647,21 +663,9 @@ int work_init(mpvss_ctx* ctx, mpvss_ctx::Work& w, hipStream_t main_stream) {
   } else {
     // a block slot's stream carries the latency-bound chain of its box: highest priority, so that it never queues
     // behind (or shares a hardware queue with) the wide launches, which go to the slot's low-priority second stream
-    static const int use_prio = fd_env("MPVSS_STREAM_PRIO", 1);
-    // MPVSS_X_CUS = K > 0 (experiment, profiles/r04_cu_partition_ab.txt): the latency-bound X path on K CUs of its own, the
-    // wide launches on the other 256 - K (hipExtStreamCreateWithCUMask: contiguous bit ranges map to K/8 CUs of every XCD)
-    static const int x_cus = fd_env("MPVSS_X_CUS", 0);
-    if (x_cus > 0 && x_cus < 256) {
-      uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int b = 0; b < 256; ++b) (b < x_cus ? lo : hi)[b >> 5] |= 1u << (b & 31);
-      HIPCHK(ctx, hipExtStreamCreateWithCUMask(&w.sx, 8, lo));
-      HIPCHK(ctx, hipExtStreamCreateWithCUMask(&w.sa, 8, hi));
-      HIPCHK(ctx, hipExtStreamCreateWithCUMask(&w.sb, 8, hi));
-      HIPCHK(ctx, hipEventCreateWithFlags(&w.ev_x, hipEventDisableTiming));
-    } else {
-      HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, use_prio ? ctx->prio_high : 0));
-      HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, use_prio ? ctx->prio_low : 0));
-    }
+    // (the X path on CUs of its own -- CU-masked streams -- was measured and is 2.2x slower: profiles/r04_cu_partition_ab.txt)
+    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sa, hipStreamNonBlocking, ctx->prio_high));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, ctx->prio_low));
   }
   for (hipEvent_t* e : {&w.ev_fork, &w.ev_gr})
     HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -679,8 +683,6 @@ void work_destroy(mpvss_ctx::Work& w, bool owns_sa) {
   for (hipEvent_t e : {w.ev_fork, w.ev_gr})
     if (e) (void)hipEventDestroy(e);
   if (w.ev_a2) (void)hipEventDestroy(w.ev_a2);
-  if (w.ev_x) (void)hipEventDestroy(w.ev_x);
-  if (w.sx) { (void)hipStreamSynchronize(w.sx); (void)hipStreamDestroy(w.sx); }
   if (w.root) (void)hipHostFree(w.root);
   if (w.sb) (void)hipStreamDestroy(w.sb);
   if (w.sa && owns_sa) (void)hipStreamDestroy(w.sa);
@@ -706,7 +708,7 @@ extern "C" int mpvss_ctx_create(int device_id, mpvss_ctx** out) {
     return MPVSS_E_DEVICE;
   }
   ctx->stream_b = ctx->work0.sb;
-  ctx->pipelined_hint = fd_env("MPVSS_PIPELINED", 0) != 0;
+  ctx->pipelined_env = fd_env("MPVSS_PIPELINED", 0) != 0;
   *out = ctx;
   return MPVSS_OK;
 }
@@ -733,17 +735,6 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
       if (b->p) (void)hipFree(b->p);
     delete xb;
   }
-  for (mpvss_ctx::ModpXBatch* xb : ctx->modp_xb) {
-    work_destroy(xb->work, true);
-    if (xb->x.p) (void)hipFree(xb->x.p);
-    if (xb->done) (void)hipEventDestroy(xb->done);
-    if (xb->pin) (void)hipHostFree(xb->pin);
-    for (hipEvent_t e : xb->spans.ev_pool)
-      if (e) (void)hipEventDestroy(e);
-    delete xb;
-  }
-  for (hipEvent_t e : ctx->a2_done)
-    if (e) (void)hipEventDestroy(e);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->consts) (void)hipFree(ctx->consts);
   if (ctx->consts_q) (void)hipFree(ctx->consts_q);
@@ -754,16 +745,16 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   }
   if (ctx->scalar_stream) (void)hipStreamDestroy(ctx->scalar_stream);
   if (ctx->pair_tables) (void)hipFree(ctx->pair_tables);
-  for (DevBuf* b : {&ctx->deal.keys, &ctx->deal.p, &ctx->deal.w, &ctx->deal.r, &ctx->deal.pos, &ctx->deal.coef, &ctx->deal.c})
-    if (b->p) (void)hipFree(b->p);
-  if (ctx->deal.pin) (void)hipHostFree(ctx->deal.pin);
+  for (mpvss_ctx::DealBufs* d : ctx->deal_pool) {
+    for (DevBuf* b : {&d->keys, &d->p, &d->w, &d->r, &d->pos, &d->coef, &d->c})
+      if (b->p) (void)hipFree(b->p);
+    if (d->pin) (void)hipHostFree(d->pin);
+    delete d;
+  }
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : ctx->slot) {
     if (sl.pin) (void)hipHostFree(sl.pin);
     if (sl.done) (void)hipEventDestroy(sl.done);
-    if (sl.ev_xa1) (void)hipEventDestroy(sl.ev_xa1);
-    for (hipEvent_t e : sl.ev_slice)
-      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : sl.spans.ev_pool) (void)hipEventDestroy(e);
   }
   delete ctx;
@@ -949,8 +940,8 @@ int stage_positions(mpvss_ctx* ctx, int space, const int64_t* positions, size_t 
 // simultaneous inversion) and then cost ONE Montgomery product per share and coefficient (modp_kernels.hip).
 // Whether the path applies (consecutive positions, no X that is 0 mod q) is decided ON THE DEVICE through a flag that
 // gates the kernels, so the pipelined callers never synchronise.
-// MPVSS_FD=0 disables the path, MPVSS_FD_CHAINS overrides the number of chains, MPVSS_FD_MAX_T / MPVSS_FD_MIN_SHARES
-// bound the thresholds and batch sizes it is used for.
+// MPVSS_FD=0 disables the path (every X by the Horner kernel); MPVSS_FD_MIN_SHARES lowers the batch size it is used
+// from, so that tests can drive it with small inputs.
 
 // stream callback: out = in^-1 mod q (canonical big-endian), ok = 0 when in is 0 mod q.  No HIP calls in here.
 // q as 256 big-endian bytes, assembled from its limbs
@@ -978,7 +969,8 @@ void invert_root_on_host(void* p) {
 // does the forward-difference path apply to this run of shares?  (host-side part of the decision)
 bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
   static const int fd_on = fd_env("MPVSS_FD", 1);
-  static const size_t max_t = (size_t)fd_env("MPVSS_FD_MAX_T", 1024), min_shares = (size_t)fd_env("MPVSS_FD_MIN_SHARES", 4096);
+  static const size_t min_shares = (size_t)fd_env("MPVSS_FD_MIN_SHARES", 4096);
+  constexpr size_t max_t = 1024;
   bool fd = fd_on && t >= 16 && t <= max_t && cnt >= 16 * t && cnt >= min_shares;
   if (fd && hpos) {                       // host positions: decide here; device positions are checked by a kernel
     for (size_t i = 0; i < cnt && fd; ++i) fd = hpos[i] == hpos[0] + (int64_t)i;
@@ -1015,7 +1007,6 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
     return modp_launch_fd_step_boxes(sf, sb, bx_st, chains, tt, w0_, clen, cnt_, xm_, bx_xm_, hand_, bx_hand_, B, (int*)ctx->w->fd_flag.p, fault,
                                      ctx->consts, ctx->stream);
   };
-  static const int fd_chains_env = fd_env("MPVSS_FD_CHAINS", 0);
   const bool fd = fd_applies(t, hpos, cnt);
   if (!fd) {
     if (B > 1)
@@ -1033,13 +1024,12 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // sooner; more chains shorten the stepping but cost Horner work.
   // measured optima on MI355X: chains of about 8192 members (n=65536: 8 chains for t = 16..256), fewer when the
   // seeds are dear (t = 512: 4), never longer than 16384 members (n=131072, t=1024: 8)
-  int S = fd_chains_env > 0 ? fd_chains_env
-                            : (int)std::max<size_t>(std::max<size_t>(std::min<size_t>(2048 / t, cnt / 8192), cnt / 16384), 4);
+  int S = (int)std::max<size_t>(std::max<size_t>(std::min<size_t>(2048 / t, cnt / 8192), cnt / 16384), 4);
   // a call that has the GPU to itself: more, shorter chains -- the extra seeds are one wide launch on an idle chip, the
-  // stepping (the serial part) shrinks in proportion (MPVSS_FD_LONE_CHAINS, 0 = as in the pipelined case)
+  // stepping (the serial part) shrinks in proportion
   const int S_pipelined = S;
-  static const int lone_chains = fd_env("MPVSS_FD_LONE_CHAINS", 16);     // measured: 8 -> 109 ms per box, 16 -> 96.5, 32 -> 104, 64 -> 115
-  if (fd_chains_env <= 0 && lone_chains > S && !ctx->busy_with_others() && t <= 256) S = lone_chains;
+  constexpr int lone_chains = 16;     // measured: 8 -> 109 ms per box, 16 -> 96.5, 32 -> 104, 64 -> 115
+  if (lone_chains > S && !ctx->busy_with_others() && t <= 256) S = lone_chains;
   const int s_max = (int)(cnt / (4 * t));      // cnt >= 16 t, so at least 4
   if (S > s_max) S = s_max;
   if (S < 1) S = 1;
@@ -1222,7 +1212,7 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
 // ---- DLEQ verifier commitments -------------------------------------------------------------------
 namespace {
 // a = B1^r * B2^c with the 64-entry table of B1.  Two kernels compute it: the pair-layout one, whose Montgomery reduction
-// runs on the matrix cores (modp_pair_kernels.hip; default), and the VALU-only one (modp_kernels.hip; MPVSS_A2_PAIR=0).
+// runs on the matrix cores (modp_pair_kernels.hip; default), and the VALU-only one (modp_kernels.hip; MPVSS_PAIR bit 0 clear).
 // Same tables, exponents and results; measured in the headline pipeline 1.08-1.12 against 0.92-0.98 M share verifications/s.
 // c_sched: sliding-window schedule of ONE shared challenge (then c_dev is unused), else fixed 4-bit windows of c_dev
 // (stride c_stride; null: B1^r alone).
@@ -1234,9 +1224,9 @@ namespace {
 // allocated for two waves per SIMD (modp_pair_kernels.hip) the tables, g^r and a1 run as fast in either layout (MPVSS_PAIR 17 /
 // 21 / 25 / 29: 1.08-1.10 M share verifications/s, profiles/r03_pair_occupancy_ab.txt) and stay VALU-only; at one wave per
 // SIMD every further pair kernel cost throughput (1.063 M for a2 alone, 1.044 M with the tables, 1.022 M with all four, 0.942 M
-// with none: profiles/r03_pair_ab.txt).  MPVSS_A2_PAIR=0 clears bit 0 (older switch).
+// with none: profiles/r03_pair_ab.txt).  MPVSS_PAIR=0 is the VALU-only engine (no MFMA anywhere).
 int pair_mask() {
-  static const int m = fd_env("MPVSS_PAIR", 49) & (fd_env("MPVSS_A2_PAIR", 1) ? 63 : 62);
+  static const int m = fd_env("MPVSS_PAIR", 49) & 63;
   return m;
 }
 int launch_table_odd(mpvss_ctx* ctx, const uint8_t* base_dev, size_t cnt, uint32_t* tab) {
@@ -1278,8 +1268,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
                                                    out_dev, comb_bits_of(ctx, comb_b1), ctx->consts, ctx->stream));
     return 0;
   }
-  static const int w6 = fd_env("MPVSS_A2_W6", 1);
-  if (!shared_b1 && w6 && c_windows == 64 && cnt >= 1024) {
+  if (!shared_b1 && c_windows == 64 && cnt >= 1024) {
     // per-share base with a full-width exponent and 256-bit second exponent(s): 6-bit windows for B1^r
     RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
     TIMED_LAUNCH(ctx, 2, launch_table64(ctx, b1_dev, cnt, (uint32_t*)ctx->w->tab1.p));
@@ -1383,95 +1372,10 @@ int wellformed_bounds(mpvss_ctx* ctx, const uint8_t** out) {
   return 0;
 }
 
-// X of one box as a batch launch left it (modp_x_batch_compute): canonical bytes, the event after which they are there, the
-// batch's forward-difference flag (one for the whole batch: a box out of line sends all of them down Horner's rule, still right)
-struct ModpPre {
-  const uint8_t* x_dev = nullptr;
-  hipEvent_t ready = nullptr;
-  const int* flag_dev = nullptr;
-  bool fd_used = false;
-  mpvss_ctx::ModpXBatch* owner = nullptr;
-};
-
-// Why: the device runs eight launches at a time (its hardware queues; more make every kernel slower: profiles/r05_c5_queues_ab.txt),
-// and a box's X path is a chain of NARROW launches -- 64 waves of Horner seeds for up to 330 ms, a few hundred stepping waves for
-// 150-240 ms at (131072, 1024) -- each of which holds a queue while it leaves the chip to others.  With ten boxes in flight the
-// queues are full of such launches and the wide ones (a2: 4096 waves) wait.  The curve groups had the same disease and the same
-// cure (ec_x_batch_compute): the X paths of a run of boxes in ONE set of launches.
-bool modp_x_box_batchable(int space, const mpvss_modp_box& bx, size_t n, size_t t) {
-  static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
-  if (!(two_streams && bx.n == n && bx.t == t && n <= MAX_CHUNK && bx.commitments && bx.positions && (bx.pubkeys || bx.keyset) && bx.shares &&
-        bx.responses && bx.challenge_host && fd_applies(t, space == MPVSS_HOST ? bx.positions : nullptr, n)))
-    return false;
-  return true;
-}
-
-int modp_x_batch_compute(mpvss_ctx* ctx, int space, const mpvss_modp_box* bx, size_t B, mpvss_ctx::ModpXBatch& xb, ModpPre* pre) {
-  const size_t n = bx[0].n, t = bx[0].t;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!xb.done) HIPCHK(ctx, hipEventCreateWithFlags(&xb.done, hipEventDisableTiming));
-  RET_IF(work_init(ctx, xb.work, nullptr));
-  struct Restore {
-    mpvss_ctx* c;
-    hipStream_t a, b;
-    mpvss_ctx::Work* w;
-    mpvss_ctx::SpanSet* sp;
-    ~Restore() { c->sp = sp; c->w = w; c->stream = a; c->stream_b = b; }
-  } restore{ctx, ctx->stream, ctx->stream_b, ctx->w, ctx->sp};
-  mpvss_ctx::Work& w = xb.work;
-  ctx->w = &w;
-  w.fd_used = false;
-  ctx->stream = w.sa;
-  ctx->stream_b = w.sb;
-  ctx->sp = &xb.spans;
-  spans_reset(ctx);
-  // the workspace comes round again after MPVSS_X_BATCH_RING batches: whatever still reads the X of its previous batch (the
-  // blocks of those boxes: tables of X, the copy to the host) is waited for ON THE DEVICE, in stream order -- no host thread blocks
-  for (hipEvent_t e : xb.readers) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
-  xb.readers.clear();
-  RET_IF(ensure(ctx, w.cbuf, B * t * EB));
-  RET_IF(ensure(ctx, w.cm, B * t * MODP_L * 4));
-  RET_IF(ensure(ctx, w.pos, B * n * 8));
-  RET_IF(ensure(ctx, xb.x, B * n * EB));
-  const size_t pin_need = space == MPVSS_HOST ? B * (t * EB + n * 8) : 0;
-  if (pin_need > xb.pin_cap) {
-    if (xb.pin) HIPCHK(ctx, hipHostFree(xb.pin));
-    xb.pin = nullptr;
-    xb.pin_cap = 0;
-    hipError_t e = hipHostMalloc(&xb.pin, pin_need, hipHostMallocDefault);
-    if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(batch staging)", e);
-    xb.pin_cap = pin_need;
-  }
-  uint8_t* dcm = (uint8_t*)w.cbuf.p;
-  int64_t* dpos = (int64_t*)w.pos.p;
-  uint8_t* hin = (uint8_t*)xb.pin;
-  for (size_t b = 0; b < B; ++b) {
-    if (space == MPVSS_HOST) {      // pinned copies: nothing of the caller's is referenced after the call returns
-      memcpy(hin, bx[b].commitments, t * EB);
-      HIPCHK(ctx, hipMemcpyAsync(dcm + b * t * EB, hin, t * EB, hipMemcpyHostToDevice, ctx->stream));
-      hin += t * EB;
-      memcpy(hin, bx[b].positions, n * 8);
-      HIPCHK(ctx, hipMemcpyAsync(dpos + b * n, hin, n * 8, hipMemcpyHostToDevice, ctx->stream));
-      hin += n * 8;
-    } else {
-      HIPCHK(ctx, hipMemcpyAsync(dcm + b * t * EB, bx[b].commitments, t * EB, hipMemcpyDeviceToDevice, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(dpos + b * n, bx[b].positions, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    }
-  }
-  w.cm_bytes_dev = dcm;
-  LAUNCHCHK(ctx, modp_launch_to_mont(dcm, (uint32_t*)w.cm.p, (int)(B * t), ctx->consts, ctx->stream));
-  uint8_t* dX = (uint8_t*)xb.x.p;
-  RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));        // (positions judged on the device: one flag for the batch)
-  HIPCHK(ctx, hipEventRecord(xb.done, ctx->stream));
-  for (size_t b = 0; b < B; ++b) pre[b] = ModpPre{dX + b * n * EB, xb.done, (const int*)w.fd_flag.p, w.fd_used, &xb};
-  return MPVSS_OK;
-}
-
 int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                 const uint8_t* responses, size_t n, const uint8_t* challenge_host,
-                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr,
-                                const ModpPre* pre = nullptr) {
+                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr) {
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
   if (n > 0 && (!commitments || !positions || (!pubkeys && !ks) || !shares || !responses || t == 0 || t > 0x7fffffff ||
                 n > 0x7fffffff))
@@ -1487,11 +1391,8 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!sl.done) {
-    // blocking wait by default: threads that absorb blocks sleep until the GPU is done instead of spinning
-    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-  }
+  if (!sl.done)      // blocking wait: threads that absorb blocks sleep until the GPU is done instead of spinning
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
   sl.n = n;
   sl.kind = 0;
   sl.nbox = 1;
@@ -1499,7 +1400,6 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   sl.fd_used = false;
   sl.fd_chunks = 0;
   sl.enqueue_ms = 0;
-  sl.slices = 0;
   if (n == 0) {
     sl.busy = true;
     ctx->commit_head(sl);
@@ -1577,8 +1477,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     if (trace_enq) marks[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
   };
   mark(0);
-  if (pre && n > MAX_CHUNK) return fail(ctx, MPVSS_E_INVALID, "verify: a batched X path needs a one-chunk block");
-  if (!pre) RET_IF(stage_commitments(ctx, space, commitments, t));       // (a batch launch has evaluated X: nothing else reads them)
+  RET_IF(stage_commitments(ctx, space, commitments, t));
   mark(1);
   const uint32_t* cg;
   RET_IF(comb_table(ctx, 0, &cg, n));
@@ -1616,15 +1515,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* da1 = (uint8_t*)ctx->w->out1.p;
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     sl.work.fd_used = false;
-    bool early_copies = false;
     const int64_t* hp = space == MPVSS_HOST ? hpos + off : nullptr;
-    static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
-    if (two_streams && ctx->w->sb && (pre || fd_applies(t, hp, cnt))) {
+    if (ctx->w->sb && fd_applies(t, hp, cnt)) {
       // The forward-difference X path is a chain of latency-bound launches that occupy few wave slots (seeds,
       // inversion tree, difference tables, stepping) and runs on the block slot's high-priority stream.  a2 = y^r Y^c
       // and g^r do not depend on X: they run beside it on the slot's low-priority stream.
-      static const int a2_w6 = fd_env("MPVSS_A2_W6", 1);
-      RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4 * (a2_w6 ? 4 : 1)));     // no reallocation while two streams are live
+      RET_IF(ensure(ctx, ctx->w->tab1, cnt * TABW * 4 * 4));     // no reallocation while two streams are live
       RET_IF(ensure(ctx, ctx->w->tab2, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
@@ -1638,23 +1534,14 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
       // Boxes in flight share the chip equally: eight boxes enqueued together finish together (a convoy).  What that
       // costs is the host's turn-around at the end of a convoy, and the cure that works is to enqueue the next box as
-      // soon as a box's GPU work is done instead of after its transcript is hashed (run_box_pipeline,
-      // MPVSS_ISSUE_ON_GPU_DONE: 0.90-0.93 -> 0.97 M share verifications/s at K = 20).  Ordering the wide launches
-      // between boxes -- box k's tables, a2 and g^r wait for those of box k - MPVSS_A2_CONCURRENCY, so that boxes
-      // finish oldest first -- was measured as well and LOSES (1: 0.75 M, 2: 0.86 M, 3: 0.89 M against 0.97 M
-      // unordered; profiles/r02_pipeline_scheduling_ab.txt): one box's a2 is 4096 waves for 3072 wave slots, and with
-      // few of them in flight the tail of each launch leaves slots empty.  Default 0 = unordered.
-      static const unsigned a2_conc = (unsigned)fd_env("MPVSS_A2_CONCURRENCY", 0);
-      const unsigned long long seq = ctx->a2_seq++;
-      if (a2_conc > 0 && a2_conc < mpvss_ctx::A2_RING && seq >= a2_conc) {
-        hipEvent_t prev = ctx->a2_done[(seq - a2_conc) % mpvss_ctx::A2_RING];
-        if (prev) HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, prev, 0));
-      }
+      // soon as a box's GPU work is done instead of after its transcript is hashed (run_box_pipeline: 0.90-0.93 -> 0.97 M
+      // share verifications/s at K = 20).  What was measured and LOST, and is no longer in the source (DESIGN.md section 10
+      // names the files): ordering the wide launches between boxes so that they finish oldest first; a2 in share ranges
+      // with the hash following range by range; the inputs' and early outputs' copies ahead of the last kernel.
       // one challenge for every share of the box: a sliding-window schedule made on the host replaces the 64 fixed windows
       // of X^c and Y^c (about 51 products each) and their tables hold the odd powers only (8 instead of 14 products)
-      static const int sliding = fd_env("MPVSS_C_SLIDING", 1);
       const uint16_t* dsched = nullptr;
-      if (sliding && a2_w6 && c_windows == 64) {        // (with registered keys too: a1's X^c follows it; the key-table kernel keeps Y's full table)
+      if (c_windows == 64) {        // (with registered keys too: a1's X^c follows it; the key-table kernel keeps Y's full table)
         uint16_t* hs = sl.work.root[0].csched;
         sliding_schedule(sl.work.root[0].challenge, hs);
         if (hs[0] > 0) {
@@ -1662,53 +1549,12 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           dsched = (const uint16_t*)ctx->w->csched.p;
         }
       }
-      // MPVSS_A2_SLICES (default 1 = off: measured, profiles/r05_a2_slices_ab.txt -- 4 ranges cost 2-3 % of steady-state throughput and give nothing back at K = 20): see the a2 launch below.  Only for a box that is ONE block of one chunk and is
-      // absorbed by a thread of the library's pipeline with other boxes in flight (pipelined_hint) -- a lone call gains nothing.
-      static const unsigned a2_slices = (unsigned)fd_env("MPVSS_A2_SLICES", 1);
-      static const size_t a2_slice_min = (size_t)fd_env("MPVSS_A2_SLICE_MIN", 8192);
-      unsigned nsl = 1;
-      if (a2_slices > 1 && a2_w6 && c_windows == 64 && !use_keys && off == 0 && cnt == n && ctx->pipelined_hint &&
-          ctx->pipeline_depth >= 4 && n >= 2 * a2_slice_min) {
-        // (d boxes in flight run d ranges at a time: the chip's 2048 a2 wave slots stay full while d >= the number of ranges)
-        nsl = (unsigned)std::min<size_t>(std::min<size_t>(a2_slices, mpvss_ctx::BlockSlot::MAX_SLICES), n / a2_slice_min);
-        nsl = std::min<unsigned>(nsl, (unsigned)ctx->pipeline_depth);
-        for (unsigned k = 0; k < nsl; ++k) {
-          sl.slice_end[k] = k + 1 == nsl ? n : ((n * (k + 1) / nsl) & ~(size_t)63);
-          if (!sl.ev_slice[k]) {
-            static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-            HIPCHK(ctx, hipEventCreateWithFlags(&sl.ev_slice[k], hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-          }
-        }
-        if (!sl.ev_xa1) {
-          static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-          HIPCHK(ctx, hipEventCreateWithFlags(&sl.ev_xa1, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-        }
-      }
       // registered keys: without the chain of 2046 squarings beside them, g^r and a1 = g^r X^c pay for their layout -- both on the
-      // pair layout then (MPVSS_KEYSET_PAIR; measured 1.65-1.72 -> 1.80-1.86 M share verifications/s, profiles/r05_keyset_ab.txt)
-      static const int ks_pair_all = fd_env("MPVSS_KEYSET_PAIR", 1);
-      const bool pair_gr = (pair_mask() & 4) || (use_keys && ks_pair_all && (pair_mask() & 1));
-      const bool pair_a1 = (pair_mask() & 8) || (use_keys && ks_pair_all && (pair_mask() & 1));
-      auto launch_gr = [&]() -> int {
-        if (pair_gr && comb_bits_of(ctx, cg) == 16)
-          TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, (const uint8_t*)dr, (int)cnt, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
-                                                           ctx->pair_tables, ctx->stream));
-        else
-          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
-                                                               (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
-                                                               ctx->stream));
-        HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
-        return 0;
-      };
+      // pair layout then (measured 1.65-1.72 -> 1.80-1.86 M share verifications/s, profiles/r05_keyset_ab.txt)
+      const bool pair_gr = (pair_mask() & 4) || (use_keys && (pair_mask() & 1));
+      const bool pair_a1 = (pair_mask() & 8) || (use_keys && (pair_mask() & 1));
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
-        // Y is an input: its copy into the staging (the transcript hashes it) leaves first, not with the outputs at the end -- the
-        // boxes of a run's last convoy finish together, and 4 x 16 MB per box behind the last kernel is what the hashes then wait for
-        static const int early_env = fd_env("MPVSS_EARLY_COPIES", 0);      // measured (profiles/r05_tail_ab.txt): no gain at K = 20, off
-        if (nsl <= 1 && early_env) {
-          HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-          early_copies = true;
-        }
         // the schedule travels on THIS stream, ahead of a2; the a1 launch on the other stream waits for ev_gr, recorded below
         if (dsched)
           HIPCHK(ctx, hipMemcpyAsync(ctx->w->csched.p, sl.work.root[0].csched, (1 + 2 * (size_t)sl.work.root[0].csched[0]) * 2,
@@ -1717,36 +1563,20 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         if (dsched && !use_keys) TIMED_LAUNCH(ctx, 2, launch_table_odd(ctx, (const uint8_t*)dY, cnt, t2p));
         else TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dY, (int)cnt, t2p, ctx->consts, ctx->stream));
         if (use_keys) {
-          // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c
+          // registered keys: y^r from the per-key tables (256 products, no squarings of its own) beside Y^c; on the pair
+          // layout with the a2 kernel's pair bit (85 / 122 instead of 153 / 191 issue slots per operation)
           const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
-          // (MPVSS_KEYSET_PAIR, default on with the a2 kernel's pair bit: 85 / 122 instead of 153 / 191 issue slots per operation)
-          static const int ks_pair = fd_env("MPVSS_KEYSET_PAIR", 1);
-          if (ks_pair && (pair_mask() & 1) && cnt >= 64)
+          if ((pair_mask() & 1) && cnt >= 64)
             TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp_pair(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2, ctx->consts,
                                                                   ctx->pair_tables, ctx->stream));
           else
-          TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
-                                                           ctx->consts, ctx->stream));
-        } else if (a2_w6 && c_windows == 64) {
+            TIMED_LAUNCH(ctx, 3, modp_launch_keyset_dual_exp(kt, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, (int)cnt, da2,
+                                                             ctx->consts, ctx->stream));
+        } else if (c_windows == 64) {
           // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, launch_table64(ctx, (const uint8_t*)dy, cnt, t1p));
-          if (nsl > 1) {
-            // a2 in `nsl` launches over consecutive share ranges, each followed by ITS copy to the staging and an event: the
-            // absorbing thread hashes range k (X, Y, a1 are on the host by then -- the other stream has the priority, and g^r,
-            // which a1 waits for, went ahead of a2) while range k + 1 is on the GPU.  A wave of this kernel works for the same
-            // 36 ms whatever the grid, so a range costs nothing as long as other boxes fill the chip -- which is when this is used.
-            RET_IF(launch_gr());
-            for (unsigned k = 0; k < nsl; ++k) {
-              const size_t lo = k == 0 ? 0 : sl.slice_end[k - 1], hi = sl.slice_end[k];
-              TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p + lo * 4 * TABW, t2p + lo * TABW, (const uint8_t*)dr + lo * EB,
-                                                      (const uint8_t*)dchal, 0, dsched, hi - lo, da2 + lo * EB));
-              HIPCHK(ctx, hipMemcpyAsync(h2 + (off + lo) * EB, da2 + lo * EB, (hi - lo) * EB, hipMemcpyDeviceToHost, ctx->stream));
-              HIPCHK(ctx, hipEventRecord(sl.ev_slice[k], ctx->stream));
-            }
-          } else {
-            TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
-          }
+          TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));
@@ -1754,21 +1584,18 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                     (int)cnt, da2, ctx->consts, ctx->stream));
         }
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
-        {
-          hipEvent_t& mine = ctx->a2_done[seq % mpvss_ctx::A2_RING];
-          if (!mine) HIPCHK(ctx, hipEventCreateWithFlags(&mine, hipEventDisableTiming));
-          HIPCHK(ctx, hipEventRecord(mine, ctx->stream));
-        }
-        // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase (ahead of a sliced a2)
-        if (nsl <= 1) RET_IF(launch_gr());
+        // g^r_i needs only the responses: it runs behind a2 instead of after the stepping phase
+        if (pair_gr && comb_bits_of(ctx, cg) == 16)
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb16_exp_pair(cg, (const uint8_t*)dr, (int)cnt, (uint32_t*)ctx->w->gr_m.p, ctx->consts,
+                                                           ctx->pair_tables, ctx->stream));
+        else
+          TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp_split(cg, cg, 0, (const uint8_t*)dr, (const uint8_t*)dchal, 0, 0,
+                                                               (int)cnt, nullptr, 1, (uint32_t*)ctx->w->gr_m.p, comb_bits_of(ctx, cg), ctx->consts,
+                                                               ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
       mark(2);
-      if (pre) {        // X came from a batch launch: wait for it (the a2 side is already running)
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, pre->ready, 0));
-        dX = const_cast<uint8_t*>(pre->x_dev);
-      } else {
-        RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
-      }
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
       mark(3);
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
@@ -1792,17 +1619,6 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                                c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                                comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
-      if (early_copies) {      // X and a1 leave as soon as a1 is done (a2, on the other stream, usually is not yet)
-        HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      }
-      if (nsl > 1) {      // X, Y, a1 leave as soon as a1 is done; a2 has left range by range on the other stream
-        HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipEventRecord(sl.ev_xa1, ctx->stream));
-        sl.slices = nsl;
-      }
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
     } else {
       // X_i                                                  participant.rs:423-434
@@ -1812,26 +1628,20 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
                        0, c_windows, cnt, da2));
     }
-    if (early_copies) {
-      HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    } else if (sl.slices <= 1) {
-      HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (sl.work.fd_used || (pre && pre->fd_used)) {     // the device's decision for this chunk (1 = forward differences held, 0 = fell back)
+    HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h1 + off * EB, da1, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h2 + off * EB, da2, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
+    if (sl.work.fd_used) {     // the device's decision for this chunk (1 = forward differences held, 0 = fell back)
       sl.fd_used = true;
       if (sl.fd_chunks < FLAGS)
-        HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, pre ? (const void*)pre->flag_dev : (const void*)sl.work.fd_flag.p, 4,
-                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
       ++sl.fd_chunks;
     }
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
   }
   mark(4);
   HIPCHK(ctx, hipEventRecord(sl.done, ctx->stream));
-  if (pre && pre->owner) pre->owner->readers.push_back(sl.done);
   sl.busy = true;      // only a fully enqueued block occupies the slot (an error above leaves it free)
   sl.enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
   if (trace_enq && sl.enqueue_ms > 3.0)
@@ -1855,14 +1665,14 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
 //              schedule: about 38 products per share more)
 //   absorb   : one transcript per box over its rows of the block's staging
 // Same bytes as one block per box (tests/test_gpu_configs.py::test_c2_boxes_share_one_a2_launch).
+constexpr size_t GROUP_MAX_BOX = 16384;      // boxes up to this size travel in groups
 size_t group_shares_max() {
-  static const size_t v = (size_t)fd_env("MPVSS_GROUP_SHARES", 32768);      // 0: every box its own block; measured on C2: 16384 and 32768 -> 1.06-1.07 M, 65536 -> 0.97-1.00 M
+  constexpr size_t v = 32768;      // shares per group block; measured on C2: 16384 and 32768 -> 1.06-1.07 M, 65536 -> 0.97-1.00 M
   return v < MAX_CHUNK ? v : MAX_CHUNK;
 }
 bool box_groupable(const mpvss_modp_box& bx, size_t n, size_t t, int space) {
-  static const int two_streams = fd_env("MPVSS_TWO_STREAMS", 1);
-  static const size_t max_n = (size_t)fd_env("MPVSS_GROUP_MAX_BOX", 16384);
-  if (!(two_streams && bx.n == n && bx.t == t && n <= max_n && 2 * n <= group_shares_max() && !bx.keyset && bx.commitments &&
+  constexpr size_t max_n = GROUP_MAX_BOX;
+  if (!(bx.n == n && bx.t == t && n <= max_n && 2 * n <= group_shares_max() && !bx.keyset && bx.commitments &&
         bx.positions && bx.pubkeys && bx.shares && bx.responses && bx.challenge_host && fits_256_bits(bx.challenge_host) &&
         fd_applies(t, nullptr, n)))
     return false;
@@ -1878,14 +1688,10 @@ int verify_group_compute_locked(mpvss_ctx* ctx, int space, const mpvss_modp_box*
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!sl.done) {
-    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-  }
+  if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
   sl.n = N;
   sl.nbox = (unsigned)B;
   sl.kind = 0;
-  sl.slices = 0;
   sl.check_positions = false;
   sl.fd_used = false;
   sl.fd_chunks = 0;
@@ -2006,17 +1812,7 @@ int verify_group_compute_locked(mpvss_ctx* ctx, int space, const mpvss_modp_box*
                                                            comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     HIPCHK(ctx, hipEventRecord(w.ev_gr, ctx->stream));
   }
-  if (w.sx) {          // the X path on its own CUs; the block's stream takes over when X is there
-    HIPCHK(ctx, hipStreamWaitEvent(w.sx, w.ev_fork, 0));
-    {
-      Swap sw(ctx, w.sx);
-      RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
-      HIPCHK(ctx, hipEventRecord(w.ev_x, ctx->stream));
-    }
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, w.ev_x, 0));
-  } else {
-    RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
-  }
+  RET_IF(eval_x(ctx, t, dpos, nullptr, n, dX, B, n));
   {
     const uint32_t* tx;
     RET_IF(number_tables(ctx, dX, N, w.tab3, &tx));
@@ -2041,9 +1837,57 @@ int verify_group_compute_locked(mpvss_ctx* ctx, int space, const mpvss_modp_box*
   return MPVSS_OK;
 }
 
+// Room for `count` more blocks in the ring (context lock held; released while waiting).  Blocks whose consumer is at work -- another
+// thread's one-call entry point, a pipeline, a claimed block -- free their slots by themselves: wait for them.  When only blocks of
+// the explicit block API fill the ring nobody but the caller can absorb them: an error, as it always was.
+int wait_for_room(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, unsigned count = 1) {
+  auto room = [&] {
+    if (ctx->free_top < count) return false;
+    for (unsigned k = 0; k < count; ++k)
+      if (ctx->ring[(ctx->head + k) % mpvss_ctx::NSLOT] >= 0) return false;
+    return true;
+  };
+  while (!room()) {
+    if (!ctx->consumers_at_work())
+      return fail(ctx, MPVSS_E_INVALID, "every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
+    ctx->slot_cv.wait(lk);
+  }
+  return 0;
+}
+
+// Which block an absorb call works on (context lock held).  ticket == null: the oldest block that waits for a FIFO consumer
+// (the explicit block API); ticket + !by_position: the block mpvss_block_claim handed out under this number; ticket +
+// by_position: the caller's OWN block of this number (mpvss_ctx::own_last: the one-call entry points and the library's box
+// pipeline).  `kind` / `kind2`: the slot kinds the calling entry point absorbs.  Returns null with the error recorded.
+mpvss_ctx::BlockSlot* select_block(mpvss_ctx* ctx, const unsigned long long* ticket, bool by_position, int kind, int kind2, const char* who) {
+  char msg[160];
+  auto bad = [&](const char* what) -> mpvss_ctx::BlockSlot* {
+    snprintf(msg, sizeof(msg), "%s: %s", who, what);
+    (void)fail(ctx, MPVSS_E_INVALID, msg);
+    return nullptr;
+  };
+  mpvss_ctx::BlockSlot* sl;
+  if (!ticket) {
+    sl = &ctx->fifo_front();
+    if (!sl->busy) return bad("no block in flight");
+    if (sl->kind != kind && sl->kind != kind2) return bad("the oldest block in flight belongs to another entry point");
+    ++ctx->tail;
+  } else {
+    sl = &ctx->ring_slot((unsigned)*ticket);
+    if (by_position) {
+      if (!sl->busy || !sl->owned || sl->absorbing) return bad("no block of this caller at this position");
+    } else {
+      if (!sl->busy || !sl->claimed) return bad("no block was claimed with this ticket");
+    }
+    if (sl->kind != kind && sl->kind != kind2) return bad("the block belongs to another entry point");
+    sl->claimed = false;
+  }
+  return sl;
+}
+
 // Called with `lk` (the context lock) held.  The lock is RELEASED while this thread waits for the block's GPU work
 // and hashes it, so that other host threads can enqueue blocks or absorb the next ones meanwhile (every box has its
-// own transcript; a 65536-share box is 40 ms of SHA-256).  Blocks are handed out in FIFO order at entry.
+// own transcript; a 65536-share box is 35 ms of SHA-256).
 int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
                                uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out = nullptr,
                                const unsigned long long* ticket = nullptr, bool by_position = false,
@@ -2051,30 +1895,21 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   // states > 1: `state` holds that many transcript states, one per box of a GROUP block (its nbox); box_bad[b] = 1 marks a
   // box with a negative position (device-resident positions are looked at here)
   if (!state) return fail(ctx, MPVSS_E_INVALID, "absorb: null transcript state");
-  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ticket ? (unsigned)*ticket : ctx->tail);
-  // only the library's own pipeline makes groups and knows how many states to bring; nothing is consumed otherwise
-  if (sl.busy && sl.kind == 0 && ((sl.nbox ? sl.nbox : 1u) != states || (states > 1 && (x_out || a1_out || a2_out || y_out))))
-    return fail(ctx, MPVSS_E_INVALID, "absorb: the block is a group of boxes (one transcript state per box)");
-  if (ticket && by_position) {       // the library's own pipeline: the block at ring position *ticket, whatever the FIFO order
-    if (!sl.busy || sl.absorbing || sl.claimed) return fail(ctx, MPVSS_E_INVALID, "absorb: no block at this position");
-    if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the block at this position is not a MODP distribution block");
-    if ((int)((unsigned)*ticket + 1u - ctx->tail) > 0) ctx->tail = (unsigned)*ticket + 1u;
-  } else if (ticket) {
-    if (!sl.busy || !sl.claimed || sl.ticket != (unsigned)*ticket)
-      return fail(ctx, MPVSS_E_INVALID, "absorb: no block was claimed with this ticket");
-    if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the claimed block is not a MODP distribution block");
-    sl.claimed = false;
-  } else {
-    if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "absorb: no block in flight");
-    if (sl.kind != 0) return fail(ctx, MPVSS_E_INVALID, "absorb: the oldest block in flight is a verify_share batch");
-    ++ctx->tail;
+  {
+    // only the library's own pipeline makes groups and knows how many states to bring; nothing is consumed otherwise
+    mpvss_ctx::BlockSlot& peek = ticket ? ctx->ring_slot((unsigned)*ticket) : ctx->fifo_front();
+    if (peek.busy && peek.kind == 0 && ((peek.nbox ? peek.nbox : 1u) != states || (states > 1 && (x_out || a1_out || a2_out || y_out))))
+      return fail(ctx, MPVSS_E_INVALID, "absorb: the block is a group of boxes (one transcript state per box)");
   }
+  mpvss_ctx::BlockSlot* slp = select_block(ctx, ticket, by_position, 0, 0, "absorb");
+  if (!slp) return MPVSS_E_INVALID;
+  mpvss_ctx::BlockSlot& sl = *slp;
   const size_t n = sl.n;
   const size_t nbox = sl.nbox ? sl.nbox : 1;
   if (n == 0) {
     ctx->release(sl);
     sl.absorbing = false;
-    ctx->gpu_done.fetch_add(1);
+    if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
     return MPVSS_OK;
   }
   sl.absorbing = true;
@@ -2083,7 +1918,7 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
     if (e_dev != hipSuccess) {               // give the slot back: the block is lost, the ring is not
       ctx->release(sl);
       sl.absorbing = false;
-      ctx->gpu_done.fetch_add(1);
+      if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
       return fail(ctx, MPVSS_E_DEVICE, "absorb: hipSetDevice", e_dev);
     }
   }
@@ -2094,29 +1929,9 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   const uint8_t* h1 = hY + n * EB;
   const uint8_t* h2 = h1 + n * EB;
   bool positions_ok = true;
-  double sliced_hash_ms = 0;
-  size_t hashed = 0;                 // shares of a sliced block already in the transcript
-  mpvss::Sha256 tr_sl;
-  if (sl.slices > 1 && nbox == 1) {
-    // a2 arrives range by range (verify_block_compute_locked): hash range k while range k + 1 is still on the GPU
-    hipError_t es = hipEventSynchronize(sl.ev_xa1);
-    if (es == hipSuccess && sl.check_positions) {
-      const int64_t* pos = (const int64_t*)(h2 + n * EB);
-      for (size_t i = 0; i < n && positions_ok; ++i) positions_ok = pos[i] >= 0;
-    }
-    memcpy(&tr_sl, state, sizeof(tr_sl));
-    for (unsigned k = 0; k + 1 < sl.slices && es == hipSuccess && positions_ok; ++k) {     // (the last range after sl.done, below)
-      es = hipEventSynchronize(sl.ev_slice[k]);
-      if (es != hipSuccess) break;
-      const auto t0 = std::chrono::steady_clock::now();
-      frame_shares(tr_sl, hX, hY, h1, h2, hashed, sl.slice_end[k]);
-      hashed = sl.slice_end[k];
-      sliced_hash_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-  }
   const hipError_t e = hipEventSynchronize(sl.done);
   const auto t_w1 = std::chrono::steady_clock::now();
-  ctx->gpu_done.fetch_add(1);
+  if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
   if (e == hipSuccess) {
     if (sl.check_positions && nbox == 1) {
       const int64_t* pos = (const int64_t*)(h2 + n * EB);
@@ -2138,12 +1953,12 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
       }
     } else if (positions_ok) {
       mpvss::Sha256 tr;
-      if (hashed > 0) memcpy(&tr, &tr_sl, sizeof(tr)); else memcpy(&tr, state, sizeof(tr));
+      memcpy(&tr, state, sizeof(tr));
       // the caller's copies of the arrays (the one-call entry points: 64 MB per 65536 shares) beside the hash, not behind it
       const bool copies = (x_out || y_out || a1_out || a2_out) && n * EB >= ((size_t)1 << 20);
       hsc::parallel_indices(copies ? 2 : 1, [&](unsigned k) {
         if (k == 0) {
-          frame_shares(tr, hX, hY, h1, h2, hashed, n);     // dleq.rs:87-99, share order = array order
+          frame_shares(tr, hX, hY, h1, h2, 0, n);     // dleq.rs:87-99, share order = array order
           if (copies) return;
         }
         if (x_out) memcpy(x_out, hX, n * EB);
@@ -2171,8 +1986,8 @@ int verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk,
   {
     mpvss_ctx::PipeStats& ps = ctx->pstats;
     ps.enqueue_ms += sl.enqueue_ms;
-    ps.wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count() - sliced_hash_ms;
-    ps.hash_ms += std::chrono::duration<double, std::milli>(t_h1 - t_w1).count() + sliced_hash_ms;
+    ps.wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count();
+    ps.hash_ms += std::chrono::duration<double, std::milli>(t_h1 - t_w1).count();
     for (int k = 0; k < 4; ++k) {
       ps.kernel_ms[k] += ctx->kernel_ms[k];
       ps.kernel_launches[k] += (unsigned long long)ctx->kernel_launches[k];
@@ -2316,13 +2131,12 @@ extern "C" int mpvss_block_claim(mpvss_ctx* ctx, unsigned long long* ticket_out)
   if (!ctx) return MPVSS_E_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!ticket_out) return fail(ctx, MPVSS_E_INVALID, "claim: null ticket");
-  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
-  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "claim: no block in flight");
+  mpvss_ctx::BlockSlot& sl = ctx->fifo_front();
+  if (!sl.busy) return fail(ctx, MPVSS_E_INVALID, "claim: no block in flight");
   if (sl.kind != 0 && sl.kind != 2) return fail(ctx, MPVSS_E_INVALID, "claim: the oldest block in flight is not a distribution block");
   sl.absorbing = true;
   sl.claimed = true;
-  sl.ticket = ctx->tail;
-  *ticket_out = ctx->tail;
+  *ticket_out = sl.pos;
   ++ctx->tail;
   return MPVSS_OK;
 }
@@ -2342,29 +2156,34 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   if (!ctx) return MPVSS_E_INVALID;
   std::unique_lock<std::mutex> lk(ctx->mu);
   if (!verdict || !challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify_distribution: bad argument");
-  if (ctx->head != ctx->tail)
-    return fail(ctx, MPVSS_E_INVALID, "verify_distribution: blocks of the block API are in flight, absorb them first");
   *verdict = 0;
   uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
   mpvss_transcript_init(state);
+  // Any number of host threads may be in here on one context (the crate goes parallel over dealers the same way,
+  // participant.rs:490-500): each enqueues its box under the lock, owns the block by its number and absorbs exactly that one
+  // with the lock released -- T callers keep T boxes in flight, which is what the library's own pipeline does for verify_many.
+  RET_IF(wait_for_room(ctx, lk));
   RET_IF(verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
                                      challenge_host));
-  RET_IF(verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host));
+  const unsigned long long pos = ctx->own_last(1);
+  RET_IF(verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host, nullptr, &pos, true));
   return mpvss_modp_transcript_verdict(state, challenge_host, verdict, digest32_out);
 }
 
 // ---- many boxes, pipelined inside the library -------------------------------------------------------------
 // The calling thread enqueues the GPU work of up to `depth` boxes ahead; `hash_threads` library threads wait for the
-// boxes in FIFO order and hash them (every box has its own transcript, so the hashes of consecutive boxes run side
-// by side).  Nothing of this depends on the caller's scheduler.
+// boxes in enqueue order and hash them (every box has its own transcript, so the hashes of consecutive boxes run side
+// by side).  Nothing of this depends on the caller's scheduler.  The pipeline owns its blocks by number (mpvss_ctx::own_last),
+// so other host threads may use the one-call entry points or the block API on the same context meanwhile; a second pipeline
+// call on the context waits for the first (pipe_mu: the batched X paths' workspaces belong to one run at a time).
 namespace {
 
 int ec_verify_block_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* state, uint8_t* x_out,
-                                  uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out, const unsigned long long* ticket = nullptr);     // capi_ec.inc
+                                  uint8_t* a1_out, uint8_t* a2_out, uint8_t* y_out, const unsigned long long* ticket = nullptr,
+                                  bool by_position = false);     // capi_ec.inc
 
-// issue(b): enqueue box b (called with the context lock held); finish(idx, state): verdict of box idx from its state
-// issue(b, &parts): enqueue box b as `parts` consecutive blocks (called with the context lock held; a box in several parts
-// has its transcript absorbed part by part, in order, by ONE worker); finish(idx, state): verdict of box idx from its state
+// issue(b, &nbox): enqueue box b as ONE block (called with the context lock held); *nbox > 1: the block is a group of the boxes
+// b .. b + nbox - 1 (one transcript each).  finish(idx, state): verdict of box idx from its state.
 // begin(idx, state) (optional): the state box idx's transcript starts from -- the initial one by default; a chained run (several
 // engines, one box: mpvss_modp_verify_many_chained) takes it from the engine before, false = that engine failed;
 // give_up(idx) (optional): box idx will not reach finish() (malformed here, or failed upstream): a chained run passes that on
@@ -2376,46 +2195,46 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   if (hash_threads < 1) hash_threads = 1;
   if (hash_threads > max_threads) hash_threads = max_threads;
   if (depth < 1) depth = 1;
-  if (depth > (int)mpvss_ctx::NSLOT) depth = (int)mpvss_ctx::NSLOT;
+  if (depth > (int)mpvss_ctx::NSLOT - 8) depth = (int)mpvss_ctx::NSLOT - 8;
+  std::lock_guard<std::mutex> one_pipeline(ctx->pipe_mu);      // (always taken before the context lock)
   struct Hint {
-    mpvss_ctx* c; bool was; int was_depth;
-    Hint(mpvss_ctx* c_, bool on, int d) : c(c_) {
+    mpvss_ctx* c; bool on;
+    Hint(mpvss_ctx* c_, bool on_) : c(c_), on(on_) {
+      if (!on) return;
       std::lock_guard<std::mutex> lk(c->mu);
-      was = c->pipelined_hint; was_depth = c->pipeline_depth;
-      if (on) { c->pipelined_hint = true; c->pipeline_depth = d; }
+      ++c->pipelines_running;
     }
-    ~Hint() { std::lock_guard<std::mutex> lk(c->mu); c->pipelined_hint = was; c->pipeline_depth = was_depth; }
-  } hint(ctx, count > 2 && depth > 1, depth);
-  struct Ent { size_t box; unsigned parts; bool bad; unsigned nbox; };   // one entry per enqueued block; parts: blocks of its box (first entry); nbox > 1: a group block of boxes box .. box+nbox-1
+    ~Hint() {
+      if (!on) return;
+      std::lock_guard<std::mutex> lk(c->mu);
+      --c->pipelines_running;
+    }
+  } hint(ctx, count > 2 && depth > 1);
+  struct Ent { size_t box; unsigned pos; bool bad; bool ec; unsigned nbox; };   // one entry per enqueued block (pos: its number in the context's ring); nbox > 1: a group block of boxes box .. box+nbox-1
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    size_t issued = 0, claimed = 0, low = 0;   // blocks enqueued / handed to workers; low: blocks 0 .. low-1 are absorbed (their ring positions are free)
-    std::vector<Ent> order;                     // order[k]: the k-th block enqueued by this run
-    std::vector<char> blk_done;
-    bool stop = false;                          // no more boxes will be issued
+    size_t issued = 0, claimed = 0, absorbed = 0;   // blocks enqueued / handed to workers / absorbed (their slots are free again)
+    std::vector<Ent> order;                         // order[k]: the k-th block enqueued by this run
+    bool stop = false;                              // no more boxes will be issued
     int rc = MPVSS_OK;
   } sh;
   sh.order.reserve(count + 8);
-  sh.blk_done.reserve(count + 8);
-  const unsigned base_tail = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->tail; }();
   // `depth` bounds the blocks whose GPU work is pending; a block whose GPU work is done but whose transcript is still being
-  // hashed keeps its slot (the ring has NSLOT of them) without holding back the enqueueing of the next one
-  static const int issue_on_gpu_done = fd_env("MPVSS_ISSUE_ON_GPU_DONE", 1);
-  const unsigned long long gpu_done0 = ctx->gpu_done.load();
+  // hashed keeps its slot (the ring has NSLOT of them) without holding back the enqueueing of the next one (measured: issuing
+  // on GPU completion instead of after the hash, 0.90-0.93 -> 0.97 M share verifications/s at K = 20)
+  std::atomic<unsigned long long> gpu_done{0};      // this run's blocks whose GPU work has completed (seen by an absorbing thread)
 
   auto worker = [&]() {
     for (;;) {
-      size_t seq0;
       Ent ent;
       {
         std::unique_lock<std::mutex> l(sh.m);
         sh.cv.wait(l, [&] { return sh.claimed < sh.issued || sh.stop; });
         if (sh.claimed >= sh.issued) return;       // stop and nothing left
-        seq0 = sh.claimed;
-        ent = sh.order[seq0];
-        sh.claimed += ent.parts;                   // the parts of a box are enqueued (and counted in `issued`) together
+        ent = sh.order[sh.claimed++];
       }
+      const unsigned long long pos = ent.pos;
       int rc = MPVSS_OK;
       if (ent.nbox > 1) {          // a group of boxes in one block: one transcript each
         std::vector<uint8_t> states((size_t)ent.nbox * MPVSS_TRANSCRIPT_STATE_BYTES);
@@ -2424,13 +2243,11 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
         int prc;
         {
           std::unique_lock<std::mutex> lk(ctx->mu);
-          const unsigned long long pos = (unsigned long long)(base_tail + (unsigned)seq0);
           prc = verify_block_absorb_locked(ctx, lk, states.data(), nullptr, nullptr, nullptr, nullptr, &pos, true, ent.nbox, bad.data());
         }
         {
           std::lock_guard<std::mutex> l(sh.m);
-          sh.blk_done[seq0] = 1;
-          while (sh.low < sh.blk_done.size() && sh.blk_done[sh.low]) ++sh.low;
+          ++sh.absorbed;
         }
         sh.cv.notify_all();
         if (prc != MPVSS_OK) rc = prc;
@@ -2451,43 +2268,29 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
       }
       uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
       bool malformed = ent.bad;
-      size_t box = ent.box;
       if (!begin(ent.box, state)) {              // (may wait: a chained run receives the state from the engine before)
         mpvss_transcript_init(state);
         malformed = true;
       }
-      for (unsigned p = 0; p < ent.parts; ++p) {
-        size_t seq = seq0 + p;
-        int prc;
-        {
-          std::unique_lock<std::mutex> lk(ctx->mu);
-          const unsigned long long pos = (unsigned long long)(base_tail + (unsigned)seq);
-          if (ctx->ring_slot((unsigned)pos).kind == 2 || ctx->ring_slot(ctx->tail).kind == 2) {
-            // curve-group blocks are handed out in FIFO order under the context lock (always one block per box)
-            seq = (size_t)(ctx->tail - base_tail);
-            prc = ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr);
-          } else {
-            prc = verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr, &pos, true);
-          }
-        }
-        {
-          std::lock_guard<std::mutex> l(sh.m);
-          if (seq < sh.order.size()) {
-            if (ent.parts == 1) box = sh.order[seq].box, malformed = sh.order[seq].bad;
-            sh.blk_done[seq] = 1;
-          }
-          while (sh.low < sh.blk_done.size() && sh.blk_done[sh.low]) ++sh.low;
-        }
-        sh.cv.notify_all();
-        // A box the engine rejects as malformed (an invalid curve encoding, a scalar that is not reduced, a negative
-        // position in device memory) is THAT box's business: its verdict stays 0 -- the reference answers `false` to
-        // structural problems, participant.rs:415-420 -- and the other boxes of the run are verified as usual
-        // (mpvss_last_error still names the reason).  Only device and allocation errors end the run.
-        if (prc == MPVSS_E_INVALID) malformed = true;
-        else if (prc != MPVSS_OK && rc == MPVSS_OK) rc = prc;
+      int prc;
+      {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        prc = ent.ec ? ec_verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr, &pos, true)
+                     : verify_block_absorb_locked(ctx, lk, state, nullptr, nullptr, nullptr, nullptr, &pos, true);
       }
-      if (rc == MPVSS_OK && !malformed && box < count) rc = finish(box, state);
-      else if (box < count) give_up(box);
+      {
+        std::lock_guard<std::mutex> l(sh.m);
+        ++sh.absorbed;
+      }
+      sh.cv.notify_all();
+      // A box the engine rejects as malformed (an invalid curve encoding, a scalar that is not reduced, a negative
+      // position in device memory) is THAT box's business: its verdict stays 0 -- the reference answers `false` to
+      // structural problems, participant.rs:415-420 -- and the other boxes of the run are verified as usual
+      // (mpvss_last_error still names the reason).  Only device and allocation errors end the run.
+      if (prc == MPVSS_E_INVALID) malformed = true;
+      else if (prc != MPVSS_OK) rc = prc;
+      if (rc == MPVSS_OK && !malformed) rc = finish(ent.box, state);
+      else give_up(ent.box);
       if (rc != MPVSS_OK) {
         std::lock_guard<std::mutex> l(sh.m);
         if (sh.rc == MPVSS_OK) sh.rc = rc;
@@ -2507,39 +2310,42 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
   for (size_t b = 0; b < count; b += nbox) {
     {
       std::unique_lock<std::mutex> l(sh.m);
-      // slots are a ring: a block may be enqueued once the block NSLOT positions before it has been absorbed (the threads
-      // finish in any order); a box takes at most 8 positions
       auto may_issue = [&] {
         if (sh.rc != MPVSS_OK) return true;
-        if (!issue_on_gpu_done) return sh.issued - sh.low < (size_t)depth;
-        const size_t pending_gpu = sh.issued - (size_t)(ctx->gpu_done.load() - gpu_done0);
-        return pending_gpu < (size_t)depth && sh.issued - sh.low + 8 < (size_t)mpvss_ctx::NSLOT;
+        const size_t pending_gpu = sh.issued - (size_t)gpu_done.load();
+        return pending_gpu < (size_t)depth && sh.issued - sh.absorbed + 8 < (size_t)mpvss_ctx::NSLOT;
       };
       while (!may_issue()) sh.cv.wait_for(l, std::chrono::microseconds(200));
       if (sh.rc != MPVSS_OK) break;
     }
     int rc;
-    unsigned parts = 0;                      // blocks actually enqueued for this box (also when a later part was rejected)
     nbox = 1;                                // boxes this call enqueued (> 1: one group block)
+    unsigned head0, head1;
+    bool ec = false;
     {
-      std::lock_guard<std::mutex> lk(ctx->mu);
-      rc = issue(b, &parts, &nbox);
+      std::unique_lock<std::mutex> lk(ctx->mu);
+      rc = wait_for_room(ctx, lk);           // (other callers' blocks share the ring)
+      head0 = ctx->head;
+      if (rc == MPVSS_OK) rc = issue(b, &nbox);
+      head1 = ctx->head;
+      if (head1 != head0) {                  // what was enqueued is this run's, also when the box was rejected half-way
+        ctx->own_last(head1 - head0, &gpu_done);
+        ec = ctx->ring_slot(head0).kind == 2;
+      }
     }
     if (nbox < 1) nbox = 1;
     {
       std::lock_guard<std::mutex> l(sh.m);
       const bool bad = rc == MPVSS_E_INVALID;     // malformed box: verdict 0, the run goes on (what was enqueued is still absorbed)
       if (rc == MPVSS_OK || bad) {
-        for (unsigned p = 0; p < parts; ++p) {
-          sh.order.push_back(Ent{b, p == 0 ? parts : 0u, bad, nbox});
-          sh.blk_done.push_back(0);
-        }
-        sh.issued += parts;
+        for (unsigned p = head0; p != head1; ++p) sh.order.push_back(Ent{b, p, bad, ec, nbox});
+        sh.issued += head1 - head0;
         rc = MPVSS_OK;
       } else if (sh.rc == MPVSS_OK) {
         sh.rc = rc;
       }
     }
+    if (rc == MPVSS_OK && head1 == head0) give_up(b);      // rejected before anything was enqueued: no worker will see the box
     sh.cv.notify_all();
     if (rc != MPVSS_OK) break;
   }
@@ -2548,7 +2354,7 @@ int run_box_pipeline(mpvss_ctx* ctx, size_t count, int depth, int hash_threads, 
     sh.stop = true;
   }
   sh.cv.notify_all();
-  for (auto& th : pool) th.join();     // the workers drain every issued block, so no slot stays busy
+  for (auto& th : pool) th.join();     // the workers drain every issued block, so no slot of this run stays busy
   return sh.rc;
 }
 
@@ -2561,33 +2367,15 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!boxes || !verdicts) return fail(ctx, MPVSS_E_INVALID, "verify_many: bad argument");
-    if (ctx->head != ctx->tail)
-      return fail(ctx, MPVSS_E_INVALID, "verify_many: blocks of the block API are in flight, absorb them first");
   }
   for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
   if (digests32) memset(digests32, 0, 32 * count);       // a malformed box has no transcript: verdict 0, digest zero
-  // Optional (MPVSS_TAIL_PARTS > 1, off by default): the last MPVSS_TAIL_BOXES boxes of a run are enqueued in MPVSS_TAIL_PARTS
-  // parts of consecutive shares each, absorbed in order by one worker -- nothing follows them, so their transcript hashes (40 ms
-  // per 65536 shares, strictly sequential: dleq.rs:87-99) otherwise start when the GPU has nothing left to do; in parts, the
-  // hash of part k runs beside the GPU work of part k+1.  Measured at K = 20 (profiles/r03_tail_ab.txt): the last box in 4
-  // parts is within the run-to-run noise of the plain run (1.006 against 1.007 M, three runs each); the last 12 boxes in 2 or 4
-  // parts LOSE a third (0.59-0.75 M: quarter-size blocks are inefficient on the forward-difference path).
-  static const int tail_parts = fd_env("MPVSS_TAIL_PARTS", 1);
-  static const size_t tail_boxes = (size_t)fd_env("MPVSS_TAIL_BOXES", 1);
-  static const size_t tail_min_part = (size_t)fd_env("MPVSS_TAIL_MIN_PART", 8192);     // shares per part at least (tests lower it)
-  // MPVSS_X_BATCH: X paths of up to this many consecutive large boxes of one shape in the same launches (0 / 1: every box on its own).
-  // A batch workspace (several GB at (131072, 1024): the hand-over buffers of four boxes' stepping) is reused after `xring` batches; the
-  // new batch waits on the device for the blocks that still read the old one's X (ModpXBatch::readers).
-  static const int xbatch = fd_env("MPVSS_X_BATCH", 1);
-  const size_t xB = xbatch > 1 ? (size_t)std::min(xbatch, 16) : 1;
-  static const size_t xring = (size_t)std::max(2, fd_env("MPVSS_X_BATCH_RING", 5));
-  std::vector<ModpPre> pre(xB > 1 ? count : 0);
-  std::vector<char> has_pre(count, 0), looked(count, 0);
-  size_t batch_no = 0;
   // The key cache (mpvss_ctx_set_key_cache): a public-key array that enough large boxes of THIS call present -- same pointer, same n:
   // inside one call that is the same array -- gets its tables built once, now; those boxes then take the registered-key path
   // (a2 in 613 instead of 2 620 products), the tables are freed when the call returns.  Boxes that bring a key set of their own, small
   // boxes (they travel in groups) and boxes whose challenge does not fit 256 bits (decided per block) are left as they are.
+  // Whatever goes wrong with the tables (no room in HBM, any other failure of the build) costs speed, not the call: those boxes
+  // are verified the plain way.
   std::vector<const mpvss_keyset*> auto_ks(count, nullptr);
   struct AutoKeys {
     mpvss_ctx* c;
@@ -2596,29 +2384,34 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   } auto_keys{ctx, {}};
   const int cache_min = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->key_cache_min_boxes; }();
   if (cache_min >= 2) {
-    static const size_t small_max = (size_t)fd_env("MPVSS_GROUP_MAX_BOX", 16384);
     std::vector<char> seen(count, 0);
     for (size_t b = 0; b < count; ++b) {
       const mpvss_modp_box& bx = boxes[b];
-      if (seen[b] || bx.keyset || !bx.pubkeys || bx.n <= small_max || bx.n > MAX_CHUNK) continue;
+      if (seen[b] || bx.keyset || !bx.pubkeys || bx.n <= GROUP_MAX_BOX || bx.n > MAX_CHUNK) continue;
       std::vector<size_t> same;
       for (size_t k = b; k < count; ++k)
         if (!boxes[k].keyset && boxes[k].pubkeys == bx.pubkeys && boxes[k].n == bx.n) { same.push_back(k); seen[k] = 1; }
       if ((int)same.size() < cache_min) continue;
+      // leave the block slots' workspaces their room: the tables may take what is free now minus a reserve of 3 GB per box in flight
+      size_t free_b = 0, total_b = 0;
+      const size_t table_b = bx.n * ((size_t)modp_keyset_words_per_key() * 4 + EB);
+      const size_t reserve_b = ((size_t)3 << 30) * (size_t)std::max(1, std::min(depth, (int)mpvss_ctx::NSLOT));
+      if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (free_b < table_b || free_b - table_b < reserve_b) continue;
       mpvss_keyset* ks = nullptr;
-      const int rc = mpvss_modp_keyset_create(ctx, space, bx.pubkeys, bx.n, &ks);
-      if (rc == MPVSS_E_NOMEM) {        // no room for the tables: these boxes are verified the plain way
+      if (mpvss_modp_keyset_create(ctx, space, bx.pubkeys, bx.n, &ks) != MPVSS_OK) {
         (void)hipGetLastError();
+        std::lock_guard<std::mutex> g(ctx->err_mu);
+        ctx->err.clear();               // tolerated: nothing of it may show up as this call's error
         continue;
       }
-      if (rc != MPVSS_OK) return rc;
       auto_keys.made.push_back(ks);
       for (size_t k : same) auto_ks[k] = ks;
     }
   }
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
-      [&](size_t b, unsigned* parts, unsigned* nbox) {
+      [&](size_t b, unsigned* nbox) {
         const mpvss_modp_box& bx = boxes[b];
         // a run of consecutive boxes of this box's shape (small ones): ONE block for all of them
         if (bx.n > 0 && 2 * bx.n <= group_shares_max() && box_groupable(bx, bx.n, bx.t, space)) {
@@ -2628,37 +2421,13 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
           if (B >= 2) {
             const int rc = verify_group_compute_locked(ctx, space, boxes + b, B);
             if (rc != MPVSS_OK) return rc;
-            *parts = 1;
             *nbox = (unsigned)B;
             return (int)MPVSS_OK;
           }
         }
-        const size_t P = (b + tail_boxes >= count && count >= 3 && tail_parts > 1 && tail_parts <= 8 && bx.n >= (size_t)tail_parts * tail_min_part &&
-                          bx.commitments && bx.positions && (bx.pubkeys || bx.keyset) && bx.shares && bx.responses)
-                             ? (size_t)tail_parts : 1;
-        // the X paths of a run of large boxes of one shape by the same launches (modp_x_batch_compute); every box keeps its own block
-        if (xB > 1 && P == 1 && !looked[b]) {
-          size_t Bx = 0;
-          while (Bx < xB && b + Bx < count && modp_x_box_batchable(space, boxes[b + Bx], bx.n, bx.t)) ++Bx;
-          for (size_t i = 0; i < std::max<size_t>(Bx, 1); ++i) looked[b + i] = 1;
-          if (Bx >= 2) {
-            while (ctx->modp_xb.size() < xring) ctx->modp_xb.push_back(new mpvss_ctx::ModpXBatch());
-            const int rc = modp_x_batch_compute(ctx, space, boxes + b, Bx, *ctx->modp_xb[batch_no++ % xring], &pre[b]);
-            if (rc != MPVSS_OK) return rc;
-            for (size_t i = 0; i < Bx; ++i) has_pre[b + i] = 1;
-          }
-        }
-        for (size_t p = 0; p < P; ++p) {
-          const size_t lo = (bx.n * p / P) & ~(size_t)15, hi = p + 1 == P ? bx.n : ((bx.n * (p + 1) / P) & ~(size_t)15);
-          const mpvss_keyset* use_ks = bx.keyset ? bx.keyset : auto_ks[b];
-          const int rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions + lo,
-                                                     bx.pubkeys ? bx.pubkeys + lo * EB : nullptr, bx.shares + lo * EB,
-                                                     bx.responses + lo * EB, hi - lo, bx.challenge_host, use_ks,
-                                                     (bx.keyset ? bx.key_offset : 0) + lo, nullptr, (P == 1 && has_pre[b]) ? &pre[b] : nullptr);
-          if (rc != MPVSS_OK) return rc;
-          ++*parts;
-        }
-        return (int)MPVSS_OK;
+        const mpvss_keyset* use_ks = bx.keyset ? bx.keyset : auto_ks[b];
+        return verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses, bx.n,
+                                           bx.challenge_host, use_ks, bx.keyset ? bx.key_offset : 0);
       },
       [&](size_t idx, const uint8_t* state) {
         return mpvss_modp_transcript_verdict(state, boxes[idx].challenge_host, &verdicts[idx],
@@ -2684,22 +2453,17 @@ extern "C" int mpvss_modp_verify_many_chained(mpvss_ctx* ctx, int space, const m
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!boxes || !verdicts) return fail(ctx, MPVSS_E_INVALID, "verify_many_chained: bad argument");
-    if (ctx->head != ctx->tail)
-      return fail(ctx, MPVSS_E_INVALID, "verify_many_chained: blocks of the block API are in flight, absorb them first");
   }
   for (size_t i = 0; i < count; ++i) verdicts[i] = 0;
   if (digests32) memset(digests32, 0, 32 * count);
   return run_box_pipeline(
       ctx, count, depth, hash_threads,
-      [&](size_t b, unsigned* parts, unsigned* nbox) {
+      [&](size_t b, unsigned* nbox) {
         const mpvss_modp_box& bx = boxes[b];
         *nbox = 1;
-        const int rc = verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
-                                                   bx.n, bx.challenge_host, bx.keyset, bx.key_offset,
-                                                   wellformed_dev_out ? wellformed_dev_out[b] : nullptr);
-        if (rc != MPVSS_OK) return rc;
-        *parts = 1;
-        return (int)MPVSS_OK;
+        return verify_block_compute_locked(ctx, space, bx.commitments, bx.t, bx.positions, bx.pubkeys, bx.shares, bx.responses,
+                                           bx.n, bx.challenge_host, bx.keyset, bx.key_offset,
+                                           wellformed_dev_out ? wellformed_dev_out[b] : nullptr);
       },
       [&](size_t idx, const uint8_t* state) {
         if (state_out) {
@@ -2815,10 +2579,7 @@ int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, c
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "verify_shares: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!sl.done) {
-    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-  }
+  if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
   sl.n = n;
   sl.kind = 1;
   sl.check_positions = false;
@@ -2900,15 +2661,15 @@ int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, c
   return MPVSS_OK;
 }
 
-int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* verdicts_host) {
-  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
-  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "verify_shares_absorb: no batch in flight");
-  if (sl.kind != 1) return fail(ctx, MPVSS_E_INVALID, "verify_shares_absorb: the oldest block in flight is a verify_distribution block");
+int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* verdicts_host,
+                                const unsigned long long* own_pos = nullptr) {
+  mpvss_ctx::BlockSlot* slp = select_block(ctx, own_pos, own_pos != nullptr, 1, 1, "verify_shares_absorb");
+  if (!slp) return MPVSS_E_INVALID;
+  mpvss_ctx::BlockSlot& sl = *slp;
   const size_t n = sl.n;
-  ++ctx->tail;
   if (n == 0) {
     ctx->release(sl);
-    ctx->gpu_done.fetch_add(1);
+    if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
     return MPVSS_OK;
   }
   sl.absorbing = true;
@@ -2917,7 +2678,7 @@ int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk
     if (e_dev != hipSuccess) {               // give the slot back: the block is lost, the ring is not
       ctx->release(sl);
       sl.absorbing = false;
-      ctx->gpu_done.fetch_add(1);
+      if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
       return fail(ctx, MPVSS_E_DEVICE, "absorb: hipSetDevice", e_dev);
     }
   }
@@ -2925,7 +2686,7 @@ int verify_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk
   const auto t_w0 = std::chrono::steady_clock::now();
   const hipError_t e = hipEventSynchronize(sl.done);
   const auto t_w1 = std::chrono::steady_clock::now();
-  ctx->gpu_done.fetch_add(1);
+  if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
   if (e == hipSuccess && verdicts_host) memcpy(verdicts_host, sl.pin, n);
   lk.lock();
   ctx->release(sl);
@@ -2965,10 +2726,10 @@ extern "C" int mpvss_modp_verify_shares(mpvss_ctx* ctx, int space, const uint8_t
   std::unique_lock<std::mutex> lk(ctx->mu);
   if (n == 0) return MPVSS_OK;
   if (!pk || !s || !y || !c || !r || !verdicts_host) return fail(ctx, MPVSS_E_INVALID, "verify_shares: bad argument");
-  if (ctx->head != ctx->tail)
-    return fail(ctx, MPVSS_E_INVALID, "verify_shares: blocks of the block API are in flight, absorb them first");
+  RET_IF(wait_for_room(ctx, lk));
   RET_IF(verify_shares_compute_locked(ctx, space, pk, s, y, c, r, n, nullptr));
-  return verify_shares_absorb_locked(ctx, lk, verdicts_host);
+  const unsigned long long pos = ctx->own_last(1);
+  return verify_shares_absorb_locked(ctx, lk, verdicts_host, &pos);
 }
 
 // ---- distribute_secret, group part ---------------------------------------------------------------------
@@ -3011,13 +2772,9 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   if (sl.busy) return fail(ctx, MPVSS_E_INVALID, "distribute: every block slot (MPVSS_BLOCK_SLOTS) is in flight, absorb one first");
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!sl.done) {
-    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-  }
+  if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
   sl.n = n;
   sl.kind = 0;                 // absorbed like a verifier's block: same staging layout, same hash
-  sl.slices = 0;
   sl.nbox = 1;
   sl.check_positions = false;
   sl.fd_used = false;
@@ -3121,17 +2878,12 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
       Swap sw(ctx, ctx->w->sb);
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:213-216)
       uint32_t* ty = (uint32_t*)ctx->w->tab1.p;
-      static const int twin = fd_env("MPVSS_DEALER_BUCKETS", 1);
-      if (cnt >= 1024 && twin) {
+      if (cnt >= 1024) {
         // same base, two exponents: right-to-left buckets share the 2 045 squarings (tab1 holds buckets + occupancy)
         const size_t bw = modp_twin_exp_bucket_words();
         RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
         uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
         TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dp, (const uint8_t*)dw, cnt, bk, bk + cnt * bw, dY, da2));
-      } else if (cnt >= 1024) {   // 64-entry tables, 6-bit windows: 341 products per exponentiation instead of 511
-        TIMED_LAUNCH(ctx, 2, modp_launch_build_table64((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, ty, ty, (const uint8_t*)dp, nullptr, 0, nullptr, cnt, dY));
-        TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, ty, ty, (const uint8_t*)dw, nullptr, 0, nullptr, cnt, da2));
       } else {
         TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
         TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dY,
@@ -3231,15 +2983,15 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
                 !a2_out || t == 0 || t > 0x7fffffff))
     return fail(ctx, MPVSS_E_INVALID, "distribute: bad argument");
   if (t > n) return fail(ctx, MPVSS_E_INVALID, "distribute: threshold > number of public keys (participant.rs:166)");
-  if (ctx->head != ctx->tail)
-    return fail(ctx, MPVSS_E_INVALID, "distribute: blocks of the block API are in flight, absorb them first");
   uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
   mpvss_transcript_init(state);
   const bool dev = space == MPVSS_DEVICE;
+  RET_IF(wait_for_room(ctx, lk));
   RET_IF(distribute_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, p_values, witnesses, n, dev ? x_out : nullptr,
                                          dev ? y_out : nullptr, dev ? a1_out : nullptr, dev ? a2_out : nullptr));
+  const unsigned long long pos = ctx->own_last(1);
   RET_IF(verify_block_absorb_locked(ctx, lk, state, dev ? nullptr : x_out, dev ? nullptr : a1_out, dev ? nullptr : a2_out,
-                                    dev ? nullptr : y_out));
+                                    dev ? nullptr : y_out, &pos, true));
   if (digest32_out) {
     mpvss::Sha256 tr;
     memcpy(&tr, state, sizeof(tr));
@@ -3285,8 +3037,7 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
     // the dealer) once the host has the second exponent  e2 = w * (1/x) mod (q-1)  -- exact for every Y that is a unit
     // mod q; a Y that is 0 mod q (not a group element) would make S = 0 and the reduced exponent matter, so such a
     // batch takes the two dependent exponentiations.  Host buffers and at least 1024 shares (as for the dealer).
-    static const int twin = fd_env("MPVSS_EXTRACT_SHARED_SQUARINGS", 1);
-    bool shared = twin && space == MPVSS_HOST && cnt >= 1024;
+    bool shared = space == MPVSS_HOST && cnt >= 1024;
     if (shared) {
       uint8_t qb[EB];
       modq_modulus_bytes(qb);
@@ -3368,10 +3119,7 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
   }
   const auto t_enq0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (!sl.done) {
-    static const int blocking = fd_env("MPVSS_BLOCKING_SYNC", 1);
-    HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-  }
+  if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
   sl.n = n;
   sl.kind = 4;
   sl.check_positions = false;
@@ -3452,24 +3200,23 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
 }
 
 int extract_shares_absorb_locked(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, uint8_t* s_out_host, uint8_t* c_out_host) {
-  mpvss_ctx::BlockSlot& sl = ctx->ring_slot(ctx->tail);
-  if (!sl.busy || sl.absorbing) return fail(ctx, MPVSS_E_INVALID, "extract_shares_absorb: no batch in flight");
-  if (sl.kind != 4) return fail(ctx, MPVSS_E_INVALID, "extract_shares_absorb: the oldest block in flight belongs to another entry point");
+  mpvss_ctx::BlockSlot* slp = select_block(ctx, nullptr, false, 4, 4, "extract_shares_absorb");
+  if (!slp) return MPVSS_E_INVALID;
+  mpvss_ctx::BlockSlot& sl = *slp;
   const size_t n = sl.n;
-  ++ctx->tail;
   sl.absorbing = true;
   {
     const hipError_t e_dev = hipSetDevice(ctx->device);
     if (e_dev != hipSuccess) {
       ctx->release(sl);
       sl.absorbing = false;
-      ctx->gpu_done.fetch_add(1);
+      if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
       return fail(ctx, MPVSS_E_DEVICE, "absorb: hipSetDevice", e_dev);
     }
   }
   lk.unlock();
   const hipError_t e = hipEventSynchronize(sl.done);
-  ctx->gpu_done.fetch_add(1);
+  if (sl.gpu_done_ctr) sl.gpu_done_ctr->fetch_add(1);
   if (e == hipSuccess) {
     const uint8_t* hS = (const uint8_t*)sl.pin;
     const uint8_t* hc = hS + n * EB;

@@ -9,6 +9,10 @@
 //!   extract_secret_share (n)     src/participant.rs:294-353                          -> mpvss_modp_extract_shares
 //!   reconstruct                  src/participant.rs:462-561                          -> mpvss_modp_reconstruct
 //!
+//! `crate::participant::Participant<G>` wraps these in the reference's method names.  Every function here may be called from
+//! several threads at once on one engine (the library keeps one box per caller in flight: rayon over dealers, as
+//! participant.rs:490-500 goes parallel over shares).
+//!
 //! Never compiled in this repository's environment (no Rust toolchain).
 use mpvss_rs::group::Group;
 use mpvss_rs::polynomial::Polynomial;
@@ -18,7 +22,7 @@ use num_traits::Zero;
 
 use crate::engine::EngineError;
 use crate::ffi;
-use crate::groups::{be256, HipModpGroup};
+use crate::groups::{be256, HipModpGroup, HipRistretto255Group, HipSecp256k1Group};
 
 /// Flat, positions-ordered view of a box: exactly the arrays the C ABI takes.
 pub struct FlatBox {
@@ -108,13 +112,16 @@ pub fn verify_many(group: &HipModpGroup, boxes: &[&DistributionSharesBox<HipModp
 }
 
 /// n calls of `Participant::verify_share` (participant.rs:361-386) against one distribution box: one verdict each.
-pub fn verify_shares(group: &HipModpGroup, share_boxes: &[ShareBox<HipModpGroup>], bx: &DistributionSharesBox<HipModpGroup>) -> Vec<bool> {
+/// `publickeys[i]` is the `publickey` argument of the i-th call: the key the encrypted share is looked up under and h1 of the proof.
+pub fn verify_shares(group: &HipModpGroup, share_boxes: &[ShareBox<HipModpGroup>], publickeys: &[BigInt],
+                     bx: &DistributionSharesBox<HipModpGroup>) -> Vec<bool> {
+    assert_eq!(share_boxes.len(), publickeys.len());
     let mut live = Vec::new();
     let (mut pk, mut s, mut y, mut c, mut r) = (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
-    for (i, sb) in share_boxes.iter().enumerate() {
-        if let Some(enc) = bx.shares.get(&group.element_to_bytes(&sb.publickey)) {     // missing share -> false (:368-372)
+    for (i, (sb, key)) in share_boxes.iter().zip(publickeys).enumerate() {
+        if let Some(enc) = bx.shares.get(&group.element_to_bytes(key)) {     // missing share -> false (:368-372)
             live.push(i);
-            pk.extend_from_slice(&be256(&sb.publickey));
+            pk.extend_from_slice(&be256(key));
             s.extend_from_slice(&be256(&sb.share));
             y.extend_from_slice(&be256(enc));
             c.extend_from_slice(&be256(&sb.challenge));
@@ -190,23 +197,21 @@ pub fn distribute_secret(group: &HipModpGroup, secret: &BigInt, publickeys: &[Bi
     bx
 }
 
-/// n participants decrypt and prove at once (participant.rs:294-353); witnesses drawn here like the reference's callers do.
-pub fn extract_secret_shares(group: &HipModpGroup, bx: &DistributionSharesBox<HipModpGroup>, private_keys: &[BigInt]) -> Vec<Option<ShareBox<HipModpGroup>>> {
-    let order = group.order().clone();
+/// n participants decrypt and prove at once (participant.rs:294-353): `witnesses[i]` is the `w` argument of the i-th call.
+pub fn extract_secret_shares(group: &HipModpGroup, bx: &DistributionSharesBox<HipModpGroup>, private_keys: &[BigInt], witnesses: &[BigInt])
+    -> Vec<Option<ShareBox<HipModpGroup>>> {
+    assert_eq!(private_keys.len(), witnesses.len());
     let mut idx = Vec::new();
     let (mut pk, mut y, mut xinv, mut w) = (Vec::new(), Vec::new(), Vec::new(), Vec::new());
-    let mut wits = Vec::new();
     let mut pubs = Vec::new();
     for (i, x) in private_keys.iter().enumerate() {
         let public_key = group.generate_public_key(x);
         let (Some(enc), Some(inv)) = (bx.shares.get(&group.element_to_bytes(&public_key)), group.scalar_inverse(x)) else { continue };
-        let wit = group.generate_private_key();
         idx.push(i);
         pk.extend_from_slice(&be256(&public_key));
         y.extend_from_slice(&be256(enc));
         xinv.extend_from_slice(&be256(&inv));
-        w.extend_from_slice(&be256(&wit));
-        wits.push(wit);
+        w.extend_from_slice(&be256(&witnesses[i]));
         pubs.push(public_key);
     }
     let m = idx.len();
@@ -215,7 +220,6 @@ pub fn extract_secret_shares(group: &HipModpGroup, bx: &DistributionSharesBox<Hi
     group.engine.expect(rc, "extract_secret_shares");
     let xs: Vec<u8> = idx.iter().flat_map(|&i| be256(&private_keys[i])).collect();
     unsafe { ffi::mpvss_modp_dleq_responses(w.as_ptr(), xs.as_ptr(), c.as_ptr(), 1, m, r.as_mut_ptr(), 0) };     // r = w - x c, dleq.rs:42-50
-    let _ = order;
     let big = |b: &[u8]| BigInt::from_bytes_be(Sign::Plus, b);
     let mut out: Vec<Option<ShareBox<HipModpGroup>>> = (0..private_keys.len()).map(|_| None).collect();
     for (k, &i) in idx.iter().enumerate() {
@@ -248,51 +252,216 @@ pub fn reconstruct(group: &HipModpGroup, share_boxes: &[ShareBox<HipModpGroup>],
 }
 
 // ---- curve groups: the same flat layout with 33 / 32-byte elements and 32-byte scalars --------------------------------
-/// Generic over the two curve groups: `enc` serialises an element, `sc` a scalar, in the boundary's byte order.
-pub fn ec_verify_distribution_shares<G: Group>(engine: &crate::Engine, group_id: i32, group: &G, bx: &DistributionSharesBox<G>,
-                                               enc: impl Fn(&G::Element) -> Vec<u8>, sc: impl Fn(&G::Scalar) -> Vec<u8>) -> bool {
+/// What the generic curve bodies below need from a HIP-backed curve group beyond `Group`: its id at the C boundary, the
+/// boundary encodings (33-byte SEC1 / 32-byte ristretto255 elements, 32-byte scalars in the group's byte order) and its order.
+pub trait CurveCodec: Group {
+    const GROUP_ID: i32;
+    const ENC: usize;
+    fn engine(&self) -> &crate::Engine;
+    fn enc(e: &Self::Element) -> Vec<u8>;
+    fn dec(b: &[u8]) -> Option<Self::Element>;
+    fn sc(s: &Self::Scalar) -> [u8; 32];
+    fn sc_from(b: &[u8; 32]) -> Self::Scalar;
+    /// the group order as the reference's `order_as_bigint()` gives it
+    fn order_bigint(&self) -> &BigInt;
+    /// a BigInt below the order as a scalar, as participant.rs:1134-1143 / ristretto255.rs:78-106 convert it
+    fn scalar_of(v: &BigInt) -> Self::Scalar;
+}
+
+impl CurveCodec for HipSecp256k1Group {
+    const GROUP_ID: i32 = ffi::MPVSS_GROUP_SECP256K1;
+    const ENC: usize = 33;
+    fn engine(&self) -> &crate::Engine { &self.engine }
+    fn enc(e: &Self::Element) -> Vec<u8> { crate::groups::secp::point_bytes(e).to_vec() }
+    fn dec(b: &[u8]) -> Option<Self::Element> { crate::groups::secp::point_from(b.try_into().ok()?) }
+    fn sc(s: &Self::Scalar) -> [u8; 32] { crate::groups::secp::scalar_bytes(s) }
+    fn sc_from(b: &[u8; 32]) -> Self::Scalar { crate::groups::secp::scalar_from(b) }
+    fn order_bigint(&self) -> &BigInt { self.order_as_bigint() }
+    fn scalar_of(v: &BigInt) -> Self::Scalar { crate::groups::secp::scalar_from_bigint(v) }
+}
+
+impl CurveCodec for HipRistretto255Group {
+    const GROUP_ID: i32 = ffi::MPVSS_GROUP_RISTRETTO255;
+    const ENC: usize = 32;
+    fn engine(&self) -> &crate::Engine { &self.engine }
+    fn enc(e: &Self::Element) -> Vec<u8> { crate::groups::rist::point_bytes(e).to_vec() }
+    fn dec(b: &[u8]) -> Option<Self::Element> { crate::groups::rist::point_from(b.try_into().ok()?) }
+    fn sc(s: &Self::Scalar) -> [u8; 32] { s.to_bytes() }
+    fn sc_from(b: &[u8; 32]) -> Self::Scalar { curve25519_dalek::scalar::Scalar::from_bytes_mod_order(*b) }
+    fn order_bigint(&self) -> &BigInt { self.order_as_bigint() }
+    fn scalar_of(v: &BigInt) -> Self::Scalar { HipRistretto255Group::bigint_to_scalar(v) }
+}
+
+/// SHA256(bytes(G^s)) as a big-endian integer reduced mod the group order: what the curve groups XOR onto the secret
+/// (participant.rs:1229-1246 / 1694-1701, and back in :1495-1508 / 1939-1946)
+fn ec_mask<G: CurveCodec>(group: &G, g_s: &G::Element) -> BigUint {
+    let gb = group.element_to_bytes(g_s);
+    let mut h = [0u8; 32];
+    unsafe { ffi::mpvss_sha256(gb.as_ptr(), gb.len(), h.as_mut_ptr()) };
+    BigUint::from_bytes_be(&h) % group.order_bigint().to_biguint().unwrap()
+}
+
+/// Drop-in body of `Participant<Secp256k1Group / Ristretto255Group>::verify_distribution_shares` (participant.rs:1384-1444, 1827-1887)
+pub fn ec_verify_distribution_shares<G: CurveCodec>(group: &G, bx: &DistributionSharesBox<G>) -> bool {
     let (mut cm, mut pos, mut pk, mut sh, mut rs) = (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
     for c in &bx.commitments {
-        cm.extend(enc(c));
+        cm.extend(G::enc(c));
     }
     for y in &bx.publickeys {
         let key = group.element_to_bytes(y);
         let (Some(p), Some(r), Some(s)) = (bx.positions.get(&key), bx.responses.get(&key), bx.shares.get(&key)) else { return false };
         pos.push(*p);
-        pk.extend(enc(y));
-        sh.extend(enc(s));
-        rs.extend(sc(r));
+        pk.extend(G::enc(y));
+        sh.extend(G::enc(s));
+        rs.extend_from_slice(&G::sc(r));
     }
-    let ch = sc(&bx.challenge);
+    let ch = G::sc(&bx.challenge);
     let mut verdict = 0i32;
     let rc = unsafe {
-        ffi::mpvss_ec_verify_distribution(engine.raw(), group_id, ffi::MPVSS_HOST, cm.as_ptr(), bx.commitments.len(), pos.as_ptr(), pk.as_ptr(),
-                                          sh.as_ptr(), rs.as_ptr(), pos.len(), ch.as_ptr(), &mut verdict, std::ptr::null_mut(),
+        ffi::mpvss_ec_verify_distribution(group.engine().raw(), G::GROUP_ID, ffi::MPVSS_HOST, cm.as_ptr(), bx.commitments.len(), pos.as_ptr(),
+                                          pk.as_ptr(), sh.as_ptr(), rs.as_ptr(), pos.len(), ch.as_ptr(), &mut verdict, std::ptr::null_mut(),
                                           std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut())
     };
-    rc == ffi::MPVSS_OK && verdict == 1
+    rc == ffi::MPVSS_OK && verdict == 1        // an encoding the engine rejects is `false`, like a failed check in the reference
 }
 
-/// The dealer's whole box for a curve group in one call (`mpvss_ec_deal`): the body of `distribute_secret`
-/// (participant.rs:1094-1274 secp256k1, 1573-1717 ristretto255) between "draw the polynomial and the witnesses" and "put the maps
-/// together" -- P(i) mod order (:1155-1157 / :1619-1621), X_i, Y_i, a1_i, a2_i, the transcript digest, the challenge
-/// c = hash_to_scalar(digest) (:1200-1210 / :1662-1672) and the responses r_i = w_i - P(i) c -- everything on the device.
-/// `coeffs` / `witnesses`: 32-byte scalars in the boundary's byte order, `pubkeys`: encoded elements; returns
-/// (Y encodings, digest, challenge bytes, response bytes) or the library's error code.
-pub fn ec_deal(engine: &crate::Engine, group_id: i32, enc_len: usize, coeffs: &[u8], pubkeys: &[u8], witnesses: &[u8])
-               -> Result<(Vec<u8>, [u8; 32], [u8; 32], Vec<u8>), i32> {
-    let (t, n) = (coeffs.len() / 32, witnesses.len() / 32);
-    let positions: Vec<i64> = (1..=n as i64).collect();                                 // :1139,1151,1198
-    let mut y = vec![0u8; n * enc_len];
+/// Drop-in body of `distribute_secret` for the curve groups (participant.rs:1094-1274, 1573-1717): polynomial and witnesses drawn as
+/// the reference draws them, then ONE `mpvss_ec_deal` call -- P(i) mod order, X_i, Y_i, a1_i, a2_i, the transcript digest, the
+/// challenge and the responses on the device.
+pub fn ec_distribute_secret<G: CurveCodec>(group: &G, secret: &BigInt, publickeys: &[G::Element], threshold: u32) -> DistributionSharesBox<G> {
+    assert!(threshold as usize <= publickeys.len());                                   // participant.rs:1100
+    let (n, t) = (publickeys.len(), threshold as usize);
+    let order = group.order_bigint().clone();
+    let mut polynomial = Polynomial::new();
+    polynomial.init((threshold - 1) as i32, &order);                                   // :1107-1113
+    let coeff_scalars: Vec<G::Scalar> = polynomial.coefficients.iter().map(|a| G::scalar_of(a)).collect();
+    let coeffs: Vec<u8> = coeff_scalars.iter().flat_map(|a| G::sc(a)).collect();
+    let eng = group.engine();
+    let mut cm = vec![0u8; t * G::ENC];
+    let rc = unsafe { ffi::mpvss_ec_batch_exp_generator(eng.raw(), G::GROUP_ID, ffi::MPVSS_HOST, coeffs.as_ptr(), t, cm.as_mut_ptr()) };
+    eng.expect(rc, "distribute_secret: commitments");                                  // C_j = a_j G, :1130-1152
+    let positions: Vec<i64> = (1..=n as i64).collect();                                // :1127, 1155-1157, 1212
+    let witnesses: Vec<u8> = (0..n).flat_map(|_| G::sc(&group.generate_private_key())).collect();   // :1177
+    let pk: Vec<u8> = publickeys.iter().flat_map(|y| G::enc(y)).collect();
+    let mut y = vec![0u8; n * G::ENC];
     let mut r = vec![0u8; n * 32];
     let (mut digest, mut challenge) = ([0u8; 32], [0u8; 32]);
     let rc = unsafe {
-        ffi::mpvss_ec_deal(engine.raw(), group_id, coeffs.as_ptr(), t, positions.as_ptr(), pubkeys.as_ptr(), witnesses.as_ptr(), n,
+        ffi::mpvss_ec_deal(eng.raw(), G::GROUP_ID, coeffs.as_ptr(), t, positions.as_ptr(), pk.as_ptr(), witnesses.as_ptr(), n,
                            std::ptr::null_mut(), y.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), digest.as_mut_ptr(),
                            challenge.as_mut_ptr(), r.as_mut_ptr())
     };
-    if rc != ffi::MPVSS_OK {
-        return Err(rc);
+    eng.expect(rc, "distribute_secret");
+    let mut pos_map = std::collections::HashMap::new();
+    let mut share_map = std::collections::HashMap::new();
+    let mut resp_map = std::collections::HashMap::new();
+    for (i, pkey) in publickeys.iter().enumerate() {
+        let key = group.element_to_bytes(pkey);
+        pos_map.insert(key.clone(), positions[i]);
+        share_map.insert(key.clone(), G::dec(&y[i * G::ENC..(i + 1) * G::ENC]).expect("engine returns canonical encodings"));
+        resp_map.insert(key, G::sc_from(r[i * 32..(i + 1) * 32].try_into().unwrap()));
     }
-    Ok((y, digest, challenge, r))
+    // U = secret XOR (SHA256(bytes(s G)) mod order), s = P(0)                         :1226-1250 / 1690-1702
+    let g_s = group.generate_public_key(&coeff_scalars[0]);
+    let u = secret.to_biguint().unwrap() ^ ec_mask(group, &g_s);
+    let commitments: Vec<G::Element> =
+        (0..t).map(|j| G::dec(&cm[j * G::ENC..(j + 1) * G::ENC]).expect("engine returns canonical encodings")).collect();
+    let mut bx = DistributionSharesBox::new();
+    bx.init(&commitments, pos_map, share_map, publickeys, &G::sc_from(&challenge), resp_map, &BigInt::from_biguint(Sign::Plus, u));
+    bx
+}
+
+/// n calls of `extract_secret_share` (participant.rs:1282-1338, 1725-1781) at once: `witnesses[i]` is the i-th call's `w`.
+pub fn ec_extract_secret_shares<G: CurveCodec>(group: &G, bx: &DistributionSharesBox<G>, private_keys: &[G::Scalar], witnesses: &[G::Scalar])
+    -> Vec<Option<ShareBox<G>>> {
+    assert_eq!(private_keys.len(), witnesses.len());
+    let mut idx = Vec::new();
+    let (mut pk, mut y, mut xinv, mut w, mut xs) = (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
+    let mut pubs = Vec::new();
+    for (i, x) in private_keys.iter().enumerate() {
+        let public_key = group.generate_public_key(x);
+        let (Some(enc), Some(inv)) = (bx.shares.get(&group.element_to_bytes(&public_key)), group.scalar_inverse(x)) else { continue };
+        idx.push(i);
+        pk.extend(G::enc(&public_key));
+        y.extend(G::enc(enc));
+        xinv.extend_from_slice(&G::sc(&inv));
+        w.extend_from_slice(&G::sc(&witnesses[i]));
+        xs.extend_from_slice(&G::sc(x));
+        pubs.push(public_key);
+    }
+    let m = idx.len();
+    let mut out: Vec<Option<ShareBox<G>>> = (0..private_keys.len()).map(|_| None).collect();
+    if m == 0 {
+        return out;
+    }
+    let (mut s, mut c, mut r) = (vec![0u8; m * G::ENC], vec![0u8; m * 32], vec![0u8; m * 32]);
+    let eng = group.engine();
+    let rc = unsafe {
+        ffi::mpvss_ec_extract_shares(eng.raw(), G::GROUP_ID, ffi::MPVSS_HOST, pk.as_ptr(), y.as_ptr(), xinv.as_ptr(), w.as_ptr(), m, s.as_mut_ptr(),
+                                     c.as_mut_ptr())
+    };
+    eng.expect(rc, "extract_secret_shares");
+    unsafe { ffi::mpvss_ec_dleq_responses(G::GROUP_ID, w.as_ptr(), xs.as_ptr(), c.as_ptr(), 1, m, r.as_mut_ptr(), 0) };     // r = w - x c, dleq.rs:42-50
+    for (k, &i) in idx.iter().enumerate() {
+        let mut sb = ShareBox::new();
+        sb.init(pubs[k].clone(), G::dec(&s[k * G::ENC..(k + 1) * G::ENC]).expect("engine returns canonical encodings"),
+                G::sc_from(c[k * 32..(k + 1) * 32].try_into().unwrap()), G::sc_from(r[k * 32..(k + 1) * 32].try_into().unwrap()));
+        out[i] = Some(sb);
+    }
+    out
+}
+
+/// n calls of `verify_share` (participant.rs:1346-1371, 1789-1814) against one distribution box: one verdict each.
+pub fn ec_verify_shares<G: CurveCodec>(group: &G, share_boxes: &[ShareBox<G>], publickeys: &[G::Element], bx: &DistributionSharesBox<G>) -> Vec<bool> {
+    assert_eq!(share_boxes.len(), publickeys.len());
+    let mut live = Vec::new();
+    let (mut pk, mut s, mut y, mut c, mut r) = (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
+    for (i, (sb, key)) in share_boxes.iter().zip(publickeys).enumerate() {
+        if let Some(enc) = bx.shares.get(&group.element_to_bytes(key)) {     // missing share -> false (:1355-1361)
+            live.push(i);
+            pk.extend(G::enc(key));
+            s.extend(G::enc(&sb.share));
+            y.extend(G::enc(enc));
+            c.extend_from_slice(&G::sc(&sb.challenge));
+            r.extend_from_slice(&G::sc(&sb.response));
+        }
+    }
+    let mut out = vec![false; share_boxes.len()];
+    if live.is_empty() {
+        return out;
+    }
+    let mut verdicts = vec![0u8; live.len()];
+    let rc = unsafe {
+        ffi::mpvss_ec_verify_shares(group.engine().raw(), G::GROUP_ID, ffi::MPVSS_HOST, pk.as_ptr(), s.as_ptr(), y.as_ptr(), c.as_ptr(),
+                                    r.as_ptr(), live.len(), verdicts.as_mut_ptr())
+    };
+    group.engine().expect(rc, "verify_shares");
+    for (k, i) in live.into_iter().enumerate() {
+        out[i] = verdicts[k] == 1;
+    }
+    out
+}
+
+/// Drop-in body of `reconstruct` for the curve groups (participant.rs:1452-1516, 1895-1953).
+pub fn ec_reconstruct<G: CurveCodec>(group: &G, share_boxes: &[ShareBox<G>], bx: &DistributionSharesBox<G>) -> Option<BigInt> {
+    if share_boxes.len() < bx.commitments.len() {
+        return None;
+    }
+    let mut shares = std::collections::BTreeMap::new();
+    for sb in share_boxes {
+        let position = bx.positions.get(&group.element_to_bytes(&sb.publickey))?;
+        shares.insert(*position, G::enc(&sb.share));
+    }
+    let positions: Vec<i64> = shares.keys().copied().collect();
+    let s: Vec<u8> = shares.values().flatten().copied().collect();
+    let (mut gs, mut mask) = (vec![0u8; G::ENC], [0u8; 32]);
+    let rc = unsafe {
+        ffi::mpvss_ec_reconstruct(group.engine().raw(), G::GROUP_ID, ffi::MPVSS_HOST, positions.as_ptr(), s.as_ptr(), positions.len(), gs.as_mut_ptr(),
+                                  mask.as_mut_ptr())
+    };
+    if rc != ffi::MPVSS_OK {
+        return None;
+    }
+    let secret = BigUint::from_bytes_be(&mask) ^ bx.U.to_biguint().unwrap();
+    Some(BigInt::from_biguint(Sign::Plus, secret))
 }

@@ -4,7 +4,7 @@
 use std::ffi::CStr;
 use std::fmt;
 use std::ptr;
-use std::sync::Arc;
+use std::sync::{Arc, OnceLock};
 
 use crate::ffi;
 
@@ -50,6 +50,20 @@ impl Engine {
 
     pub fn device_count() -> i32 {
         unsafe { ffi::mpvss_device_count() }
+    }
+
+    /// The process's shared engine: one context on device `MPVSS_DEVICE` (default 0), created on first use.  `HipModpGroup::new()`
+    /// and its curve twins hand every caller this one, as `ModpGroup::new()` hands every caller the same group parameters:
+    /// participants built from separate `new()` calls then share one block pipeline, and T threads each verifying its own dealer's
+    /// box (`verify_distribution_shares`, one box per call) keep T boxes in flight on the GPU.
+    pub fn shared() -> Engine {
+        static SHARED: OnceLock<Engine> = OnceLock::new();
+        SHARED
+            .get_or_init(|| {
+                let device = std::env::var("MPVSS_DEVICE").ok().and_then(|v| v.parse::<i32>().ok()).unwrap_or(0);
+                Engine::new(device).expect("MI355X engine")
+            })
+            .clone()
     }
 
     pub(crate) fn raw(&self) -> *mut ffi::mpvss_ctx {

@@ -21,9 +21,19 @@ pub struct HipModpGroup {
 }
 
 impl HipModpGroup {
-    /// Same construction convention as `ModpGroup::new()` (modp.rs:44-69): an `Arc` to share between participants.
-    pub fn new(device_id: i32) -> Arc<Self> {
-        let engine = Engine::new(device_id).expect("MI355X engine");
+    /// Same construction convention as `ModpGroup::new()` (modp.rs:44-69): an `Arc` to share between participants.  The engine
+    /// is the process's shared one for device `MPVSS_DEVICE` (default 0): every group made this way talks to the same context,
+    /// so participants built from separate `new()` calls (examples/mpvss_all.rs:11-16) still share one pipeline.
+    pub fn new() -> Arc<Self> {
+        Self::with_engine(Engine::shared())
+    }
+
+    /// A group bound to a context of its own on GPU `device_id`.
+    pub fn with_device(device_id: i32) -> Arc<Self> {
+        Self::with_engine(Engine::new(device_id).expect("MI355X engine"))
+    }
+
+    fn with_engine(engine: Engine) -> Arc<Self> {
         let q = BigInt::parse_bytes(
             b"ffffffffffffffffc90fdaa22168c234c4c6628b80dc1cd129024e088a67cc74020bbea63b139b22514a08798e3404dd\
               ef9519b3cd3a431b302b0a6df25f14374fe1356d6d51c245e485b576625e7ec6f44c42e9a637ed6b0bff5cb6f406b7ed\
@@ -42,6 +52,36 @@ impl HipModpGroup {
     fn from_be256(b: &[u8; 256]) -> BigInt {
         BigInt::from_bytes_be(Sign::Plus, b)
     }
+
+    /// modp.rs:87-89 (inherent, like the reference's: `group.modulus().to_biguint()` in examples/mpvss_all.rs:42)
+    pub fn modulus(&self) -> &BigInt {
+        &self.q
+    }
+
+    /// modp.rs:92-94
+    pub fn subgroup_order_value(&self) -> &BigInt {
+        &self.g
+    }
+}
+
+/// x with a x = 1 (mod m), or None when gcd(a, m) != 1 -- the contract of the reference's crate-private `Util::mod_inverse`
+/// (util.rs:33-41; `mod util` is private in src/lib.rs:27, so a crate outside the reference carries its own).  Iterative extended
+/// Euclid on (m, a mod m): the same residue in [0, m) as the reference's recursive form returns.
+pub(crate) fn mod_inverse(a: &BigInt, m: &BigInt) -> Option<BigInt> {
+    let (mut r0, mut r1) = (m.clone(), a.mod_floor(m));
+    let (mut t0, mut t1) = (BigInt::zero(), BigInt::one());
+    while !r1.is_zero() {
+        let (q, r2) = r0.div_mod_floor(&r1);
+        let t2 = &t0 - &q * &t1;
+        r0 = r1;
+        r1 = r2;
+        t0 = t1;
+        t1 = t2;
+    }
+    if r0 != BigInt::one() {
+        return None;
+    }
+    Some(t0.mod_floor(m))
 }
 
 impl Group for HipModpGroup {
@@ -72,8 +112,8 @@ impl Group for HipModpGroup {
         Self::from_be256(&out)
     }
 
-    fn scalar_inverse(&self, x: &BigInt) -> Option<BigInt> { mpvss_rs::util::Util::mod_inverse(x, &self.order) }   // modp.rs:134-136
-    fn element_inverse(&self, x: &BigInt) -> Option<BigInt> { mpvss_rs::util::Util::mod_inverse(x, &self.q) }      // modp.rs:138-140
+    fn scalar_inverse(&self, x: &BigInt) -> Option<BigInt> { mod_inverse(x, &self.order) }   // modp.rs:134-136
+    fn element_inverse(&self, x: &BigInt) -> Option<BigInt> { mod_inverse(x, &self.q) }      // modp.rs:138-140
 
     /// modp.rs:142-148
     fn hash_to_scalar(&self, data: &[u8]) -> BigInt {

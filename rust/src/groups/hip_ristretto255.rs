@@ -26,11 +26,35 @@ pub(crate) fn point_bytes(p: &RistrettoPoint) -> [u8; 32] { p.compress().to_byte
 pub(crate) fn point_from(b: &[u8; 32]) -> Option<RistrettoPoint> { CompressedRistretto(*b).decompress() }
 
 impl HipRistretto255Group {
-    pub fn new(device_id: i32) -> Arc<Self> {
-        let order_bigint = BigInt::parse_bytes(b"1000000000000000000000000000000014def9dea2f79cd65812631a5cf5d3ed", 16).unwrap();
-        Arc::new(HipRistretto255Group { engine: Engine::new(device_id).expect("MI355X engine"), order_scalar: Scalar::ZERO, order_bigint })
+    /// Same convention as `Ristretto255Group::new()` (ristretto255.rs:51): the process's shared engine (device `MPVSS_DEVICE`, default 0).
+    pub fn new() -> Arc<Self> {
+        Self::with_engine(Engine::shared())
     }
+    /// A group bound to a context of its own on GPU `device_id`.
+    pub fn with_device(device_id: i32) -> Arc<Self> {
+        Self::with_engine(Engine::new(device_id).expect("MI355X engine"))
+    }
+    fn with_engine(engine: Engine) -> Arc<Self> {
+        let order_bigint = BigInt::parse_bytes(b"1000000000000000000000000000000014def9dea2f79cd65812631a5cf5d3ed", 16).unwrap();
+        Arc::new(HipRistretto255Group { engine, order_scalar: Scalar::ZERO, order_bigint })
+    }
+    /// ristretto255.rs:66-68
     pub fn order_as_bigint(&self) -> &BigInt { &self.order_bigint }
+
+    /// ristretto255.rs:78-106: a BigInt already reduced mod l, big-endian, to dalek's little-endian Scalar
+    pub fn bigint_to_scalar(bigint: &BigInt) -> Scalar {
+        let be = bigint.to_bytes_be().1;
+        let mut le = [0u8; 32];
+        for (dst, src) in le.iter_mut().zip(be.iter().rev()) {
+            *dst = *src;
+        }
+        Scalar::from_bytes_mod_order(le)
+    }
+
+    /// ristretto255.rs:108-125
+    pub fn scalar_to_bigint(scalar: &Scalar) -> BigInt {
+        BigInt::from_bytes_le(num_bigint::Sign::Plus, &scalar.to_bytes())
+    }
 }
 
 impl Group for HipRistretto255Group {

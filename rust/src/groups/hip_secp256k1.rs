@@ -38,9 +38,17 @@ pub(crate) fn scalar_from(b: &[u8; 32]) -> Scalar {
 }
 
 impl HipSecp256k1Group {
-    pub fn new(device_id: i32) -> Arc<Self> {
+    /// Same convention as `Secp256k1Group::new()` (secp256k1.rs:44): the process's shared engine (device `MPVSS_DEVICE`, default 0).
+    pub fn new() -> Arc<Self> {
+        Self::with_engine(Engine::shared())
+    }
+    /// A group bound to a context of its own on GPU `device_id`.
+    pub fn with_device(device_id: i32) -> Arc<Self> {
+        Self::with_engine(Engine::new(device_id).expect("MI355X engine"))
+    }
+    fn with_engine(engine: Engine) -> Arc<Self> {
         let order_bigint = BigInt::parse_bytes(b"fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141", 16).unwrap();
-        Arc::new(HipSecp256k1Group { engine: Engine::new(device_id).expect("MI355X engine"), order_placeholder: Scalar::ONE, order_bigint })
+        Arc::new(HipSecp256k1Group { engine, order_placeholder: Scalar::ONE, order_bigint })
     }
     /// secp256k1.rs:186-188
     pub fn order_as_bigint(&self) -> &BigInt { &self.order_bigint }

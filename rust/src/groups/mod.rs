@@ -3,6 +3,14 @@ mod hip_modp;
 mod hip_ristretto255;
 mod hip_secp256k1;
 
+/// boundary encodings of the two curve groups (crate::batch::CurveCodec)
+pub(crate) mod secp {
+    pub(crate) use super::hip_secp256k1::{point_bytes, point_from, scalar_bytes, scalar_from, scalar_from_bigint};
+}
+pub(crate) mod rist {
+    pub(crate) use super::hip_ristretto255::{point_bytes, point_from};
+}
+
 pub use hip_modp::HipModpGroup;
 pub use hip_ristretto255::HipRistretto255Group;
 pub use hip_secp256k1::HipSecp256k1Group;

@@ -9,6 +9,8 @@
 //! * [`batch`] holds what makes the GPU worthwhile: the three loops of the hot path
 //!   (`distribute_secret`, `verify_distribution_shares`, `verify_share`) as single batched calls, plus batched
 //!   `extract_secret_share`, `reconstruct` and key generation.
+//! * [`participant::Participant`] is the reference's `Participant<G>` surface over those calls -- same constructors, fields and
+//!   method names (participant.rs:158, 1085, 1564) -- so that `examples/mpvss_all*.rs` change one `use` line and the group type.
 //!
 //! STATUS: this crate has never been compiled -- the repository's build image has no cargo / rustc.  The C ABI
 //! it binds (include/mpvss_hip.h) is what the repository tests; the C++ mirror under mpvss_rs_amd/host/ is the
@@ -17,9 +19,13 @@ pub mod batch;
 pub mod engine;
 pub mod ffi;
 pub mod groups;
+pub mod participant;
 
 pub use engine::{Engine, EngineError};
 pub use groups::{HipModpGroup, HipRistretto255Group, HipSecp256k1Group};
+pub use participant::{ModpParticipant, Participant, Ristretto255Participant, Secp256k1Participant};
+// the reference's helpers a program written against it imports from the crate root (src/lib.rs:49-58)
+pub use mpvss_rs::{string_from_secret, string_to_secret};
 
 /// Call once at the top of `main`, before anything in the process touches HIP: asks the ROCm runtime for the 8 hardware
 /// queues the block pipeline is tuned for (sets `GPU_MAX_HW_QUEUES=8` unless the variable is already set; the library

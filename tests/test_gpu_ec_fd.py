@@ -64,13 +64,6 @@ def test_ec_fd_equals_horner():
         a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": l1, "MPVSS_EC_FD_QUAD": quad, "CHECK_ORACLE": "1" if quad == "2" else ""})
         for case, ha, hb in zip(CASES, a, b):
             assert ha == hb, (case, quad, l1)
-    # secp256k1 with eight lanes per point addition (OctSecp: stepping and tables; off by default)
-    a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "0", "MPVSS_EC_FD_QUAD": "2", "MPVSS_EC_FD_OCT": "1"})
-    assert a == b
-    # the quad stepping alone: seeds by 8 lanes bit by bit, tables by one workgroup per chain (round 5: the two runs round 4 had
-    # folded into one to save time are separate again -- the suite has the room)
-    a = run({"MPVSS_EC_FD": "1", "MPVSS_EC_FD_L1": "0", "MPVSS_EC_FD_QUAD": "2", "MPVSS_EC_FD_SEEDS_WIN": "0", "MPVSS_EC_FD_TABLE_QUAD": "0"})
-    assert a == b
 
 
 @pytest.mark.parametrize("fault", ["1", "2"])

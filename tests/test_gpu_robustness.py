@@ -270,150 +270,3 @@ def test_block_wellformedness_bytes(engine):
     assert got == [0, 0, 1, 0, 0, 1, 0, 1, 1] + [1] * 30 + [0]
     ref = engine.verify_distribution(flat["commitments"], flat["positions"], bytes(pk), bytes(sh), bytes(rs), flat["challenge"])
     assert verdict == (ref["verdict"], ref["digest"]) and verdict[0] is False
-
-
-def test_last_box_of_a_run_is_absorbed_in_parts():
-    """mpvss_modp_verify_many enqueues the LAST box of a run in MPVSS_TAIL_PARTS parts of consecutive shares, absorbed in
-    order by one worker (so that its transcript hash overlaps its own GPU work).  Same verdicts and digests as one
-    verify_distribution per box -- honest, tampered in the first / a middle / the last part, a negative position in a late
-    part (the box is malformed: verdict False, zero digest), with host and keyset-free boxes.  The switches are read once
-    per process, so the run happens in a child process with small parts."""
-    code = r"""
-import sys
-sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
-import mpvss_oracle as O
-from helpers import make_modp_instance
-from mpvss_rs_amd import Engine
-eng = Engine(0)
-g, privs, pks, coeffs, ws, box = make_modp_instance(203, 5, 77)
-flat = O.box_to_flat(g, box)
-as_box = lambda f, **kw: dict({"commitments": f["commitments"], "positions": f["positions"], "pubkeys": f["publickeys"],
-                               "shares": f["shares"], "responses": f["responses"], "challenge": f["challenge"]}, **kw)
-def tamper(share):
-    b = bytearray(flat["responses"]); b[share * 256 + 100] ^= 1; return as_box(flat, responses=bytes(b))
-good = as_box(flat)
-one = lambda b: (lambda r: (r["verdict"], r["digest"]))(eng.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
-want_good = one(good)
-assert want_good == (True, box["_digest"])
-for last in (good, tamper(3), tamper(101), tamper(202)):
-    for depth, threads in ((2, 1), (8, 4)):
-        got = eng.verify_many([good, tamper(7), good, last], depth=depth, hash_threads=threads)
-        assert got == [want_good, one(tamper(7)), want_good, one(last)], (got, depth)
-neg = as_box(flat, positions=flat["positions"][:150] + [-5] + flat["positions"][151:])
-assert eng.verify_many([good, good, neg], depth=4, hash_threads=2) == [want_good, want_good, (False, bytes(32))]
-assert eng.verify_many([good, good, good], depth=4, hash_threads=2) == [want_good] * 3
-assert eng.blocks_in_flight() == (0, 0)
-print("parts ok")
-""" % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"))
-    env = dict(os.environ, MPVSS_TAIL_PARTS="4", MPVSS_TAIL_MIN_PART="16")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0 and "parts ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
-
-
-def test_a2_in_share_ranges_hashed_while_the_next_range_computes():
-    """With several boxes in flight mpvss_modp_verify_many launches a box's a2 = y^r Y^c as MPVSS_A2_SLICES consecutive share ranges,
-    each followed by its own copy and event, and the absorbing thread hashes range k while range k + 1 is on the GPU (round 5: the
-    K = 20 tail).  Same verdicts and digests as one unsliced verify_distribution per box: honest boxes of two shapes (so that they are
-    not grouped into one block; 4200 shares: ranges end at 1024 / 2048 / 3136 / 4200), one bit flipped in the first, a middle and the
-    last range, a negative position (malformed: verdict False, zero digest), few and many threads.  Child process: the switches are
-    read once."""
-    code = r"""
-import sys, random
-sys.path.insert(0, %r)
-from mpvss_rs_amd import Engine
-EB = 256
-eng = Engine(0)
-rng = random.Random(11)
-def make(n, t):
-    sc = lambda k: b"".join(rng.randrange(1, 2**2040).to_bytes(EB, "big") for _ in range(k))
-    coeffs, pos = sc(t), list(range(7, 7 + n))
-    pk = eng.batch_exp_fixed_base((2).to_bytes(EB, "big"), sc(n))
-    cm = eng.batch_exp_fixed_base((4).to_bytes(EB, "big"), coeffs)
-    d = eng.deal(coeffs, pos, pk, sc(n))
-    return dict(commitments=cm, positions=pos, pubkeys=pk, shares=d["Y"], responses=d["responses"], challenge=d["challenge"]), d["digest"]
-A, dA = make(4200, 16)
-B, dB = make(4352, 20)
-def tamper(b, share, field="responses"):
-    x = bytearray(b[field]); x[share * EB + 100] ^= 1; return dict(b, **{field: bytes(x)})
-one = lambda b: (lambda r: (r["verdict"], r["digest"]))(eng.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
-assert one(A) == (True, dA) and one(B) == (True, dB)
-boxes = [A, B, tamper(A, 3), B, tamper(A, 2500), tamper(B, 4351, "shares"), A, tamper(B, 1024), A, B]
-want = [one(b) for b in boxes]
-assert [w[0] for w in want] == [True, True, False, True, False, False, True, False, True, True]
-for depth, threads in ((4, 1), (8, 4), (10, 8)):
-    assert eng.verify_many(boxes, depth=depth, hash_threads=threads) == want, (depth, threads)
-neg = dict(A, positions=A["positions"][:4000] + [-5] + A["positions"][4001:])
-assert eng.verify_many([A, B, neg, B, A], depth=5, hash_threads=2) == [(True, dA), (True, dB), (False, bytes(32)), (True, dB), (True, dA)]
-assert eng.blocks_in_flight() == (0, 0) and eng.fd_stats()[1] == 0
-st = eng.pipeline_stats()
-assert st["kernel_launches"][3] >= 4 * 30, st       # the a2 launches really went out in ranges
-print("slices ok")
-""" % ROOT
-    env = dict(os.environ, MPVSS_A2_SLICES="4", MPVSS_A2_SLICE_MIN="512")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0 and "slices ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
-
-
-def test_x_paths_of_several_large_boxes_in_the_same_launches():
-    """MPVSS_X_BATCH: mpvss_modp_verify_many evaluates the X paths of a run of large boxes of one shape by the SAME launches (the box as
-    the second grid dimension, a workspace of the batch's own), every box keeping its own block for the rest (round 5: the device runs
-    eight launches at a time and a box's X path is a chain of narrow ones).  Same verdicts and digests as one verify_distribution per
-    box: runs of 3 + 3 + 1 boxes with another shape in between, one bit flipped in a commitment / a response / a share of boxes inside
-    a batch, a box whose positions are not consecutive (host memory: it is left out of the batch; device memory: the batch's flag
-    falls and Horner's rule computes every X of that batch), a ring of two batch workspaces so that they are reused while blocks of
-    the previous batch are still in flight."""
-    code = r"""
-import sys, random, ctypes as C
-sys.path.insert(0, %r)
-import torch
-from mpvss_rs_amd import Engine, capi
-EB = 256
-eng = Engine(0)
-rng = random.Random(12)
-def make(n, t, p0):
-    sc = lambda k: b"".join(rng.randrange(1, 2**2040).to_bytes(EB, "big") for _ in range(k))
-    coeffs, pos = sc(t), list(range(p0, p0 + n))
-    pk = eng.batch_exp_fixed_base((2).to_bytes(EB, "big"), sc(n))
-    cm = eng.batch_exp_fixed_base((4).to_bytes(EB, "big"), coeffs)
-    d = eng.deal(coeffs, pos, pk, sc(n))
-    return dict(commitments=cm, positions=pos, pubkeys=pk, shares=d["Y"], responses=d["responses"], challenge=d["challenge"]), d["digest"]
-A, dA = make(16500, 16, 1)
-A2, dA2 = make(16500, 16, 40001)
-B, dB = make(17000, 20, 5)
-def tamper(b, field, at):
-    x = bytearray(b[field]); x[at] ^= 1; return dict(b, **{field: bytes(x)})
-one = lambda b: (lambda r: (r["verdict"], r["digest"]))(eng.verify_distribution(b["commitments"], b["positions"], b["pubkeys"], b["shares"], b["responses"], b["challenge"]))
-swapped = dict(A, positions=A["positions"][:100] + [A["positions"][101], A["positions"][100]] + A["positions"][102:])
-boxes = [A, tamper(A2, "commitments", 5 * EB + 17), A2, B, tamper(A, "responses", 16499 * EB + 255), A2, tamper(A, "shares", 3), A, swapped, A2, A, B, B]
-want = [one(b) for b in boxes]
-assert [w[0] for w in want] == [True, False, True, True, False, True, False, True, False, True, True, True, True]
-assert want[0] == (True, dA) and want[2] == (True, dA2) and want[3] == (True, dB)
-f0 = eng.fd_stats()
-for depth, threads in ((3, 1), (6, 3), (12, 6)):
-    assert eng.verify_many(boxes, depth=depth, hash_threads=threads) == want, (depth, threads)
-f1 = eng.fd_stats()
-assert f1[0] - f0[0] == 3 * len(boxes) - 3 and f1[1] == f0[1], (f0, f1)        # every box but the swapped one took forward differences, none fell back
-# the same boxes in device memory: positions are judged on the device, the swapped box sits INSIDE a batch and drops its flag
-dev = torch.device("cuda", 0)
-keep = []
-def dbox(b):
-    t8 = lambda x: torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev)
-    ts = [t8(b[k]) for k in ("commitments", "pubkeys", "shares", "responses")] + [torch.tensor(b["positions"], dtype=torch.int64, device=dev)]
-    ch = (C.c_uint8 * EB).from_buffer_copy(b["challenge"])
-    keep.append((ts, ch))
-    return capi.ModpBox(ts[0].data_ptr(), len(b["commitments"]) // EB, ts[4].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(),
-                        len(b["positions"]), C.cast(ch, C.c_void_p), None, 0)
-arr = (capi.ModpBox * len(boxes))(*[dbox(b) for b in boxes])
-torch.cuda.synchronize()
-verdicts = (C.c_int * len(boxes))(); digests = (C.c_uint8 * (32 * len(boxes)))()
-eng._check(eng.lib.mpvss_modp_verify_many(eng.ctx, capi.MPVSS_DEVICE, arr, len(boxes), 6, 3, verdicts, C.cast(digests, C.c_void_p)), "verify_many(device)")
-got = [(bool(verdicts[i]), bytes(digests)[32 * i:32 * i + 32]) for i in range(len(boxes))]
-assert got == want, got
-f2 = eng.fd_stats()
-assert f2[1] - f1[1] >= 1, (f1, f2)                 # the batch around the swapped box fell back to Horner's rule -- and was still right
-assert eng.blocks_in_flight() == (0, 0)
-print("xbatch ok")
-""" % ROOT
-    env = dict(os.environ, MPVSS_X_BATCH="3", MPVSS_X_BATCH_RING="2")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
-    assert out.returncode == 0 and "xbatch ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
