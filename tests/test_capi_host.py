@@ -201,6 +201,85 @@ def test_signature_parsers_notice_a_drifted_argument():
         assert got["mpvss_x"] != ("c_int", want), bad
 
 
+def _rust_sources():
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "rust", "src", "**", "*.rs"), recursive=True) + glob.glob(os.path.join(root, "rust", "examples", "*.rs")))
+    return {os.path.relpath(f, root): open(f).read() for f in files}
+
+
+def _reference_api():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_api.json")) as fh:
+        return json.load(fh)
+
+
+def _strip_rust_comments(text):
+    import re
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def test_rust_names_only_public_paths_of_the_reference():
+    """Every `mpvss_rs::...` path rust/ uses (code, not comments) must be PUBLIC in the reference (tests/golden/reference_api.json,
+    made by tools/gen_reference_api.py from src/lib.rs and the files of its `pub mod`s): round 5 called `mpvss_rs::util::Util`, a
+    private module (src/lib.rs:27) -- E0603, the crate would not have built."""
+    import re
+    api = _reference_api()
+    public = set(api["public_paths"])
+    used = {}
+    for rel, text in _rust_sources().items():
+        code = _strip_rust_comments(text)
+        for m in re.finditer(r"mpvss_rs::((?:[a-z_0-9]+::)*)(\{[^}]*\}|[A-Za-z_0-9]+)", code):
+            prefix, last = m.group(1), m.group(2)
+            names = [x.strip() for x in last.strip("{}").split(",")] if last.startswith("{") else [last]
+            for nm in names:
+                if nm:
+                    used.setdefault("mpvss_rs::" + prefix + nm, set()).add(rel)
+    assert used, "rust/ no longer names the reference crate at all?"
+    not_public = {p: sorted(f) for p, f in used.items() if p not in public}
+    assert not not_public, f"rust/ names paths that are not public in the reference: {not_public}"
+    for mod in api["private_modules"]:
+        for rel, text in _rust_sources().items():
+            assert f"mpvss_rs::{mod}" not in _strip_rust_comments(text), (rel, mod)
+    # the manifest's dependency is the crate the listing was made from
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cargo = open(os.path.join(root, "rust", "Cargo.toml")).read()
+    assert re.search(r'^mpvss-rs = "%s' % api["version"].split(".")[0], cargo, re.M), "rust/Cargo.toml depends on another major version"
+
+
+def test_rust_participant_has_the_reference_method_surface():
+    """rust/src/participant.rs: a `Participant<G>` with the reference's fields (privatekey, publickey public; group private), the
+    generic constructors, and for each of the three groups an impl block with the reference's methods -- same names, same receiver,
+    same parameter names in the same order (participant.rs:158, 1085, 1564)."""
+    import re
+    api = _reference_api()
+    text = _rust_sources()[os.path.join("rust", "src", "participant.rs")]
+    code = _strip_rust_comments(text)
+    fields = re.search(r"pub struct Participant<G: Group> \{(.*?)\}", code, re.S).group(1)
+    assert re.findall(r"pub ([a-z_]+):", fields) == api["participant_fields"]["public"]
+    assert [f for f in re.findall(r"^\s+([a-z_]+):", fields, re.M)] == api["participant_fields"]["private"]
+    starts = [(m.start(), m.group(1)) for m in re.finditer(r"^impl(?:<[^>]*>)? Participant<([A-Za-z0-9_]+)>", code, re.M)]
+    ours = {}
+    for k, (pos, who) in enumerate(starts):
+        end = starts[k + 1][0] if k + 1 < len(starts) else len(code)
+        for m in re.finditer(r"^    pub fn ([a-z_0-9]+)\s*\(([^)]*)\)", code[pos:end], re.M | re.S):
+            params = [p.strip().split(":")[0].strip() for p in m.group(2).split(",") if p.strip()]
+            ours.setdefault(who, {})[m.group(1)] = {"receiver": params[0] if params and "self" in params[0] else None,
+                                                    "params": [p for p in params if "self" not in p]}
+    pairs = {"G": "G", "ModpGroup": "HipModpGroup", "Secp256k1Group": "HipSecp256k1Group", "Ristretto255Group": "HipRistretto255Group"}
+    for ref_group, our_group in pairs.items():
+        want, got = api["participant_impls"][ref_group], ours.get(our_group, {})
+        for name, sig in want.items():
+            assert name in got, f"Participant<{our_group}> lacks {name}"
+            assert got[name] == sig, (our_group, name, got[name], sig)
+    # nothing but an accessor beyond the reference's surface in the generic block
+    assert set(ours["G"]) - set(api["participant_impls"]["G"]) <= {"group"}
+    # the crate root offers what a program written against the reference imports from it
+    lib = _strip_rust_comments(_rust_sources()[os.path.join("rust", "src", "lib.rs")])
+    for name in ("Participant", "ModpParticipant", "Secp256k1Participant", "Ristretto255Participant", "string_to_secret", "string_from_secret"):
+        assert re.search(r"pub use [^;]*\b%s\b" % name, lib), name
+
+
 def test_header_is_plain_c_and_cxx():
     """The boundary is a C ABI: include/mpvss_hip.h must compile on its own as C99 and as C++11 (what cgo / bindgen /
     a C++ host would feed it to), without warnings."""
