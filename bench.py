@@ -635,6 +635,12 @@ def main():
     ap.add_argument("--ec-boxes", type=int, default=64, help="boxes timed per curve group for the `ec` objects (0: skip)")
     ap.add_argument("--host-boxes", type=int, default=20, help="boxes verified from HOST buffers (PCIe included) for the "
                     "`host_buffers` figure (0: skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong", "both"), default="both",
+                    help="N > 1: `weak` -- every GPU its own --participants shares of every box (the box grows with N; `value`, as in every "
+                         "round); `strong` -- the metric's box of --participants shares split over the N GPUs (`value` is then that, "
+                         "`scaling` says so); `both` (default) -- `value` stays the weak figure and the line also carries `strong.value`")
+    ap.add_argument("--drop-in-threads", default="4,8,12,16", help="host threads of the `drop_in` figure: each calls the ONE-box entry point "
+                    "mpvss_modp_verify_distribution on the shared context (comma-separated counts; empty or 0: skip)")
     ap.add_argument("--ec-n", type=int, default=65536)
     ap.add_argument("--ec-t", type=int, default=256)
     ap.add_argument("--lone-boxes", type=int, default=2, help="boxes verified one at a time after the timed region "
@@ -678,6 +684,11 @@ def main():
     eng = capi.Engine(local_rank)     # raises if the HIP library or the GPU is missing
     lib, ctx = eng.lib, eng.ctx
     n, t = args.n, args.t
+    strong_main = world > 1 and args.scaling == "strong"
+    if strong_main:           # the metric's fixed box over N GPUs: contiguous blocks of n / N positions (participant.rs:408-448)
+        if args.n % world:
+            raise SystemExit("--scaling strong needs --participants divisible by the number of GPUs")
+        n = args.n // world
     n_total = n * world
     lo = rank * n
     import hashlib
@@ -1137,7 +1148,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong_main else "weak",
         "vs_baseline": None,
         "dtype": "u32",
         "dtype_detail": "u32 limbs (radix 2^29), u64 accumulators; the Montgomery reduction as int8 digit products on the matrix cores",
@@ -1271,21 +1282,25 @@ def main():
             assert (S2, cb2) == (S, cb)
             # block form: several batches in flight (compute forms e2 = w / x on host threads and enqueues; the challenge hash runs
             # on the device); 4 in flight, 10 timed
+            # (buffers made once and the library called directly: what a compiled caller pays -- round 5's loop re-marshalled 16 MB of
+            # Python bytes per batch inside the timed region, and formed e2 = w / x on host threads; both depended on the host)
+            xb_in = [(C.c_uint8 * (m * EB)).from_buffer_copy(b) for b in (pubkeys[sl], shares[sl], xinv, wit_bytes_b)]
+            xb_S, xb_c = (C.c_uint8 * (m * EB))(), (C.c_uint8 * (m * EB))()
+
             def extract_pipelined(count, inflight=4):
                 issued = done = 0
-                last = None
                 while done < count:
                     while issued < count and issued - done < inflight:
-                        eng.extract_shares_compute(pubkeys[sl], shares[sl], xinv, wit_bytes_b)
+                        eng._check(lib.mpvss_modp_extract_shares_compute(ctx, xb_in[0], xb_in[1], xb_in[2], xb_in[3], m), "extract_shares_compute")
                         issued += 1
-                    last = eng.extract_shares_absorb(m)
+                    eng._check(lib.mpvss_modp_extract_shares_absorb(ctx, xb_S, xb_c), "extract_shares_absorb")
                     done += 1
-                return last
+                return bytes(xb_S), bytes(xb_c)
             assert extract_pipelined(4) == (S, cb), "extract_shares block form differs from the synchronous call"
             torch.cuda.synchronize()
             t_x = time.perf_counter()
-            extract_pipelined(10)
-            extract_blk_s = (time.perf_counter() - t_x) / 10
+            extract_pipelined(12)
+            extract_blk_s = (time.perf_counter() - t_x) / 12
             result["extract_shares"] = {"value": m / extract_blk_s, "unit": "shares decrypted and proven/s", "batch": m,
                                         "batches_in_flight": 4, "value_synchronous_call": m / extract_s,
                                         "note": "extract_secret_share for `batch` participants per call, host buffers (participant.rs:294-353): "
@@ -1329,12 +1344,28 @@ def main():
             torch.cuda.synchronize()
             wbp_s = (time.perf_counter() - tw) / batches
             assert all(bool((dv == 1).all()) for dv in d_verd), "device verdict tensors"
-            result["verify_share"] = {"value": m / wbp_s, "unit": "share-box verifications/s", "batch": m,
+            # `value`: n share boxes of one distribution box in ONE library call (the reference verifies them one verify_share call each,
+            # participant.rs:361-386): the m distinct proofs tiled to n = 65536 device-resident rows, three calls, nothing of the caller's
+            # in the loop -- what round 5's driver run showed to depend on the host when the batches were driven from Python
+            tile = max(1, n // m)
+            big = [torch.cat([x] * tile) for x in (d_pk[:m * EB], d_S, d_sh[:m * EB], d_cb, d_rb)]
+            verd_big = (C.c_uint8 * (m * tile))()
+            torch.cuda.synchronize()
+            for it in range(4):
+                if it == 1:
+                    tw = time.perf_counter()
+                eng._check(lib.mpvss_modp_verify_shares(ctx, capi.MPVSS_DEVICE, vp(big[0]), vp(big[1]), vp(big[2]), vp(big[3]), vp(big[4]),
+                                                        m * tile, verd_big), "verify_shares (one call)")
+            wb_one_s = (time.perf_counter() - tw) / 3
+            assert bytes(verd_big) == b"\x01" * (m * tile), "verify_share verdicts (one call)"
+            del big
+            result["verify_share"] = {"value": m * tile / wb_one_s, "unit": "share-box verifications/s", "shares_per_call": m * tile,
+                                      "distinct_proofs": m, "value_batches_in_flight": m / wbp_s, "batch": m,
                                       "batches_in_flight": inflight, "value_synchronous_calls": m / wb_s,
                                       "note": "W_B: a1 = G^r pk^c, a2 = S^r Y^c and the per-share SHA-256 verdict (K7) on the device; "
-                                              "inputs resident in HBM; `value`: mpvss_modp_verify_shares_compute/_absorb with "
-                                              f"{inflight} batches in flight in one context, verdict bytes also left in device tensors; "
-                                              "`value_synchronous_calls`: one mpvss_modp_verify_shares call at a time"}
+                                              "inputs resident in HBM; `value`: ONE mpvss_modp_verify_shares call over `shares_per_call` proofs; "
+                                              f"`value_batches_in_flight`: mpvss_modp_verify_shares_compute/_absorb, {inflight} batches of `batch` in "
+                                              "flight driven from Python; `value_synchronous_calls`: one call of `batch` proofs at a time"}
         if world == 1:
             # dealer side in block form: inputs resident in HBM, DEAL_DEPTH boxes in flight, X_i = g^P(i) through the comb,
             # host hashing of the oldest box beside the GPU work of the next ones; plus the scalar side of one box
@@ -1585,11 +1616,17 @@ def main():
             except Exception as exc:      # noqa: BLE001 - the strong-CPU line is optional
                 result["cpu_baseline"]["openssl"] = {"value": None, "note": f"skipped: {exc}"}
         # ---------------- the other MODP shapes of BASELINE.json: C2 and one GPU's slice of C5 ----------------
-        def bench_shape(n_, t_, k, depth, lo_, what):
+        def bench_shape(n_, t_, k, depth, lo_, what, one_box_of=0):
             """k boxes of another shape through the same step functions (own participants, up to 4 distinct boxes, the slots
-            grow to the shape in an untimed pass); returns value / ms_per_box / compute of that shape."""
+            grow to the shape in an untimed pass); returns value / ms_per_box / compute of that shape.
+            one_box_of = N > 0: the participants are positions lo_+1 .. lo_+n_ of ONE seeded list of N (the same on every rank and for
+            every world size: the box -- keys, shares, transcript digest -- does not depend on how many GPUs it is split over)."""
             saved = (cur.boxes, cur.d_pk, cur.d_pos, cur.n)
-            privs_, wits_ = make_participants(n_, SEED * 1000003 + 977 * t_ + rank)
+            if one_box_of:
+                privs_all, wits_all = make_participants(one_box_of, SEED * 1000003 + 977 * t_ + 31337)
+                privs_, wits_ = privs_all[lo_:lo_ + n_], wits_all[lo_:lo_ + n_]
+            else:
+                privs_, wits_ = make_participants(n_, SEED * 1000003 + 977 * t_ + rank)
             pos_ = list(range(lo_ + 1, lo_ + n_ + 1))
             pub_ = eng.batch_exp_fixed_base(fx(2), b"".join(fx(x) for x in privs_))
             witb_ = b"".join(map(fx, wits_))
@@ -1621,6 +1658,7 @@ def main():
                 rate = wk_["slots"] * k / dt
                 st_ = eng.pipeline_stats()
                 return {"value": n_ * world * k / dt, "unit": "share verifications/s", "ms_per_box": dt / k * 1e3, "boxes": k,
+                        "digest_of_digests": hashlib.sha256(b"".join(d for _, d, _ in res_s)).hexdigest(),
                         "host_ms_per_box": {"enqueue": st_["enqueue_ms"] / max(st_["blocks"], 1), "wait": st_["wait_ms"] / max(st_["blocks"], 1),
                                             "hash": st_["hash_ms"] / max(st_["blocks"], 1)},
                         "boxes_in_flight": depth, "distinct_boxes": len(cur.boxes),
@@ -1653,6 +1691,17 @@ def main():
                 n5 = int(os.environ.get("MPVSS_BENCH_C5_N", "131072"))
                 result["c5"] = bench_shape(n5, int(os.environ.get("MPVSS_BENCH_C5_T", "1024")), k5, 12, rank * n5,
                                            f"BASELINE config C5: {n5 * world} participants over {world} GPUs")
+        # ---------------- N > 1: the metric's FIXED box (n = --participants) split over the N GPUs, beside the weak figure ----------------
+        # Rank g verifies positions [g n/N, (g+1) n/N) of every box (8192 shares per GPU at N = 8) through the same chained pipeline; the
+        # transcript's running state still travels rank to rank, but a block's hash is 35/N ms now, so the chain fill is (N-1) x 35/N ms
+        # instead of (N-1) x 35 ms.  Blocks are small: more of them in flight per rank.
+        if ((world > 1 and args.scaling == "both") or os.environ.get("MPVSS_BENCH_STRONG_AT_N1") == "1") and args.n % world == 0 \
+                and keyset[0] is None:
+            depth_s = min(RANK_DEPTH * min(world, 4), capi.BLOCK_SLOTS - 16)
+            result["strong"] = bench_shape(args.n // world, t, args.steps, depth_s, rank * (args.n // world),
+                                           f"strong scaling: ONE box of {args.n} participants split over {world} GPUs", one_box_of=args.n)
+            result["strong"]["scaling"] = "strong"
+            result["strong"]["n_per_gpu"] = args.n // world
         # ---------------- the same boxes handed over in HOST memory (PCIe included); never `value` ----------------
         if world == 1 and args.host_boxes > 0:
             pos_arr = (C.c_int64 * n)(*positions)
@@ -1678,6 +1727,68 @@ def main():
                                       "boxes": args.host_boxes,
                                       "note": "same boxes, every input in pageable host memory: the library copies them into pinned "
                                               "staging and over PCIe (3 x n x 256 B per box) inside the timed calls; not `value`"}
+        # ---------------- the reference's call shape: ONE box per call, T concurrent callers on one context; never `value` ----------------
+        # What `rust/src/batch.rs::verify_distribution_shares` / `Participant::verify_distribution_shares` bind (participant.rs:399-455):
+        # mpvss_modp_verify_distribution, one box, blocking.  T host threads each take their share of the SAME K distinct boxes of the
+        # headline run (the crate goes parallel the same way, participant.rs:490-500); ctypes releases the GIL for the duration of a
+        # foreign call, so these are compiled callers as far as the library is concerned.  Every call's verdict and digest is gated.
+        dthreads = [int(x) for x in args.drop_in_threads.split(",") if x.strip() and int(x) > 0]
+        if world == 1 and dthreads and keyset[0] is None:
+            def one_call(bx, space, hbufs):
+                verdict, dg = C.c_int(0), (C.c_uint8 * 32)()
+                if space == capi.MPVSS_DEVICE:
+                    rcode = lib.mpvss_modp_verify_distribution(ctx, space, vp(bx.d_cm), bx.t, vp(d_pos), vp(d_pk), vp(bx.d_sh), vp(bx.d_rs), bx.n,
+                                                               C.cast(bx.ch_buf, C.c_void_p), C.byref(verdict), dg, None, None, None)
+                else:
+                    rcode = lib.mpvss_modp_verify_distribution(ctx, space, hbufs[0], bx.t, C.cast(pos_arr_d, C.c_void_p), pk_host, hbufs[1], hbufs[2],
+                                                               bx.n, C.cast(bx.ch_buf, C.c_void_p), C.byref(verdict), dg, None, None, None)
+                eng._check(rcode, "verify_distribution (drop_in)")
+                if verdict.value != 1 or bytes(dg) != bx.dealer_digest:
+                    raise AssertionError("drop_in: verdict or digest wrong")
+
+            def drop_in_run(T, space, seq, hb):
+                errs = []
+
+                def worker(k):
+                    try:
+                        for i in range(k, len(seq), T):
+                            one_call(seq[i], space, hb[i % len(hb)] if hb else None)
+                    except BaseException as exc:      # noqa: BLE001
+                        errs.append(exc)
+                ths = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
+                torch.cuda.synchronize()
+                t_d = time.perf_counter()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                el = time.perf_counter() - t_d
+                if errs:
+                    raise errs[0]
+                return el
+
+            seq_d = [boxes[s % len(boxes)] for s in range(args.steps)]
+            pos_arr_d = (C.c_int64 * n)(*positions)
+            pk_host = (C.c_uint8 * len(pubkeys)).from_buffer_copy(pubkeys)
+            drop_in_run(max(dthreads) + 2, capi.MPVSS_DEVICE, seq_d[:max(dthreads) + 2], None)      # slots of the most callers, untimed
+            by_t = {}
+            for T in dthreads:
+                by_t[T] = min(drop_in_run(T, capi.MPVSS_DEVICE, seq_d, None) for _ in range(2)) / len(seq_d)
+            t_best = min(by_t, key=by_t.get)
+            lone_s = drop_in_run(1, capi.MPVSS_DEVICE, seq_d[:4], None) / 4
+            # host buffers (what a Rust caller's Vec<u8>s are), at the best thread count: PCIe and the pinned copies inside the calls
+            hb_d = [[(C.c_uint8 * len(b)).from_buffer_copy(b) for b in (bx.commitments, bx.shares, bx.responses)] for bx in boxes]
+            drop_in_run(t_best + 2, capi.MPVSS_HOST, seq_d[:t_best + 2], hb_d)                     # pinned staging of those slots, untimed
+            host_s = min(drop_in_run(t_best, capi.MPVSS_HOST, seq_d, hb_d) for _ in range(2)) / len(seq_d)
+            lone_host_s = drop_in_run(1, capi.MPVSS_HOST, seq_d[:4], hb_d) / 4
+            del hb_d
+            result["drop_in"] = {"value": n / by_t[t_best], "threads": t_best, "value_lone": n / lone_s,
+                                 "value_host_buffers": n / host_s, "value_lone_host_buffers": n / lone_host_s,
+                                 "by_threads": {str(T): n / v for T, v in by_t.items()}, "boxes": len(seq_d), "unit": "share verifications/s",
+                                 "vs_verify_many": (n / by_t[t_best]) / value,
+                                 "note": "T host threads, each calling the ONE-box mpvss_modp_verify_distribution (participant.rs:399-455; what "
+                                         "rust/src/participant.rs binds) on ONE context over the K distinct boxes of the headline run, best of two "
+                                         "passes per T; `value_lone`: one caller, one box at a time (its box's latency); not `value`"}
         # ---------------- opt-in variant: registered public keys (include/mpvss_hip.h) ----------------
         # NOT the headline: `value` above recomputes y_i^r_i from the bare keys in every step.  Here the per-key tables
         # are built once (timed separately) and the same K steps are repeated against them -- the situation of a verifier

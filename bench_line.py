@@ -40,11 +40,13 @@ _PATHS = (
     ("configs", "c2", "value"), ("configs", "c2", "compute", "frac"),
     ("configs", "c5_slice", "value"), ("configs", "c5_slice", "ms_per_box"), ("configs", "c5_slice", "compute", "frac"),
     ("c5", "value"), ("c5", "ms_per_box"),
+    ("strong", "value"), ("strong", "ms_per_box"), ("strong", "n_per_gpu"), ("strong", "scaling"),
     ("c5_whole_box", "value"), ("c5_whole_box", "ms_per_box"), ("c5_whole_box", "blocks"),
     ("rccl", "backend"), ("rccl", "rccl_world_size"), ("rccl", "data_collectives"), ("rccl", "bytes_per_rank_per_box"),
     ("verify_share", "value"), ("extract_shares", "value"),
     ("distribute", "value"), ("distribute", "value_end_to_end"), ("distribute", "value_one_call_host_buffers_end_to_end"),
     ("host_buffers", "value"),
+    ("drop_in", "value"), ("drop_in", "threads"), ("drop_in", "value_lone"), ("drop_in", "value_host_buffers"),
     ("registered_keys", "value"), ("registered_keys", "value_steady_state"), ("registered_keys", "value_transparent"), ("registered_keys", "table_bytes"), ("registered_keys", "table_build_s"),
     ("ec", "secp256k1", "value"), ("ec", "secp256k1", "compute", "frac"),
     ("ec", "secp256k1", "kernel_ms_isolated", "box_on_the_gpu_ms"),
@@ -58,7 +60,7 @@ _PATHS = (
 )
 # dropped in this order, a whole top-level object at a time, should a line still come out too long
 _EXPENDABLE = ("host", "host_buffers", "extract_shares", "verify_share", "registered_keys", "distribute", "ec", "configs",
-               "rccl", "c5", "c5_whole_box")
+               "rccl", "c5", "c5_whole_box", "strong", "drop_in")
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 

@@ -129,6 +129,8 @@ int modq_launch_poly_eval(const uint32_t* coef, int t, const int64_t* positions,
                           const void* cs_q, hipStream_t s);
 int modq_launch_responses(const uint8_t* w_be, const uint8_t* alpha_be, const uint8_t* cneg_be, int c_parity, int count,
                           uint8_t* out_be, const void* cs_q, hipStream_t s);
+/* out[i] = a[i] * b[i] mod (q-1), 256-byte big-endian each (device pointers) */
+int modq_launch_mul(const uint8_t* a_be, const uint8_t* b_be, int count, uint8_t* out_be, const void* cs_q, hipStream_t s);
 int modp_launch_gather_rows(const uint32_t* src, size_t src_stride_words, size_t row_words, int boxes, uint32_t* dst, hipStream_t s);
 int modp_launch_spread_rows(const uint8_t* rows, int group, int count, uint8_t* out, hipStream_t s);
 #ifdef __cplusplus

@@ -293,6 +293,31 @@ k_modq_responses(const uint8_t* __restrict__ w_be, const uint8_t* __restrict__ a
   store_canonical_be256(out_be + (size_t)x * 256, a, false, slot, cs, n, ln, live, parity);
 }
 
+// out[x] = a[x] * b[x] mod (q-1): the scalar ring's product per share (Group::scalar_mul, modp.rs:180-182) -- the
+// participant's second exponent w_i / x_i of a batched extract_secret_share (participant.rs:310-323) without host work.
+// Residue mod q' by one Montgomery product of a R with the plain b, parity = that of the integer product (q - 1 is even).
+extern "C" __global__ void __launch_bounds__(BLOCK_THREADS) WAVES_ATTR
+k_modq_mul(const uint8_t* __restrict__ a_be, const uint8_t* __restrict__ b_be, int count, uint8_t* __restrict__ out_be,
+           const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_BLOCK * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int xi = blockIdx.x * NUMS_PER_BLOCK + (threadIdx.x >> 2);
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + (threadIdx.x >> 2) * SLOT_WORDS;
+  u32 n[LPL], a[LPL], b[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  load_be256(a, a_be + (size_t)x * 256, ln);
+  const int parity = (int)(a_be[(size_t)x * 256 + 255] & b_be[(size_t)x * 256 + 255] & 1u);
+  to_mont(a, slot, cs, n, ln);                       // a R mod q'
+  load_be256(b, b_be + (size_t)x * 256, ln);
+  slot_store(slot, b, ln);
+  __builtin_amdgcn_wave_barrier();
+  mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);         // a b mod q' (plain, < 2q')
+  __builtin_amdgcn_wave_barrier();
+  store_canonical_be256(out_be + (size_t)x * 256, a, false, slot, cs, n, ln, live, parity);
+}
+
 // ---------------------------------------------------------------------------------------
 // X_i = prod_j C_j^(i^j)   (participant.rs:423-434) evaluated by Horner's rule in the
 // exponent:  X_i = (..((C_{t-1})^i * C_{t-2})^i .. )^i * C_0 .  Identical group element for
@@ -1569,6 +1594,12 @@ extern "C" int modq_launch_responses(const uint8_t* w_be, const uint8_t* alpha_b
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modq_responses, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, w_be, alpha_be, cneg_be, c_parity, count,
                      out_be, (const ModpConsts*)cs_q);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modq_launch_mul(const uint8_t* a_be, const uint8_t* b_be, int count, uint8_t* out_be, const void* cs_q, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modq_mul, dim3(grid_for(count)), dim3(BLOCK_THREADS), 0, s, a_be, b_be, count, out_be, (const ModpConsts*)cs_q);
   return (int)hipGetLastError();
 }
 

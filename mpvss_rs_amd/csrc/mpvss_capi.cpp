@@ -3047,15 +3047,11 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
         shared = memcmp(hy + i * EB, zero, EB) != 0 && memcmp(hy + i * EB, qb, EB) != 0;
     }
     if (shared) {
-      std::vector<uint8_t> e2(cnt * EB);
-      const uint8_t *hx = xinv + off * EB, *hw = w + off * EB;
-      const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-      hsc::parallel_indices(nt, [&](unsigned k) {
-        for (size_t i = k; i < cnt; i += nt) mpvss_modp_scalar_mul(hw + i * EB, hx + i * EB, e2.data() + i * EB);
-      });
-      const void* de2;
-      RET_IF(stage_in(ctx, space, e2.data(), cnt * EB, ctx->w->in_d, &de2));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // e2 is a local buffer: its copy must have left before it dies
+      // e2 = w / x mod (q-1) on the device (the scalar ring's product kernel): no host threads, whatever the host has of them
+      RET_IF(modq_consts(ctx));
+      RET_IF(ensure(ctx, ctx->w->in_d, cnt * EB));
+      uint8_t* de2 = (uint8_t*)ctx->w->in_d.p;
+      LAUNCHCHK(ctx, modq_launch_mul((const uint8_t*)dw, (const uint8_t*)dxi, (int)cnt, de2, ctx->consts_q, ctx->stream));
       const size_t bw = modp_twin_exp_bucket_words();
       RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
       uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
@@ -3095,7 +3091,7 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
 }
 
 // ---- extract_secret_share in block form -------------------------------------------------------------------------
-// compute: host -> e2 = w / x mod (q-1) on host threads, then ONLY enqueues: S and a2 = S^w from one chain of squarings (the
+// compute ONLY enqueues: e2 = w / x mod (q-1) by the scalar ring's product kernel, S and a2 = S^w from one chain of squarings (the
 // dealer's bucket kernels), a1 = G^w through the comb, the challenge c_i by K7 on the device, D2H of S and c into the slot's
 // pinned staging.  absorb: waits for the oldest batch and hands out S (n x 256) and c (n x 256, big-endian scalars).
 // Batches share the block slots and the FIFO order with the other block calls (slot kind 4).  Host buffers; every Y must be
@@ -3144,8 +3140,8 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
   ctx->stream_b = sl.work.sb;
   ctx->sp = &sl.spans;
   spans_reset(ctx);
-  // pinned staging: outputs S [n][256], c [n][32]; inputs pk, y, xinv, w, e2 [n][256] each
-  const size_t need = n * EB + n * 32 + 5 * n * EB;
+  // pinned staging: outputs S [n][256], c [n][32]; inputs pk, y, xinv, w [n][256] each
+  const size_t need = n * EB + n * 32 + 4 * n * EB;
   if (need > sl.cap) {
     if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
     sl.pin = nullptr;
@@ -3157,25 +3153,28 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
   uint8_t* hS = (uint8_t*)sl.pin;
   uint8_t* hc = hS + n * EB;
   uint8_t* in = hc + n * 32;
-  uint8_t *hpk = in, *hy = in + n * EB, *hxi = in + 2 * n * EB, *hw = in + 3 * n * EB, *he2 = in + 4 * n * EB;
-  memcpy(hpk, pk, n * EB);
-  memcpy(hy, y, n * EB);
-  memcpy(hxi, xinv, n * EB);
-  memcpy(hw, w, n * EB);
-  {
-    const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    hsc::parallel_indices(nt, [&](unsigned k) {
-      for (size_t i = k; i < n; i += nt) mpvss_modp_scalar_mul(hw + i * EB, hxi + i * EB, he2 + i * EB);     // w * (1/x) mod (q-1)
-    });
-  }
+  uint8_t *hpk = in, *hy = in + n * EB, *hxi = in + 2 * n * EB, *hw = in + 3 * n * EB;
+  const unsigned par = n * EB >= ((size_t)4 << 20) ? 4 : 1;      // (side by side from 4 MB each: the lock is held)
+  hsc::parallel_indices(par, [&](unsigned k) {
+    for (unsigned j = k; j < 4; j += par) {
+      if (j == 0) memcpy(hpk, pk, n * EB);
+      else if (j == 1) memcpy(hy, y, n * EB);
+      else if (j == 2) memcpy(hxi, xinv, n * EB);
+      else memcpy(hw, w, n * EB);
+    }
+  });
   const uint32_t* cG;
   RET_IF(comb_table(ctx, 1, &cG, n));
-  const void *dpk, *dy, *dxi, *dw, *de2;
+  RET_IF(modq_consts(ctx));
+  const void *dpk, *dy, *dxi, *dw;
   RET_IF(stage_in(ctx, MPVSS_HOST, hpk, n * EB, ctx->w->in_a, &dpk));
   RET_IF(stage_in(ctx, MPVSS_HOST, hy, n * EB, ctx->w->in_b, &dy));
   RET_IF(stage_in(ctx, MPVSS_HOST, hxi, n * EB, ctx->w->in_c, &dxi));
   RET_IF(stage_in(ctx, MPVSS_HOST, hw, n * EB, ctx->w->in_d, &dw));
-  RET_IF(stage_in(ctx, MPVSS_HOST, he2, n * EB, ctx->w->in_e, &de2));
+  // e2 = w * (1/x) mod (q-1): the scalar ring's product kernel, in stream order (round 6: this was 16 host threads under the lock)
+  RET_IF(ensure(ctx, ctx->w->in_e, n * EB));
+  const uint8_t* de2 = (const uint8_t*)ctx->w->in_e.p;
+  LAUNCHCHK(ctx, modq_launch_mul((const uint8_t*)dw, (const uint8_t*)dxi, (int)n, (uint8_t*)ctx->w->in_e.p, ctx->consts_q, ctx->stream));
   RET_IF(ensure(ctx, ctx->w->xbe, n * EB));
   RET_IF(ensure(ctx, ctx->w->out1, n * EB));
   RET_IF(ensure(ctx, ctx->w->out2, n * EB));

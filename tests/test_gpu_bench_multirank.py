@@ -36,7 +36,7 @@ def _line(out):
     return compact, detail
 
 
-def _run(ranks, steps, n, depth, timeout=900, extra_env=None, config_boxes="0"):
+def _run(ranks, steps, n, depth, timeout=900, extra_env=None, config_boxes="0", scaling="weak", threshold="64"):
     env = dict(os.environ, MPVSS_BENCH_SMOKE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     if depth is not None:                  # None: the boxes in flight per rank follow bench.py's own formula for that world size
         env["MPVSS_BENCH_DEPTH"] = str(depth)
@@ -44,8 +44,9 @@ def _run(ranks, steps, n, depth, timeout=900, extra_env=None, config_boxes="0"):
         env.pop("MPVSS_BENCH_DEPTH", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps",
-           str(steps), "--warmup", "1", "--participants", str(n), "--threshold", "64", "--cpu-sample", "0", "--wb-shares", "0",
-           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0", "--config-boxes", config_boxes]
+           str(steps), "--warmup", "1", "--participants", str(n), "--threshold", threshold, "--cpu-sample", "0", "--wb-shares", "0",
+           "--registered-keys", "0", "--ec-boxes", "0", "--lone-boxes", "0", "--host-boxes", "0", "--config-boxes", config_boxes,
+           "--scaling", scaling, "--drop-in-threads", "0", "--steady-steps", "0"]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
@@ -131,3 +132,30 @@ def test_the_python_driven_blocks_still_agree_with_the_chained_pipeline():
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
         _, res = _line(out)
         assert res["host"]["pipeline"].startswith(name) and res["rccl"]["data_collectives"] >= 5 and res["value"] > 0
+
+
+def test_strong_scaling_the_same_box_over_one_two_and_eight_ranks():
+    """`--scaling both` (the default at N > 1): beside the weak figure the line carries `strong` -- the metric's FIXED box split into N
+    contiguous blocks, rank g verifying positions [g n/N, (g+1) n/N).  The box is made from one seeded list of participants whatever
+    the world size, so the digests of its K boxes must be the SAME at 8 ranks (4096 shares per rank), at 2 ranks and in the one-rank
+    run (MPVSS_BENCH_STRONG_AT_N1: the whole box on one engine): a lost or crossed running state, or a block at the wrong offset,
+    changes them.  `--scaling strong` makes that figure the line's `value` and says so in `scaling`."""
+    dig = {}
+    for ranks in (1, 2, 8):
+        out = _run(ranks, 3, 32768, 4 if ranks < 8 else None, timeout=600, scaling="both", threshold="32",
+                   extra_env={"MPVSS_BENCH_STRONG_AT_N1": "1", "OMP_NUM_THREADS": "2"})
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        compact, res = _line(out)
+        assert "secondary_error" not in res
+        st = res["strong"]
+        assert st["scaling"] == "strong" and st["n_per_gpu"] == 32768 // ranks and st["boxes"] == 3 and st["value"] > 0
+        assert compact["strong"]["value"] == pytest.approx(st["value"], rel=1e-5)
+        assert res["scaling"] == "weak" and res["config"]["n_per_gpu"] == 32768          # `value` is still the weak figure
+        dig[ranks] = st["digest_of_digests"]
+        assert res["compute"]["fd_fallbacks"] == 0
+    assert dig[1] == dig[2] == dig[8], dig
+    out = _run(2, 3, 32768, 4, timeout=420, scaling="strong", threshold="32")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    _, res = _line(out)
+    assert res["scaling"] == "strong" and res["config"]["n_per_gpu"] == 16384 and "32768 participants in the box" in res["config"]["workload_detail"]
+    assert "strong" not in res and res["value"] > 0
