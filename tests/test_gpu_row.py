@@ -1,0 +1,118 @@
+"""The row layout (mpvss_rs_amd/csrc/bn_row.h: 16 lanes per number, the latency-bound launches of a box that has the chip to
+itself): (a) one Montgomery product / squaring per operand pair against Python integers on operands at the bounds of the integer
+model; (b) the Horner seed kernel k_modp_commit_eval_row behind the X path of a lone call -- the same X, bit for bit, as the quad
+kernel (MPVSS_FD_ROW=0), as Horner's rule for every position (MPVSS_FD=0), and as Python's pow on a sample (participant.rs:423-434)."""
+import os
+import random
+import struct
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, L = 29, 72
+M29 = (1 << W) - 1
+LIM = M29 + 512
+
+
+def test_row_product_and_square_on_edge_operands(tmp_path):
+    import mpvss_oracle as O
+    N = O.ModpGroup().q
+    R = 1 << (W * L)
+    exe = os.path.join(ROOT, "tests", "_build", "row_unit")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mpvss_rs_amd", "csrc"), "../../tests/_build/row_unit"])
+    rng = random.Random(0x50E)
+    canon = lambda v: [(v >> (W * j)) & M29 for j in range(L)]
+    value = lambda l: sum(x << (W * j) for j, x in enumerate(l))
+
+    def loose():          # a value below 2N whose limbs are "almost normalised" (up to 2^29 - 1 + 2^9), as a product leaves them
+        while True:
+            l = canon(rng.randrange(2 * N))
+            for j in range(L - 1):
+                if rng.random() < 0.3 and l[j + 1] > 0:
+                    l[j] += 1 << W
+                    l[j + 1] -= 1
+                    l[j] = min(l[j], LIM)
+            if value(l) < 2 * N:
+                return l
+    maxl = [LIM] * 70 + [0, 0]
+    while value(maxl) >= 2 * N:
+        maxl[69] //= 2
+    half = 1 << 1044
+    named = [canon(v) for v in (0, 1, 2, N - 1, N, N + 1, 2 * N - 1, 2 * N - 2, half, half - 1, half + 1, M29, 1 << W,
+                                (1 << (W * 5)) - 1, 1 << (W * 5), (1 << (W * 70)) - 1)] + [maxl]
+    pairs = [(a, b) for a in named for b in named]
+    for _ in range(1500):
+        pairs.append((canon(rng.randrange(2 * N)), canon(rng.randrange(2 * N))))
+    for _ in range(1500):
+        pairs.append((loose(), loose()))
+    pairs.append((maxl, maxl))
+    n = len(pairs)
+    assert n % 4 != 0                                                    # the last wave is ragged
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<72I", *canon(N)))
+        for a, b in pairs:
+            f.write(struct.pack("<72I", *a) + struct.pack("<72I", *b))
+    res = subprocess.run([exe, str(inp), str(outp), str(n)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = open(outp, "rb").read()
+    assert len(raw) == n * 2 * 288
+    Rinv = pow(R, -1, N)
+    for i, (a, b) in enumerate(pairs):
+        x, y = value(a), value(b)
+        for which, (p, q) in enumerate(((x, y), (x, x))):
+            limbs = struct.unpack_from("<72I", raw, (2 * i + which) * 288)
+            v = value(limbs)
+            assert max(limbs) <= LIM and limbs[71] == 0, (i, which, hex(max(limbs)))
+            assert v < 2 * N and v % N == p * q * Rinv % N, (i, which)
+
+
+CHILD = r"""
+import os, sys, random, hashlib
+sys.path.insert(0, %r)
+from mpvss_rs_amd import Engine
+EB = 256
+eng = Engine(0)
+rng = random.Random(77)
+sc = lambda k: b"".join(rng.randrange(1 << 2048).to_bytes(EB, "big") for _ in range(k))
+out = []
+for n, t, p0 in ((4096, 16, 1), (8229, 40, 3), (16384 + 5, 256, 70001), (4200, 17, (1 << 40) + 5)):
+    cm = eng.batch_exp_fixed_base((4).to_bytes(EB, "big"), sc(t))
+    X = eng.commit_eval(cm, list(range(p0, p0 + n)))
+    out.append(hashlib.sha256(X).hexdigest())
+    if os.environ.get("CHECK_POW") == "1":
+        Q = int(os.environ["MODP_Q"])
+        cs = [int.from_bytes(cm[j * EB:(j + 1) * EB], "big") for j in range(t)]
+        for i in (0, 1, n // 2, n - 1):
+            want = 1
+            for j, c in enumerate(cs):
+                want = want * pow(c, (p0 + i) ** j, Q) %% Q
+            assert int.from_bytes(X[i * EB:(i + 1) * EB], "big") == want, (n, t, i)
+print("DIGESTS " + " ".join(out))
+print("FD", eng.fd_stats())
+"""
+
+
+def _child(env):
+    import mpvss_oracle as O
+    e = dict(os.environ, MODP_Q=str(O.ModpGroup().q), **env)
+    out = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=e, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGESTS ")][0]
+    return line.split()[1:], out.stdout
+
+
+def test_row_seeds_give_the_same_x_as_the_quad_seeds_and_as_horner():
+    """A lone mpvss_modp_commit_eval call over consecutive positions takes forward differences with ALL seeds by Horner's rule -- by
+    the row-layout kernel by default.  Four shapes (ragged seed counts, a threshold that is not a multiple of 4, positions beyond
+    2^40): the X arrays must hash the same with MPVSS_FD_ROW=0 (quad seeds) and with MPVSS_FD=0 (Horner for every position, no
+    forward differences at all); four positions per shape against Python's pow; no fall-back."""
+    row, log = _child({"CHECK_POW": "1"})
+    assert "FD (4, 0)" in log, log[-300:]
+    quad, _ = _child({"MPVSS_FD_ROW": "0"})
+    horner, _ = _child({"MPVSS_FD": "0"})
+    assert row == quad == horner
