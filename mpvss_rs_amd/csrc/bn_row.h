@@ -1,12 +1,15 @@
 // 2048-bit Montgomery arithmetic for gfx950, "row" layout: one number is spread over the 16 lanes of a DPP row
-// (4 numbers per 64-lane wavefront).  For the LATENCY-bound launches of a box that has the chip to itself.
+// (4 numbers per 64-lane wavefront).  For a LATENCY-bound launch that has the chip to itself.
 //
-// Why (round 6): the Horner seeds of a lone box are 4096 numbers x ~7 900 strictly sequential Montgomery operations.  In the
+// Why (round 6): the Horner seeds of a lone X path are 4096 numbers x ~7 900 strictly sequential Montgomery operations.  In the
 // quad layout (bn_quad.h: 4 lanes per number, 18 limbs per lane) that is 256 waves on 1 024 SIMDs and 52 ms -- a wave alone on
-// its SIMD issues one VALU instruction every ~5 cycles whatever its instruction-level parallelism, so the launch's time is the
-// instruction count of ONE number's chain: 41 instructions per row (36 multiply-adds + 5) x 72 rows per product.  Sixteen lanes
-// per number cut the row to 5 + 5 multiply-adds + 5 = 15 instructions (a squaring: 3 + 5 + 5 = 13): 0.37 of the latency for
-// 1.3x the issue slots per number, on 1 024 waves -- one per SIMD -- instead of 256.
+// its SIMD issues one VALU instruction every ~5 cycles whatever its instruction-level parallelism, so the launch's time follows
+// the instruction count of ONE number's chain: 41 instructions per row (36 multiply-adds + 5) x 72 rows per product.  Sixteen
+// lanes per number cut the row to 5 + 5 multiply-adds + 5 = 15 instructions (a squaring: 3 + 5 + 5 = 13) for 1.3x the issue slots
+// per number, on 1 024 waves -- one per SIMD -- instead of 256.  Measured alone on the chip: the seed launch 52 -> 28 ms
+// (0.55, not the 0.37 of the instruction count: the DPP and LDS round trips of a row do not shrink with it), the X path of a
+// stand-alone commit_eval 68.5 -> 47.7 ms (profiles/r06_commit_eval_alone.txt).  Inside a verifier's box it LOSES: the box is bound
+// by the sum of its work, not by this chain (mpvss_capi.cpp::eval_x).
 //
 // Representation: radix 2^29, 72 limbs, R = 2^2088 -- the SAME Montgomery domain and the same 72-word limb form in HBM as the
 // quad and pair layouts; lane l of the row owns limb slots 5l .. 5l+4 of 80 (slots 72..79 are zero: lane 14 holds two limbs,

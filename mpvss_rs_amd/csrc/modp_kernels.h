@@ -58,7 +58,7 @@ int modp_launch_keyset_dual_exp(const uint32_t* ks, const uint32_t* tab2, const 
 int modp_pair_tables_upload(void** dev_tables);
 int modp_launch_dual_exp_w6_pair(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
                                  size_t c_stride, const uint16_t* c_sched, int count, uint8_t* out, const void* cs,
-                                 const void* pair_tables, hipStream_t s, int lone);
+                                 const void* pair_tables, hipStream_t s);
 /* pair-layout forms of the table builders (entries 64, or 16 with odd_only), of the wide-comb exponentiation g^e1 (mode 1
    of modp_launch_comb_dual_exp_split with the 16-bit comb) and of p_m * B2^c for a scheduled shared c (modp_launch_comb_dual_exp_sched) */
 int modp_launch_build_table_pair(const uint8_t* base_be, int count, uint32_t* tab, int entries, int odd_only, const void* cs,
@@ -129,10 +129,11 @@ int modq_launch_poly_eval(const uint32_t* coef, int t, const int64_t* positions,
                           const void* cs_q, hipStream_t s);
 int modq_launch_responses(const uint8_t* w_be, const uint8_t* alpha_be, const uint8_t* cneg_be, int c_parity, int count,
                           uint8_t* out_be, const void* cs_q, hipStream_t s);
-/* row layout (modp_row_kernels.hip, bn_row.h: 16 lanes per number): the Horner seeds of a box that has the chip to itself -- X at
+/* row layout (modp_row_kernels.hip, bn_row.h: 16 lanes per number): the Horner seeds of an X path that has the chip to itself -- X at
  * `count` positions per box in Montgomery limb form; gate != null: only when *gate == gate_want */
 int modp_launch_commit_eval_row_boxes(const uint32_t* cm, int t, const int64_t* positions, size_t box_positions, int count, int boxes,
-                                      uint32_t* x_m, size_t box_out, const int* gate, int gate_want, const void* cs, hipStream_t s);
+                                      uint32_t* x_m, size_t box_out, const int* gate, int gate_want, const void* cs, hipStream_t s,
+                                      int prio);
 /* test hook: out = a * b R^-1 (sq == 0) or a^2 R^-1 through the row-layout product, limb form in and out */
 int modp_launch_row_unit(const uint32_t* a_m, const uint32_t* b_m, int count, int sq, uint32_t* out_m, const void* cs, hipStream_t s);
 /* out[i] = a[i] * b[i] mod (q-1), 256-byte big-endian each (device pointers) */

@@ -190,22 +190,16 @@ struct PairNext {
 };
 }  // namespace
 
-// The a2 kernel exists twice, same body: k_modp_dual_exp_w6_pair with the 240 registers two waves per SIMD allow (no scratch) -- what
-// the pipeline runs, where other boxes' waves fill the chip anyway -- and k_modp_dual_exp_w6_pair_lone capped at 224 (36 bytes of
-// scratch, the same 36.7-37.3 ms alone on the chip: profiles/r05_a2_vgpr_cap_ab.txt) for a box that has the chip to ITSELF.  Two
-// waves of 240 leave 32 of a SIMD's 512 registers: no wave of the box's own X path fits beside them, and a SIMD that already holds
-// such a wave takes only ONE a2 wave -- the lone box's a2 launch then needs two rounds (69 instead of 37 ms,
-// profiles/r06_lone_box_timeline_before.txt).  At 224 two a2 waves and a row-layout wave of the X path (<= 64 registers,
-// modp_row_kernels.hip) share a SIMD.  (The attribute counts the unified file in halves on gfx90a and later:
-// amdgpu_num_vgpr(N / 2) caps the kernel at N.)
-#ifndef A2_LONE_NUM_VGPR
-#define A2_LONE_NUM_VGPR 224
-#endif
-namespace {
-__device__ __forceinline__ void dual_exp_w6_pair_body(const u32* __restrict__ tab1, const u32* __restrict__ tab2,
-                                                      const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ c_all, size_t c_stride,
-                                                      int count, uint8_t* __restrict__ out_be, const ModpConsts* __restrict__ cs,
-                                                      const uint16_t* __restrict__ c_sched, const Tables* __restrict__ gtab) {
+// (A register cap on this kernel -- 224 / 216 / 208 instead of the 240 two waves per SIMD allow, so that a wave of a box's own X
+// path fits beside two a2 waves on a SIMD -- was measured in the pipeline in round 5 (nothing, profiles/r05_a2_vgpr_cap_ab.txt) and
+// for a box that has the chip to itself in round 6 (a twin of the kernel capped at 224 / 208: the call gets SLOWER, 128 against 122 ms:
+// co-resident X-path waves take issue slots the a2 waves would have used -- the box is bound by the sum of its work, not by who
+// waits for whom; profiles/r06_lone_box_schedule_ab.txt).  Not in the source any more.)
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
+k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
+                        const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
+                        const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched,
+                        const Tables* __restrict__ gtab) {
   __shared__ PairShared sh;
   tables_to_lds(&sh.tb, gtab);
   const PairLane pl = make_pair_lane();
@@ -402,21 +396,6 @@ struct PairCtx {          // what every pair kernel sets up the same way
     pc.junk = sh.junk[wave_];                                                              \
     pc.tb = &sh.tb;                                                                        \
   }
-}  // namespace
-
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
-k_modp_dual_exp_w6_pair(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
-                        const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
-                        const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched, const Tables* __restrict__ gtab) {
-  dual_exp_w6_pair_body(tab1, tab2, e1_be, c_all, c_stride, count, out_be, cs, c_sched, gtab);
-}
-extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR __attribute__((amdgpu_num_vgpr(A2_LONE_NUM_VGPR / 2)))
-k_modp_dual_exp_w6_pair_lone(const u32* __restrict__ tab1, const u32* __restrict__ tab2, const uint8_t* __restrict__ e1_be,
-                             const uint8_t* __restrict__ c_all, size_t c_stride, int count, uint8_t* __restrict__ out_be,
-                             const ModpConsts* __restrict__ cs, const uint16_t* __restrict__ c_sched, const Tables* __restrict__ gtab) {
-  dual_exp_w6_pair_body(tab1, tab2, e1_be, c_all, c_stride, count, out_be, cs, c_sched, gtab);
-}
-
 
 // ---------------------------------------------------------------------------------------
 // Window tables of per-share bases (part of ModpGroup::exp, modp.rs:122-128), pair layout.  Same HBM format as the quad
@@ -922,14 +901,10 @@ static inline int pair_grid(int count) { return (count + 32 * PAIR_WAVES - 1) / 
 
 extern "C" int modp_launch_dual_exp_w6_pair(const uint32_t* tab1, const uint32_t* tab2, const uint8_t* e1, const uint8_t* c,
                                             size_t c_stride, const uint16_t* c_sched, int count, uint8_t* out, const void* cs,
-                                            const void* pair_tables, hipStream_t s, int lone) {
+                                            const void* pair_tables, hipStream_t s) {
   if (count <= 0) return 0;
-  if (lone)      // the register-capped twin: leaves room for the box's own X-path waves on every SIMD
-    hipLaunchKernelGGL(k_modp_dual_exp_w6_pair_lone, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab1, tab2, e1, c, c_stride, count,
-                       out, (const ModpConsts*)cs, c_sched, (const Tables*)pair_tables);
-  else
-    hipLaunchKernelGGL(k_modp_dual_exp_w6_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab1, tab2, e1, c, c_stride, count,
-                       out, (const ModpConsts*)cs, c_sched, (const Tables*)pair_tables);
+  hipLaunchKernelGGL(k_modp_dual_exp_w6_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, tab1, tab2, e1, c, c_stride, count,
+                     out, (const ModpConsts*)cs, c_sched, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
-// Row-layout kernels (bn_row.h: 16 lanes per number) for the latency-bound launches of a MODP box that has the chip to itself.
+// Row-layout kernels (bn_row.h: 16 lanes per number) for a latency-bound launch that has the chip to itself.
 //
-//   k_modp_commit_eval_row : the Horner seeds of the forward-difference X path (participant.rs:423-434 at the seed positions):
+//   k_modp_commit_eval_row : the Horner seeds of the forward-difference X path of a stand-alone mpvss_modp_commit_eval call
+//                            (participant.rs:423-434 at the seed positions; src/mpvss.rs:110-123):
 //                            the same program as k_modp_commit_eval (modp_kernels.hip) -- X_i = (..(C_{t-1}^i C_{t-2})^i ..)^i C_0 by
 //                            one Montgomery-product site that only chooses its LDS operand -- with a third of the instructions on
 //                            a number's sequential chain.  Output: Montgomery limb form (what the inversion tree, the difference
@@ -28,17 +29,16 @@ struct ModpConsts {             // same layout as in modp_kernels.hip: N, R^2 mo
 #endif
 
 // One wave = 4 numbers.  LDS per wave: operand slot + saved-base slot per number, one shared slot holding one_m.
-// amdgpu_num_vgpr(48) = 96 registers at most: such a wave fits beside two a2 waves of the lone-box variant (208 each).
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48)))
+extern "C" __global__ void __launch_bounds__(64)
 k_modp_commit_eval_row(const u32* __restrict__ cm, int t, const int64_t* __restrict__ positions, int count, u32* __restrict__ x_m,
                        const int* __restrict__ gate, int gate_want, const ModpConsts* __restrict__ cs, size_t box_cm_words,
-                       size_t box_positions, size_t box_out) {
+                       size_t box_positions, size_t box_out, int prio) {
   __shared__ __attribute__((aligned(16))) u32 lds[(2 * NUMS_PER_WAVE + 1) * SLOT_WORDS];
   cm += blockIdx.y * box_cm_words;
   positions += blockIdx.y * box_positions;
   x_m += blockIdx.y * box_out * L;
   if (gate != nullptr && *gate != gate_want) return;
-  __builtin_amdgcn_s_setprio(ROW_SETPRIO);
+  if (prio) __builtin_amdgcn_s_setprio(ROW_SETPRIO);
   const Lane ln = make_lane();
   const int num = threadIdx.x >> 4;
   const int xi = blockIdx.x * NUMS_PER_WAVE + num;
@@ -109,7 +109,7 @@ k_modp_commit_eval_row(const u32* __restrict__ cm, int t, const int64_t* __restr
 }
 
 // test hook (tests/test_gpu_row.py): out[x] = a[x] * b[x] R^-1 (sq == 0) or a[x]^2 R^-1 (sq != 0), limb form in and out
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48)))
+extern "C" __global__ void __launch_bounds__(64)
 k_modp_row_unit(const u32* __restrict__ a_m, const u32* __restrict__ b_m, int count, int sq, u32* __restrict__ out_m,
                 const ModpConsts* __restrict__ cs) {
   __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
@@ -131,10 +131,10 @@ k_modp_row_unit(const u32* __restrict__ a_m, const u32* __restrict__ b_m, int co
 
 extern "C" int modp_launch_commit_eval_row_boxes(const uint32_t* cm, int t, const int64_t* positions, size_t box_positions, int count,
                                                  int boxes, uint32_t* x_m, size_t box_out, const int* gate, int gate_want, const void* cs,
-                                                 hipStream_t s) {
+                                                 hipStream_t s, int prio) {
   if (count <= 0 || boxes <= 0) return 0;
   hipLaunchKernelGGL(k_modp_commit_eval_row, dim3((count + NUMS_PER_WAVE - 1) / NUMS_PER_WAVE, boxes), dim3(64), 0, s, cm, t, positions,
-                     count, x_m, gate, gate_want, (const ModpConsts*)cs, (size_t)t * L, box_positions, box_out);
+                     count, x_m, gate, gate_want, (const ModpConsts*)cs, (size_t)t * L, box_positions, box_out, prio);
   return (int)hipGetLastError();
 }
 

@@ -982,8 +982,13 @@ bool fd_applies(size_t t, const int64_t* hpos, size_t cnt) {
 // boxes > 1: a GROUP of same-shaped boxes in one set of launches -- box b has its commitments at w.cm + b * t rows, its `cnt`
 // positions at dpos + b * box_positions (0: the boxes share one array) and its X at dX + b * cnt rows; one flag for the group.
 int pair_mask();     // which kernels take the pair layout (below)
+// x_alone: nothing of the caller runs beside this X path (the stand-alone mpvss_modp_commit_eval): its Horner seeds then take the
+// row-layout kernel (modp_row_kernels.hip: 16 lanes per seed, 1024 waves instead of 256 -- the seed launch 52 -> 28 ms, the whole
+// X path 68.5 -> 47.7 ms at (65536, 256), profiles/r06_commit_eval_alone.txt).  NOT inside a verifier's block: there the box is
+// bound by the sum of its work, the wider layout costs 1.3x the issue slots per seed, and the call gets slower (148 against 122 ms,
+// profiles/r06_lone_box_schedule_ab.txt).
 int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX, size_t boxes = 1,
-           size_t box_positions = 0) {
+           size_t box_positions = 0, bool x_alone = false) {
   const int B = (int)boxes;
   // The stepping kernels on the pair layout (MPVSS_PAIR bit 5) from MPVSS_FD_PAIR_MIN_T commitments: stages of 32 levels, 122
   // instead of 191 issue slots per product, but half as many waves with longer steps.  Measured (profiles/r03_fd_pair_ab.txt):
@@ -1048,8 +1053,6 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
   // share and costs a serial chain (about 15 ms of a lone box's latency): a call that has the GPU to itself keeps the
   // wide Horner launch for all S*t seeds.
   static const int two_level_env = fd_env("MPVSS_FD_L1", 1);
-  // MPVSS_FD_ROW (default 1): the seeds of a call that has the chip to itself by the row-layout kernel; 0: the quad-layout one (tests, A/B)
-  static const int row_seeds = fd_env("MPVSS_FD_ROW", 1);
   const bool two_level = S > 1 && (two_level_env >= 2 || (two_level_env == 1 && ctx->busy_with_others()));
   // product tree of the simultaneous inversion: level l turns ms[l] numbers into ms[l+1] group totals
   constexpr int G = 16;
@@ -1164,11 +1167,9 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
                                               ctx->consts, ctx->stream));
     LAUNCHCHK(ctx, launch_step(state_fwd, state_bwd, bx_state, 1, (int)t, 0, m0, m0, xseed, bx_xm,
                                (uint32_t*)((uint8_t*)w.fd_hand_s.p + hand_s), bx_hand_s, inject_fault == 3 ? 1 : 0));
-  } else if (row_seeds && !ctx->busy_with_others()) {
-    // a call that has the chip to itself: 16 lanes per seed (modp_row_kernels.hip) -- 1024 waves, one per SIMD, a third of the
-    // instructions on every seed's sequential chain (52 -> 2x ms at (65536, 256), profiles/r06_lone_box_timeline_*.txt)
+  } else if (x_alone && !ctx->busy_with_others()) {
     LAUNCHCHK(ctx, modp_launch_commit_eval_row_boxes((const uint32_t*)w.cm.p, (int)t, dpos + seed0, box_positions, m0, B, xseed, cnt, flag, 1,
-                                                     ctx->consts, ctx->stream));
+                                                     ctx->consts, ctx->stream, 1));
   } else {
     LAUNCHCHK(ctx, modp_launch_commit_eval_boxes((const uint32_t*)w.cm.p, (int)t, dpos + seed0, box_positions, m0, B, xseed, nullptr,
                                                  cnt, flag, 1, ctx->consts, ctx->stream));
@@ -1210,7 +1211,7 @@ extern "C" int mpvss_modp_commit_eval(mpvss_ctx* ctx, int space, const uint8_t* 
     RET_IF(ensure(ctx, ctx->w->xbe, n * EB));
     dout = (uint8_t*)ctx->w->xbe.p;
   }
-  RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions : nullptr, n, dout));
+  RET_IF(eval_x(ctx, t, dpos, space == MPVSS_HOST ? positions : nullptr, n, dout, 1, 0, true));
   if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, x_out, dout, n * EB));
   RET_IF(spans_collect(ctx));
   return MPVSS_OK;
@@ -1246,10 +1247,10 @@ int launch_table64(mpvss_ctx* ctx, const uint8_t* base_dev, size_t cnt, uint32_t
 }
 
 int launch_dual_exp_w6(mpvss_ctx* ctx, const uint32_t* t1, const uint32_t* t2, const uint8_t* r_dev, const uint8_t* c_dev,
-                       size_t c_stride, const uint16_t* c_sched, size_t cnt, uint8_t* out_dev, bool lone = false) {
+                       size_t c_stride, const uint16_t* c_sched, size_t cnt, uint8_t* out_dev) {
   if (pair_mask() & 1)
     return modp_launch_dual_exp_w6_pair(t1, t2, r_dev, c_dev, c_stride, c_sched, (int)cnt, out_dev, ctx->consts, ctx->pair_tables,
-                                        ctx->stream, lone ? 1 : 0);
+                                        ctx->stream);
   if (c_sched) return modp_launch_dual_exp_w6_sched(t1, t2, r_dev, c_sched, (int)cnt, out_dev, ctx->consts, ctx->stream);
   return modp_launch_dual_exp_w6(t1, t2, r_dev, c_dev, c_stride, (int)cnt, out_dev, ctx->consts, ctx->stream);
 }
@@ -1583,9 +1584,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
           // 6-bit windows for y^r (64-entry tables, 18 KB per share): 341 products instead of 511
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, launch_table64(ctx, (const uint8_t*)dy, cnt, t1p));
-          // (a box that has the chip to itself: the register-capped twin of the kernel, so that its own X-path waves fit beside it)
-          TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2,
-                                                  !ctx->busy_with_others()));
+          TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, t1p, t2p, (const uint8_t*)dr, (const uint8_t*)dchal, 0, dsched, cnt, da2));
         } else {
           uint32_t* t1p = (uint32_t*)ctx->w->tab1.p;
           TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, t1p, ctx->consts, ctx->stream));

@@ -16,7 +16,9 @@ def fx(v):
     return v.to_bytes(EB, "big")
 
 
-@pytest.mark.parametrize("n,t,key_offset", [(8192, 16, 0), (8192, 32, 64)])
+# (8192: whole pair-layout waves; 8200 and 4133: a ragged last wave whose padding lanes repeat the last share; 48: below the
+#  64-share switch, the quad-layout key-table kernel -- ADVICE r5)
+@pytest.mark.parametrize("n,t,key_offset", [(8192, 16, 0), (8192, 32, 64), (8200, 16, 3), (4133, 16, 0), (48, 3, 5)])
 def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
     rng = random.Random(1000 * t + key_offset)
     nk = n + key_offset + 3
@@ -38,7 +40,8 @@ def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
     blocks0, fallbacks0 = engine.fd_stats()
     engine.verify_block_compute(cm, pos, sub, shares, resp, chal)
     st0, X0, A10, A20 = engine.verify_block_absorb_dump(capi.transcript_init(), n)
-    assert engine.fd_stats() == (blocks0 + 1, fallbacks0)      # forward differences were used and held
+    if n >= 4096:
+        assert engine.fd_stats() == (blocks0 + 1, fallbacks0)      # forward differences were used and held
 
     ks = engine.keyset_create(pk)
     try:
@@ -59,7 +62,7 @@ def test_keyset_block_equals_plain_block(engine, n, t, key_offset):
     assert A21 == A20 and st1 == st0
     assert A22 == A23 and st2 == st3
     c = int.from_bytes(chal, "big")
-    for i in (0, 1, 2, 5, 6, n // 2, n - 1):
+    for i in (0, 1, 2, 5, 6, n // 2, n - 2, n - 1):
         y = keys[key_offset + i]
         Y = int.from_bytes(shares[i * EB:(i + 1) * EB], "big")
         r = int.from_bytes(resp[i * EB:(i + 1) * EB], "big")
@@ -119,3 +122,90 @@ def test_key_cache_behind_the_unchanged_verify_many(engine):
     assert engine.pipeline_stats(reset=True)["kernel_launches"][2] == tables_plain - 6
     with pytest.raises(capi.EngineError):
         engine.set_key_cache(1)
+
+
+def test_key_tables_at_the_headline_shape():
+    """The configuration bench.py times as `registered_keys` (missing 4): n = 65536, t = 256, 19.3 GB of tables.  Three
+    dealers' boxes against one key array through mpvss_modp_verify_many with the context's key cache on, and through an explicit key
+    set: the digests are the dealers', a seeded 1 % of the shares (X, a1, a2 dumped through the key-set block path) equal Python's
+    pow (helpers.modp_fast_share), a flipped response bit and a flipped share bit are rejected with the digests the plain path
+    gives.  Own process: the 19 GB go back to the device afterwards."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, random, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import modp_fast_share, parallel_map
+from mpvss_rs_amd import Engine, capi
+EB = 256
+def main():
+    eng = Engine(0)
+    rng = random.Random(65536)
+    fx = lambda v: v.to_bytes(EB, "big")
+    sc = lambda k: b"".join(rng.randrange(1, 1 << 2040).to_bytes(EB, "big") for _ in range(k))
+    n, t = 65536, 256
+    pos = list(range(1, n + 1))
+    pk = eng.batch_exp_fixed_base(fx(2), sc(n))
+    wit = sc(n)
+    boxes = []
+    for b in range(3):
+        coeffs = sc(t)
+        d = eng.deal(coeffs, pos, pk, wit)
+        boxes.append(dict(commitments=eng.batch_exp_fixed_base(fx(4), coeffs), positions=pos, pubkeys=pk, shares=d["Y"], responses=d["responses"],
+                          challenge=d["challenge"], digest=d["digest"], X=d["X"], a1=d["a1"], a2=d["a2"]))
+    flip = lambda b, at: b[:at] + bytes([b[at] ^ 1]) + b[at + 1:]
+    bad_r = dict(boxes[1], responses=flip(boxes[1]["responses"], 40000 * EB + 77))
+    bad_Y = dict(boxes[2], shares=flip(boxes[2]["shares"], 65535 * EB + 255))
+    seq = [boxes[0], bad_r, boxes[1], bad_Y, boxes[2]]
+    pkb = (C.c_uint8 * len(pk)).from_buffer_copy(pk)
+    posb = (C.c_int64 * n)(*pos)
+    keep, arr = [], (capi.ModpBox * len(seq))()
+    for i, b in enumerate(seq):
+        bufs = [(C.c_uint8 * len(b[k])).from_buffer_copy(b[k]) for k in ("commitments", "shares", "responses", "challenge")]
+        keep.append(bufs)
+        arr[i] = capi.ModpBox(C.addressof(bufs[0]), t, C.addressof(posb), C.addressof(pkb), C.addressof(bufs[1]), C.addressof(bufs[2]), n,
+                              C.addressof(bufs[3]), None, 0)
+    def run():
+        vd, dg = (C.c_int * len(seq))(), (C.c_uint8 * (32 * len(seq)))()
+        eng._check(eng.lib.mpvss_modp_verify_many(eng.ctx, capi.MPVSS_HOST, arr, len(seq), 5, 4, vd, C.cast(dg, C.c_void_p)), "verify_many")
+        return [(bool(vd[i]), bytes(dg)[32 * i:32 * i + 32]) for i in range(len(seq))]
+    plain = run()
+    assert [v for v, _ in plain] == [True, False, True, False, True]
+    assert [plain[i][1] for i in (0, 2, 4)] == [b["digest"] for b in boxes]
+    eng.pipeline_stats(reset=True)
+    assert eng.set_key_cache(3) == 0
+    cached = run()
+    assert eng.set_key_cache(0) == 3
+    assert cached == plain, "key cache at (65536, 256): verdicts or digests differ from the plain path"
+    assert eng.pipeline_stats(reset=True)["kernel_launches"][2] < 3 * len(seq), "the key tables were not used"
+    # the explicit key set, block form, with dumps: every X / a1 / a2 equals the dealer's; a seeded 1 %% against Python's pow
+    ks = eng.keyset_create(pk)
+    try:
+        assert eng.keyset_bytes(ks) == n * (8 * 128 * 288 + 256)
+        b = boxes[0]
+        eng.verify_block_compute_keyset(b["commitments"], pos, ks, 0, b["shares"], b["responses"], b["challenge"])
+        st, X, A1, A2 = eng.verify_block_absorb_dump(capi.transcript_init(), n)
+        assert capi.transcript_verdict(st, b["challenge"]) == (True, b["digest"])
+        assert (X, A1, A2) == (b["X"], b["a1"], b["a2"])
+        idx = sorted(random.Random(7).sample(range(n), 655)) + [0, n - 1]
+        outs = parallel_map(modp_fast_share, [(b["commitments"], pos[i], pk[i * EB:(i + 1) * EB], b["shares"][i * EB:(i + 1) * EB],
+                                               b["responses"][i * EB:(i + 1) * EB], b["challenge"]) for i in idx])
+        for i, (x, a1, a2) in zip(idx, outs):
+            s = slice(i * EB, (i + 1) * EB)
+            assert (X[s], A1[s], A2[s]) == (x, a1, a2), i
+    finally:
+        eng.keyset_destroy(ks)
+    assert eng.fd_stats()[1] == 0
+    print("keyset headline ok")
+if __name__ == "__main__":
+    main()
+""" % (root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
+    script = os.path.join(root, "tests", "_build", "keyset_headline_child.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    with open(script, "w") as fh:
+        fh.write(code)
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=1200,
+                         env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    assert out.returncode == 0 and "keyset headline ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -82,8 +82,13 @@ sc = lambda k: b"".join(rng.randrange(1 << 2048).to_bytes(EB, "big") for _ in ra
 out = []
 for n, t, p0 in ((4096, 16, 1), (8229, 40, 3), (16384 + 5, 256, 70001), (4200, 17, (1 << 40) + 5)):
     cm = eng.batch_exp_fixed_base((4).to_bytes(EB, "big"), sc(t))
-    X = eng.commit_eval(cm, list(range(p0, p0 + n)))
+    pos = list(range(p0, p0 + n))
+    X = eng.commit_eval(cm, pos)                          # stand-alone X path: row-layout seeds
     out.append(hashlib.sha256(X).hexdigest())
+    # the same X inside a verifier's block (quad-layout seeds): the dumped X of a box with arbitrary keys, shares, responses
+    junk = sc(n)
+    res = eng.verify_distribution(cm, pos, junk, junk, junk, (12345).to_bytes(EB, "big"), dump=True)
+    assert res["X"] == X, (n, t, "X of the block path differs from the stand-alone call")
     if os.environ.get("CHECK_POW") == "1":
         Q = int(os.environ["MODP_Q"])
         cs = [int.from_bytes(cm[j * EB:(j + 1) * EB], "big") for j in range(t)]
@@ -93,7 +98,6 @@ for n, t, p0 in ((4096, 16, 1), (8229, 40, 3), (16384 + 5, 256, 70001), (4200, 1
                 want = want * pow(c, (p0 + i) ** j, Q) %% Q
             assert int.from_bytes(X[i * EB:(i + 1) * EB], "big") == want, (n, t, i)
 print("DIGESTS " + " ".join(out))
-print("FD", eng.fd_stats())
 """
 
 
@@ -103,16 +107,14 @@ def _child(env):
     out = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=e, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGESTS ")][0]
-    return line.split()[1:], out.stdout
+    return line.split()[1:]
 
 
 def test_row_seeds_give_the_same_x_as_the_quad_seeds_and_as_horner():
-    """A lone mpvss_modp_commit_eval call over consecutive positions takes forward differences with ALL seeds by Horner's rule -- by
-    the row-layout kernel by default.  Four shapes (ragged seed counts, a threshold that is not a multiple of 4, positions beyond
-    2^40): the X arrays must hash the same with MPVSS_FD_ROW=0 (quad seeds) and with MPVSS_FD=0 (Horner for every position, no
-    forward differences at all); four positions per shape against Python's pow; no fall-back."""
-    row, log = _child({"CHECK_POW": "1"})
-    assert "FD (4, 0)" in log, log[-300:]
-    quad, _ = _child({"MPVSS_FD_ROW": "0"})
-    horner, _ = _child({"MPVSS_FD": "0"})
-    assert row == quad == horner
+    """A stand-alone mpvss_modp_commit_eval over consecutive positions takes forward differences with ALL seeds by Horner's rule in
+    the row layout; inside a verifier's block the same X path takes the quad-layout seed kernel.  Four shapes (ragged seed counts,
+    a threshold that is not a multiple of 4, positions beyond 2^40): the two X arrays are equal byte for byte, they hash the same
+    with MPVSS_FD=0 (Horner for every position, no forward differences at all), and four positions per shape equal Python's pow."""
+    row = _child({"CHECK_POW": "1"})
+    horner = _child({"MPVSS_FD": "0"})
+    assert row == horner
