@@ -31,7 +31,7 @@ for rep in $(seq $REPS); do
     NAME=${NAMES[$v]}
     # shellcheck disable=SC2086
     env ${ENVSTR[$v]} MPVSS_BENCH_DETAIL=/tmp/ab_detail.json python3 bench.py --gpus 1 --steps $STEPS --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 \
-        --host-boxes 0 --config-boxes 0 --lone-boxes 1 --steady-steps $STEADY >/dev/null 2>/dev/null
+        --host-boxes 0 --config-boxes 0 --lone-boxes 1 --steady-steps $STEADY --drop-in-threads 0 >/dev/null 2>/dev/null
     python3 -c "
 import json
 d = json.load(open('/tmp/ab_detail.json'))

@@ -11,7 +11,7 @@ while [ $# -gt 0 ]; do
   ENVS=()
   while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
   env "${ENVS[@]}" python3 bench.py --gpus 1 --steps 6 --warmup 2 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 \
-      --host-boxes 0 --config-boxes $BOXES --lone-boxes 0 2>gpurun_out/ab_c2_err.txt | python3 -c "
+      --host-boxes 0 --config-boxes $BOXES --lone-boxes 0 --drop-in-threads 0 2>gpurun_out/ab_c2_err.txt | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 c = d.get('configs', {})

@@ -22,7 +22,7 @@ for rep in $(seq $REPS); do
     NAME=${NAMES[$v]}
     # shellcheck disable=SC2086
     env ${ENVSTR[$v]} MPVSS_BENCH_CONFIGS=c5_slice MPVSS_BENCH_DETAIL=/tmp/ab_c5_detail.json python3 bench.py --gpus 1 --steps 2 --warmup 1 --cpu-sample 0 \
-        --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --config-boxes $((BOXES * 8)) --lone-boxes 0 --steady-steps 0 >/dev/null 2>gpurun_out/ab_c5_err.txt
+        --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --config-boxes $((BOXES * 8)) --lone-boxes 0 --steady-steps 0 --drop-in-threads 0 >/dev/null 2>gpurun_out/ab_c5_err.txt
     python3 -c "
 import json
 d = json.load(open('/tmp/ab_c5_detail.json'))

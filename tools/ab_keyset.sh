@@ -22,7 +22,7 @@ for rep in $(seq $REPS); do
     NAME=${NAMES[$v]}
     # shellcheck disable=SC2086
     env ${ENVSTR[$v]} MPVSS_BENCH_DETAIL=/tmp/ab_ks_detail.json python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 1 \
-        --ec-boxes 0 --host-boxes 0 --config-boxes 0 --lone-boxes 0 --steady-steps 0 >/dev/null 2>gpurun_out/ab_ks_err.txt
+        --ec-boxes 0 --host-boxes 0 --config-boxes 0 --lone-boxes 0 --steady-steps 0 --drop-in-threads 0 >/dev/null 2>gpurun_out/ab_ks_err.txt
     python3 -c "
 import json
 d = json.load(open('/tmp/ab_ks_detail.json'))

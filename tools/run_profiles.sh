@@ -11,10 +11,10 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
-ARGS="bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --config-boxes 0 --lone-boxes 2 --steady-steps 0"
-LONE="bench.py --steps 3 --warmup 1 --lone-boxes 2 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --config-boxes 0 --steady-steps 0"
-PMCARGS="bench.py --steps 2 --warmup 1 --lone-boxes 0 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 2 --host-boxes 0 --config-boxes 0 --steady-steps 0"
-ECARGS="bench.py --steps 2 --warmup 1 --lone-boxes 0 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --host-boxes 0 --config-boxes 0 --steady-steps 0"
+ARGS="bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --config-boxes 0 --lone-boxes 2 --steady-steps 0 --drop-in-threads 0"
+LONE="bench.py --steps 3 --warmup 1 --lone-boxes 2 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 0 --host-boxes 0 --config-boxes 0 --steady-steps 0 --drop-in-threads 0"
+PMCARGS="bench.py --steps 2 --warmup 1 --lone-boxes 0 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --ec-boxes 2 --host-boxes 0 --config-boxes 0 --steady-steps 0 --drop-in-threads 0"
+ECARGS="bench.py --steps 2 --warmup 1 --lone-boxes 0 --cpu-sample 0 --wb-shares 0 --registered-keys 0 --host-boxes 0 --config-boxes 0 --steady-steps 0 --drop-in-threads 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 grep "^{\"metric\"" $OUT/trace.log > $OUT/bench_under_rocprof.json
 export MPVSS_BENCH_DEPTH=1
