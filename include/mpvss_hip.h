@@ -217,6 +217,17 @@ int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, 
  * (src/participant.rs:399-455 with the same `publickeys` each time) gets without touching its code.  0 (the default): off.
  * Returns the previous setting, or a negative error. */
 int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes);
+/* ... and ACROSS calls, for callers that verify ONE box per call (the crate's call shape, src/participant.rs:399-455) against the
+ * same participants again and again (round 6): with max_sets >= 1, mpvss_modp_verify_distribution identifies a HOST public-key array
+ * by a SHA-256 tree hash of its bytes (16.8 MB per 65536 keys: eight slices hashed side by side, 1-2 ms, outside the context lock -- a
+ * pointer may be re-used for other keys between calls, content may not), and the min_sightings-th box against the same array (default 2) builds its per-key
+ * tables once; every later box against it takes the registered-key path.  At most max_sets (<= 8) sets have tables at a time (19.3 GB
+ * per 65536 keys): the least recently used set that no block in flight reads makes room; tables that do not fit beside the block
+ * slots' workspaces, or whose build fails, cost speed, not the call.  Same verdicts and digests as without the cache
+ * (tests/test_gpu_keyset.py).  Boxes in device memory, small boxes (n <= 16384), boxes larger than one chunk and boxes whose challenge
+ * does not fit 256 bits are left alone.  0: off (the default; frees the sets no block reads).  Returns the previous max_sets, or a
+ * negative error. */
+int mpvss_ctx_set_key_cache_lru(mpvss_ctx* ctx, int max_sets, int min_sightings);
 void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* keyset);
 size_t mpvss_modp_keyset_bytes(const mpvss_keyset* keyset);
 int mpvss_modp_verify_block_compute_keyset(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_verify_distribution", "mpvss_ec_verify_shares", "mpvss_ec_verify_shares_compute", "mpvss_ec_verify_shares_absorb", "mpvss_ec_distribute", "mpvss_ec_distribute_compute", "mpvss_ec_distribute_absorb", "mpvss_ec_hash_to_scalar",
     "mpvss_ec_block_absorb_claimed", "mpvss_ec_poly_eval_device", "mpvss_ec_dleq_responses_device", "mpvss_ec_deal_compute", "mpvss_ec_deal",
     "mpvss_modp_extract_shares", "mpvss_ec_extract_shares", "mpvss_last_kernel_launches",
-    "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes", "mpvss_ctx_set_key_cache",
+    "mpvss_modp_keyset_create", "mpvss_modp_keyset_destroy", "mpvss_modp_keyset_bytes", "mpvss_ctx_set_key_cache", "mpvss_ctx_set_key_cache_lru",
     "mpvss_modp_verify_block_compute_keyset", "mpvss_modp_fd_stats",
     "mpvss_modp_verify_many", "mpvss_modp_verify_many_chained", "mpvss_pipeline_stats_get", "mpvss_blocks_in_flight", "mpvss_sha256_uses_shani", "mpvss_issue_probe",
     "mpvss_modp_verify_shares_compute", "mpvss_modp_verify_shares_absorb",
@@ -109,6 +109,8 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_fd_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.mpvss_modp_keyset_create.argtypes = [vp, ci, u8p, sz, C.POINTER(vp)]
     lib.mpvss_ctx_set_key_cache.argtypes = [vp, ci]
+    lib.mpvss_ctx_set_key_cache_lru.argtypes = [vp, ci, ci]
+    lib.mpvss_ctx_set_key_cache_lru.restype = ci
     lib.mpvss_modp_keyset_destroy.argtypes = [vp, vp]
     lib.mpvss_modp_keyset_destroy.restype = None
     lib.mpvss_modp_keyset_bytes.argtypes = [vp]
@@ -357,6 +359,14 @@ class Engine:
         """verify_many builds per-key tables by itself for key arrays that >= min_boxes large boxes of one call share (0: off)"""
         rc = int(self.lib.mpvss_ctx_set_key_cache(self.ctx, int(min_boxes)))
         self._check(rc if rc < 0 else 0, "set_key_cache")
+        return rc
+
+    def set_key_cache_lru(self, max_sets: int, min_sightings: int = 2) -> int:
+        """mpvss_ctx_set_key_cache_lru: key tables ACROSS one-box calls, keyed by the SHA-256 of the host key array (0: off).
+        Returns the previous max_sets."""
+        rc = int(self.lib.mpvss_ctx_set_key_cache_lru(self.ctx, int(max_sets), int(min_sightings)))
+        if rc < 0:
+            self._check(rc, "set_key_cache_lru")
         return rc
 
     def keyset_destroy(self, keyset) -> None:

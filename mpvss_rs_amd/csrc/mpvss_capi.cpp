@@ -210,6 +210,20 @@ struct mpvss_ctx {
   // MPVSS_PIPELINED=1): a block then never takes the configuration meant for a call that has the GPU to itself, not even
   // the first ones of the run
   int key_cache_min_boxes = 0;   // mpvss_ctx_set_key_cache: verify_many registers key arrays that this many large boxes of a call share (0: off)
+  // Key tables ACROSS calls (mpvss_ctx_set_key_cache_lru): the one-box entry point looks the SHA-256 of a host key array up here; an
+  // array seen `kc_min_sightings` times gets its tables built once and every later box against it takes the registered-key path.
+  // Least recently used sets without blocks in flight make room; `users` counts the blocks that still read an entry's tables.
+  struct KeyCacheEntry {
+    uint8_t digest[32];
+    size_t n = 0;
+    mpvss_keyset* ks = nullptr;
+    unsigned users = 0, sightings = 0;
+    unsigned long long last_use = 0;
+  };
+  std::vector<KeyCacheEntry> kc;
+  std::atomic<int> kc_max_sets{0};
+  int kc_min_sightings = 2;
+  unsigned long long kc_clock = 0;
   bool pipelined_env = false;    // MPVSS_PIPELINED=1
   int pipelines_running = 0;     // library box pipelines under way on this context (several host threads may each run one)
   bool pipelined_hint() const { return pipelined_env || pipelines_running > 0; }
@@ -745,6 +759,12 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   }
   if (ctx->scalar_stream) (void)hipStreamDestroy(ctx->scalar_stream);
   if (ctx->pair_tables) (void)hipFree(ctx->pair_tables);
+  for (auto& x : ctx->kc)
+    if (x.ks) {
+      if (x.ks->table.p) (void)hipFree(x.ks->table.p);
+      if (x.ks->keys.p) (void)hipFree(x.ks->keys.p);
+      delete x.ks;
+    }
   for (mpvss_ctx::DealBufs* d : ctx->deal_pool) {
     for (DevBuf* b : {&d->keys, &d->p, &d->w, &d->r, &d->pos, &d->coef, &d->c})
       if (b->p) (void)hipFree(b->p);
@@ -1603,7 +1623,9 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
         HIPCHK(ctx, hipEventRecord(ctx->w->ev_gr, ctx->stream));
       }
       mark(2);
-      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX));
+      // (registered keys: a2 is a quarter of its usual work, so a box that has the chip to itself is its X path's latency -- there the
+      // row-layout seeds pay: 122.8 -> 103.5 ms per lone call, profiles/r06_lone_key_cache.txt; without key tables they lose, eval_x)
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, 1, 0, use_keys));
       mark(3);
       // a1 = g^r * X^c: once X is known only X^c and one product remain
       {
@@ -2055,10 +2077,18 @@ extern "C" int mpvss_modp_verify_block_compute_flags(mpvss_ctx* ctx, int space, 
 }
 
 // ---- registered public keys -------------------------------------------------------------------------
+namespace {
+int keyset_create_locked(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out);
+}
 extern "C" int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out) {
   if (!ctx || !out) return MPVSS_E_INVALID;
   *out = nullptr;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  return keyset_create_locked(ctx, space, pubkeys, n, out);
+}
+namespace {
+int keyset_create_locked(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out) {
+  *out = nullptr;
   if (!pubkeys || n == 0 || n > 0x7fffffff / 8) return fail(ctx, MPVSS_E_INVALID, "keyset_create: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   mpvss_keyset* ks = new mpvss_keyset();
@@ -2088,6 +2118,89 @@ extern "C" int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k1).count());
   *out = ks;
   return MPVSS_OK;
+}
+
+void keyset_free_locked(mpvss_ctx* ctx, mpvss_keyset* ks) {      // (no block may still read the tables: the caller's business)
+  (void)hipSetDevice(ctx->device);
+  if (ks->table.p) (void)hipFree(ks->table.p);
+  if (ks->keys.p) (void)hipFree(ks->keys.p);
+  delete ks;
+}
+
+// The cross-call key cache (context lock held): the key set to verify a box of `n` shares against the HOST key array with this SHA-256
+// against, or null for the plain path.  A returned set has its `users` count raised: key_cache_release() when the box is absorbed.
+mpvss_keyset* key_cache_acquire(mpvss_ctx* ctx, const uint8_t digest[32], const uint8_t* pubkeys_host, size_t n) {
+  const int max_sets = ctx->kc_max_sets.load();
+  if (max_sets <= 0) return nullptr;
+  mpvss_ctx::KeyCacheEntry* e = nullptr;
+  for (auto& x : ctx->kc)
+    if (x.n == n && memcmp(x.digest, digest, 32) == 0) { e = &x; break; }
+  if (!e) {
+    if (ctx->kc.size() >= 64) {                    // sightings without tables are cheap, but not unbounded: forget the oldest such record
+      size_t victim = ctx->kc.size();
+      for (size_t i = 0; i < ctx->kc.size(); ++i)
+        if (!ctx->kc[i].ks && (victim == ctx->kc.size() || ctx->kc[i].last_use < ctx->kc[victim].last_use)) victim = i;
+      if (victim == ctx->kc.size()) return nullptr;
+      ctx->kc.erase(ctx->kc.begin() + (long)victim);
+    }
+    ctx->kc.emplace_back();
+    e = &ctx->kc.back();
+    memcpy(e->digest, digest, 32);
+    e->n = n;
+  }
+  e->last_use = ++ctx->kc_clock;
+  ++e->sightings;
+  if (!e->ks) {
+    if ((int)e->sightings < ctx->kc_min_sightings) return nullptr;
+    // room: at most max_sets sets with tables -- the least recently used one that no block reads goes
+    int with_tables = 0;
+    for (auto& x : ctx->kc) with_tables += x.ks != nullptr;
+    while (with_tables >= max_sets) {
+      mpvss_ctx::KeyCacheEntry* lru = nullptr;
+      for (auto& x : ctx->kc)
+        if (x.ks && x.users == 0 && (!lru || x.last_use < lru->last_use)) lru = &x;
+      if (!lru) return nullptr;                     // every set is in use: this box goes the plain way
+      keyset_free_locked(ctx, lru->ks);
+      lru->ks = nullptr;
+      lru->sightings = 0;
+      --with_tables;
+    }
+    // HBM: the tables may take what is free now minus a reserve for the block slots' workspaces (32 GB: a dozen headline boxes)
+    size_t free_b = 0, total_b = 0;
+    const size_t table_b = n * ((size_t)modp_keyset_words_per_key() * 4 + EB);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (free_b < table_b || free_b - table_b < ((size_t)32 << 30)) return nullptr;
+    mpvss_keyset* ks = nullptr;
+    if (keyset_create_locked(ctx, MPVSS_HOST, pubkeys_host, n, &ks) != MPVSS_OK) {      // costs speed, not the call
+      (void)hipGetLastError();
+      std::lock_guard<std::mutex> g(ctx->err_mu);
+      ctx->err.clear();
+      return nullptr;
+    }
+    e->ks = ks;
+  }
+  ++e->users;
+  return e->ks;
+}
+void key_cache_release(mpvss_ctx* ctx, const mpvss_keyset* ks) {
+  for (auto& x : ctx->kc)
+    if (x.ks == ks && x.users > 0) { --x.users; return; }
+}
+}  // namespace
+
+extern "C" int mpvss_ctx_set_key_cache_lru(mpvss_ctx* ctx, int max_sets, int min_sightings) {
+  if (!ctx) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (max_sets < 0 || max_sets > 8 || min_sightings < 1) return fail(ctx, MPVSS_E_INVALID, "set_key_cache_lru: 0 <= max_sets <= 8, min_sightings >= 1");
+  const int prev = ctx->kc_max_sets.load();
+  ctx->kc_max_sets.store(max_sets);
+  ctx->kc_min_sightings = min_sightings;
+  if (max_sets == 0) {                               // off: drop what no block reads (sets in use go when the context does)
+    for (auto& x : ctx->kc)
+      if (x.ks && x.users == 0) { keyset_free_locked(ctx, x.ks); x.ks = nullptr; }
+    ctx->kc.erase(std::remove_if(ctx->kc.begin(), ctx->kc.end(), [](const mpvss_ctx::KeyCacheEntry& x) { return x.ks == nullptr; }), ctx->kc.end());
+  }
+  return prev;
 }
 
 extern "C" int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes) {
@@ -2167,12 +2280,32 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   *verdict = 0;
   uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
   mpvss_transcript_init(state);
+  // The cross-call key cache (mpvss_ctx_set_key_cache_lru): a host key array is identified by its SHA-256 (16.8 MB: 8 ms on this
+  // thread, outside the lock), looked up, and -- seen often enough -- verified against per-key tables built once.
+  const mpvss_keyset* cached = nullptr;
+  if (ctx->kc_max_sets.load() > 0 && space == MPVSS_HOST && pubkeys && n > GROUP_MAX_BOX && n <= MAX_CHUNK && fits_256_bits(challenge_host)) {
+    lk.unlock();
+    // (a tree hash: SHA-256 of the SHA-256s of eight slices, hashed side by side -- 16.8 MB in 1-2 ms instead of 8)
+    uint8_t kd[32], leaves[8][32];
+    const size_t bytes = n * EB, slice = (bytes + 7) / 8;
+    hsc::parallel_indices(8, [&](unsigned k) {
+      const size_t lo = std::min(bytes, (size_t)k * slice), hi = std::min(bytes, lo + slice);
+      mpvss::sha256(pubkeys + lo, hi - lo, leaves[k]);
+    });
+    mpvss::sha256(&leaves[0][0], sizeof(leaves), kd);
+    lk.lock();
+    cached = key_cache_acquire(ctx, kd, pubkeys, n);
+  }
+  struct CacheUse {
+    mpvss_ctx* c; const mpvss_keyset* ks;
+    ~CacheUse() { if (ks) key_cache_release(c, ks); }       // (the context lock is held again whenever this call returns)
+  } cache_use{ctx, cached};
   // Any number of host threads may be in here on one context (the crate goes parallel over dealers the same way,
   // participant.rs:490-500): each enqueues its box under the lock, owns the block by its number and absorbs exactly that one
   // with the lock released -- T callers keep T boxes in flight, which is what the library's own pipeline does for verify_many.
   RET_IF(wait_for_room(ctx, lk));
-  RET_IF(verify_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, shares, responses, n,
-                                     challenge_host));
+  RET_IF(verify_block_compute_locked(ctx, space, commitments, t, positions, cached ? nullptr : pubkeys, shares, responses, n,
+                                     challenge_host, cached, 0));
   const unsigned long long pos = ctx->own_last(1);
   RET_IF(verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host, nullptr, &pos, true));
   return mpvss_modp_transcript_verdict(state, challenge_host, verdict, digest32_out);

@@ -116,6 +116,17 @@ impl Engine {
         Ok(rc)
     }
 
+    /// Key tables ACROSS calls for one-box callers (`Participant::verify_distribution_shares` against the same participants again
+    /// and again): the engine recognises a key array by its SHA-256, builds its per-key tables at the `min_sightings`-th box and keeps
+    /// at most `max_sets` sets (19.3 GB per 65536 keys), least recently used first out.  0: off.  Returns the previous `max_sets`.
+    pub fn set_key_cache_lru(&self, max_sets: i32, min_sightings: i32) -> Result<i32, EngineError> {
+        let rc = unsafe { ffi::mpvss_ctx_set_key_cache_lru(self.ctx.0, max_sets, min_sightings) };
+        if rc < 0 {
+            self.check(rc)?;
+        }
+        Ok(rc)
+    }
+
     /// For trait methods that cannot return an error (`Group::exp`): a failing engine is a programmer / hardware
     /// error there, as a panic in the reference's arithmetic crates would be.
     pub(crate) fn expect(&self, rc: i32, what: &str) {

@@ -120,6 +120,7 @@ unsafe extern "C" {
     // ---- registered public keys
     pub fn mpvss_modp_keyset_create(ctx: *mut mpvss_ctx, space: c_int, pubkeys: *const u8, n: usize, out: *mut *mut mpvss_keyset) -> c_int;
     pub fn mpvss_ctx_set_key_cache(ctx: *mut mpvss_ctx, min_boxes: c_int) -> c_int;
+    pub fn mpvss_ctx_set_key_cache_lru(ctx: *mut mpvss_ctx, max_sets: c_int, min_sightings: c_int) -> c_int;
     pub fn mpvss_modp_keyset_destroy(ctx: *mut mpvss_ctx, keyset: *mut mpvss_keyset);
     pub fn mpvss_modp_keyset_bytes(keyset: *const mpvss_keyset) -> usize;
     pub fn mpvss_modp_verify_block_compute_keyset(ctx: *mut mpvss_ctx, space: c_int, commitments: *const u8, t: usize, positions: *const i64,

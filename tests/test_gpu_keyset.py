@@ -209,3 +209,71 @@ if __name__ == "__main__":
     out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=1200,
                          env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
     assert out.returncode == 0 and "keyset headline ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_key_cache_across_one_box_calls(engine):
+    """mpvss_ctx_set_key_cache_lru(ctx, 1, 2): one-box calls (mpvss_modp_verify_distribution, host buffers: the crate's call shape) against
+    the same participants -- the second box against a key array builds its tables, later ones take them; same verdicts and digests as
+    with the cache off (honest boxes of three dealers, a flipped response bit, a flipped share bit, a challenge beyond 256 bits);
+    a SECOND key array with room for one set only evicts the first (least recently used, nothing in flight) and the first is rebuilt
+    when it comes back; the same array in another buffer (another pointer, same bytes) is recognised, one changed key byte is another
+    array; 6 threads at once get the sequential results; device-memory boxes are left alone; switching the cache off frees the sets."""
+    import ctypes as C
+    import threading
+    n, t = 16500, 16
+    rng = random.Random(99)
+    sc = lambda k: b"".join(rng.randrange(1, 1 << 2040).to_bytes(EB, "big") for _ in range(k))
+    pos = list(range(5, 5 + n))
+    pkA = engine.batch_exp_fixed_base(fx(2), sc(n))
+    pkB = engine.batch_exp_fixed_base(fx(2), sc(n))
+
+    def deal(pk):
+        coeffs = sc(t)
+        d = engine.deal(coeffs, pos, pk, sc(n))
+        return dict(commitments=engine.batch_exp_fixed_base(fx(4), coeffs), pubkeys=pk, shares=d["Y"], responses=d["responses"],
+                    challenge=d["challenge"], digest=d["digest"])
+    a1, a2, a3, b1 = deal(pkA), deal(pkA), deal(pkA), deal(pkB)
+    flip = lambda b, at: b[:at] + bytes([b[at] ^ 1]) + b[at + 1:]
+    cases = [a1, a2, dict(a2, responses=flip(a2["responses"], 700 * EB + 9)), a3, dict(a3, shares=flip(a3["shares"], 16499 * EB + 255)),
+             dict(a1, challenge=fx((1 << 300) + 5)), b1, a1, dict(a2, pubkeys=bytes(bytearray(pkA))),      # the same keys in another buffer
+             dict(a1, pubkeys=flip(pkA, 100 * EB + 200))]                                                  # one key changed: another array
+    verify = lambda b: (lambda r: (r["verdict"], r["digest"]))(engine.verify_distribution(b["commitments"], pos, b["pubkeys"], b["shares"],
+                                                                                          b["responses"], b["challenge"]))
+    assert engine.set_key_cache_lru(0) == 0
+    plain = [verify(b) for b in cases]
+    assert [v for v, _ in plain] == [True, True, False, True, False, False, True, True, True, False]
+    assert plain[0][1] == a1["digest"] and plain[6][1] == b1["digest"]
+    engine.pipeline_stats(reset=True)
+    [verify(b) for b in cases]
+    tables_plain = engine.pipeline_stats(reset=True)["kernel_launches"][2]          # three table launches per box without the cache
+    assert tables_plain == 3 * len(cases)
+    assert engine.set_key_cache_lru(1, 2) == 0
+    try:
+        cached = [verify(b) for b in cases]
+        assert cached == plain
+        # with tables: two launches per box (Y and X).  Plain: a1 (first sighting of A), the wide challenge, b1 (first sighting of B) and
+        # the changed array (first sighting); a2 is the second sighting of A: built there and used from then on
+        launches = engine.pipeline_stats(reset=True)["kernel_launches"][2]
+        assert launches == 3 * 4 + 2 * (len(cases) - 4), launches
+        # B twice more: its second sighting evicts A (room for one set); A again: first sighting after the eviction is plain, then rebuilt
+        seq = [b1, b1, a1, a1, a1]
+        want = [plain[6], plain[6], plain[0], plain[0], plain[0]]
+        assert [verify(b) for b in seq] == want
+        launches = engine.pipeline_stats(reset=True)["kernel_launches"][2]
+        assert launches == 2 + 2 + 3 + 2 + 2, launches            # b1: built at its second sighting overall (the first was above)
+        # six threads, mixed boxes
+        res = [None] * 6
+
+        def work(k):
+            res[k] = [verify(cases[(k + j) % len(cases)]) for j in range(4)]
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+        [th.start() for th in ths]
+        [th.join() for th in ths]
+        for k in range(6):
+            assert res[k] == [plain[(k + j) % len(cases)] for j in range(4)], k
+        assert engine.blocks_in_flight() == (0, 0)
+    finally:
+        assert engine.set_key_cache_lru(0) == 1
+    assert verify(a1) == plain[0]
+    with pytest.raises(capi.EngineError):
+        engine.set_key_cache_lru(9)
