@@ -143,8 +143,8 @@ def horner_modmuls(positions, t):
 
 
 EC_COUNTERS_FILE = os.path.join("profiles", "r04_ec_counters.json")      # PMC evidence taken on the headline shapes (committed files;
-TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")          # the curve kernels have not changed since round 4's passes)
-for _name, _old in (("EC_COUNTERS_FILE", ("r04_", "r03_")), ("TRAFFIC_FILE", ("r05_", "r04_"))):      # (the round before's file until this round's exists)
+TRAFFIC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")          # the curve kernels have not changed since round 4's passes)
+for _name, _old in (("EC_COUNTERS_FILE", ("r04_", "r03_")), ("TRAFFIC_FILE", ("r06_", "r05_"))):      # (the round before's file until this round's exists)
     if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), globals()[_name])):
         globals()[_name] = globals()[_name].replace(*_old)
 
@@ -1794,9 +1794,44 @@ def main():
             finally:
                 eng.set_key_cache_lru(0)
             del hb_d
+            # the dealers' side of the same shape: T threads each calling the one-call mpvss_modp_deal (participant.rs:160-286: P(i), group
+            # work, transcript, challenge, responses) from host buffers; every dealer its own polynomial; the library hands each call a
+            # set of input / secret buffers from its pool
+            deal_calls = []
+            for k in range(t_best):
+                bx_k = boxes[k % len(boxes)]
+                call_k, outs_k = eng.deal_call(b"".join(fx(a) for a in bx_k.coeffs), positions, pubkeys, bx_k.wit_bytes)
+                deal_calls.append((call_k, outs_k, bx_k))
+            deal_errs = []
+
+            def deal_worker(k, reps):
+                try:
+                    for _ in range(reps):
+                        deal_calls[k][0]()
+                except BaseException as exc:      # noqa: BLE001
+                    deal_errs.append(exc)
+
+            def deal_run(reps):
+                ths = [threading.Thread(target=deal_worker, args=(k, reps)) for k in range(t_best)]
+                t_dd = time.perf_counter()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                if deal_errs:
+                    raise deal_errs[0]
+                return time.perf_counter() - t_dd
+            deal_run(1)
+            deal_dd_s = deal_run(2) / (2 * t_best)
+            for call_k, outs_k, bx_k in deal_calls:              # every caller gets ITS box: the digest of the block-form dealer's
+                got_k = outs_k()
+                assert got_k["digest"] == bx_k.dealer_digest and got_k["Y"] == bx_k.shares and got_k["challenge"] == bx_k.challenge, \
+                    "drop_in deal: a concurrent mpvss_modp_deal call returned another box"
+            del deal_calls
             result["drop_in"] = {"value": n / by_t[t_best], "threads": t_best, "value_lone": n / lone_s,
                                  "value_host_buffers": n / host_s, "value_lone_host_buffers": n / lone_host_s,
                                  "value_key_cache": n / kc_s if kc_s else None, "value_lone_key_cache": n / kc_lone_s if kc_lone_s else None,
+                                 "deal_value": n / deal_dd_s,
                                  "by_threads": {str(T): n / v for T, v in by_t.items()}, "boxes": len(seq_d), "unit": "share verifications/s",
                                  "vs_verify_many": (n / by_t[t_best]) / value,
                                  "note": "T host threads, each calling the ONE-box mpvss_modp_verify_distribution (participant.rs:399-455; what "

@@ -6,10 +6,10 @@
 //! `impl Participant<ModpGroup>` / `<Secp256k1Group>` / `<Ristretto255Group>` blocks (participant.rs:158, 1085, 1564) -- a
 //! `Participant<HipModpGroup>` of the reference has `new` / `with_arc` / `initialize` and nothing to reach its group with.  So the
 //! drop-in is this type: same fields (`privatekey`, `publickey` public), same constructors, same five methods with the same
-//! names, argument order and types (the group type aside).  A program written against the reference changes ONE `use` line and
-//! the group type -- rust/examples/mpvss_all*.rs are the reference's examples with exactly that edit.
+//! names, argument order and types (the group type aside).  A program written against the reference changes its `use` lines and
+//! the group type (the diff is in INTEGRATION.md section 1); rust/examples/roundtrip.rs runs the whole protocol through this surface.
 //! tests/test_capi_host.py holds the method names and arities of the three blocks below against a listing of the reference's
-//! (tests/golden/reference_api.json, made by tools/gen_reference_api.py in the build container).
+//! (tests/reference_api/reference_api.json, made by tools/gen_reference_api.py in the build container).
 //!
 //! Bodies are the batched calls of [`crate::batch`]: one library call per method, whatever n.  Every method may be called from
 //! many threads at once on participants that share an engine (`Group: Send + Sync`, group.rs:24): the library keeps one box per

@@ -210,7 +210,7 @@ def _rust_sources():
 
 def _reference_api():
     import json
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_api.json")) as fh:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_api", "reference_api.json")) as fh:
         return json.load(fh)
 
 
@@ -220,7 +220,7 @@ def _strip_rust_comments(text):
 
 
 def test_rust_names_only_public_paths_of_the_reference():
-    """Every `mpvss_rs::...` path rust/ uses (code, not comments) must be PUBLIC in the reference (tests/golden/reference_api.json,
+    """Every `mpvss_rs::...` path rust/ uses (code, not comments) must be PUBLIC in the reference (tests/reference_api/reference_api.json,
     made by tools/gen_reference_api.py from src/lib.rs and the files of its `pub mod`s): round 5 called `mpvss_rs::util::Util`, a
     private module (src/lib.rs:27) -- E0603, the crate would not have built."""
     import re

@@ -2,10 +2,10 @@
 """Lists what a crate OUTSIDE the reference can name and what its Participant offers: the public module paths and top-level public
 items of AlexiaChen/mpvss-rs (src/lib.rs and the files of its `pub mod`s) and, for every hand-specialised
 `impl Participant<...Group>` block of src/participant.rs, the public methods with their parameter names -- NAMES ONLY, no source
-text.  The reference does not travel to the GPU box, so the listing is committed (tests/golden/reference_api.json) and
+text.  The reference does not travel to the GPU box, so the listing is committed (tests/reference_api/reference_api.json) and
 tests/test_capi_host.py holds rust/ against it: every `mpvss_rs::` path rust/ uses must be public (round 5 used the private
 `mpvss_rs::util`), and the Participant of rust/src/participant.rs must offer the same methods with the same arity.
-Run in the build container:  python3 tools/gen_reference_api.py [/root/reference] > tests/golden/reference_api.json"""
+Run in the build container:  python3 tools/gen_reference_api.py [/root/reference] > tests/reference_api/reference_api.json"""
 import json
 import os
 import re
