@@ -1767,7 +1767,7 @@ def main():
                     raise errs[0]
                 return el
 
-            seq_d = [boxes[s % len(boxes)] for s in range(args.steps)]
+            seq_d = [boxes[s % len(boxes)] for s in range(max(2 * args.steps, 40))]      # (the K distinct boxes twice: a run of T callers ends ragged)
             pos_arr_d = (C.c_int64 * n)(*positions)
             pk_host = (C.c_uint8 * len(pubkeys)).from_buffer_copy(pubkeys)
             drop_in_run(max(dthreads) + 2, capi.MPVSS_DEVICE, seq_d[:max(dthreads) + 2], None)      # slots of the most callers, untimed

@@ -103,17 +103,23 @@ def test_the_c5_object_of_an_eight_gpu_run_in_small():
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["rccl"]["data_collectives"] >= 3 + 3
 
 
-def test_eight_ranks_at_the_real_world_size():
+@pytest.fixture(scope="module")
+def eight_rank_run():
+    """ONE eight-rank run for the two tests below: `--scaling both` (the default the driver gets at N > 1), the forced-small `c5` object."""
+    out = _run(8, 6, 2048, None, timeout=600, extra_env={"MPVSS_BENCH_C5_N": "4096", "MPVSS_BENCH_C5_T": "64", "OMP_NUM_THREADS": "2"},
+               config_boxes="3", scaling="both")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return _line(out)
+
+
+def test_eight_ranks_at_the_real_world_size(eight_rank_run):
     """The first real `--gpus 8` is the driver's: everything that depends on the WORLD SIZE rather than on the GPU count runs
     here with eight ranks on the one GPU of the test box (gloo) -- the boxes in flight per rank from bench.py's own formula
     (no MPVSS_BENCH_DEPTH), eight hash threads per rank receiving the running state by box tag from the rank before and sending
     it on, the per-box all-gather of eight ranks' flag bytes reaped in order, the verdict broadcast from the last rank, and the
     `c5` object that only an eight-rank line carries (forced small: 8 x 4096 participants, t = 64).  A clean exit with the line
     IS the parity check (bench.py aborts unless every box verifies with the dealer's digest on every rank)."""
-    out = _run(8, 6, 2048, None, timeout=600, extra_env={"MPVSS_BENCH_C5_N": "4096", "MPVSS_BENCH_C5_T": "64", "OMP_NUM_THREADS": "2"},
-               config_boxes="3")
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    _, res = _line(out)
+    _, res = eight_rank_run
     assert "secondary_error" not in res
     assert res["n_gpus"] == 8 and res["steps"] == 6 and "16384 participants in the box" in res["config"]["workload_detail"]
     assert res["rccl"]["rccl_world_size"] == 8 and res["rccl"]["data_collectives"] >= 6
@@ -124,38 +130,34 @@ def test_eight_ranks_at_the_real_world_size():
     assert res["compute"]["fd_fallbacks"] == 0
 
 
+def test_strong_scaling_the_same_box_over_one_and_eight_ranks(eight_rank_run):
+    """`--scaling both` (the default at N > 1): beside the weak figure the line carries `strong` -- the metric's FIXED box (here 2048
+    participants) split into N contiguous blocks, rank g verifying positions [g n/N, (g+1) n/N).  The box is made from one seeded list
+    of participants whatever the world size, so the digests of its K boxes must be the SAME at 8 ranks (256 shares per rank) and in the
+    one-rank run (MPVSS_BENCH_STRONG_AT_N1: the whole box on one engine): a lost or crossed running state, or a block at the wrong
+    offset, changes them.  (`--scaling strong`, which makes that figure the line's `value`, is exercised two tests below.)"""
+    compact, res = eight_rank_run
+    st = res["strong"]
+    assert st["scaling"] == "strong" and st["n_per_gpu"] == 256 and st["boxes"] == 6 and st["value"] > 0
+    assert compact["strong"]["value"] == pytest.approx(st["value"], rel=1e-5)
+    assert res["scaling"] == "weak" and res["config"]["n_per_gpu"] == 2048            # `value` is still the weak figure
+    out = _run(1, 6, 2048, 4, timeout=420, scaling="both", extra_env={"MPVSS_BENCH_STRONG_AT_N1": "1"})
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    _, one = _line(out)
+    assert one["strong"]["n_per_gpu"] == 2048 and one["strong"]["boxes"] == 6
+    assert one["strong"]["digest_of_digests"] == st["digest_of_digests"]
+
+
 def test_the_python_driven_blocks_still_agree_with_the_chained_pipeline():
     """MPVSS_BENCH_CHAINED=0 keeps round 3's N > 1 flow (blocks driven from a Python thread pool: compute / claim /
     absorb_claimed) beside the library's chained pipeline; both must verify the same boxes with the dealers' digests."""
     for mode, name in (("0", "verify_block_compute / block_claim / absorb_claimed"), ("1", "mpvss_modp_verify_many_chained")):
-        out = _run(2, 5, 4096, 4, timeout=420, extra_env={"MPVSS_BENCH_CHAINED": mode})
+        # (the chained run with `--scaling strong`: the timed region itself is the fixed 8192-share box split over the two ranks)
+        out = _run(2, 5, 4096 if mode == "0" else 8192, 4, timeout=420, extra_env={"MPVSS_BENCH_CHAINED": mode},
+                   scaling="weak" if mode == "0" else "strong")
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
         _, res = _line(out)
         assert res["host"]["pipeline"].startswith(name) and res["rccl"]["data_collectives"] >= 5 and res["value"] > 0
-
-
-def test_strong_scaling_the_same_box_over_one_two_and_eight_ranks():
-    """`--scaling both` (the default at N > 1): beside the weak figure the line carries `strong` -- the metric's FIXED box split into N
-    contiguous blocks, rank g verifying positions [g n/N, (g+1) n/N).  The box is made from one seeded list of participants whatever
-    the world size, so the digests of its K boxes must be the SAME at 8 ranks (4096 shares per rank), at 2 ranks and in the one-rank
-    run (MPVSS_BENCH_STRONG_AT_N1: the whole box on one engine): a lost or crossed running state, or a block at the wrong offset,
-    changes them.  `--scaling strong` makes that figure the line's `value` and says so in `scaling`."""
-    dig = {}
-    for ranks in (1, 2, 8):
-        out = _run(ranks, 3, 32768, 4 if ranks < 8 else None, timeout=600, scaling="both", threshold="32",
-                   extra_env={"MPVSS_BENCH_STRONG_AT_N1": "1", "OMP_NUM_THREADS": "2"})
-        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-        compact, res = _line(out)
-        assert "secondary_error" not in res
-        st = res["strong"]
-        assert st["scaling"] == "strong" and st["n_per_gpu"] == 32768 // ranks and st["boxes"] == 3 and st["value"] > 0
-        assert compact["strong"]["value"] == pytest.approx(st["value"], rel=1e-5)
-        assert res["scaling"] == "weak" and res["config"]["n_per_gpu"] == 32768          # `value` is still the weak figure
-        dig[ranks] = st["digest_of_digests"]
-        assert res["compute"]["fd_fallbacks"] == 0
-    assert dig[1] == dig[2] == dig[8], dig
-    out = _run(2, 3, 32768, 4, timeout=420, scaling="strong", threshold="32")
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    _, res = _line(out)
-    assert res["scaling"] == "strong" and res["config"]["n_per_gpu"] == 16384 and "32768 participants in the box" in res["config"]["workload_detail"]
-    assert "strong" not in res and res["value"] > 0
+        if mode == "1":
+            assert res["scaling"] == "strong" and res["config"]["n_per_gpu"] == 4096 and "strong" not in res
+            assert "8192 participants in the box" in res["config"]["workload_detail"]
