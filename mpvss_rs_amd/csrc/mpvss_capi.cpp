@@ -97,6 +97,11 @@ struct mpvss_ctx {
   // blocks, and the shared workspace of the synchronous entry points is anybody's then.  Every deal in flight borrows one set
   // from a pool (grow-only, most recently returned first), so that several host threads can deal on one context at once.
   struct DealBufs { DevBuf keys, p, w, r, pos, coef, c; void* pin = nullptr; size_t pin_cap = 0; bool in_use = false; };
+  // Pinned buffers of the one-box entry point for callers that hand over HOST memory: the caller's thread copies its inputs in here
+  // with the context lock RELEASED (48 MB at the headline shape: 2-5 ms that other callers' enqueues and absorbs no longer wait for),
+  // the block's H2D copies read it, the block's absorb gives it back.  One per call in flight, grow-only.
+  struct HostStage { void* pin = nullptr; size_t cap = 0; bool in_use = false; };
+  std::vector<HostStage*> stage_pool;
   std::vector<DealBufs*> deal_pool;
   DealBufs* deal_acquire() {
     for (size_t i = deal_pool.size(); i-- > 0;)
@@ -759,6 +764,10 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
   }
   if (ctx->scalar_stream) (void)hipStreamDestroy(ctx->scalar_stream);
   if (ctx->pair_tables) (void)hipFree(ctx->pair_tables);
+  for (mpvss_ctx::HostStage* h : ctx->stage_pool) {
+    if (h->pin) (void)hipHostFree(h->pin);
+    delete h;
+  }
   for (auto& x : ctx->kc)
     if (x.ks) {
       if (x.ks->table.p) (void)hipFree(x.ks->table.p);
@@ -1403,7 +1412,10 @@ int wellformed_bounds(mpvss_ctx* ctx, const uint8_t** out) {
 int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t,
                                 const int64_t* positions, const uint8_t* pubkeys, const uint8_t* shares,
                                 const uint8_t* responses, size_t n, const uint8_t* challenge_host,
-                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr) {
+                                const mpvss_keyset* ks = nullptr, size_t key_offset = 0, uint8_t* wf_dev_out = nullptr,
+                                const uint8_t* prestaged = nullptr) {
+  // prestaged (space == MPVSS_HOST only): PINNED memory that already holds pubkeys | shares | responses (n x 256 each) | commitments
+  // (t x 256) and stays valid until the block is absorbed: the inputs are not copied again
   if (!challenge_host) return fail(ctx, MPVSS_E_INVALID, "verify: null challenge");
   if (n > 0 && (!commitments || !positions || (!pubkeys && !ks) || !shares || !responses || t == 0 || t > 0x7fffffff ||
                 n > 0x7fffffff))
@@ -1459,7 +1471,7 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   // nothing of the caller's is referenced after this call returns.
   constexpr size_t FLAGS = 64;                 // chunks per block whose flags are kept (the rest count as held)
   const size_t out_bytes = n * EB * 4 + n * 8 + FLAGS * 4;
-  const size_t need = out_bytes + (space == MPVSS_HOST ? 3 * n * EB + t * EB : 0);
+  const size_t need = out_bytes + ((space == MPVSS_HOST && !prestaged) ? 3 * n * EB + t * EB : 0);
   if (need > sl.cap) {
     if (sl.pin) HIPCHK(ctx, hipHostFree(sl.pin));
     sl.pin = nullptr;
@@ -1474,7 +1486,13 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
   uint8_t* h2 = h1 + n * EB;
   int64_t* hpos = (int64_t*)(h2 + n * EB);
   int* hflags = (int*)((uint8_t*)sl.pin + n * EB * 4 + n * 8);
-  if (space == MPVSS_HOST) {
+  if (space == MPVSS_HOST && prestaged) {
+    memcpy(hpos, positions, n * 8);
+    if (!ks) pubkeys = prestaged;
+    shares = prestaged + n * EB;
+    responses = prestaged + 2 * n * EB;
+    commitments = prestaged + 3 * n * EB;
+  } else if (space == MPVSS_HOST) {
     uint8_t* in = (uint8_t*)sl.pin + out_bytes;
     // three arrays of n x 256 bytes (48 MB at the headline shape) into pinned memory: this thread holds the context lock, so the
     // copies run side by side on helper threads (4-5 ms -> 1.5 ms of lock-held time per box).  (The host_buffers figure of the bench
@@ -2280,21 +2298,60 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   *verdict = 0;
   uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
   mpvss_transcript_init(state);
-  // The cross-call key cache (mpvss_ctx_set_key_cache_lru): a host key array is identified by its SHA-256 (16.8 MB: 8 ms on this
-  // thread, outside the lock), looked up, and -- seen often enough -- verified against per-key tables built once.
+  // Host callers: the inputs go into a pinned buffer of the call's own with the lock RELEASED (other callers enqueue and absorb
+  // meanwhile), and -- with the cross-call key cache on (mpvss_ctx_set_key_cache_lru) -- the key array is identified beside those
+  // copies by a SHA-256 tree hash of its bytes (eight slices: 16.8 MB in 1-2 ms), looked up, and, seen often enough, verified
+  // against per-key tables built once.
+  const bool whole = n > 0 && n <= MAX_CHUNK && commitments && positions && pubkeys && shares && responses && t > 0 && t <= 0x7fffffff;
+  const bool prestage = space == MPVSS_HOST && whole && n * EB >= ((size_t)4 << 20);
+  const bool want_cache = ctx->kc_max_sets.load() > 0 && space == MPVSS_HOST && whole && n > GROUP_MAX_BOX && fits_256_bits(challenge_host);
+  mpvss_ctx::HostStage* hs = nullptr;
+  if (prestage) {
+    const size_t bytes = 3 * n * EB + t * EB;
+    for (auto* x : ctx->stage_pool)
+      if (!x->in_use && x->cap >= bytes) { hs = x; break; }
+    if (!hs) {
+      for (auto* x : ctx->stage_pool)
+        if (!x->in_use) { hs = x; break; }
+      if (!hs) {
+        hs = new (std::nothrow) mpvss_ctx::HostStage();
+        if (!hs) return fail(ctx, MPVSS_E_NOMEM, "verify_distribution: staging");
+        ctx->stage_pool.push_back(hs);
+      }
+      HIPCHK(ctx, hipSetDevice(ctx->device));
+      if (hs->pin) (void)hipHostFree(hs->pin);       // (not in use: nothing reads it)
+      hs->pin = nullptr;
+      hs->cap = 0;
+      const hipError_t e = hipHostMalloc(&hs->pin, bytes, hipHostMallocDefault);
+      if (e != hipSuccess) return fail(ctx, MPVSS_E_NOMEM, "hipHostMalloc(call staging)", e);
+      hs->cap = bytes;
+    }
+    hs->in_use = true;
+  }
+  struct StageUse {
+    mpvss_ctx::HostStage* h;
+    ~StageUse() { if (h) h->in_use = false; }             // (the context lock is held again whenever this call returns)
+  } stage_use{hs};
   const mpvss_keyset* cached = nullptr;
-  if (ctx->kc_max_sets.load() > 0 && space == MPVSS_HOST && pubkeys && n > GROUP_MAX_BOX && n <= MAX_CHUNK && fits_256_bits(challenge_host)) {
+  if (prestage || want_cache) {
     lk.unlock();
-    // (a tree hash: SHA-256 of the SHA-256s of eight slices, hashed side by side -- 16.8 MB in 1-2 ms instead of 8)
     uint8_t kd[32], leaves[8][32];
+    uint8_t* in = hs ? (uint8_t*)hs->pin : nullptr;
     const size_t bytes = n * EB, slice = (bytes + 7) / 8;
-    hsc::parallel_indices(8, [&](unsigned k) {
-      const size_t lo = std::min(bytes, (size_t)k * slice), hi = std::min(bytes, lo + slice);
-      mpvss::sha256(pubkeys + lo, hi - lo, leaves[k]);
+    hsc::parallel_indices((prestage ? 3u : 0u) + (want_cache ? 8u : 0u), [&](unsigned k) {
+      if (prestage && k < 3) {
+        if (k == 0) memcpy(in, pubkeys, bytes);
+        else if (k == 1) memcpy(in + bytes, shares, bytes);
+        else { memcpy(in + 2 * bytes, responses, bytes); memcpy(in + 3 * bytes, commitments, t * EB); }
+        return;
+      }
+      const unsigned j = k - (prestage ? 3u : 0u);
+      const size_t lo = std::min(bytes, (size_t)j * slice), hi = std::min(bytes, lo + slice);
+      mpvss::sha256(pubkeys + lo, hi - lo, leaves[j]);
     });
-    mpvss::sha256(&leaves[0][0], sizeof(leaves), kd);
+    if (want_cache) mpvss::sha256(&leaves[0][0], sizeof(leaves), kd);
     lk.lock();
-    cached = key_cache_acquire(ctx, kd, pubkeys, n);
+    if (want_cache) cached = key_cache_acquire(ctx, kd, pubkeys, n);
   }
   struct CacheUse {
     mpvss_ctx* c; const mpvss_keyset* ks;
@@ -2305,7 +2362,7 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   // with the lock released -- T callers keep T boxes in flight, which is what the library's own pipeline does for verify_many.
   RET_IF(wait_for_room(ctx, lk));
   RET_IF(verify_block_compute_locked(ctx, space, commitments, t, positions, cached ? nullptr : pubkeys, shares, responses, n,
-                                     challenge_host, cached, 0));
+                                     challenge_host, cached, 0, nullptr, hs ? (const uint8_t*)hs->pin : nullptr));
   const unsigned long long pos = ctx->own_last(1);
   RET_IF(verify_block_absorb_locked(ctx, lk, state, x_out_host, a1_out_host, a2_out_host, nullptr, &pos, true));
   return mpvss_modp_transcript_verdict(state, challenge_host, verdict, digest32_out);

@@ -113,6 +113,7 @@ void Sha256::reset() {
   static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
                                  0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
   memcpy(h, iv, sizeof(iv));
+  memset(buf, 0, sizeof(buf));      // (the 128-byte transcript state crosses the C ABI and travels rank to rank: no stack garbage in it)
   total = 0;
   fill = 0;
 }

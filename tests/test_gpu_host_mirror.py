@@ -39,3 +39,14 @@ def test_curve_group_examples_print_recovered_secret(binary, message):
         out = subprocess.run([os.path.join(ROOT, "examples", binary), seed], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr
         assert out.stdout.splitlines() == [f"secret message: {message}"] + [f"r{k} str: {message}" for k in (1, 2, 3)]
+
+
+def test_compiled_callers_one_box_per_call_on_one_context():
+    """examples/drop_in_threads.cpp: six std::threads each calling mpvss_modp_verify_distribution -- ONE box per call, the reference's
+    call shape (participant.rs:399-455) -- on one context over five dealers' boxes: every call must give verdict 1 and its dealer's
+    digest (the program exits non-zero otherwise), a tampered box is rejected.  The compiled twin of bench.py's `drop_in` leg."""
+    _build()
+    out = subprocess.run([os.path.join(ROOT, "examples", "drop_in_threads"), "4200", "16", "5", "6", "2"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.splitlines()[-1] == "ok" and "6 compiled callers" in out.stdout
