@@ -1821,24 +1821,42 @@ def main():
                 if deal_errs:
                     raise deal_errs[0]
                 return time.perf_counter() - t_dd
+            def deal_check():
+                for call_k, outs_k, bx_k in deal_calls:          # every caller gets ITS box: the digest of the block-form dealer's
+                    got_k = outs_k()
+                    assert got_k["digest"] == bx_k.dealer_digest and got_k["Y"] == bx_k.shares and got_k["challenge"] == bx_k.challenge, \
+                        "drop_in deal: a concurrent mpvss_modp_deal call returned another box"
             deal_run(1)
             deal_dd_s = deal_run(2) / (2 * t_best)
-            for call_k, outs_k, bx_k in deal_calls:              # every caller gets ITS box: the digest of the block-form dealer's
-                got_k = outs_k()
-                assert got_k["digest"] == bx_k.dealer_digest and got_k["Y"] == bx_k.shares and got_k["challenge"] == bx_k.challenge, \
-                    "drop_in deal: a concurrent mpvss_modp_deal call returned another box"
+            deal_check()
+            # ... and with the cross-call key cache on: Y_i = y_i^P(i) and a2_i = y_i^w_i from the participants' key tables
+            # (k_modp_keyset_twin_exp_pair) instead of the bucket kernels -- the same boxes, byte for byte
+            deal_kc_s = deal_kc_lone_s = None
+            try:
+                eng.set_key_cache_lru(1, 1)
+                deal_run(1)                                      # tables built inside the first call; every caller's slot warm
+                deal_kc_s = deal_run(2) / (2 * t_best)
+                deal_check()
+                t_dd = time.perf_counter()
+                for _ in range(3):
+                    deal_calls[0][0]()
+                deal_kc_lone_s = (time.perf_counter() - t_dd) / 3
+            finally:
+                eng.set_key_cache_lru(0)
             del deal_calls
             result["drop_in"] = {"value": n / by_t[t_best], "threads": t_best, "value_lone": n / lone_s,
                                  "value_host_buffers": n / host_s, "value_lone_host_buffers": n / lone_host_s,
                                  "value_key_cache": n / kc_s if kc_s else None, "value_lone_key_cache": n / kc_lone_s if kc_lone_s else None,
-                                 "deal_value": n / deal_dd_s,
+                                 "deal_value": n / deal_dd_s, "deal_value_key_cache": n / deal_kc_s if deal_kc_s else None,
+                                 "deal_value_lone_key_cache": n / deal_kc_lone_s if deal_kc_lone_s else None,
                                  "by_threads": {str(T): n / v for T, v in by_t.items()}, "boxes": len(seq_d), "unit": "share verifications/s",
                                  "vs_verify_many": (n / by_t[t_best]) / value,
                                  "note": "T host threads, each calling the ONE-box mpvss_modp_verify_distribution (participant.rs:399-455; what "
                                          "rust/src/participant.rs binds) on ONE context over the K distinct boxes of the headline run, best of two "
                                          "passes per T; `value_lone`: one caller, one box at a time (its box's latency); `value_key_cache` / `value_lone_key_cache`: host "
                                          "buffers with the cross-call key cache on (tables of the participants' keys built once, 19.3 GB; the key array "
-                                         "is hashed inside every call); not `value`"}
+                                         "is hashed inside every call); `deal_value`: T threads x the one-call mpvss_modp_deal (shares dealt/s), "
+                                         "`deal_value_key_cache` / `deal_value_lone_key_cache`: the same with the dealer's y^P(i), y^w from the key tables; not `value`"}
         # ---------------- opt-in variant: registered public keys (include/mpvss_hip.h) ----------------
         # NOT the headline: `value` above recomputes y_i^r_i from the bare keys in every step.  Here the per-key tables
         # are built once (timed separately) and the same K steps are repeated against them -- the situation of a verifier

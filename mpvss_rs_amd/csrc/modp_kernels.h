@@ -111,6 +111,9 @@ int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* e1, const u
                               uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s);
 int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupancy, int count, uint8_t* out1, uint8_t* out2,
                                const void* cs, hipStream_t s);
+/* the dealer against registered keys: out1 = y^e1, out2 = y^e2 from the key tables (full-width exponents), pair layout */
+int modp_launch_keyset_twin_exp_pair(const uint32_t* ks, const uint8_t* e1, const uint8_t* e2, int count, uint8_t* out1, uint8_t* out2,
+                                     const void* cs, const void* pair_tables, hipStream_t s);
 /* a2 = y^r Y^c against a registered key's table, pair layout (same table and program as modp_launch_keyset_dual_exp) */
 int modp_launch_keyset_dual_exp_pair(const uint32_t* ks, const uint32_t* tab2, const uint8_t* r, const uint8_t* c, int count, uint8_t* out,
                                      const void* cs, const void* pair_tables, hipStream_t s);

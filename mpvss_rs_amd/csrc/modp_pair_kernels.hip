@@ -578,6 +578,50 @@ k_modp_keyset_dual_exp_pair(const u32* __restrict__ ks, size_t key_words, const 
 }
 
 // ---------------------------------------------------------------------------------------
+// The dealer against REGISTERED keys: Y_i = y_i^P(i) and a2_i = y_i^w_i (participant.rs:219, dleq.rs:213-216) from the per-key tables of
+// k_modp_keyset_dual_exp_pair -- 252 squarings and 296 table products per exponent instead of the bucket kernels' shared 2 045 squarings
+// and 820 products for both: 115 K instead of 274 K issue slots per share.  blockIdx.y picks the exponent set; full-width exponents
+// (eight 256-bit rows, P(i) and w_i are residues mod q - 1).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
+k_modp_keyset_twin_exp_pair(const u32* __restrict__ ks, size_t key_words, const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be,
+                            int count, uint8_t* __restrict__ out1_be, uint8_t* __restrict__ out2_be,
+                            const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  const uint8_t* e_be = blockIdx.y ? e2_be : e1_be;
+  uint8_t* out_be = blockIdx.y ? out2_be : out1_be;
+  const uint8_t* e = e_be + (size_t)pc.x * 256;
+  auto digit = [&](int j, int w) -> u32 {
+    const int g = 256 * j + 7 * w, b = g >> 3;
+    const u32 lo = e[255 - b];
+    const u32 hi = (b + 1 < 256) ? e[254 - b] : 0u;
+    const int top = 256 - 7 * w;
+    return ((lo | (hi << 8)) >> (g & 7)) & (u32)((1 << (top < 7 ? top : 7)) - 1);
+  };
+  const u32* kt = ks + (size_t)pc.x * key_words;
+  u32 acc[LP];
+  load_pair_limbs(acc, cs->one_m, pl);
+  //   s = 0 squaring (bit cur), 1 .. 8 key table j = s - 1 (cur divisible by 7), 9 closing: leave the Montgomery domain
+  int cur = 7 * 36, s = 1;
+  while (true) {
+    const u32* fill = nullptr;
+    if (s >= 1 && s <= 8) fill = kt + ((size_t)(s - 1) * 128 + digit(s - 1, cur / 7)) * L;
+    else if (s == 9) fill = cs->one;
+    pair_step<true>(acc, s == 0, fill, acc, pc.slot, pc.junk, pc.tb, pl);
+    if (s == 9) break;
+    if (s == 0) {
+      if (cur % 7 == 0) s = 1; else --cur;
+    } else if (s == 8) {
+      if (cur == 0) s = 9; else { --cur; s = 0; }
+    } else {
+      ++s;
+    }
+  }
+  store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);
+}
+
+// ---------------------------------------------------------------------------------------
 // One base, two exponents (the dealer: Y_i = y_i^P(i) and a2_i = y_i^w_i, participant.rs:219, dleq.rs:213-216; the
 // participant: S_i = Y_i^(1/x_i) and a2_i = S_i^w_i, participant.rs:310-314): the right-to-left bucket phase of
 // k_modp_twin_exp_buckets (modp_kernels.hip -- same windows, same buckets and occupancy masks in HBM, the same combine kernel
@@ -978,6 +1022,14 @@ extern "C" int modp_launch_fd_step_pair_tiled_boxes(uint32_t* state, uint32_t* s
     hipLaunchKernelGGL(k_modp_fd_step_pair_tile, dim3(2 * chains * (tpad / 32), boxes), dim3(64), 0, s, state, state_back, chains, t, tpad,
                        w0, chain_len, count, x_m, hand, gate, diag, tile_steps, (const ModpConsts*)cs, (const Tables*)pair_tables, box_state,
                        box_xm, box_hand);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_keyset_twin_exp_pair(const uint32_t* ks, const uint8_t* e1, const uint8_t* e2, int count, uint8_t* out1,
+                                                uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_keyset_twin_exp_pair, dim3(pair_grid(count), 2), dim3(64 * PAIR_WAVES), 0, s, ks, modp_keyset_words_per_key(), e1,
+                     e2, count, out1, out2, (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }
 

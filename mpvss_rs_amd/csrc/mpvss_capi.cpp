@@ -2204,6 +2204,33 @@ void key_cache_release(mpvss_ctx* ctx, const mpvss_keyset* ks) {
   for (auto& x : ctx->kc)
     if (x.ks == ks && x.users > 0) { --x.users; return; }
 }
+// The identity of a host key array in the cache: SHA-256 over the SHA-256 of eight slices of its bytes (hashed side by side on helper
+// threads: 16.8 MB in 1-2 ms).  key_slice_digest is one leaf, for callers that run the leaves beside other work.
+constexpr unsigned KEY_SLICES = 8;
+void key_slice_digest(const uint8_t* pubkeys, size_t n, unsigned j, uint8_t leaf[32]) {
+  const size_t bytes = n * EB, slice = (bytes + KEY_SLICES - 1) / KEY_SLICES;
+  const size_t lo = std::min(bytes, (size_t)j * slice), hi = std::min(bytes, lo + slice);
+  mpvss::sha256(pubkeys + lo, hi - lo, leaf);
+}
+void key_array_digest(const uint8_t* pubkeys, size_t n, uint8_t out[32]) {
+  uint8_t leaves[KEY_SLICES][32];
+  hsc::parallel_indices(KEY_SLICES, [&](unsigned j) { key_slice_digest(pubkeys, n, j, leaves[j]); });
+  mpvss::sha256(&leaves[0][0], sizeof(leaves), out);
+}
+struct CacheUse {          // gives a cached key set back when the call that acquired it returns (the context lock is held again then)
+  mpvss_ctx* c; const mpvss_keyset* ks;
+  ~CacheUse() { if (ks) key_cache_release(c, ks); }
+};
+// The dealer's side of the cross-call cache (context lock held on entry and on return, released while the keys are hashed): the key
+// set for a box dealt to the n keys of this HOST array, or null -- the cache is off, the box is small, or the keys are new.
+const mpvss_keyset* dealer_key_cache(mpvss_ctx* ctx, std::unique_lock<std::mutex>& lk, const uint8_t* pubkeys_host, size_t n) {
+  if (ctx->kc_max_sets.load() <= 0 || n <= GROUP_MAX_BOX || !(pair_mask() & 1)) return nullptr;
+  uint8_t kd[32];
+  lk.unlock();
+  key_array_digest(pubkeys_host, n, kd);
+  lk.lock();
+  return key_cache_acquire(ctx, kd, pubkeys_host, n);
+}
 }  // namespace
 
 extern "C" int mpvss_ctx_set_key_cache_lru(mpvss_ctx* ctx, int max_sets, int min_sightings) {
@@ -2335,28 +2362,23 @@ extern "C" int mpvss_modp_verify_distribution(mpvss_ctx* ctx, int space, const u
   const mpvss_keyset* cached = nullptr;
   if (prestage || want_cache) {
     lk.unlock();
-    uint8_t kd[32], leaves[8][32];
+    uint8_t kd[32], leaves[KEY_SLICES][32];
     uint8_t* in = hs ? (uint8_t*)hs->pin : nullptr;
-    const size_t bytes = n * EB, slice = (bytes + 7) / 8;
-    hsc::parallel_indices((prestage ? 3u : 0u) + (want_cache ? 8u : 0u), [&](unsigned k) {
+    const size_t bytes = n * EB;
+    hsc::parallel_indices((prestage ? 3u : 0u) + (want_cache ? KEY_SLICES : 0u), [&](unsigned k) {
       if (prestage && k < 3) {
         if (k == 0) memcpy(in, pubkeys, bytes);
         else if (k == 1) memcpy(in + bytes, shares, bytes);
         else { memcpy(in + 2 * bytes, responses, bytes); memcpy(in + 3 * bytes, commitments, t * EB); }
         return;
       }
-      const unsigned j = k - (prestage ? 3u : 0u);
-      const size_t lo = std::min(bytes, (size_t)j * slice), hi = std::min(bytes, lo + slice);
-      mpvss::sha256(pubkeys + lo, hi - lo, leaves[j]);
+      key_slice_digest(pubkeys, n, k - (prestage ? 3u : 0u), leaves[k - (prestage ? 3u : 0u)]);
     });
     if (want_cache) mpvss::sha256(&leaves[0][0], sizeof(leaves), kd);
     lk.lock();
     if (want_cache) cached = key_cache_acquire(ctx, kd, pubkeys, n);
   }
-  struct CacheUse {
-    mpvss_ctx* c; const mpvss_keyset* ks;
-    ~CacheUse() { if (ks) key_cache_release(c, ks); }       // (the context lock is held again whenever this call returns)
-  } cache_use{ctx, cached};
+  CacheUse cache_use{ctx, cached};
   // Any number of host threads may be in here on one context (the crate goes parallel over dealers the same way,
   // participant.rs:490-500): each enqueues its box under the lock, owns the block by its number and absorbs exactly that one
   // with the lock released -- T callers keep T boxes in flight, which is what the library's own pipeline does for verify_many.
@@ -2956,7 +2978,16 @@ int modq_consts(mpvss_ctx* ctx);
 int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t, const int64_t* positions,
                                     const uint8_t* pubkeys, const uint8_t* p_values, const uint8_t* witnesses, size_t n,
                                     uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out,
-                                    const DealPoly* poly = nullptr) {
+                                    const DealPoly* poly = nullptr, const mpvss_keyset* ks = nullptr, size_t key_offset = 0) {
+  // ks: the participants' keys are REGISTERED (a key set of the caller's, or the context's cross-call cache): shares
+  // key_offset .. key_offset + n of the set; the keys come from its device copy and Y = y^p, a2 = y^w from its tables
+  if (ks && (key_offset > ks->n || n > ks->n - key_offset))
+    return fail(ctx, MPVSS_E_INVALID, "distribute: shares outside the registered key set");
+  int key_space = space;
+  if (ks) {
+    pubkeys = (const uint8_t*)ks->keys.p + key_offset * EB;
+    key_space = MPVSS_DEVICE;
+  }
   if (poly) {
     if (space != MPVSS_DEVICE || commitments || (!poly->coeffs_host && !poly->limbs_dev) || !poly->positions_dev || !poly->p_dev_out ||
         poly->t == 0 || poly->t > 0x7fffffff || n > MAX_CHUNK)
@@ -3045,7 +3076,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   }
   if (space == MPVSS_HOST) {
     uint8_t* in = (uint8_t*)sl.pin + out_bytes;
-    memcpy(in, pubkeys, n * EB); pubkeys = in;
+    if (!ks) { memcpy(in, pubkeys, n * EB); pubkeys = in; }
     memcpy(in + n * EB, p_values, n * EB); p_values = in + n * EB;
     memcpy(in + 2 * n * EB, witnesses, n * EB); witnesses = in + 2 * n * EB;
     if (commitments) { memcpy(in + 3 * n * EB, commitments, t * EB); commitments = in + 3 * n * EB; memcpy(hpos, positions, n * 8); }
@@ -3056,7 +3087,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   for (size_t off = 0; off < n; off += MAX_CHUNK) {
     const size_t cnt = (n - off < MAX_CHUNK) ? n - off : MAX_CHUNK;
     const void *dy, *dp, *dw;
-    RET_IF(stage_in(ctx, space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
+    RET_IF(stage_in(ctx, key_space, pubkeys + off * EB, cnt * EB, ctx->w->in_a, &dy));
     RET_IF(stage_in(ctx, space, p_values + off * EB, cnt * EB, ctx->w->in_b, &dp));
     RET_IF(stage_in(ctx, space, witnesses + off * EB, cnt * EB, ctx->w->in_c, &dw));
     RET_IF(ensure(ctx, ctx->w->xbe, cnt * EB));
@@ -3076,7 +3107,12 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
       Swap sw(ctx, ctx->w->sb);
       // y-tables once, two exponent sets: Y = y^p (participant.rs:219), a2 = y^w (dleq.rs:213-216)
       uint32_t* ty = (uint32_t*)ctx->w->tab1.p;
-      if (cnt >= 1024) {
+      if (ks && (pair_mask() & 1) && cnt >= 64) {
+        // registered keys: both powers from the per-key tables, 2 x (252 squarings + 296 products) instead of 2 045 + 820
+        const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
+        TIMED_LAUNCH(ctx, 3, modp_launch_keyset_twin_exp_pair(kt, (const uint8_t*)dp, (const uint8_t*)dw, (int)cnt, dY, da2, ctx->consts,
+                                                              ctx->pair_tables, ctx->stream));
+      } else if (cnt >= 1024) {
         // same base, two exponents: right-to-left buckets share the 2 045 squarings (tab1 holds buckets + occupancy)
         const size_t bw = modp_twin_exp_bucket_words();
         RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
@@ -3184,9 +3220,12 @@ extern "C" int mpvss_modp_distribute(mpvss_ctx* ctx, int space, const uint8_t* c
   uint8_t state[MPVSS_TRANSCRIPT_STATE_BYTES];
   mpvss_transcript_init(state);
   const bool dev = space == MPVSS_DEVICE;
+  // (cross-call key cache, host callers: dealers to the same long-lived participants find the keys' tables built)
+  const mpvss_keyset* cached = (!dev && n > 0 && n <= MAX_CHUNK) ? dealer_key_cache(ctx, lk, pubkeys, n) : nullptr;
+  CacheUse cache_use{ctx, cached};
   RET_IF(wait_for_room(ctx, lk));
   RET_IF(distribute_block_compute_locked(ctx, space, commitments, t, positions, pubkeys, p_values, witnesses, n, dev ? x_out : nullptr,
-                                         dev ? y_out : nullptr, dev ? a1_out : nullptr, dev ? a2_out : nullptr));
+                                         dev ? y_out : nullptr, dev ? a1_out : nullptr, dev ? a2_out : nullptr, nullptr, cached, 0));
   const unsigned long long pos = ctx->own_last(1);
   RET_IF(verify_block_absorb_locked(ctx, lk, state, dev ? nullptr : x_out, dev ? nullptr : a1_out, dev ? nullptr : a2_out,
                                     dev ? nullptr : y_out, &pos, true));

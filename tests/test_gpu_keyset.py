@@ -277,3 +277,67 @@ def test_key_cache_across_one_box_calls(engine):
     assert verify(a1) == plain[0]
     with pytest.raises(capi.EngineError):
         engine.set_key_cache_lru(9)
+
+
+def test_dealer_takes_key_tables_from_the_cross_call_cache(engine):
+    """mpvss_ctx_set_key_cache_lru with dealers (mpvss_modp_deal, mpvss_modp_distribute: host buffers, the crate's distribute_secret):
+    a dealer to participants whose keys have tables computes Y_i = y_i^P(i) and a2_i = y_i^w_i from them (k_modp_keyset_twin_exp_pair:
+    full-width exponents, eight 256-bit rows) -- byte-identical X, Y, a1, a2, digest, challenge and responses to the bucket kernels'
+    (cache off), at a ragged size, with edge witnesses (0, 1, q - 2, 2^2047, row boundaries); Y and a2 of those against Python integers;
+    the box verifies; four dealers at once; dealers and verifiers share one set of tables."""
+    import threading
+    n, t = 16500, 7
+    rng = random.Random(4242)
+    sc = lambda k: b"".join(rng.randrange(1, 1 << 2040).to_bytes(EB, "big") for _ in range(k))
+    pos = list(range(3, 3 + n))
+    pk = engine.batch_exp_fixed_base(fx(2), sc(n))
+    q = Q
+    edge = [0, 1, q - 2, 1 << 2047, (1 << 256) - 1, 1 << 256, (1 << 1792) - 1, (1 << 2047) + (1 << 255), 127, 128]
+    wit = bytearray(sc(n))
+    at = [0, 1, 31, 32, 63, 64, 8191, 16383, 16384, n - 1]
+    for i, w in zip(at, edge):
+        wit[i * EB:(i + 1) * EB] = w.to_bytes(EB, "big")
+    wit = bytes(wit)
+    coeffs = sc(t)
+    assert engine.set_key_cache_lru(0) == 0
+    engine.pipeline_stats(reset=True)
+    plain = engine.deal(coeffs, pos, pk, wit)
+    ms_plain = engine.pipeline_stats(reset=True)["kernel_ms"][3]
+    for i, w in zip(at, edge):
+        y = int.from_bytes(pk[i * EB:(i + 1) * EB], "big")
+        assert int.from_bytes(plain["a2"][i * EB:(i + 1) * EB], "big") == pow(y, w, q), i
+    assert engine.set_key_cache_lru(1, 1) == 0
+    try:
+        cached = engine.deal(coeffs, pos, pk, wit)             # first sighting builds the tables (min_sightings 1) and uses them
+        ms_cached = engine.pipeline_stats(reset=True)["kernel_ms"][3]
+        for k in plain:
+            assert cached[k] == plain[k], k
+        assert ms_cached < 0.8 * ms_plain, (ms_cached, ms_plain)          # 2 x 548 instead of 2 865 operations per share
+        # P(i) through the scalar ring on the host, Y against Python integers at the edge positions
+        p_values = capi.poly_eval(0, coeffs, pos)
+        for i in at:
+            y = int.from_bytes(pk[i * EB:(i + 1) * EB], "big")
+            assert int.from_bytes(cached["Y"][i * EB:(i + 1) * EB], "big") == pow(y, int.from_bytes(p_values[i * EB:(i + 1) * EB], "big"), q), i
+        cm = engine.batch_exp_fixed_base(fx(4), coeffs)
+        r = engine.verify_distribution(cm, pos, pk, cached["Y"], cached["responses"], cached["challenge"])     # (the verifier takes the tables too)
+        assert r["verdict"] and r["digest"] == plain["digest"]
+        # the one-call distribute with P(i) given
+        d = engine.distribute(cm, pos, pk, p_values, wit)
+        for k in ("X", "Y", "a1", "a2", "digest"):
+            assert d[k] == plain[k], k
+        # four dealers at once, each its own polynomial and witnesses
+        jobs = [(sc(t), sc(n)) for _ in range(4)]
+        res = [None] * 4
+
+        def work(k):
+            res[k] = engine.deal(jobs[k][0], pos, pk, jobs[k][1])
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        [th.start() for th in ths]
+        [th.join() for th in ths]
+        assert engine.blocks_in_flight() == (0, 0)
+    finally:
+        assert engine.set_key_cache_lru(0) == 1
+    for k in range(4):
+        want = engine.deal(jobs[k][0], pos, pk, jobs[k][1])
+        for f in want:
+            assert res[k][f] == want[f], (k, f)
