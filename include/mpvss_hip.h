@@ -207,7 +207,9 @@ int mpvss_modp_verify_many_chained(mpvss_ctx* ctx, int space, const mpvss_modp_b
  * (about as much work as verifying 1.5 boxes); verify_block_compute_keyset then computes a2_i = y_i^r_i * Y_i^c with
  * 613 products instead of 2 620.  Results are identical to mpvss_modp_verify_block_compute on the same keys.
  * Shares i of the call use keys key_offset + i of the set.  Destroy a key set only after the blocks using it have
- * been absorbed. */
+ * been absorbed.  The DEALER to registered keys (round 6: mpvss_modp_deal_compute_keyset, and mpvss_modp_deal / mpvss_modp_distribute
+ * through the cross-call cache below) takes Y_i = y_i^P(i) and a2_i = y_i^w_i (participant.rs:219, dleq.rs:213-216) from the same
+ * tables: 2 x 548 instead of 2 865 Montgomery operations per share, byte-identical results. */
 int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size_t n, mpvss_keyset** out);
 /* The same behind the UNCHANGED call (round 5): with min_boxes >= 2, mpvss_modp_verify_many builds the tables by itself for every
  * public-key array that at least min_boxes large boxes (more shares than the grouped small boxes have) of ONE call present -- the
@@ -225,8 +227,9 @@ int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes);
  * per 65536 keys): the least recently used set that no block in flight reads makes room; tables that do not fit beside the block
  * slots' workspaces, or whose build fails, cost speed, not the call.  Same verdicts and digests as without the cache
  * (tests/test_gpu_keyset.py).  Boxes in device memory, small boxes (n <= 16384), boxes larger than one chunk and boxes whose challenge
- * does not fit 256 bits are left alone.  0: off (the default; frees the sets no block reads).  Returns the previous max_sets, or a
- * negative error. */
+ * does not fit 256 bits are left alone.  Dealers count as well: mpvss_modp_deal and mpvss_modp_distribute (host buffers, n > 16384)
+ * look their key array up the same way, and a dealer's call is a sighting like a verifier's.  0: off (the default; frees the sets no
+ * block reads).  Returns the previous max_sets, or a negative error. */
 int mpvss_ctx_set_key_cache_lru(mpvss_ctx* ctx, int max_sets, int min_sightings);
 void mpvss_modp_keyset_destroy(mpvss_ctx* ctx, mpvss_keyset* keyset);
 size_t mpvss_modp_keyset_bytes(const mpvss_keyset* keyset);
@@ -293,14 +296,21 @@ int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_
  * witnesses, the commitments C_j = g^a_j (mpvss_modp_batch_exp_fixed_base) and U.  x_out, a1_out, a2_out, digest32_out and
  * challenge_out256 are optional; t <= n < 2^31: like the reference, the call has no size limit of its own -- a box of more than
  * 262144 shares is cut into blocks internally (one transcript; the GPU works on one block while the host hashes the one before).
- * The call keeps its inputs and intermediate secrets in buffers of its own, admits one deal at a time per context, and
- * zeroes P(i), the witnesses and the staged coefficients (device and pinned host copies) before it returns. */
+ * The call keeps its inputs and intermediate secrets in buffers of its own (a set per deal in flight from the context's pool:
+ * several host threads may deal on one context at once), and zeroes P(i), the witnesses and the staged coefficients (device and
+ * pinned host copies) before it returns. */
 int mpvss_modp_deal(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_host,
                     const uint8_t* pubkeys_host, const uint8_t* witnesses_host, size_t n, uint8_t* x_out, uint8_t* y_out,
                     uint8_t* a1_out, uint8_t* a2_out, uint8_t* digest32_out, uint8_t* challenge_out256, uint8_t* r_out);
 int mpvss_modp_deal_compute(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
                             const uint8_t* pubkeys_dev, const uint8_t* witnesses_dev, size_t n, uint8_t* p_dev_out,
                             uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out);
+/* mpvss_modp_deal_compute to REGISTERED keys: shares i of the block go to keys key_offset + i of `keyset` (mpvss_modp_keyset_create);
+ * Y_i and a2_i come from the key tables.  Same outputs as mpvss_modp_deal_compute with those keys. */
+int mpvss_modp_deal_compute_keyset(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
+                                   const mpvss_keyset* keyset, size_t key_offset, const uint8_t* witnesses_dev, size_t n,
+                                   uint8_t* p_dev_out, uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out,
+                                   uint8_t* a2_dev_out);
 
 /* ---- elliptic-curve groups --------------------------------------------------------------------
  * The same entry points for the reference's two curve groups, selected by `group`:

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "mpvss_ec_transcript_absorb", "mpvss_ec_transcript_verdict", "mpvss_ec_verify_many",
     "mpvss_modp_scalar_mul", "mpvss_modp_scalar_sub", "mpvss_ec_scalar_mul", "mpvss_ec_scalar_sub",
     "mpvss_modp_dleq_responses", "mpvss_ec_dleq_responses", "mpvss_modp_poly_eval", "mpvss_ec_poly_eval",
-    "mpvss_modp_poly_eval_device", "mpvss_modp_dleq_responses_device", "mpvss_modp_deal_compute", "mpvss_modp_deal",
+    "mpvss_modp_poly_eval_device", "mpvss_modp_dleq_responses_device", "mpvss_modp_deal_compute", "mpvss_modp_deal_compute_keyset", "mpvss_modp_deal",
     "mpvss_modp_reconstruct", "mpvss_ec_reconstruct",
     "mpvss_box_wire_size", "mpvss_box_serialize", "mpvss_box_parse", "mpvss_box_verify_wire",
     "mpvss_modp_distribute_compute", "mpvss_modp_distribute_absorb",
@@ -182,6 +182,7 @@ def load_library() -> C.CDLL:
     lib.mpvss_modp_poly_eval_device.argtypes = [vp, u8p, sz, vp, sz, vp]
     lib.mpvss_modp_dleq_responses_device.argtypes = [vp, vp, vp, u8p, sz, vp]
     lib.mpvss_modp_deal_compute.argtypes = [vp, u8p, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.mpvss_modp_deal_compute_keyset.argtypes = [vp, u8p, sz, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     lib.mpvss_modp_deal.argtypes = [vp, u8p, sz, i64p, u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.mpvss_ec_poly_eval.argtypes = [ci, u8p, sz, i64p, sz, u8p, ci]
     lib.mpvss_modp_reconstruct.argtypes = [vp, ci, i64p, u8p, sz, u8p, u8p]
@@ -423,6 +424,14 @@ class Engine:
         kc, pc = _buf(coeffs)
         self._check(self.lib.mpvss_modp_deal_compute(self.ctx, pc, len(coeffs) // EB, positions_dev_ptr, pubkeys_dev_ptr,
                                                      witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None), "deal_compute")
+
+    def deal_compute_keyset(self, coeffs: bytes, positions_dev_ptr: int, keyset, key_offset: int, witnesses_dev_ptr: int, n: int,
+                            p_dev_out_ptr: int) -> None:
+        """deal_compute to registered keys (keyset_create): Y and a2 from the key tables, same outputs"""
+        kc, pc = _buf(coeffs)
+        self._check(self.lib.mpvss_modp_deal_compute_keyset(self.ctx, pc, len(coeffs) // EB, positions_dev_ptr, keyset, key_offset,
+                                                            witnesses_dev_ptr, n, p_dev_out_ptr, None, None, None, None),
+                    "deal_compute_keyset")
 
     def deal_call(self, coeffs: bytes, positions: Sequence[int], pubkeys: bytes, witnesses: bytes):
         """(call, outputs) for mpvss_modp_deal over ctypes buffers made ONCE: `call()` is the library call alone -- what a compiled

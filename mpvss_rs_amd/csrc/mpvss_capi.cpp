@@ -3200,6 +3200,18 @@ extern "C" int mpvss_modp_deal_compute(mpvss_ctx* ctx, const uint8_t* coeffs_hos
                                          y_dev_out, a1_dev_out, a2_dev_out, &poly);
 }
 
+extern "C" int mpvss_modp_deal_compute_keyset(mpvss_ctx* ctx, const uint8_t* coeffs_host, size_t t, const int64_t* positions_dev,
+                                              const mpvss_keyset* keyset, size_t key_offset, const uint8_t* witnesses_dev, size_t n,
+                                              uint8_t* p_dev_out, uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out,
+                                              uint8_t* a2_dev_out) {
+  if (!ctx || !keyset) return MPVSS_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return fail(ctx, MPVSS_E_INVALID, "deal_compute_keyset: no shares");
+  const DealPoly poly{coeffs_host, t, positions_dev, p_dev_out};
+  return distribute_block_compute_locked(ctx, MPVSS_DEVICE, nullptr, 0, nullptr, nullptr, p_dev_out, witnesses_dev, n, x_dev_out,
+                                         y_dev_out, a1_dev_out, a2_dev_out, &poly, keyset, key_offset);
+}
+
 extern "C" int mpvss_modp_distribute_absorb(mpvss_ctx* ctx, uint8_t* state, uint8_t* x_out_host, uint8_t* y_out_host,
                                             uint8_t* a1_out_host, uint8_t* a2_out_host) {
   if (!ctx) return MPVSS_E_INVALID;

@@ -118,7 +118,8 @@ impl Engine {
 
     /// Key tables ACROSS calls for one-box callers (`Participant::verify_distribution_shares` against the same participants again
     /// and again): the engine recognises a key array by its SHA-256, builds its per-key tables at the `min_sightings`-th box and keeps
-    /// at most `max_sets` sets (19.3 GB per 65536 keys), least recently used first out.  0: off.  Returns the previous `max_sets`.
+    /// at most `max_sets` sets (19.3 GB per 65536 keys), least recently used first out.  Dealers (`Participant::distribute_secret`) to
+    /// the same participants take their Y_i = y_i^P(i) and a2_i = y_i^w_i from the same tables.  0: off.  Returns the previous `max_sets`.
     pub fn set_key_cache_lru(&self, max_sets: i32, min_sightings: i32) -> Result<i32, EngineError> {
         let rc = unsafe { ffi::mpvss_ctx_set_key_cache_lru(self.ctx.0, max_sets, min_sightings) };
         if rc < 0 {

@@ -147,6 +147,10 @@ unsafe extern "C" {
     pub fn mpvss_modp_deal_compute(ctx: *mut mpvss_ctx, coeffs_host: *const u8, t: usize, positions_dev: *const i64, pubkeys_dev: *const u8,
                                    witnesses_dev: *const u8, n: usize, p_dev_out: *mut u8, x_dev_out: *mut u8, y_dev_out: *mut u8,
                                    a1_dev_out: *mut u8, a2_dev_out: *mut u8) -> c_int;
+    pub fn mpvss_modp_deal_compute_keyset(ctx: *mut mpvss_ctx, coeffs_host: *const u8, t: usize, positions_dev: *const i64,
+                                          keyset: *const mpvss_keyset, key_offset: usize, witnesses_dev: *const u8, n: usize,
+                                          p_dev_out: *mut u8, x_dev_out: *mut u8, y_dev_out: *mut u8, a1_dev_out: *mut u8,
+                                          a2_dev_out: *mut u8) -> c_int;
     // ---- curve groups
     pub fn mpvss_ec_batch_exp(ctx: *mut mpvss_ctx, group: c_int, space: c_int, bases: *const u8, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn mpvss_ec_batch_mul(ctx: *mut mpvss_ctx, group: c_int, space: c_int, a: *const u8, b: *const u8, n: usize, out: *mut u8) -> c_int;

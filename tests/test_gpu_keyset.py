@@ -341,3 +341,40 @@ def test_dealer_takes_key_tables_from_the_cross_call_cache(engine):
         want = engine.deal(jobs[k][0], pos, pk, jobs[k][1])
         for f in want:
             assert res[k][f] == want[f], (k, f)
+
+
+@pytest.mark.parametrize("n,t,key_offset", [(8200, 9, 3), (4133, 4, 0), (48, 3, 5)])
+def test_deal_compute_keyset_equals_deal_compute(engine, n, t, key_offset):
+    """mpvss_modp_deal_compute_keyset (a dealer's block to REGISTERED keys, device buffers) == mpvss_modp_deal_compute with those keys:
+    P(i), X, Y, a1, a2 and the transcript state byte for byte -- ragged last waves, a key offset into a larger set, and 48 shares
+    (below the 64-share switch: the plain kernels with the set's device copy of the keys)."""
+    import torch
+    rng = random.Random(n * 31 + t)
+    sc = lambda k: b"".join(rng.randrange(1, 1 << 2040).to_bytes(EB, "big") for _ in range(k))
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to("cuda:0")
+    total = n + key_offset + 2
+    pk = engine.batch_exp_fixed_base(fx(2), sc(total))
+    pos = list(range(7, 7 + n))
+    coeffs, wit = sc(t), sc(n)
+    d_pos = torch.tensor(pos, dtype=torch.int64, device="cuda:0")
+    d_pk, d_w = dev(pk[key_offset * EB:(key_offset + n) * EB]), dev(wit)
+    d_p = [torch.zeros(n * EB, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    ks = engine.keyset_create(pk)
+    try:
+        torch.cuda.synchronize()
+        engine.deal_compute(coeffs, d_pos.data_ptr(), d_pk.data_ptr(), d_w.data_ptr(), n, d_p[0].data_ptr())
+        plain = engine.distribute_absorb(capi.transcript_init(), n)
+        engine.deal_compute_keyset(coeffs, d_pos.data_ptr(), ks, key_offset, d_w.data_ptr(), n, d_p[1].data_ptr())
+        keyed = engine.distribute_absorb(capi.transcript_init(), n)
+        assert keyed == plain
+        assert bytes(d_p[0].cpu().numpy().tobytes()) == bytes(d_p[1].cpu().numpy().tobytes())
+        for i in (0, n // 2, n - 1):              # Y_i = y_i^P(i), a2_i = y_i^w_i against Python integers
+            y = int.from_bytes(pk[(key_offset + i) * EB:(key_offset + i + 1) * EB], "big")
+            p_i = int.from_bytes(bytes(d_p[1][i * EB:(i + 1) * EB].cpu().numpy().tobytes()), "big")
+            assert int.from_bytes(keyed[2][i * EB:(i + 1) * EB], "big") == pow(y, p_i, Q)
+            assert int.from_bytes(keyed[4][i * EB:(i + 1) * EB], "big") == pow(y, int.from_bytes(wit[i * EB:(i + 1) * EB], "big"), Q)
+        with pytest.raises(capi.EngineError):     # shares beyond the set
+            engine.deal_compute_keyset(coeffs, d_pos.data_ptr(), ks, total - n + 1, d_w.data_ptr(), n, d_p[1].data_ptr())
+        assert engine.blocks_in_flight() == (0, 0)
+    finally:
+        engine.keyset_destroy(ks)
