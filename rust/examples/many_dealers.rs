@@ -4,7 +4,9 @@
 //! reaches with its own threads); a lone caller gets half of that, its box's latency.  This is how the crate itself goes
 //! parallel (rayon over shares, participant.rs:490-500) -- here over dealers, with plain threads to stay free of extra crates.
 //!
-//! usage: many_dealers [participants] [threshold] [dealers] [threads]
+//! usage: many_dealers [participants] [threshold] [dealers] [threads] [key cache: 0 | 1]
+//! key cache 1 (boxes of more than 16384 shares): the engine builds per-key tables for the participants' keys once and both the
+//! dealers' `distribute_secret` and the verifiers' calls take them (`Engine::set_key_cache_lru`; 295 KB of HBM per key).
 //! Never compiled in this repository's environment (no Rust toolchain).
 use std::sync::atomic::{AtomicUsize, Ordering};
 use std::sync::Arc;
@@ -19,6 +21,9 @@ fn main() {
     let arg = |i: usize, d: usize| std::env::args().nth(i).and_then(|v| v.parse().ok()).unwrap_or(d);
     let (n, t, dealers, threads) = (arg(1, 4096), arg(2, 64) as u32, arg(3, 24), arg(4, 12));
     let group = HipModpGroup::new();
+    if arg(5, 0) == 1 {
+        mpvss_hip::Engine::shared().set_key_cache_lru(1, 1).expect("key cache");
+    }
     // long-lived participant keys (batched key generation would be one call: batch_exp_fixed_base)
     let keys: Vec<_> = (0..n).map(|_| group.generate_public_key(&group.generate_private_key())).collect();
     let boxes: Vec<_> = (0..dealers)
