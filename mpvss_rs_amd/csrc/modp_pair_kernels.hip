@@ -468,6 +468,30 @@ k_modp_comb16_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// The dealer's two fixed-base powers, X_i = g^P(i) and a1_i = g^w_i (participant.rs:207-215 with C_j = g^a_j, dleq.rs:207-211), through the
+// same comb as canonical bytes: 127 products + the one that leaves the Montgomery domain; blockIdx.y picks the exponent set.  Beside
+// the key-table kernel (no chain of squarings next to it) the pair layout's 122 instead of 191 issue slots per product count.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
+k_modp_comb16_twin_exp_pair(const u32* __restrict__ comb16, const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, int count,
+                            uint8_t* __restrict__ out1_be, uint8_t* __restrict__ out2_be, const ModpConsts* __restrict__ cs,
+                            const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  const uint8_t* e = (blockIdx.y ? e2_be : e1_be) + (size_t)pc.x * 256;
+  uint8_t* out_be = blockIdx.y ? out2_be : out1_be;
+  auto digit16 = [&](int k) -> u32 { return ((u32)e[254 - 2 * k] << 8) | e[255 - 2 * k]; };
+  auto row = [&](int k) { return comb16 + (size_t)k * 65536 * L; };
+  u32 acc[LP];
+  load_pair_limbs(acc, row(0) + (size_t)digit16(0) * L, pl);
+  for (int k = 1; k <= 128; ++k) {
+    const u32* fill = k < 128 ? row(k) + (size_t)digit16(k) * L : cs->one;
+    pair_step<false>(acc, false, fill, acc, pc.slot, pc.junk, pc.tb, pl);
+  }
+  store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);
+}
+
+// ---------------------------------------------------------------------------------------
 // out[x] = p_m[x] * B2[x]^c for ONE shared exponent c given as a sliding-window schedule (mode 2 of
 // k_modp_comb_dual_exp with c_sched): a1 = g^r * X^c (dleq.rs:75-77) once X is known.  tab2: odd-power tables of X.
 // ---------------------------------------------------------------------------------------
@@ -964,6 +988,14 @@ extern "C" int modp_launch_comb16_exp_pair(const uint32_t* comb16, const uint8_t
                                            const void* pair_tables, hipStream_t s) {
   if (count <= 0) return 0;
   hipLaunchKernelGGL(k_modp_comb16_exp_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, comb16, e1, count, p_m,
+                     (const ModpConsts*)cs, (const Tables*)pair_tables);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_comb16_twin_exp_pair(const uint32_t* comb16, const uint8_t* e1, const uint8_t* e2, int count, uint8_t* out1,
+                                                uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_comb16_twin_exp_pair, dim3(pair_grid(count), 2), dim3(64 * PAIR_WAVES), 0, s, comb16, e1, e2, count, out1, out2,
                      (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }

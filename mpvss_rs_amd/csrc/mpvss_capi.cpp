@@ -3127,6 +3127,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
       }
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
     }
+    const bool keyed_combs = ks && (pair_mask() & 1) && cnt >= 64 && !commitments && comb_bits_of(ctx, cg) == 16;
     if (commitments) {
       const int64_t* dpos;
       const void* d;
@@ -3146,14 +3147,18 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
           HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         ++sl.fd_chunks;
       }
-    } else {
+    } else if (!keyed_combs) {
       // X_i = g^P(i): the dealer knows the polynomial
       TIMED_LAUNCH(ctx, 0, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dX,
                                                      comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     }
     // a1 = g^w (dleq.rs:207-211)
-    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt, da1,
-                                                   comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
+    if (keyed_combs)       // registered keys: X and a1 in one launch on the pair layout (no chain of squarings beside them)
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb16_twin_exp_pair(cg, (const uint8_t*)dp, (const uint8_t*)dw, (int)cnt, dX, da1, ctx->consts,
+                                                            ctx->pair_tables, ctx->stream));
+    else
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt, da1,
+                                                     comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
     HIPCHK(ctx, hipMemcpyAsync(hX + off * EB, dX, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hY + off * EB, dY, cnt * EB, hipMemcpyDeviceToHost, ctx->stream));
