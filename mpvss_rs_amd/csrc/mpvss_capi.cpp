@@ -3127,7 +3127,9 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
       }
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
     }
-    const bool keyed_combs = ks && (pair_mask() & 1) && cnt >= 64 && !commitments && comb_bits_of(ctx, cg) == 16;
+    // X = g^P(i) and a1 = g^w through the wide comb in ONE pair-layout launch (122 instead of 191 issue slots per product): 12 dealers
+    // to registered keys 1.75 -> 2.00 M shares dealt/s; beside the bucket kernels 1.076 -> 1.110 M (profiles/r06_dealer_comb_ab.txt)
+    const bool pair_combs = (pair_mask() & 1) && cnt >= 64 && !commitments && comb_bits_of(ctx, cg) == 16;
     if (commitments) {
       const int64_t* dpos;
       const void* d;
@@ -3147,13 +3149,13 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
           HIPCHK(ctx, hipMemcpyAsync(hflags + sl.fd_chunks, sl.work.fd_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         ++sl.fd_chunks;
       }
-    } else if (!keyed_combs) {
+    } else if (!pair_combs) {
       // X_i = g^P(i): the dealer knows the polynomial
       TIMED_LAUNCH(ctx, 0, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dX,
                                                      comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     }
     // a1 = g^w (dleq.rs:207-211)
-    if (keyed_combs)       // registered keys: X and a1 in one launch on the pair layout (no chain of squarings beside them)
+    if (pair_combs)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb16_twin_exp_pair(cg, (const uint8_t*)dp, (const uint8_t*)dw, (int)cnt, dX, da1, ctx->consts,
                                                             ctx->pair_tables, ctx->stream));
     else

@@ -303,9 +303,13 @@ def test_dealer_takes_key_tables_from_the_cross_call_cache(engine):
     engine.pipeline_stats(reset=True)
     plain = engine.deal(coeffs, pos, pk, wit)
     ms_plain = engine.pipeline_stats(reset=True)["kernel_ms"][3]
+    p_values = capi.poly_eval(0, coeffs, pos)
     for i, w in zip(at, edge):
         y = int.from_bytes(pk[i * EB:(i + 1) * EB], "big")
         assert int.from_bytes(plain["a2"][i * EB:(i + 1) * EB], "big") == pow(y, w, q), i
+        # (the comb's pair-layout twin launch: a1 = g^w with digits 0 and 0xffff, X = g^P(i))
+        assert int.from_bytes(plain["a1"][i * EB:(i + 1) * EB], "big") == pow(4, w, q), i
+        assert int.from_bytes(plain["X"][i * EB:(i + 1) * EB], "big") == pow(4, int.from_bytes(p_values[i * EB:(i + 1) * EB], "big"), q), i
     assert engine.set_key_cache_lru(1, 1) == 0
     try:
         cached = engine.deal(coeffs, pos, pk, wit)             # first sighting builds the tables (min_sightings 1) and uses them
@@ -314,7 +318,6 @@ def test_dealer_takes_key_tables_from_the_cross_call_cache(engine):
             assert cached[k] == plain[k], k
         assert ms_cached < 0.8 * ms_plain, (ms_cached, ms_plain)          # 2 x 548 instead of 2 865 operations per share
         # P(i) through the scalar ring on the host, Y against Python integers at the edge positions
-        p_values = capi.poly_eval(0, coeffs, pos)
         for i in at:
             y = int.from_bytes(pk[i * EB:(i + 1) * EB], "big")
             assert int.from_bytes(cached["Y"][i * EB:(i + 1) * EB], "big") == pow(y, int.from_bytes(p_values[i * EB:(i + 1) * EB], "big"), q), i
