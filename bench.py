@@ -1781,19 +1781,6 @@ def main():
             drop_in_run(t_best + 2, capi.MPVSS_HOST, seq_d[:t_best + 2], hb_d)                     # pinned staging of those slots, untimed
             host_s = min(drop_in_run(t_best, capi.MPVSS_HOST, seq_d, hb_d) for _ in range(2)) / len(seq_d)
             lone_host_s = drop_in_run(1, capi.MPVSS_HOST, seq_d[:4], hb_d) / 4
-            # ... and with the context's cross-call key cache on (mpvss_ctx_set_key_cache_lru): the same one-box calls, the library
-            # recognises the participants' key array by its SHA-256 (hashed inside every call) and verifies against per-key tables it
-            # built at the second box -- the tables are there when the timed calls start; opt-in, never `value`
-            kc_s = kc_lone_s = None
-            try:
-                eng.set_key_cache_lru(1, 2)
-                drop_in_run(2, capi.MPVSS_HOST, seq_d[:4], hb_d)                                # second sighting: tables built here
-                drop_in_run(t_best + 2, capi.MPVSS_HOST, seq_d[:t_best + 2], hb_d)
-                kc_s = min(drop_in_run(t_best, capi.MPVSS_HOST, seq_d, hb_d) for _ in range(2)) / len(seq_d)
-                kc_lone_s = drop_in_run(1, capi.MPVSS_HOST, seq_d[:4], hb_d) / 4
-            finally:
-                eng.set_key_cache_lru(0)
-            del hb_d
             # the dealers' side of the same shape: T threads each calling the one-call mpvss_modp_deal (participant.rs:160-286: P(i), group
             # work, transcript, challenge, responses) from host buffers; every dealer its own polynomial; the library hands each call a
             # set of input / secret buffers from its pool
@@ -1829,12 +1816,21 @@ def main():
             deal_run(1)
             deal_dd_s = deal_run(2) / (2 * t_best)
             deal_check()
-            # ... and with the cross-call key cache on: Y_i = y_i^P(i) and a2_i = y_i^w_i from the participants' key tables
-            # (k_modp_keyset_twin_exp_pair) instead of the bucket kernels -- the same boxes, byte for byte
+            # ... and with the context's cross-call key cache on (mpvss_ctx_set_key_cache_lru; ONE session for the verifiers and the
+            # dealers: the 19 GB of tables are allocated once): the same one-box calls, the library recognises the participants' key
+            # array by its SHA-256 (hashed inside every call) and verifies against per-key tables it built at the second box -- the
+            # tables are there when the timed calls start; opt-in, never `value`.  The dealers to the same keys then take
+            # Y_i = y_i^P(i) and a2_i = y_i^w_i from those tables (k_modp_keyset_twin_exp_pair) instead of the bucket kernels -- the
+            # same boxes, byte for byte
+            kc_s = kc_lone_s = None
             deal_kc_s = deal_kc_lone_s = None
             try:
-                eng.set_key_cache_lru(1, 1)
-                deal_run(1)                                      # tables built inside the first call; every caller's slot warm
+                eng.set_key_cache_lru(1, 2)
+                drop_in_run(2, capi.MPVSS_HOST, seq_d[:4], hb_d)                                # second sighting: tables built here
+                drop_in_run(t_best + 2, capi.MPVSS_HOST, seq_d[:t_best + 2], hb_d)
+                kc_s = min(drop_in_run(t_best, capi.MPVSS_HOST, seq_d, hb_d) for _ in range(2)) / len(seq_d)
+                kc_lone_s = drop_in_run(1, capi.MPVSS_HOST, seq_d[:4], hb_d) / 4
+                deal_run(1)                                      # every dealing caller's slot warm
                 deal_kc_s = deal_run(2) / (2 * t_best)
                 deal_check()
                 t_dd = time.perf_counter()
@@ -1843,7 +1839,7 @@ def main():
                 deal_kc_lone_s = (time.perf_counter() - t_dd) / 3
             finally:
                 eng.set_key_cache_lru(0)
-            del deal_calls
+            del deal_calls, hb_d
             result["drop_in"] = {"value": n / by_t[t_best], "threads": t_best, "value_lone": n / lone_s,
                                  "value_host_buffers": n / host_s, "value_lone_host_buffers": n / lone_host_s,
                                  "value_key_cache": n / kc_s if kc_s else None, "value_lone_key_cache": n / kc_lone_s if kc_lone_s else None,

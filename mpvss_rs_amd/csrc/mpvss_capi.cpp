@@ -214,6 +214,17 @@ struct mpvss_ctx {
   // a run of many boxes is under way (mpvss_*_verify_many with more than two boxes, or the caller said so through
   // MPVSS_PIPELINED=1): a block then never takes the configuration meant for a call that has the GPU to itself, not even
   // the first ones of the run
+  // The key caches' table memory outlives a key set: allocating 19 GB costs 0.5-1.1 s in a busy process (hipMalloc maps the pages;
+  // measured, MPVSS_TRACE_KEYSET) against 61 ms for building the tables of 65536 keys, so the buffer of a set the caches drop is
+  // kept for the next set they build (one buffer; freed when both caches are switched off, when the context goes, or when any
+  // workspace allocation of the context fails for lack of memory).
+  void* spare_table = nullptr;
+  size_t spare_table_cap = 0;
+  void drop_spare_table() {
+    if (spare_table) (void)hipFree(spare_table);
+    spare_table = nullptr;
+    spare_table_cap = 0;
+  }
   int key_cache_min_boxes = 0;   // mpvss_ctx_set_key_cache: verify_many registers key arrays that this many large boxes of a call share (0: off)
   // Key tables ACROSS calls (mpvss_ctx_set_key_cache_lru): the one-box entry point looks the SHA-256 of a host key array up here; an
   // array seen `kc_min_sightings` times gets its tables built once and every later box against it takes the registered-key path.
@@ -350,6 +361,11 @@ int ensure(mpvss_ctx* ctx, DevBuf& b, size_t bytes) {
     b.cap = 0;
   }
   hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess && ctx->spare_table) {      // the key caches' spare table buffer gives way to a workspace
+    (void)hipGetLastError();
+    ctx->drop_spare_table();
+    e = hipMalloc(&b.p, bytes);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();     // the runtime's last-error slot is sticky: the launchers' `return hipGetLastError()` must not see this
     b.p = nullptr;
@@ -780,6 +796,7 @@ extern "C" void mpvss_ctx_destroy(mpvss_ctx* ctx) {
     if (d->pin) (void)hipHostFree(d->pin);
     delete d;
   }
+  ctx->drop_spare_table();
   for (hipEvent_t e : ctx->main_spans.ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : ctx->slot) {
     if (sl.pin) (void)hipHostFree(sl.pin);
@@ -2120,7 +2137,23 @@ int keyset_create_locked(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size
   static const int trace_ks = fd_env("MPVSS_TRACE_KEYSET", 0);      // stderr: allocation against table build
   const auto t_k0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&ks->keys.p, n * EB);
-  if (e == hipSuccess) e = hipMalloc(&ks->table.p, n * modp_keyset_words_per_key() * 4);
+  const size_t table_bytes = n * modp_keyset_words_per_key() * 4;
+  if (e == hipSuccess) {
+    if (ctx->spare_table && ctx->spare_table_cap >= table_bytes) {      // the buffer a cache dropped a set from
+      ks->table.p = ctx->spare_table;
+      ks->table.cap = ctx->spare_table_cap;
+      ctx->spare_table = nullptr;
+      ctx->spare_table_cap = 0;
+    } else {
+      e = hipMalloc(&ks->table.p, table_bytes);
+      if (e != hipSuccess && ctx->spare_table) {
+        (void)hipGetLastError();
+        ctx->drop_spare_table();
+        e = hipMalloc(&ks->table.p, table_bytes);
+      }
+      if (e == hipSuccess) ks->table.cap = table_bytes;
+    }
+  }
   if (e != hipSuccess) return cleanup(fail(ctx, MPVSS_E_NOMEM, "keyset_create: hipMalloc", e));
   const auto t_k1 = std::chrono::steady_clock::now();
   e = hipMemcpyAsync(ks->keys.p, pubkeys, n * EB, space == MPVSS_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -2138,9 +2171,20 @@ int keyset_create_locked(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size
   return MPVSS_OK;
 }
 
-void keyset_free_locked(mpvss_ctx* ctx, mpvss_keyset* ks) {      // (no block may still read the tables: the caller's business)
+// (no block may still read the tables: the caller's business)  keep: the set belonged to one of the context's key caches and a cache
+// is still on -- its table buffer becomes the spare (the larger of the two stays)
+void keyset_free_locked(mpvss_ctx* ctx, mpvss_keyset* ks, bool keep = false) {
   (void)hipSetDevice(ctx->device);
-  if (ks->table.p) (void)hipFree(ks->table.p);
+  keep = keep && (ctx->key_cache_min_boxes > 0 || ctx->kc_max_sets.load() > 0);
+  if (ks->table.p) {
+    if (keep && ks->table.cap > ctx->spare_table_cap) {
+      ctx->drop_spare_table();
+      ctx->spare_table = ks->table.p;
+      ctx->spare_table_cap = ks->table.cap;
+    } else {
+      (void)hipFree(ks->table.p);
+    }
+  }
   if (ks->keys.p) (void)hipFree(ks->keys.p);
   delete ks;
 }
@@ -2178,7 +2222,7 @@ mpvss_keyset* key_cache_acquire(mpvss_ctx* ctx, const uint8_t digest[32], const 
       for (auto& x : ctx->kc)
         if (x.ks && x.users == 0 && (!lru || x.last_use < lru->last_use)) lru = &x;
       if (!lru) return nullptr;                     // every set is in use: this box goes the plain way
-      keyset_free_locked(ctx, lru->ks);
+      keyset_free_locked(ctx, lru->ks, true);
       lru->ks = nullptr;
       lru->sightings = 0;
       --with_tables;
@@ -2187,6 +2231,7 @@ mpvss_keyset* key_cache_acquire(mpvss_ctx* ctx, const uint8_t digest[32], const 
     size_t free_b = 0, total_b = 0;
     const size_t table_b = n * ((size_t)modp_keyset_words_per_key() * 4 + EB);
     if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    free_b += ctx->spare_table_cap;                 // (what a dropped set left behind is there to be used)
     if (free_b < table_b || free_b - table_b < ((size_t)32 << 30)) return nullptr;
     mpvss_keyset* ks = nullptr;
     if (keyset_create_locked(ctx, MPVSS_HOST, pubkeys_host, n, &ks) != MPVSS_OK) {      // costs speed, not the call
@@ -2244,6 +2289,7 @@ extern "C" int mpvss_ctx_set_key_cache_lru(mpvss_ctx* ctx, int max_sets, int min
     for (auto& x : ctx->kc)
       if (x.ks && x.users == 0) { keyset_free_locked(ctx, x.ks); x.ks = nullptr; }
     ctx->kc.erase(std::remove_if(ctx->kc.begin(), ctx->kc.end(), [](const mpvss_ctx::KeyCacheEntry& x) { return x.ks == nullptr; }), ctx->kc.end());
+    if (ctx->key_cache_min_boxes == 0) ctx->drop_spare_table();      // both caches off: the spare buffer goes too
   }
   return prev;
 }
@@ -2254,6 +2300,10 @@ extern "C" int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes) {
   if (min_boxes < 0 || min_boxes == 1) return fail(ctx, MPVSS_E_INVALID, "set_key_cache: min_boxes must be 0 (off) or >= 2");
   const int prev = ctx->key_cache_min_boxes;
   ctx->key_cache_min_boxes = min_boxes;
+  if (min_boxes == 0 && ctx->kc_max_sets.load() == 0) {
+    (void)hipSetDevice(ctx->device);
+    ctx->drop_spare_table();                                           // both caches off: the spare buffer goes too
+  }
   return prev;
 }
 
@@ -2600,7 +2650,12 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
   struct AutoKeys {
     mpvss_ctx* c;
     std::vector<mpvss_keyset*> made;
-    ~AutoKeys() { for (mpvss_keyset* k : made) mpvss_modp_keyset_destroy(c, k); }
+    ~AutoKeys() {          // (every block of the call is absorbed: nothing reads the tables) -- the buffer stays for the next call's
+      if (made.empty()) return;
+      (void)mpvss_ctx_synchronize(c);
+      std::lock_guard<std::mutex> lk(c->mu);
+      for (mpvss_keyset* k : made) keyset_free_locked(c, k, true);
+    }
   } auto_keys{ctx, {}};
   const int cache_min = [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->key_cache_min_boxes; }();
   if (cache_min >= 2) {
@@ -2617,6 +2672,7 @@ extern "C" int mpvss_modp_verify_many(mpvss_ctx* ctx, int space, const mpvss_mod
       const size_t table_b = bx.n * ((size_t)modp_keyset_words_per_key() * 4 + EB);
       const size_t reserve_b = ((size_t)3 << 30) * (size_t)std::max(1, std::min(depth, (int)mpvss_ctx::NSLOT));
       if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); continue; }
+      free_b += [&] { std::lock_guard<std::mutex> lk(ctx->mu); return ctx->spare_table_cap; }();      // what the last call's tables left behind
       if (free_b < table_b || free_b - table_b < reserve_b) continue;
       mpvss_keyset* ks = nullptr;
       if (mpvss_modp_keyset_create(ctx, space, bx.pubkeys, bx.n, &ks) != MPVSS_OK) {

@@ -112,14 +112,27 @@ def test_key_cache_behind_the_unchanged_verify_many(engine):
     tables_plain = engine.pipeline_stats(reset=True)["kernel_launches"][2]
     assert [v for v, _ in plain] == [True, False, True, True, False, True, False, True]
     assert plain[0][1] == d1["digest"] and plain[3][1] == dB["digest"] and plain[5][1] == d3["digest"]
+    import torch
+    table_b = n * 1024 * 72 * 4                       # 295 KB per key
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
     assert engine.set_key_cache(3) == 0
     try:
         cached = run()
+        launches = engine.pipeline_stats(reset=True)["kernel_launches"][2]
+        # the tables' BUFFER outlives the call (allocating it costs more than building the tables): held while the cache is on, taken by
+        # the next call's tables (no second buffer), given back when the cache is switched off
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free0 - free1 > 0.9 * table_b, (free0, free1)
+        assert run() == plain
+        free2 = torch.cuda.mem_get_info()[0]
+        assert abs(free1 - free2) < 0.2 * table_b, (free1, free2)
     finally:
         assert engine.set_key_cache(0) == 3
+    assert torch.cuda.mem_get_info()[0] - free1 > 0.8 * table_b
     assert cached == plain
     # six of the eight boxes went through the key tables: no 64-entry table of y was built for them
-    assert engine.pipeline_stats(reset=True)["kernel_launches"][2] == tables_plain - 6
+    assert launches == tables_plain - 6
     with pytest.raises(capi.EngineError):
         engine.set_key_cache(1)
 
