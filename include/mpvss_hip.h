@@ -217,6 +217,9 @@ int mpvss_modp_keyset_create(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, 
  * them when the call returns.  Building costs about one box of GPU time (60 ms per 65536 keys, 295 KB of HBM per key); a box then
  * takes 37 instead of 59 ms: it pays from the third box.  What a verifier of many dealers' boxes against the same participants
  * (src/participant.rs:399-455 with the same `publickeys` each time) gets without touching its code.  0 (the default): off.
+ * While either key cache is on the context keeps the table BUFFER of the last set it dropped (one buffer) for the next set it builds
+ * -- allocating 19 GB can cost ten times what building the tables does --; it is released when both caches are off, with the
+ * context, or as soon as a workspace allocation of the context fails for lack of memory.
  * Returns the previous setting, or a negative error. */
 int mpvss_ctx_set_key_cache(mpvss_ctx* ctx, int min_boxes);
 /* ... and ACROSS calls, for callers that verify ONE box per call (the crate's call shape, src/participant.rs:399-455) against the
