@@ -1915,7 +1915,8 @@ def main():
                     "value": n * args.steps / el_k, "value_steady_state": ks_steady, "boxes_in_flight": ks_depth,
                     "value_transparent": n * args.steps / el_t,
                     "value_transparent_is": "the same K steps through the plain mpvss_modp_verify_many call with mpvss_ctx_set_key_cache(ctx, 3): "
-                                            "the library registers the key array the boxes share by itself, inside the timed call",
+                                            "the library registers the key array the boxes share by itself and builds its tables inside the timed call "
+                                            "(in the buffer the context kept from the warm-up call's tables)",
                     "unit": "share verifications/s", "ms_per_step": el_k / args.steps * 1e3,
                     "table_bytes": table_bytes, "table_build_s": build_s, "modmul_per_share": mm_k / n,
                     "modmul_equivalents_per_s": mm_k / (el_k / args.steps),
