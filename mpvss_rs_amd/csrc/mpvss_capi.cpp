@@ -3034,7 +3034,10 @@ int modq_consts(mpvss_ctx* ctx);
 int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commitments, size_t t, const int64_t* positions,
                                     const uint8_t* pubkeys, const uint8_t* p_values, const uint8_t* witnesses, size_t n,
                                     uint8_t* x_dev_out, uint8_t* y_dev_out, uint8_t* a1_dev_out, uint8_t* a2_dev_out,
-                                    const DealPoly* poly = nullptr, const mpvss_keyset* ks = nullptr, size_t key_offset = 0) {
+                                    const DealPoly* poly = nullptr, const mpvss_keyset* ks = nullptr, size_t key_offset = 0,
+                                    hipEvent_t run_after = nullptr) {
+  // run_after: this block's GPU work starts when that event has fired (the `done` event of the block before it in a box that a lone
+  // dealer cuts into blocks: they run one after the other, each filling the chip, and block k is hashed while block k + 1 computes)
   // ks: the participants' keys are REGISTERED (a key set of the caller's, or the context's cross-call cache): shares
   // key_offset .. key_offset + n of the set; the keys come from its device copy and Y = y^p, a2 = y^w from its tables
   if (ks && (key_offset > ks->n || n > ks->n - key_offset))
@@ -3108,6 +3111,7 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
   uint8_t* h2 = h1 + n * EB;
   int64_t* hpos = (int64_t*)(h2 + n * EB);
   int* hflags = (int*)((uint8_t*)sl.pin + n * EB * 4 + n * 8);
+  if (run_after) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, run_after, 0));      // (the second stream forks from this one below)
   if (poly) {
     // P(i) mod (q-1) first, on this block's own stream: the group work below reads it in stream order (k_modq_poly_eval)
     RET_IF(modq_consts(ctx));

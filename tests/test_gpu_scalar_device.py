@@ -210,3 +210,40 @@ print("chunked deal ok")
         subprocess.check_call(["make", "-C", os.path.join(root, "mpvss_rs_amd", "csrc"), "examples", "-s"])
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "all passed" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_lone_deal_in_chained_blocks_equals_the_one_block_dealer(engine):
+    """A dealer that has the chip to itself deals a large box in blocks, block k + 1 starting on the GPU when block k is done, so that the
+    transcript of block k is hashed while block k + 1 computes (capi_scalar.inc): blocks of 65536 shares, of 32768 with the participants'
+    key tables.  131109 shares = 65536 + 65536 + 37 = 4 x 32768 + 37 (a ragged last block of less than one wave): every output, the digest,
+    the challenge and the responses equal the ONE-block dealer's (mpvss_modp_distribute with P(i) from the host's scalar ring, and the
+    responses by the host functions); the box verifies; the same with key tables (cross-call cache: blocks at key offsets 0, 32768, ...);
+    a negative position in the last block fails the call and leaves nothing in the ring."""
+    n, t = 131109, 5
+    rng = random.Random(9091)
+    sc = lambda k: b"".join(rng.randrange(1, 1 << 2040).to_bytes(EB, "big") for _ in range(k))
+    pos = list(range(2, 2 + n))
+    pk = engine.batch_exp_fixed_base(fx(2), sc(n))
+    coeffs, wit = sc(t), sc(n)
+    cm = engine.batch_exp_fixed_base(fx(4), coeffs)
+    p_values = capi.poly_eval(0, coeffs, pos)
+    assert engine.blocks_in_flight() == (0, 0)
+    one = engine.distribute(cm, pos, pk, p_values, wit)                # one block of n shares (X from the commitments)
+    got = engine.deal(coeffs, pos, pk, wit)                           # chained blocks
+    for k in ("X", "Y", "a1", "a2", "digest"):
+        assert got[k] == one[k], k
+    import hashlib
+    c = int.from_bytes(hashlib.sha256(got["digest"]).digest(), "big") % QH
+    assert got["challenge"] == fx(c)
+    assert got["responses"] == capi.dleq_responses(0, wit, p_values, fx(c))
+    r = engine.verify_distribution(cm, pos, pk, got["Y"], got["responses"], got["challenge"])
+    assert r["verdict"] and r["digest"] == got["digest"]
+    assert engine.set_key_cache_lru(1, 1) == 0
+    try:
+        keyed = engine.deal(coeffs, pos, pk, wit)
+    finally:
+        assert engine.set_key_cache_lru(0) == 1
+    assert keyed == got
+    with pytest.raises(EngineError):
+        engine.deal(coeffs, pos[:-1] + [-4], pk, wit)
+    assert engine.blocks_in_flight() == (0, 0)
