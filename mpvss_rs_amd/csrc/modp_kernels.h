@@ -111,7 +111,7 @@ int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* e1, const u
                               uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s);
 int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupancy, int count, uint8_t* out1, uint8_t* out2,
                                const void* cs, hipStream_t s);
-/* out1 = g^e1, out2 = g^e2 through the wide comb (16-bit teeth), canonical bytes, pair layout (the dealer's X and a1 beside the key tables) */
+/* out1 = g^e1, out2 = g^e2 through the wide comb (16-bit teeth), canonical bytes, pair layout (the dealer's X and a1; e2 == NULL: out1 alone) */
 int modp_launch_comb16_twin_exp_pair(const uint32_t* comb16, const uint8_t* e1, const uint8_t* e2, int count, uint8_t* out1, uint8_t* out2,
                                      const void* cs, const void* pair_tables, hipStream_t s);
 /* the dealer against registered keys: out1 = y^e1, out2 = y^e2 from the key tables (full-width exponents), pair layout */

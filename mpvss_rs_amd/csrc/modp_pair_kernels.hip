@@ -995,7 +995,8 @@ extern "C" int modp_launch_comb16_exp_pair(const uint32_t* comb16, const uint8_t
 extern "C" int modp_launch_comb16_twin_exp_pair(const uint32_t* comb16, const uint8_t* e1, const uint8_t* e2, int count, uint8_t* out1,
                                                 uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s) {
   if (count <= 0) return 0;
-  hipLaunchKernelGGL(k_modp_comb16_twin_exp_pair, dim3(pair_grid(count), 2), dim3(64 * PAIR_WAVES), 0, s, comb16, e1, e2, count, out1, out2,
+  // e2 == nullptr: one exponent set (the participant's a1 = G^w)
+  hipLaunchKernelGGL(k_modp_comb16_twin_exp_pair, dim3(pair_grid(count), e2 ? 2 : 1), dim3(64 * PAIR_WAVES), 0, s, comb16, e1, e2, count, out1, out2,
                      (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }

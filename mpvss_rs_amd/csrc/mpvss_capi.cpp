@@ -3372,8 +3372,12 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
       RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
       uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
       TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, cnt, bk, bk + cnt * bw, dS, da2));
-      TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
-                                                     da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));              // a1 = G^w
+      if ((pair_mask() & 1) && comb_bits_of(ctx, cG) == 16)                                                                // a1 = G^w
+        TIMED_LAUNCH(ctx, 1, modp_launch_comb16_twin_exp_pair(cG, (const uint8_t*)dw, nullptr, (int)cnt, da1, nullptr, ctx->consts,
+                                                              ctx->pair_tables, ctx->stream));
+      else
+        TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
+                                                       da1, comb_bits_of(ctx, cG), ctx->consts, ctx->stream));
     } else {
       RET_IF(exp_dev(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, cnt, dS));                       // S = Y^(1/x)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt,
@@ -3501,8 +3505,12 @@ int extract_shares_compute_locked(mpvss_ctx* ctx, const uint8_t* pk, const uint8
   uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
   // S = Y^(1/x) and a2 = S^w = Y^(w/x) from one chain of squarings (participant.rs:310-314, dleq.rs:213-216)
   TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, n, bk, bk + n * bw, dS, da2));
-  TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)n, da1,
-                                                 comb_bits_of(ctx, cG), ctx->consts, ctx->stream));                         // a1 = G^w
+  if ((pair_mask() & 1) && n >= 64 && comb_bits_of(ctx, cG) == 16)                                                           // a1 = G^w
+    TIMED_LAUNCH(ctx, 1, modp_launch_comb16_twin_exp_pair(cG, (const uint8_t*)dw, nullptr, (int)n, da1, nullptr, ctx->consts,
+                                                          ctx->pair_tables, ctx->stream));
+  else
+    TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)n, da1,
+                                                   comb_bits_of(ctx, cG), ctx->consts, ctx->stream));
   // c_i = hash_to_scalar(SHA256(framed(pk_i) framed(Y_i) framed(a1_i) framed(a2_i)))   (participant.rs:329-343), K7
   TIMED_LAUNCH(ctx, 0, verdict_launch_modp_challenge((const uint8_t*)dpk, (const uint8_t*)dy, da1, da2, (int)n, dc, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(hS, dS, n * EB, hipMemcpyDeviceToHost, ctx->stream));
