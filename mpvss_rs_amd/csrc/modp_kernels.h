@@ -111,6 +111,9 @@ int modp_launch_twin_exp_pair(const uint8_t* base_be, const uint8_t* e1, const u
                               uint32_t* occupancy, uint8_t* out1, uint8_t* out2, const void* cs, const void* pair_tables, hipStream_t s);
 int modp_launch_bucket_combine(const uint32_t* buckets, const uint32_t* occupancy, int count, uint8_t* out1, uint8_t* out2,
                                const void* cs, hipStream_t s);
+/* out = g^r * B2^c, c a 256-bit exponent per share (stride c_stride; 0: shared), B2's 16-entry table in tab2 (stride 16 entries), pair layout */
+int modp_launch_comb16_dual_exp_pair(const uint32_t* comb16, const uint32_t* tab2, const uint8_t* r, const uint8_t* c, size_t c_stride, int count,
+                                     uint8_t* out, const void* cs, const void* pair_tables, hipStream_t s);
 /* out1 = g^e1, out2 = g^e2 through the wide comb (16-bit teeth), canonical bytes, pair layout (the dealer's X and a1; e2 == NULL: out1 alone) */
 int modp_launch_comb16_twin_exp_pair(const uint32_t* comb16, const uint8_t* e1, const uint8_t* e2, int count, uint8_t* out1, uint8_t* out2,
                                      const void* cs, const void* pair_tables, hipStream_t s);

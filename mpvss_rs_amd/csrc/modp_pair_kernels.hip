@@ -492,6 +492,48 @@ k_modp_comb16_twin_exp_pair(const u32* __restrict__ comb16, const uint8_t* __res
 }
 
 // ---------------------------------------------------------------------------------------
+// out[x] = g^r[x] * B2[x]^c[x] with a 256-bit c of the share's own (verify_share: a1 = G^r pk^c, dleq.rs:66-77 via participant.rs:376-385):
+// B2^c by fixed 4-bit windows of the low 256 bits of c against B2's 16-entry table (252 squarings, 64 products), then the 128 comb
+// products of g^r on the same accumulator -- mode 0 of k_modp_comb_dual_exp on the pair layout (85 / 122 instead of 153 / 191 slots).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * PAIR_WAVES) PAIR_OCC_ATTR
+k_modp_comb16_dual_exp_pair(const u32* __restrict__ comb16, const u32* __restrict__ tab2, const uint8_t* __restrict__ r_be,
+                            const uint8_t* __restrict__ c_be, size_t c_stride, int count, uint8_t* __restrict__ out_be,
+                            const ModpConsts* __restrict__ cs, const Tables* __restrict__ gtab) {
+  PAIR_KERNEL_PROLOGUE(gtab, count)
+  const PairLane& pl = pc.pl;
+  const uint8_t* r = r_be + (size_t)pc.x * 256;
+  const uint8_t* c = c_be + (size_t)pc.x * c_stride;
+  const u32* t2 = tab2 + (size_t)pc.x * 16 * L;
+  auto nibble = [&](int w) -> u32 { const u32 b = c[255 - (w >> 1)]; return (w & 1) ? (b >> 4) : (b & 15); };
+  auto digit16 = [&](int k) -> u32 { return ((u32)r[254 - 2 * k] << 8) | r[255 - 2 * k]; };
+  u32 acc[LP];
+  load_pair_limbs(acc, t2 + (size_t)nibble(63) * L, pl);        // top window: load instead of multiply
+  //   s = 0 .. 3 the squarings in front of window w, 4 its product; then k = 0 .. 127 the comb rows, then the closing product
+  int w = 62, s = 0, k = -1;
+  while (true) {
+    const u32* fill = nullptr;
+    bool sq = false;
+    if (w >= 0) {
+      if (s < 4) sq = true; else fill = t2 + (size_t)nibble(w) * L;
+    } else if (k < 128) {
+      fill = comb16 + ((size_t)k * 65536 + digit16(k)) * L;
+    } else {
+      fill = cs->one;
+    }
+    pair_step<true>(acc, sq, fill, acc, pc.slot, pc.junk, pc.tb, pl);
+    if (w >= 0) {
+      if (s < 4) ++s; else { s = 0; --w; if (w < 0) k = 0; }
+    } else if (k < 128) {
+      ++k;
+    } else {
+      break;
+    }
+  }
+  store_canonical_pair(out_be + (size_t)pc.x * 256, acc, pc.slot, cs, pl, pc.live);
+}
+
+// ---------------------------------------------------------------------------------------
 // out[x] = p_m[x] * B2[x]^c for ONE shared exponent c given as a sliding-window schedule (mode 2 of
 // k_modp_comb_dual_exp with c_sched): a1 = g^r * X^c (dleq.rs:75-77) once X is known.  tab2: odd-power tables of X.
 // ---------------------------------------------------------------------------------------
@@ -997,6 +1039,14 @@ extern "C" int modp_launch_comb16_twin_exp_pair(const uint32_t* comb16, const ui
   if (count <= 0) return 0;
   // e2 == nullptr: one exponent set (the participant's a1 = G^w)
   hipLaunchKernelGGL(k_modp_comb16_twin_exp_pair, dim3(pair_grid(count), e2 ? 2 : 1), dim3(64 * PAIR_WAVES), 0, s, comb16, e1, e2, count, out1, out2,
+                     (const ModpConsts*)cs, (const Tables*)pair_tables);
+  return (int)hipGetLastError();
+}
+
+extern "C" int modp_launch_comb16_dual_exp_pair(const uint32_t* comb16, const uint32_t* tab2, const uint8_t* r, const uint8_t* c, size_t c_stride,
+                                                int count, uint8_t* out, const void* cs, const void* pair_tables, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_comb16_dual_exp_pair, dim3(pair_grid(count)), dim3(64 * PAIR_WAVES), 0, s, comb16, tab2, r, c, c_stride, count, out,
                      (const ModpConsts*)cs, (const Tables*)pair_tables);
   return (int)hipGetLastError();
 }

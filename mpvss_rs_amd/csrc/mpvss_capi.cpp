@@ -1318,6 +1318,12 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
   size_t s1 = TABW;
   RET_IF(number_tables(ctx, b2_dev, cnt, t2buf ? *t2buf : ctx->w->tab2, &t2));
   if (comb_b1) {   // B1 is a generator with a comb table: no squarings for B1^r
+    if ((pair_mask() & 1) && c_windows == 64 && cnt >= 64 && comb_bits_of(ctx, comb_b1) == 16) {
+      // (verify_share's a1 = G^r pk^c: 45 K instead of 75 K issue slots per share on the pair layout)
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb16_dual_exp_pair(comb_b1, t2, r_dev, c_dev, c_stride, (int)cnt, out_dev, ctx->consts,
+                                                            ctx->pair_tables, ctx->stream));
+      return 0;
+    }
     TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(comb_b1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt,
                                                    out_dev, comb_bits_of(ctx, comb_b1), ctx->consts, ctx->stream));
     return 0;
