@@ -1620,8 +1620,11 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       }
       // registered keys: without the chain of 2046 squarings beside them, g^r and a1 = g^r X^c pay for their layout -- both on the
       // pair layout then (measured 1.65-1.72 -> 1.80-1.86 M share verifications/s, profiles/r05_keyset_ab.txt)
-      const bool pair_gr = (pair_mask() & 4) || (use_keys && (pair_mask() & 1));
-      const bool pair_a1 = (pair_mask() & 8) || (use_keys && (pair_mask() & 1));
+      // (a box that has the chip to itself too: g^r and a1 are the END of its critical path -- 123.8 -> 121 ms per lone call; in the
+      //  pipeline the layouts measure the same, profiles/r06_pair_gr_ab.txt)
+      const bool short_tail = (use_keys || !ctx->busy_with_others()) && (pair_mask() & 1);
+      const bool pair_gr = (pair_mask() & 4) || short_tail;
+      const bool pair_a1 = (pair_mask() & 8) || short_tail;
       {
         Swap sw(ctx, ctx->w->sb);      // the box's own low-priority stream: the boxes in flight share the chip
         // the schedule travels on THIS stream, ahead of a2; the a1 launch on the other stream waits for ev_gr, recorded below
