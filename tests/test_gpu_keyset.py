@@ -351,6 +351,22 @@ def test_dealer_takes_key_tables_from_the_cross_call_cache(engine):
         [th.start() for th in ths]
         [th.join() for th in ths]
         assert engine.blocks_in_flight() == (0, 0)
+        # dealers and verifiers of the same participants at once on the one set of tables: three of each
+        mixed = [None] * 6
+
+        def mix(k):
+            if k < 3:
+                mixed[k] = engine.deal(jobs[k][0], pos, pk, jobs[k][1])
+            else:
+                mixed[k] = [engine.verify_distribution(cm, pos, pk, cached["Y"], cached["responses"], cached["challenge"]) for _ in range(2)]
+        ths = [threading.Thread(target=mix, args=(k,)) for k in range(6)]
+        [th.start() for th in ths]
+        [th.join() for th in ths]
+        assert engine.blocks_in_flight() == (0, 0)
+        for k in range(3):
+            assert mixed[k] == res[k], k
+        for k in range(3, 6):
+            assert all(v["verdict"] and v["digest"] == plain["digest"] for v in mixed[k]), k
     finally:
         assert engine.set_key_cache_lru(0) == 1
     for k in range(4):
