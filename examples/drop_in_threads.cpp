@@ -4,7 +4,9 @@
 // (rayon, src/participant.rs:490-500), here over dealers.  The C ABI directly (flat arrays, as rust/src/batch.rs::flatten makes them):
 // no maps, no Python.  bench.py's `drop_in` leg measures the same thing through ctypes threads; this program is the check that those
 // behave like compiled callers (profiles/r06_drop_in_threads_compiled.txt).
-//   build: make -C mpvss_rs_amd/csrc examples        run: ./examples/drop_in_threads [n] [t] [K boxes] [T threads] [passes]
+//   build: make -C mpvss_rs_amd/csrc examples        run: ./examples/drop_in_threads [n] [t] [K boxes] [T threads] [passes] [key cache 0|1]
+// key cache 1: the same once more with mpvss_ctx_set_key_cache_lru(ctx, 1, 2) -- the participants' key tables built once, taken by the
+// verifiers' calls AND by T concurrent dealers (mpvss_modp_deal, every dealer its own polynomial; boxes checked against the first deal).
 // Exit code 0 only if every box verified with the digest its dealer produced, from every thread, in every pass.
 #include <chrono>
 #include <cstdio>
@@ -49,6 +51,7 @@ int main(int argc, char** argv) {
   const size_t K = argc > 3 ? strtoull(argv[3], nullptr, 0) : 20;
   const unsigned T = argc > 4 ? (unsigned)strtoul(argv[4], nullptr, 0) : 12;
   const int passes = argc > 5 ? atoi(argv[5]) : 2;
+  const int key_cache = argc > 6 ? atoi(argv[6]) : 0;
   mpvss_ctx* ctx = nullptr;
   if (mpvss_ctx_create(0, &ctx) != MPVSS_OK) {
     fprintf(stderr, "no HIP device: the engine has no CPU fallback\n");
@@ -68,8 +71,11 @@ int main(int argc, char** argv) {
   }
   // K dealers: commitments C_j = g^a_j, then the whole box in one call (src/participant.rs:160-286)
   std::vector<Box> boxes(K);
+  std::vector<Bytes> all_coeffs(K), all_witnesses(K);
   for (size_t b = 0; b < K; ++b) {
     const Bytes coeffs = random_scalars(gen, t), witnesses = random_scalars(gen, n);
+    all_coeffs[b] = coeffs;
+    all_witnesses[b] = witnesses;
     Box& bx = boxes[b];
     bx.commitments.resize(t * EB);
     bx.shares.resize(n * EB);
@@ -121,6 +127,49 @@ int main(int argc, char** argv) {
   }
   printf("n=%zu t=%zu, %zu boxes: %u compiled callers, one box per call: %.1f ms per box = %.3f M share verifications/s; one caller %.1f ms = %.3f M/s\n",
          n, t, K, T, best * 1e3, (double)n / best / 1e6, lone * 1e3, (double)n / lone / 1e6);
+  // T concurrent dealers, each dealing box k % K again from its polynomial and witnesses: the same shares, digest and challenge
+  auto deal_run = [&](unsigned threads, size_t count) -> double {
+    std::vector<std::thread> pool;
+    std::vector<int> bad_deal(threads, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned k = 0; k < threads; ++k)
+      pool.emplace_back([&, k] {
+        Bytes y(n * EB), r(n * EB), ch(EB);
+        uint8_t dg[32];
+        for (size_t i = k; i < count; i += threads) {
+          const size_t b = i % K;
+          check(ctx, mpvss_modp_deal(ctx, all_coeffs[b].data(), t, positions.data(), pubkeys.data(), all_witnesses[b].data(), n, nullptr, y.data(),
+                                     nullptr, nullptr, dg, ch.data(), r.data()), "deal (threads)");
+          if (memcmp(dg, boxes[b].digest, 32) != 0 || y != boxes[b].shares || r != boxes[b].responses || ch != boxes[b].challenge) bad_deal[k] = 1;
+        }
+      });
+    for (auto& th : pool) th.join();
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int b : bad_deal)
+      if (b) {
+        fprintf(stderr, "a concurrent deal returned another box\n");
+        exit(1);
+      }
+    return s;
+  };
+  deal_run(T, T);
+  const double deal_s = deal_run(T, 2 * T) / (double)(2 * T);
+  printf("%u compiled dealers, one mpvss_modp_deal call each: %.1f ms per box = %.3f M shares dealt/s\n", T, deal_s * 1e3, (double)n / deal_s / 1e6);
+  if (key_cache) {
+    if (mpvss_ctx_set_key_cache_lru(ctx, 1, 2) < 0) check(ctx, MPVSS_E_INVALID, "set_key_cache_lru");
+    run(2, 4);                               // second sighting of the key array: its tables are built here
+    run(T + 2, T + 2);
+    double kbest = 1e30;
+    for (int p = 0; p < passes; ++p) kbest = std::min(kbest, run(T, 2 * K) / (double)(2 * K));
+    const double klone = run(1, 3) / 3;
+    deal_run(T, T);
+    const double kdeal = deal_run(T, 2 * T) / (double)(2 * T);
+    const double kdeal_lone = deal_run(1, 3) / 3;
+    printf("with the cross-call key cache: %u verifying callers %.1f ms per box = %.3f M share verifications/s (one caller %.1f ms); "
+           "%u dealers %.1f ms per box = %.3f M shares dealt/s (one dealer %.1f ms)\n",
+           T, kbest * 1e3, (double)n / kbest / 1e6, klone * 1e3, T, kdeal * 1e3, (double)n / kdeal / 1e6, kdeal_lone * 1e3);
+    (void)mpvss_ctx_set_key_cache_lru(ctx, 0, 1);
+  }
   printf("ok\n");
   mpvss_ctx_destroy(ctx);
   return 0;
