@@ -918,6 +918,9 @@ extern "C" int mpvss_modp_batch_exp(mpvss_ctx* ctx, int space, const uint8_t* ba
   return MPVSS_OK;
 }
 
+namespace {
+int pair_mask();     // which kernels take the pair layout (defined with the DLEQ launchers below)
+}
 extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const uint8_t* base_host,
                                                const uint8_t* exps, size_t n, uint8_t* out) {
   if (!ctx) return MPVSS_E_INVALID;
@@ -941,7 +944,10 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
       RET_IF(ensure(ctx, ctx->w->out1, cnt * EB));
       dout = (uint8_t*)ctx->w->out1.p;
     }
-    if (cg)
+    if (cg && (pair_mask() & 1) && cnt >= 64 && comb_bits_of(ctx, cg) == 16)      // batch keygen, commitments C_j = g^a_j: 128 products on the pair layout
+      TIMED_LAUNCH(ctx, 1, modp_launch_comb16_twin_exp_pair(cg, (const uint8_t*)de, nullptr, (int)cnt, dout, nullptr, ctx->consts,
+                                                            ctx->pair_tables, ctx->stream));
+    else if (cg)
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
                                                      dout, comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     else
