@@ -2160,12 +2160,8 @@ int keyset_create_locked(mpvss_ctx* ctx, int space, const uint8_t* pubkeys, size
       ctx->spare_table = nullptr;
       ctx->spare_table_cap = 0;
     } else {
+      ctx->drop_spare_table();                                           // (too small for this set: its memory is better free)
       e = hipMalloc(&ks->table.p, table_bytes);
-      if (e != hipSuccess && ctx->spare_table) {
-        (void)hipGetLastError();
-        ctx->drop_spare_table();
-        e = hipMalloc(&ks->table.p, table_bytes);
-      }
       if (e == hipSuccess) ks->table.cap = table_bytes;
     }
   }
