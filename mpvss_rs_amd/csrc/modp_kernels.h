@@ -144,6 +144,11 @@ int modp_launch_commit_eval_row_boxes(const uint32_t* cm, int t, const int64_t* 
                                       uint32_t* x_m, size_t box_out, const int* gate, int gate_want, const void* cs, hipStream_t s,
                                       int prio);
 /* test hook: out = a * b R^-1 (sq == 0) or a^2 R^-1 through the row-layout product, limb form in and out */
+/* out_m = B1^e1 * B2^e2 (and, with e1b, a second exponent set over the same tables behind it) in Montgomery limb form: small batches on the
+ * row layout (the latency of one number's chain); the tables and exponents of modp_launch_dual_exp */
+int modp_launch_dual_exp_row(const uint32_t* tab1, size_t tab1_stride, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
+                             const uint8_t* e2, size_t e2_stride, int e2_windows, const uint8_t* e1b, const uint8_t* e2b, int count,
+                             uint32_t* out_m, const void* cs, hipStream_t s);
 int modp_launch_row_unit(const uint32_t* a_m, const uint32_t* b_m, int count, int sq, uint32_t* out_m, const void* cs, hipStream_t s);
 /* out[i] = a[i] * b[i] mod (q-1), 256-byte big-endian each (device pointers) */
 int modq_launch_mul(const uint8_t* a_be, const uint8_t* b_be, int count, uint8_t* out_be, const void* cs_q, hipStream_t s);

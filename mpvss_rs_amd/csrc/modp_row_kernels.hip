@@ -108,6 +108,57 @@ k_modp_commit_eval_row(const u32* __restrict__ cm, int t, const int64_t* __restr
   if (live) store_lane_limbs(x_m + (size_t)x * L, acc, ln);
 }
 
+// ---------------------------------------------------------------------------------------
+// out = B1^e1 * B2^e2 for SMALL batches (the sizes of the reference's own tests and examples: a handful to a few thousand numbers):
+// the program of k_modp_dual_exp (modp_kernels.hip: 4-bit fixed windows over the numbers' 16-entry tables in HBM, 2 044 squarings + 511
+// + e2_windows products on ONE number's sequential chain) on the row layout -- a call that small is the latency of that chain, and an
+// operation of a wave that has its SIMD to itself takes 3.5 instead of 5.7 us (ModpGroup::exp, modp.rs:122-128; dleq.rs:66-84).
+// blockIdx.y = 1: a second exponent set over the same tables (the dealer's Y = y^p and a2 = y^w, participant.rs:219 / dleq.rs:213-216).
+// Output: Montgomery limb form, converted by k_modp_from_mont (one more product, the exact normalisation).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64)
+k_modp_dual_exp_row(const u32* __restrict__ tab1, size_t tab1_stride, const u32* __restrict__ tab2, size_t tab2_stride,
+                    const uint8_t* __restrict__ e1_be, const uint8_t* __restrict__ e2_be, size_t e2_stride, int e2_windows,
+                    const uint8_t* __restrict__ e1b_be, const uint8_t* __restrict__ e2b_be, int count, u32* __restrict__ out_m,
+                    const ModpConsts* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) u32 lds[NUMS_PER_WAVE * SLOT_WORDS];
+  const Lane ln = make_lane();
+  const int num = threadIdx.x >> 4;
+  const int xi = blockIdx.x * NUMS_PER_WAVE + num;
+  const bool live = xi < count;
+  const int x = live ? xi : count - 1;
+  u32* slot = lds + num * SLOT_WORDS;
+  u32 n[LPL], acc[LPL];
+  load_lane_limbs(n, cs->n, ln);
+  const u32* t1 = tab1 + (size_t)x * tab1_stride;
+  const u32* t2 = tab2 + (size_t)x * tab2_stride;
+  const uint8_t* e1 = (blockIdx.y ? e1b_be : e1_be) + (size_t)x * 256;
+  const uint8_t* e2 = (blockIdx.y ? e2b_be : e2_be) + (size_t)x * e2_stride;
+  const int first_e2 = 512 - e2_windows;
+  load_lane_limbs(acc, t1 + (size_t)(e1[0] >> 4) * L, ln);      // the first window loads tab1[d1] instead of multiplying into one
+  //   window w = 0 .. 511, most significant first; step s inside it: 0 .. 3 square, 4 tab1, 5 tab2 (the low e2_windows windows), 6 next
+  int w = 0, s = (first_e2 == 0) ? 5 : 6;
+  while (true) {
+    if (s == 6) { ++w; s = 0; }
+    if (w == 512) break;
+    const bool sq = s < 4;
+    if (sq) {
+      slot_store(slot, acc, ln);
+    } else {
+      const uint8_t* e = (s == 4) ? e1 : e2;
+      const u32 byte = e[w >> 1];
+      const u32 d = (w & 1) ? (byte & 15) : (byte >> 4);
+      slot_fill_from_global(slot, ((s == 4) ? t1 : t2) + (size_t)d * L, ln);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (sq) mont_sqr<MODP_N0INV_C>(acc, acc, slot, n, ln); else mont_mul<MODP_N0INV_C>(acc, acc, slot, n, ln);
+    __builtin_amdgcn_wave_barrier();
+    ++s;
+    if (s == 5 && w < first_e2) s = 6;
+  }
+  if (live) store_lane_limbs(out_m + ((size_t)blockIdx.y * count + x) * L, acc, ln);
+}
+
 // test hook (tests/test_gpu_row.py): out[x] = a[x] * b[x] R^-1 (sq == 0) or a[x]^2 R^-1 (sq != 0), limb form in and out
 extern "C" __global__ void __launch_bounds__(64)
 k_modp_row_unit(const u32* __restrict__ a_m, const u32* __restrict__ b_m, int count, int sq, u32* __restrict__ out_m,
@@ -127,6 +178,16 @@ k_modp_row_unit(const u32* __restrict__ a_m, const u32* __restrict__ b_m, int co
   if (sq) mont_sqr<MODP_N0INV_C>(a, a, slot, n, ln); else mont_mul<MODP_N0INV_C>(a, a, slot, n, ln);
   __builtin_amdgcn_wave_barrier();
   if (live) store_lane_limbs(out_m + (size_t)x * L, a, ln);
+}
+
+// out_m: (e1b ? 2 : 1) x count x 72 limbs, set 1 behind set 0
+extern "C" int modp_launch_dual_exp_row(const uint32_t* tab1, size_t tab1_stride, const uint32_t* tab2, size_t tab2_stride, const uint8_t* e1,
+                                        const uint8_t* e2, size_t e2_stride, int e2_windows, const uint8_t* e1b, const uint8_t* e2b, int count,
+                                        uint32_t* out_m, const void* cs, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_modp_dual_exp_row, dim3((count + NUMS_PER_WAVE - 1) / NUMS_PER_WAVE, e1b ? 2 : 1), dim3(64), 0, s, tab1, tab1_stride,
+                     tab2, tab2_stride, e1, e2, e2_stride, e2_windows, e1b, e2b, count, out_m, (const ModpConsts*)cs);
+  return (int)hipGetLastError();
 }
 
 extern "C" int modp_launch_commit_eval_row_boxes(const uint32_t* cm, int t, const int64_t* positions, size_t box_positions, int count,

@@ -121,6 +121,7 @@ struct mpvss_ctx {
     DevBuf tab3, gr_m;   // X tables of a1; gr_m: g^r_i in Montgomery form
     DevBuf verd;         // per-share verdict bytes of verify_share batches (K7)
     DevBuf csched;       // sliding-window schedule of the box's challenge
+    DevBuf row_m;        // Montgomery-form results of the row-layout kernel of small batches (dual_exp_any)
     const uint8_t* cm_bytes_dev = nullptr;   // device copy of the commitments' bytes of the current call
     struct RootJob {                         // pinned: the one real inversion of the seed phase, done by the host
       uint8_t in_be[256], out_be[256];
@@ -138,7 +139,7 @@ struct mpvss_ctx {
     std::vector<DevBuf*> all() {
       return {&in_a, &in_b, &in_c, &in_d, &in_e, &pos, &cm, &xbe, &out1, &out2, &tab1, &tab2, &tabg, &cbuf, &fd_flag,
               &fd_state, &fd_xm, &fd_xinv, &fd_pre, &fd_tot, &fd_totinv, &fd_root, &fd_hand_t, &fd_hand_s, &fd_gather, &tab3, &gr_m, &verd,
-              &csched};
+              &csched, &row_m};
     }
   };
   Work work0;
@@ -244,6 +245,9 @@ struct mpvss_ctx {
   int pipelines_running = 0;     // library box pipelines under way on this context (several host threads may each run one)
   bool pipelined_hint() const { return pipelined_env || pipelines_running > 0; }
   bool busy_with_others() const { return pipelined_hint() || NSLOT - free_top >= 2; }
+  // many blocks in flight: work counts, not the latency of one block's chains (the row layout's shorter, dearer operations lose there:
+  // 16 one-box callers of BASELINE config C2 0.50 M share verifications/s with the pair layout and forward differences, 0.45 M without)
+  bool crowded() const { return pipelined_hint() || NSLOT - free_top >= 8; }
   BlockSlot& head_slot() {
     if (ring[head % NSLOT] >= 0 || free_top == 0) return full_slot;
     return slot[free_stack[free_top - 1]];
@@ -664,13 +668,34 @@ int copy_out(mpvss_ctx* ctx, int space, void* dst, const void* dev_src, size_t b
   return 0;
 }
 
+// out = B1^e1 * B2^e2 over 16-entry window tables (k_modp_dual_exp's arguments); with e1b / outb a second exponent set over the same
+// tables.  A SMALL batch -- the sizes of the reference's own tests and examples -- is the latency of one number's chain of 2 555+
+// operations: it takes the row layout (16 lanes per number, modp_row_kernels.hip: 3.5 instead of 5.7 us per operation of a wave that has
+// its SIMD to itself; ModpGroup::exp of 16 numbers 14.5 -> 7.4 ms, profiles/r06_small_box_latency.txt) up to one wave per SIMD, larger
+// ones the quad layout's throughput.
+constexpr size_t ROW_MAX_NUMBERS = 4096;
+int dual_exp_any(mpvss_ctx* ctx, const uint32_t* t1, size_t s1, const uint32_t* t2, size_t s2, const uint8_t* e1, const uint8_t* e2,
+                 size_t e2_stride, int e2_windows, size_t cnt, uint8_t* out, const uint8_t* e1b = nullptr, const uint8_t* e2b = nullptr,
+                 uint8_t* outb = nullptr) {
+  const size_t sets = e1b ? 2 : 1;
+  if (cnt <= ROW_MAX_NUMBERS) {          // (two sets of up to 4096: two waves per SIMD, still shorter than the quad layout's chain twice)
+    RET_IF(ensure(ctx, ctx->w->row_m, sets * cnt * MODP_L * 4));
+    uint32_t* rm = (uint32_t*)ctx->w->row_m.p;
+    TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp_row(t1, s1, t2, s2, e1, e2, e2_stride, e2_windows, e1b, e2b, (int)cnt, rm, ctx->consts, ctx->stream));
+    LAUNCHCHK(ctx, modp_launch_from_mont(rm, (int)cnt, out, nullptr, ctx->consts, ctx->stream));
+    if (e1b) LAUNCHCHK(ctx, modp_launch_from_mont(rm + cnt * MODP_L, (int)cnt, outb, nullptr, ctx->consts, ctx->stream));
+    return 0;
+  }
+  TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, s1, t2, s2, e1, e2, e2_stride, e2_windows, (int)cnt, out, ctx->consts, ctx->stream));
+  if (e1b) TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, s1, t2, s2, e1b, e2b, e2_stride, e2_windows, (int)cnt, outb, ctx->consts, ctx->stream));
+  return 0;
+}
+
 // out = B^e (count numbers); bases/exps device pointers; uses tab1
 int exp_dev(mpvss_ctx* ctx, const uint8_t* bases_dev, const uint8_t* exps_dev, size_t count, uint8_t* out_dev) {
   const uint32_t* t1;
   RET_IF(number_tables(ctx, bases_dev, count, ctx->w->tab1, &t1));
-  TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, TABW, t1, TABW, exps_dev, exps_dev, EB, 0, (int)count, out_dev,
-                                            ctx->consts, ctx->stream));
-  return 0;
+  return dual_exp_any(ctx, t1, TABW, t1, TABW, exps_dev, exps_dev, EB, 0, count, out_dev);
 }
 
 }  // namespace
@@ -951,8 +976,7 @@ extern "C" int mpvss_modp_batch_exp_fixed_base(mpvss_ctx* ctx, int space, const 
       TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cg, cg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
                                                      dout, comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
     else
-      TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, (int)cnt,
-                                                dout, ctx->consts, ctx->stream));
+      RET_IF(dual_exp_any(ctx, tg, 0, tg, 0, (const uint8_t*)de, (const uint8_t*)de, EB, 0, cnt, dout));
     if (space == MPVSS_HOST) RET_IF(copy_out(ctx, space, out + off * EB, dout, cnt * EB));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -1039,8 +1063,9 @@ int pair_mask();     // which kernels take the pair layout (below)
 // X path 68.5 -> 47.7 ms at (65536, 256), profiles/r06_commit_eval_alone.txt).  NOT inside a verifier's block: there the box is
 // bound by the sum of its work, the wider layout costs 1.3x the issue slots per seed, and the call gets slower (148 against 122 ms,
 // profiles/r06_lone_box_schedule_ab.txt).
+// direct: Horner for every share whatever the positions are (a one-box call of up to ROW_MAX_NUMBERS shares, below).
 int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, size_t cnt, uint8_t* dX, size_t boxes = 1,
-           size_t box_positions = 0, bool x_alone = false) {
+           size_t box_positions = 0, bool x_alone = false, bool direct = false) {
   const int B = (int)boxes;
   // The stepping kernels on the pair layout (MPVSS_PAIR bit 5) from MPVSS_FD_PAIR_MIN_T commitments: stages of 32 levels, 122
   // instead of 191 issue slots per product, but half as many waves with longer steps.  Measured (profiles/r03_fd_pair_ab.txt):
@@ -1064,7 +1089,17 @@ int eval_x(mpvss_ctx* ctx, size_t t, const int64_t* dpos, const int64_t* hpos, s
     return modp_launch_fd_step_boxes(sf, sb, bx_st, chains, tt, w0_, clen, cnt_, xm_, bx_xm_, hand_, bx_hand_, B, (int*)ctx->w->fd_flag.p, fault,
                                      ctx->consts, ctx->stream);
   };
-  const bool fd = fd_applies(t, hpos, cnt);
+  const bool fd = !direct && fd_applies(t, hpos, cnt);
+  if (!fd && B == 1 && cnt <= ROW_MAX_NUMBERS) {
+    // a small box is the latency of one share's Horner chain ((t - 1) x about 26 operations): the row layout's kernel, 3.5 instead of
+    // 5.7 us per operation (Montgomery limbs out, converted by k_modp_from_mont)
+    RET_IF(ensure(ctx, ctx->w->fd_xm, cnt * MODP_L * 4));
+    uint32_t* xm_small = (uint32_t*)ctx->w->fd_xm.p;
+    TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval_row_boxes((const uint32_t*)ctx->w->cm.p, (int)t, dpos, 0, (int)cnt, 1, xm_small, cnt, nullptr, 0,
+                                                           ctx->consts, ctx->stream, 0));
+    LAUNCHCHK(ctx, modp_launch_from_mont(xm_small, (int)cnt, dX, nullptr, ctx->consts, ctx->stream));
+    return 0;
+  }
   if (!fd) {
     if (B > 1)
       TIMED_LAUNCH(ctx, 0, modp_launch_commit_eval_boxes((const uint32_t*)ctx->w->cm.p, (int)t, dpos, box_positions, (int)cnt, B,
@@ -1334,8 +1369,10 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
                                                    out_dev, comb_bits_of(ctx, comb_b1), ctx->consts, ctx->stream));
     return 0;
   }
-  if (!shared_b1 && c_windows == 64 && cnt >= 1024) {
+  if (!shared_b1 && c_windows == 64 && (cnt > ROW_MAX_NUMBERS || (cnt >= 1024 && ctx->crowded()))) {
     // per-share base with a full-width exponent and 256-bit second exponent(s): 6-bit windows for B1^r
+    // (up to ROW_MAX_NUMBERS shares the row layout's shorter chain wins -- 1024 shares: 23.6 -> 11.9 ms per verify call -- unless the
+    //  context is crowded)
     RET_IF(ensure(ctx, ctx->w->tab1, cnt * 4 * TABW * 4));
     TIMED_LAUNCH(ctx, 2, launch_table64(ctx, b1_dev, cnt, (uint32_t*)ctx->w->tab1.p));
     TIMED_LAUNCH(ctx, 3, launch_dual_exp_w6(ctx, (const uint32_t*)ctx->w->tab1.p, t2, r_dev, c_dev, c_stride, nullptr, cnt, out_dev));
@@ -1347,9 +1384,7 @@ int dleq_side(mpvss_ctx* ctx, const uint32_t* shared_b1, const uint8_t* b1_dev, 
   } else {
     RET_IF(number_tables(ctx, b1_dev, cnt, ctx->w->tab1, &t1));
   }
-  TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(t1, s1, t2, TABW, r_dev, c_dev, c_stride, c_windows, (int)cnt, out_dev,
-                                            ctx->consts, ctx->stream));
-  return 0;
+  return dual_exp_any(ctx, t1, s1, t2, TABW, r_dev, c_dev, c_stride, c_windows, cnt, out_dev);
 }
 }  // namespace
 
@@ -1591,7 +1626,19 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
     uint8_t* da2 = (uint8_t*)ctx->w->out2.p;
     sl.work.fd_used = false;
     const int64_t* hp = space == MPVSS_HOST ? hpos + off : nullptr;
-    if (ctx->w->sb && fd_applies(t, hp, cnt)) {
+    struct Swap {
+      mpvss_ctx* c; hipStream_t a;
+      Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
+      ~Swap() { c->stream = a; }
+    };
+    // A one-box call of up to ROW_MAX_NUMBERS shares (BASELINE config C2 and everything the reference's tests and examples use) is the
+    // latency of its chains, not work: Horner for every share ((t - 1) x 26 operations on the row layout) is shorter than the
+    // forward-difference pipeline's seeds + inversion + tables + stepping, and a2 takes the row layout too -- C2: 35.5 -> 17 ms per call.
+    // (Groups of small boxes -- mpvss_modp_verify_many -- keep the forward differences: there the work counts.  MPVSS_FD_MIN_SHARES
+    // set: the tests' way to reach the forward-difference path at small sizes, honoured.)
+    static const bool fd_min_default = getenv("MPVSS_FD_MIN_SHARES") == nullptr;
+    const bool small_direct = fd_min_default && n <= ROW_MAX_NUMBERS && !ctx->crowded();
+    if (ctx->w->sb && !small_direct && fd_applies(t, hp, cnt)) {
       // The forward-difference X path is a chain of latency-bound launches that occupy few wave slots (seeds,
       // inversion tree, difference tables, stepping) and runs on the block slot's high-priority stream.  a2 = y^r Y^c
       // and g^r do not depend on X: they run beside it on the slot's low-priority stream.
@@ -1600,11 +1647,6 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
       RET_IF(ensure(ctx, ctx->w->tab3, cnt * TABW * 4));
       RET_IF(ensure(ctx, ctx->w->gr_m, cnt * MODP_L * 4));
       const bool use_keys = ks && c_windows == 64;
-      struct Swap {
-        mpvss_ctx* c; hipStream_t a;
-        Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
-        ~Swap() { c->stream = a; }
-      };
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
       // Boxes in flight share the chip equally: eight boxes enqueued together finish together (a convoy).  What that
@@ -1699,6 +1741,21 @@ int verify_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* commit
                                                                c_windows, (int)cnt, da1, 2, (uint32_t*)ctx->w->gr_m.p,
                                                                comb_bits_of(ctx, cg), ctx->consts, ctx->stream));
       }
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
+    } else if (ctx->w->sb) {
+      // A small box, or positions that are not consecutive: a2_i = y_i^r_i * Y_i^c (dleq.rs:79-81) needs nothing of X -- it runs on
+      // the slot's second stream beside X_i (participant.rs:423-434) and a1_i = g^r_i * X_i^c (dleq.rs:75-77; X's table in tab3: a2
+      // holds tab1 and tab2).  A box of 16 shares: 20.7 -> 7.8 ms per call (profiles/r06_small_box_latency.txt).
+      HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
+      {
+        Swap sw(ctx, ctx->w->sb);
+        RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)dy, (const uint8_t*)dY, (const uint8_t*)dr, (const uint8_t*)dchal,
+                         0, c_windows, cnt, da2));
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
+      }
+      RET_IF(eval_x(ctx, t, dpos, hp, cnt, dX, 1, 0, false, small_direct));
+      RET_IF(dleq_side(ctx, nullptr, nullptr, dX, (const uint8_t*)dr, (const uint8_t*)dchal, 0, c_windows, cnt, da1, cg, &ctx->w->tab3));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
     } else {
       // X_i                                                  participant.rs:423-434
@@ -2932,9 +2989,27 @@ int verify_shares_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* pk, c
     // a1 = G^r * pk^c ; a2 = S^r * Y^c                       dleq.rs:66-84 via participant.rs:376-385
     // Only the low 256 bits of c_i enter the exponentiations: a challenge >= 2^256 can never equal the 256-bit hash,
     // and K7 gives such a share the verdict 0 whatever a1, a2 are.
-    RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64, cnt, da1, cG));
-    RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)ds, (const uint8_t*)dy, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64,
-                     cnt, da2));
+    if (ctx->w->sb && cnt <= ROW_MAX_NUMBERS) {
+      // a small batch is the latency of its longest chain: a2 (2 620 operations) on the slot's second stream beside a1 (830)
+      struct Swap {
+        mpvss_ctx* c; hipStream_t a;
+        Swap(mpvss_ctx* c_, hipStream_t s) : c(c_), a(c_->stream) { c->stream = s; }
+        ~Swap() { c->stream = a; }
+      };
+      HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->w->sb, ctx->w->ev_fork, 0));
+      {
+        Swap sw(ctx, ctx->w->sb);
+        RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)ds, (const uint8_t*)dy, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64, cnt, da2));
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
+      }
+      RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64, cnt, da1, cG, &ctx->w->tab3));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
+    } else {
+      RET_IF(dleq_side(ctx, nullptr, nullptr, (const uint8_t*)dpk, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64, cnt, da1, cG));
+      RET_IF(dleq_side(ctx, nullptr, (const uint8_t*)ds, (const uint8_t*)dy, (const uint8_t*)dr, (const uint8_t*)dc, EB, 64,
+                       cnt, da2));
+    }
     TIMED_LAUNCH(ctx, 0, verdict_launch_modp((const uint8_t*)dpk, (const uint8_t*)dy, da1, da2, (const uint8_t*)dc, (int)cnt,
                                              dv + off, ctx->stream));
     if (off + MAX_CHUNK < n) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // device buffers are reused
@@ -3183,18 +3258,17 @@ int distribute_block_compute_locked(mpvss_ctx* ctx, int space, const uint8_t* co
         const uint32_t* kt = (const uint32_t*)ks->table.p + (key_offset + off) * modp_keyset_words_per_key();
         TIMED_LAUNCH(ctx, 3, modp_launch_keyset_twin_exp_pair(kt, (const uint8_t*)dp, (const uint8_t*)dw, (int)cnt, dY, da2, ctx->consts,
                                                               ctx->pair_tables, ctx->stream));
-      } else if (cnt >= 1024) {
+      } else if (cnt > ROW_MAX_NUMBERS) {
         // same base, two exponents: right-to-left buckets share the 2 045 squarings (tab1 holds buckets + occupancy)
+        // (smaller blocks: the row-layout launch below, the latency of one chain instead of the bucket kernel's 27 ms)
         const size_t bw = modp_twin_exp_bucket_words();
         RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
         uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
         TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dp, (const uint8_t*)dw, cnt, bk, bk + cnt * bw, dY, da2));
       } else {
         TIMED_LAUNCH(ctx, 2, modp_launch_build_table((const uint8_t*)dy, (int)cnt, ty, ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, (int)cnt, dY,
-                                                  ctx->consts, ctx->stream));
-        TIMED_LAUNCH(ctx, 3, modp_launch_dual_exp(ty, TABW, ty, TABW, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt, da2,
-                                                  ctx->consts, ctx->stream));
+        // (a small box: both powers in ONE row-layout launch, side by side instead of one after the other)
+        RET_IF(dual_exp_any(ctx, ty, TABW, ty, TABW, (const uint8_t*)dp, (const uint8_t*)dp, EB, 0, cnt, dY, (const uint8_t*)dw, (const uint8_t*)dw, da2));
       }
       HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
     }

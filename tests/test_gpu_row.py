@@ -118,3 +118,65 @@ def test_row_seeds_give_the_same_x_as_the_quad_seeds_and_as_horner():
     row = _child({"CHECK_POW": "1"})
     horner = _child({"MPVSS_FD": "0"})
     assert row == horner
+
+
+def test_small_batches_through_the_row_layout_on_edge_operands(engine):
+    """Small batches (up to 4096 numbers: everything the reference's own tests and examples use) take the row-layout kernels -- the latency
+    of one number's chain: ModpGroup::exp (k_modp_dual_exp_row, modp.rs:122-128), the DLEQ verifier's commitments with per-share bases
+    and a shared or per-share challenge (dleq.rs:66-84), a fixed non-generator base (one shared table), and X_i by Horner for a small box
+    (k_modp_commit_eval_row + k_modp_from_mont, participant.rs:423-434) -- against Python integers on edge operands, at 1, 5, 4096
+    numbers (one wave per SIMD) and at 4097 (the quad layout again: the same bytes on the first 4096)."""
+    import mpvss_oracle as O
+    Q = O.ModpGroup().q
+    fx = lambda v: v.to_bytes(256, "big")
+    rng = random.Random(0x70A)
+    edge_b = [1, 2, Q - 1, Q - 2, 0, (1 << 2047) + 12345, 3, int("f0" * 256, 16) % Q]
+    edge_e = [0, 1, 2, Q - 2, 15, 16, (1 << 2047), int("ff" * 256, 16) % (Q - 1), int("0f" * 256, 16), int("f0" * 256, 16) % (Q - 1)]
+    for n in (1, 5, 4096, 4097):
+        bases = [rng.randrange(2, Q) for _ in range(n)]
+        exps = [rng.randrange(Q - 1) for _ in range(n)]
+        k = 0
+        for b in edge_b:
+            for e in edge_e:
+                if k < n:
+                    bases[k], exps[k] = b, e
+                    k += 1
+        out = engine.batch_exp(b"".join(map(fx, bases)), b"".join(map(fx, exps)))
+        sample = sorted(set(list(range(min(n, k))) + [rng.randrange(n) for _ in range(30)] + [n - 1]))
+        for i in sample:
+            assert int.from_bytes(out[i * 256:(i + 1) * 256], "big") == pow(bases[i], exps[i], Q), (n, i)
+    # the same operands through both layouts: 4097 numbers (quad) against their first 4096 (row)
+    n = 4097
+    bases = [rng.randrange(2, Q) for _ in range(n)]
+    exps = [rng.randrange(Q - 1) for _ in range(n)]
+    bb, eb = b"".join(map(fx, bases)), b"".join(map(fx, exps))
+    assert engine.batch_exp(bb, eb)[:4096 * 256] == engine.batch_exp(bb[:4096 * 256], eb[:4096 * 256])
+    # DLEQ commitments: a1 = g1^r h1^c with a non-generator g1 (one shared table, stride 0), a2 = g2^r h2^c with per-share bases;
+    # shared and per-share challenges; a challenge beyond 256 bits (512 windows)
+    n = 37
+    h1 = [rng.randrange(2, Q) for _ in range(n)]
+    g2 = [rng.randrange(2, Q) for _ in range(n)]
+    h2 = [rng.randrange(2, Q) for _ in range(n)]
+    r = [rng.randrange(Q - 1) for _ in range(n)]
+    r[0], r[1], r[2] = 0, Q - 2, 1
+    g1 = 7
+    flat = lambda xs: b"".join(map(fx, xs))
+    for cs in ([rng.randrange(1 << 256) for _ in range(n)], [rng.randrange(1 << 256)] * n, [(1 << 300) + 77] * n):
+        per = len(set(cs)) > 1
+        cs[0] = 0 if per else cs[0]
+        a1, a2 = engine.dleq_commitments(fx(g1), flat(h1), flat(g2), flat(h2), flat(r), flat(cs) if per else fx(cs[0]), per)
+        for i in range(n):
+            assert int.from_bytes(a1[i * 256:(i + 1) * 256], "big") == pow(g1, r[i], Q) * pow(h1[i], cs[i], Q) % Q, i
+            assert int.from_bytes(a2[i * 256:(i + 1) * 256], "big") == pow(g2[i], r[i], Q) * pow(h2[i], cs[i], Q) % Q, i
+    # X_i by Horner on the row layout: a box of 300 shares at scattered positions (0 and 2^40 among them), t = 9
+    t, n = 9, 300
+    cm = [pow(4, rng.randrange(1, Q - 1), Q) for _ in range(t)]
+    pos = [rng.randrange(1, 1 << 20) for _ in range(n)]
+    pos[0], pos[1], pos[2] = 0, 1 << 40, 1
+    X = engine.commit_eval(flat(cm), pos)
+    order = Q - 1
+    for i in list(range(6)) + [n - 1]:
+        want = 1
+        for j, c in enumerate(cm):
+            want = want * pow(c, pow(pos[i], j, order), Q) % Q
+        assert int.from_bytes(X[i * 256:(i + 1) * 256], "big") == want, i
