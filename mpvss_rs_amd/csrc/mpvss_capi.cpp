@@ -3437,8 +3437,10 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
     // a2 = S^w = Y^(w/x): the same base as S = Y^(1/x), so both come out of ONE chain of squarings (the bucket kernels of
     // the dealer) once the host has the second exponent  e2 = w * (1/x) mod (q-1)  -- exact for every Y that is a unit
     // mod q; a Y that is 0 mod q (not a group element) would make S = 0 and the reduced exponent matter, so such a
-    // batch takes the two dependent exponentiations.  Host buffers and at least 1024 shares (as for the dealer).
-    bool shared = space == MPVSS_HOST && cnt >= 1024;
+    // batch takes the two dependent exponentiations.  Host buffers.  Large batches: the dealer's bucket kernels; up to ROW_MAX_NUMBERS
+    // shares (the reference calls extract_secret_share for ONE participant at a time): both powers side by side in one row-layout
+    // launch over Y's window table -- the latency of one chain instead of two.
+    bool shared = space == MPVSS_HOST;
     if (shared) {
       uint8_t qb[EB];
       modq_modulus_bytes(qb);
@@ -3447,17 +3449,46 @@ extern "C" int mpvss_modp_extract_shares(mpvss_ctx* ctx, int space, const uint8_
       for (size_t i = 0; i < cnt && shared; ++i)
         shared = memcmp(hy + i * EB, zero, EB) != 0 && memcmp(hy + i * EB, qb, EB) != 0;
     }
+    bool a1_done = false;
     if (shared) {
       // e2 = w / x mod (q-1) on the device (the scalar ring's product kernel): no host threads, whatever the host has of them
       RET_IF(modq_consts(ctx));
       RET_IF(ensure(ctx, ctx->w->in_d, cnt * EB));
       uint8_t* de2 = (uint8_t*)ctx->w->in_d.p;
       LAUNCHCHK(ctx, modq_launch_mul((const uint8_t*)dw, (const uint8_t*)dxi, (int)cnt, de2, ctx->consts_q, ctx->stream));
-      const size_t bw = modp_twin_exp_bucket_words();
-      RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
-      uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
-      TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, cnt, bk, bk + cnt * bw, dS, da2));
-      if ((pair_mask() & 1) && comb_bits_of(ctx, cG) == 16)                                                                // a1 = G^w
+      if (cnt <= ROW_MAX_NUMBERS && ctx->stream_b) {
+        // (a1 = G^w, 511 comb products, on the second stream beside the two powers)
+        HIPCHK(ctx, hipEventRecord(ctx->w->ev_fork, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->w->ev_fork, 0));
+        {
+          hipStream_t main_stream = ctx->stream;
+          ctx->stream = ctx->stream_b;
+          const int rc1 = [&]() -> int {
+            TIMED_LAUNCH(ctx, 1, modp_launch_comb_dual_exp(cG, cG, 0, (const uint8_t*)dw, (const uint8_t*)dw, EB, 0, (int)cnt, da1,
+                                                           comb_bits_of(ctx, cG), ctx->consts, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->w->ev_a2, ctx->stream));
+            return 0;
+          }();
+          ctx->stream = main_stream;
+          RET_IF(rc1);
+        }
+        const uint32_t* ty;
+        RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->w->tab1, &ty));
+        RET_IF(dual_exp_any(ctx, ty, TABW, ty, TABW, (const uint8_t*)dxi, (const uint8_t*)dxi, EB, 0, cnt, dS, de2, de2, da2));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->w->ev_a2, 0));
+        a1_done = true;
+      } else if (cnt <= ROW_MAX_NUMBERS) {
+        const uint32_t* ty;
+        RET_IF(number_tables(ctx, (const uint8_t*)dy, cnt, ctx->w->tab1, &ty));
+        RET_IF(dual_exp_any(ctx, ty, TABW, ty, TABW, (const uint8_t*)dxi, (const uint8_t*)dxi, EB, 0, cnt, dS, de2, de2, da2));
+      } else {
+        const size_t bw = modp_twin_exp_bucket_words();
+        RET_IF(ensure(ctx, ctx->w->tab1, cnt * (bw + MODP_TWIN_EXTRA_WORDS) * 4 + MODP_TWIN_SLACK_BYTES));
+        uint32_t* bk = (uint32_t*)ctx->w->tab1.p;
+        TIMED_LAUNCH(ctx, 3, launch_twin_exp(ctx, (const uint8_t*)dy, (const uint8_t*)dxi, (const uint8_t*)de2, cnt, bk, bk + cnt * bw, dS, da2));
+      }
+      if (a1_done) {
+      } else if ((pair_mask() & 1) && cnt >= 64 && comb_bits_of(ctx, cG) == 16)                                            // a1 = G^w
         TIMED_LAUNCH(ctx, 1, modp_launch_comb16_twin_exp_pair(cG, (const uint8_t*)dw, nullptr, (int)cnt, da1, nullptr, ctx->consts,
                                                               ctx->pair_tables, ctx->stream));
       else
