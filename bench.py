@@ -1727,6 +1727,46 @@ def main():
                                       "boxes": args.host_boxes,
                                       "note": "same boxes, every input in pageable host memory: the library copies them into pinned "
                                               "staging and over PCIe (3 x n x 256 B per box) inside the timed calls; not `value`"}
+        # ---------------- ONE call at the reference's own sizes: latency, not throughput; never `value` ----------------
+        # BASELINE config C1 (n = 3, t = 3: examples/mpvss_all.rs) and config C2 (n = 4096, t = 64) as ONE call each from host buffers, on
+        # an idle chip, best of 5: mpvss_modp_deal (participant.rs:160-286), mpvss_modp_verify_distribution (:399-455),
+        # mpvss_modp_extract_shares (:294-353), mpvss_modp_verify_shares (:361-386); the dealer's box must verify.
+        if world == 1 and args.config_boxes != 0 and keyset[0] is None:
+            def best_ms(f, reps=5):
+                f()
+                out = []
+                for _ in range(reps):
+                    t_b = time.perf_counter()
+                    f()
+                    out.append((time.perf_counter() - t_b) * 1e3)
+                return min(out)
+
+            one_call = {}
+            rng_o = random.Random(20261004)
+            sc_o = lambda k: b"".join(fx(rng_o.randrange(1, 1 << 2040)) for _ in range(k))
+            for name_o, n_o, t_o in (("c1", 3, 3), ("c2", 4096, 64)):
+                pos_o = list(range(1, n_o + 1))
+                co_o, wi_o = sc_o(t_o), sc_o(n_o)
+                xs_o = [rng_o.randrange(3, Q - 1) | 1 for _ in range(n_o)]                      # odd and below q - 1: invertible mod q - 1
+                pk_o = eng.batch_exp_fixed_base(fx(2), b"".join(map(fx, xs_o)))
+                cm_o = eng.batch_exp_fixed_base(fx(4), co_o)
+                bx_o = eng.deal(co_o, pos_o, pk_o, wi_o)
+                res_o = eng.verify_distribution(cm_o, pos_o, pk_o, bx_o["Y"], bx_o["responses"], bx_o["challenge"])
+                assert res_o["verdict"] and res_o["digest"] == bx_o["digest"], f"one_call {name_o}: the dealer's box does not verify"
+                xi_o = b"".join(fx(pow(x, -1, Q - 1)) for x in xs_o)
+                s_o, c_o = eng.extract_shares(pk_o, bx_o["Y"], xi_o, wi_o)
+                r_o = capi.dleq_responses(0, wi_o, b"".join(map(fx, xs_o)), c_o)
+                assert all(eng.verify_shares(pk_o, s_o, bx_o["Y"], c_o, r_o)), f"one_call {name_o}: a share box does not verify"
+                one_call[name_o] = {
+                    "n": n_o, "t": t_o,
+                    "deal_ms": best_ms(lambda: eng.deal(co_o, pos_o, pk_o, wi_o)),
+                    "verify_distribution_ms": best_ms(lambda: eng.verify_distribution(cm_o, pos_o, pk_o, bx_o["Y"], bx_o["responses"], bx_o["challenge"])),
+                    "extract_shares_ms": best_ms(lambda: eng.extract_shares(pk_o, bx_o["Y"], xi_o, wi_o)),
+                    "verify_shares_ms": best_ms(lambda: eng.verify_shares(pk_o, s_o, bx_o["Y"], c_o, r_o))}
+            one_call["note"] = ("ONE call from host buffers on an idle chip, best of 5 (Python marshalling included): the sizes the reference's own "
+                                "example and BASELINE config C2 use; small batches take the row-layout kernels (16 lanes per number) -- a call is the "
+                                "latency of one 2048-bit exponentiation chain; not `value`")
+            result["one_call"] = one_call
         # ---------------- the reference's call shape: ONE box per call, T concurrent callers on one context; never `value` ----------------
         # What `rust/src/batch.rs::verify_distribution_shares` / `Participant::verify_distribution_shares` bind (participant.rs:399-455):
         # mpvss_modp_verify_distribution, one box, blocking.  T host threads each take their share of the SAME K distinct boxes of the

@@ -46,6 +46,7 @@ _PATHS = (
     ("verify_share", "value"), ("extract_shares", "value"),
     ("distribute", "value"), ("distribute", "value_end_to_end"), ("distribute", "value_one_call_host_buffers_end_to_end"),
     ("host_buffers", "value"),
+    ("one_call", "c1", "deal_ms"), ("one_call", "c1", "verify_distribution_ms"), ("one_call", "c2", "verify_distribution_ms"),
     ("drop_in", "value"), ("drop_in", "threads"), ("drop_in", "value_lone"), ("drop_in", "value_host_buffers"),
     ("drop_in", "value_key_cache"), ("drop_in", "value_lone_key_cache"), ("drop_in", "deal_value"), ("drop_in", "deal_value_key_cache"),
     ("registered_keys", "value"), ("registered_keys", "value_steady_state"), ("registered_keys", "value_transparent"), ("registered_keys", "table_bytes"), ("registered_keys", "table_build_s"),
