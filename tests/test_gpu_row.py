@@ -180,3 +180,37 @@ def test_small_batches_through_the_row_layout_on_edge_operands(engine):
         for j, c in enumerate(cm):
             want = want * pow(c, pow(pos[i], j, order), Q) % Q
         assert int.from_bytes(X[i * 256:(i + 1) * 256], "big") == want, i
+
+
+@pytest.mark.parametrize("n,t", [(4096, 64), (3000, 40), (1025, 16)])
+def test_one_box_calls_of_up_to_4096_shares_take_the_direct_path(engine, n, t):
+    """A one-box verify_distribution call of up to 4096 shares on an uncrowded context: X by Horner on the row layout, a2 by the row-layout
+    double exponentiation on the second stream, a1 behind X (BASELINE config C2 as ONE call; mpvss_capi.cpp `small_direct`).  The dealer's
+    transcript digest -- computed from X = g^P(i), a1 = g^w, a2 = y^w, i.e. by other kernels and another formula -- must come out of the
+    verifier's X_i = prod C_j^(i^j), a1 = g^r X^c, a2 = y^r Y^c for every share; a flipped response or share bit is rejected; twelve
+    callers at once (the context is crowded: forward differences and the pair layout again) get the same verdicts and digests."""
+    import threading
+    EB = 256
+    fx = lambda v: v.to_bytes(EB, "big")
+    rng = random.Random(n * 7 + t)
+    sc = lambda k: b"".join(fx(rng.randrange(1, 1 << 2040)) for _ in range(k))
+    pos = list(range(1, n + 1))
+    coeffs, wit = sc(t), sc(n)
+    pk = engine.batch_exp_fixed_base(fx(2), sc(n))
+    cm = engine.batch_exp_fixed_base(fx(4), coeffs)
+    box = engine.deal(coeffs, pos, pk, wit)
+    ok = engine.verify_distribution(cm, pos, pk, box["Y"], box["responses"], box["challenge"], dump=True)
+    assert ok["verdict"] and ok["digest"] == box["digest"]
+    assert ok["X"] == box["X"]                      # the verifier's Horner against the dealer's comb
+    flip = lambda b, at: b[:at] + bytes([b[at] ^ 1]) + b[at + 1:]
+    assert not engine.verify_distribution(cm, pos, pk, box["Y"], flip(box["responses"], (n - 1) * EB + 255), box["challenge"])["verdict"]
+    assert not engine.verify_distribution(cm, pos, pk, flip(box["Y"], 7 * EB + 100), box["responses"], box["challenge"])["verdict"]
+    res = [None] * 12
+
+    def work(k):
+        res[k] = [engine.verify_distribution(cm, pos, pk, box["Y"], box["responses"], box["challenge"]) for _ in range(3)]
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(12)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    assert all(v["verdict"] and v["digest"] == box["digest"] for r in res for v in r)
+    assert engine.blocks_in_flight() == (0, 0)
